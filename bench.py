@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the surface-conversion hot path on MI355X.
+
+Metric (BASELINE.json): Gpix/s of NV12 -> RGB conversion of 3840x2160 frames + achieved fraction of the
+HBM roofline, on 1/2/4/8 GPUs.  A "step" is one pass of the hot path over one batch of synthetic
+input: `vpf_convert_batch` over a ring of RING distinct device-resident 4K NV12 frames into RING distinct
+RGB frames (RING*37.3 MB >> the 256 MiB Infinity Cache, so the traffic is really HBM).  Inputs are resident
+in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: frames are independent, so the ring is replicated per rank (weak scaling), no data-path
+collective; ranks only meet at the timing barriers.  value = pixels converted by all ranks / max-over-ranks time.
+
+Extra flags (not used by the driver): --variant V (kernel variant), --mode single (one dispatch per frame,
+what the unmodified per-Execute() API does), --workload {nv12_rgb_4k, nv12_planar_1080p, resize_4k_720p,
+fused_4k_720p}, --sweep (table of variants on stderr), --no-cpu.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from videoprocessingframework_amd import capi  # noqa: E402  (raises if libvpfhip.so is missing: no fallback)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def _pitched(rows, row_bytes, dev, gen=None, align=256):
+    pitch = (row_bytes + align - 1) // align * align
+    if gen is None:
+        t = torch.empty((rows, pitch), dtype=torch.uint8, device=dev)
+    else:
+        t = torch.randint(0, 256, (rows, pitch), dtype=torch.uint8, device=dev, generator=gen)
+    return t, pitch
+
+
+class Workload:
+    """Device-resident ring of frames + the launch closure for one step."""
+
+    def __init__(self, name, dev, ring, variant, mode):
+        self.name, self.dev, self.ring, self.mode = name, dev, ring, mode
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000)
+        self.ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
+        self.keep = []
+        capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        if name in ("nv12_rgb_4k", "nv12_planar_1080p"):
+            self.w, self.h = (3840, 2160) if name == "nv12_rgb_4k" else (1920, 1080)
+            self.dst_fmt = capi.RGB if name == "nv12_rgb_4k" else capi.RGB_PLANAR
+            w, h = self.w, self.h
+            frames = []
+            for _ in range(ring):
+                src, sp = _pitched(h * 3 // 2, w, dev, gen)  # NV12: one W x 1.5H plane, shared pitch (reference layout)
+                if self.dst_fmt == capi.RGB:
+                    dst, dp = _pitched(h, 3 * w, dev)
+                    dd = [(dst.data_ptr(), dp)]
+                else:
+                    dst, dp = _pitched(3 * h, w, dev)  # one W x 3H allocation, plane i at base + i*H*pitch
+                    dd = [(dst.data_ptr() + i * h * dp, dp) for i in range(3)]
+                self.keep += [src, dst]
+                frames.append(([(src.data_ptr(), sp), (src.data_ptr() + h * sp, sp)], dd))
+            self.frames = frames
+            self.batch = capi.make_batch(frames)
+            self.px_per_step = ring * w * h
+            self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
+            self.launches_per_step = (ring + 15) // 16 if mode == "batch" else ring
+            self.kernel = "k_yuv420_rgb_p4 / k_nv12_rgb_p16 (NV12->RGB)"
+        elif name in ("resize_4k_720p", "fused_4k_720p"):
+            self.w, self.h, self.dw, self.dh = 3840, 2160, 1280, 720
+            w, h = self.w, self.h
+            self.items = []
+            for _ in range(ring):
+                src, sp = _pitched(h * 3 // 2, w, dev, gen)
+                mid, mp = _pitched(h, 3 * w, dev)
+                dst, dp = _pitched(self.dh, 3 * self.dw, dev)
+                self.keep += [src, mid, dst]
+                self.items.append(([(src.data_ptr(), sp), (src.data_ptr() + h * sp, sp)], [(mid.data_ptr(), mp)], [(dst.data_ptr(), dp)]))
+            self.px_per_step = ring * w * h
+            if name == "fused_4k_720p":
+                self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * self.dw * self.dh)
+                self.launches_per_step = ring
+            else:
+                self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h + 3 * w * h + 3 * self.dw * self.dh)
+                self.launches_per_step = 2 * ring
+            self.kernel = "k_convert_resize" if name == "fused_4k_720p" else "k_yuv420_rgb_p4 + k_resize"
+        else:
+            raise SystemExit(f"unknown workload {name}")
+
+    def step(self):
+        ex = self.ex
+        if self.name in ("nv12_rgb_4k", "nv12_planar_1080p"):
+            if self.mode == "batch":
+                capi.convert_batch(ex, capi.NV12, self.dst_fmt, capi.BT_709, capi.MPEG, self.w, self.h, self.batch)
+            else:
+                for s, d in self.frames:
+                    capi.convert(ex, capi.NV12, self.dst_fmt, capi.BT_709, capi.MPEG, self.w, self.h, s, d)
+        elif self.name == "fused_4k_720p":
+            for s, _, d in self.items:
+                capi.convert_resize(ex, capi.NV12, capi.RGB, capi.BT_709, capi.MPEG, self.w, self.h, s, self.dw, self.dh, d)
+        else:
+            for s, m, d in self.items:
+                capi.convert(ex, capi.NV12, capi.RGB, capi.BT_709, capi.MPEG, self.w, self.h, s, m)
+                capi.resize(ex, capi.RGB, capi.INTERP_LINEAR, self.w, self.h, m, self.dw, self.dh, d)
+
+    def verify(self):
+        """One frame of the ring against the CPU oracle (outside the timed region)."""
+        if self.name not in ("nv12_rgb_4k", "nv12_planar_1080p"):
+            return None
+        import oracle as o  # test infrastructure, used here only as the checker
+
+        w, h = self.w, self.h
+        src_t, dst_t = self.keep[0], self.keep[1]
+        src = src_t.cpu().numpy()
+        y, uv = np.ascontiguousarray(src[:h, :w]), np.ascontiguousarray(src[h:, :w])
+        st, want = o.convert(o.NV12, self.dst_fmt, o.BT_709, o.MPEG, w, h, [y, uv], o.FP32)
+        got = dst_t.cpu().numpy()
+        if self.dst_fmt == capi.RGB:
+            return bool(st == 0 and np.array_equal(got[:, :3 * w], want[0]))
+        return bool(st == 0 and all(np.array_equal(got[i * h:(i + 1) * h, :w], want[i]) for i in range(3)))
+
+
+def timed(wl: Workload, steps: int, warmup: int, dist_on: bool):
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # on the launch stream
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        wl.step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's FP32 port of NV12->RGB on the host cores, bounded sample of the same 4K workload."""
+    import oracle as o
+
+    cores = len(os.sched_getaffinity(0))
+    o.set_threads(cores)
+    w, h = 3840, 2160
+    src = o.synth(o.NV12, w, h, 1000)
+    dst = o.alloc(o.RGB, w, h, fill=1)  # pre-touched
+    o.convert(o.NV12, o.RGB, o.BT_709, o.MPEG, w, h, src, o.FP32, dst)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.convert(o.NV12, o.RGB, o.BT_709, o.MPEG, w, h, src, o.FP32, dst)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    o.set_threads(1)
+    return {"value": round(n * w * h / el / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames of 3840x2160 NV12->RGB BT.709 limited, oracle FP32 mode, OpenMP over rows, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ring", type=int, default=32, help="distinct frame pairs in the ring (32 x 37.3 MB = 1.19 GB)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--mode", choices=["batch", "single"], default="batch")
+    ap.add_argument("--workload", default="nv12_rgb_4k")
+    ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the conversion path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    if a.sweep and rank == 0:
+        for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
+            for mode in ("batch", "single"):
+                for v in (1, 2, 3, 4, 5, 6, 7, 8):
+                    wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, v, mode)
+                    _, ev = timed(wl, a.steps, a.warmup, False)
+                    gbs = wl.bytes_per_step * a.steps / ev / 1e9
+                    print(f"[sweep] {wlname:18s} {mode:6s} variant {v}: {wl.px_per_step * a.steps / ev / 1e9:8.1f} Gpix/s "
+                          f"{gbs:7.0f} GB/s ({gbs / HBM_PEAK_GBS:.3f} of 8 TB/s) ok={wl.verify()}", file=sys.stderr, flush=True)
+                    del wl
+                    torch.cuda.empty_cache()
+        for wlname in ("resize_4k_720p", "fused_4k_720p"):
+            wl = Workload(wlname, dev, 8, 0, "single")
+            _, ev = timed(wl, max(2, a.steps // 5), 1, False)
+            st = max(2, a.steps // 5)
+            print(f"[sweep] {wlname:18s}: {wl.px_per_step * st / ev / 1e9:8.1f} Gpix/s(src) {wl.bytes_per_step * st / ev / 1e9:7.0f} GB/s algorithmic",
+                  file=sys.stderr, flush=True)
+            del wl
+            torch.cuda.empty_cache()
+
+    wl = Workload(a.workload, dev, a.ring, a.variant, a.mode)
+    wall, ev = timed(wl, a.steps, a.warmup, dist_on)
+    t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
+    if dist_on:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    wall_max, ev_max = float(t[0]), float(t[1])
+    ok = wl.verify()
+
+    if rank == 0:
+        total_px = wl.px_per_step * a.steps * world
+        n_launch = wl.launches_per_step * a.steps
+        avg_launch_s = ev / n_launch  # rank 0's HIP-event time over the timed region / launches in it
+        bytes_per_launch = wl.bytes_per_step / wl.launches_per_step
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        out = {
+            "metric": "Gpix/s NV12->RGB 3840x2160 + achieved %HBM-BW",
+            "value": round(total_px / wall_max / 1e9, 2),
+            "unit": "Gpix/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(wall_max / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 (fp32 FMA arithmetic)",
+            "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {wl.w}x{wl.h} NV12 -> {'RGB' if a.workload != 'nv12_planar_1080p' else 'RGB_PLANAR'}, BT.709 limited range, "
+                                   f"ring of {a.ring} device-resident frames per GPU, {wl.launches_per_step} dispatch(es) per step",
+                       "mode": a.mode, "frames_per_step_per_gpu": a.ring, "variant": a.variant,
+                       "sharding": "independent frame rings, one process per GPU, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": wl.kernel, "bytes_per_launch": int(bytes_per_launch),
+                         "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches": n_launch},
+            "verified_vs_oracle": ok,
+        }
+        if not a.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline() if a.workload == "nv12_rgb_4k" else None
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

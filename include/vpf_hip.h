@@ -1,0 +1,177 @@
+/*
+ * vpf_hip.h — C ABI of libvpfhip: MI355X (gfx950) surface conversion / resize / remap.
+ *
+ * This is the drop-in boundary.  In the reference (NVIDIA/VideoProcessingFramework) the
+ * C++ Task layer calls closed-source NPP at exactly this edge:
+ *
+ *   reference caller                                      reference callee (NPP)            replaced by
+ *   ----------------------------------------------------  --------------------------------  -------------------
+ *   nv12_rgb::Execute        src/TC/src/TasksColorCvt.cpp:122-182  nppiNV12ToRGB_*_8u_P2C3R_Ctx     vpf_convert
+ *   nv12_bgr::Execute        TasksColorCvt.cpp:53-108             nppiNV12ToBGR_*_8u_P2C3R_Ctx     vpf_convert
+ *   nv12_yuv420::Execute     TasksColorCvt.cpp:196-240            nppiNV12ToYUV420 / nppiYCbCr420  vpf_convert
+ *   yuv420_nv12::Execute     TasksColorCvt.cpp:945-975            nppiYCbCr420_8u_P3P2R            vpf_convert
+ *   yuv420_rgb/_bgr          TasksColorCvt.cpp:322-369,383-430    nppiYUV420ToRGB / YCbCr420ToRGB  vpf_convert
+ *   rgb8_deinterleave/_inter TasksColorCvt.cpp:1059-1088,1102-1131 nppiCopy_8u_C3P3R / _P3C3R      vpf_convert
+ *   rgb_bgr / bgr_rgb        TasksColorCvt.cpp:1145-1170,1184-1209 nppiSwapChannels_8u_C3R         vpf_convert
+ *   (all other *_Impl in TasksColorCvt.cpp:245-1300)                                               vpf_convert
+ *   NppResizeSurfacePacked3C_Impl::Run   src/TC/src/Tasks.cpp:1162-1203  nppiResize_8u_C3R         vpf_resize
+ *   NppResizeSurfacePlanar_Impl::Run     Tasks.cpp:1217-1261             nppiResize_8u_C1R         vpf_resize
+ *   NppRemapSurfacePacked3C_Impl::Run    Tasks.cpp:1555-1602             nppiRemap_8u_C3R          vpf_remap
+ *
+ * Like the NPP `_Ctx` entry points it replaces, every function here takes raw device pointers,
+ * byte pitches, a size, and the stream to launch on; it owns nothing, allocates nothing, never
+ * synchronises, and reports failure through its return code (no C++ exceptions cross this edge).
+ * All launches are asynchronous on `exec->stream`.
+ *
+ * Pure C: usable from C, C++, ctypes, cgo, JNI, ... No torch / HIP types in any signature
+ * (`stream` is a hipStream_t passed as void*).
+ */
+#ifndef VPF_HIP_H_
+#define VPF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define VPF_API __attribute__((visibility("default")))
+#else
+#define VPF_API
+#endif
+
+/* Pixel formats. Numeric values are the reference's `Pixel_Format`
+ * (src/TC/inc/MemoryInterfaces.hpp:30-49); they are part of the Python ABI. */
+typedef enum vpf_pixel_format {
+  VPF_FMT_UNDEFINED = 0,
+  VPF_FMT_Y = 1,
+  VPF_FMT_RGB = 2,
+  VPF_FMT_NV12 = 3,
+  VPF_FMT_YUV420 = 4,
+  VPF_FMT_RGB_PLANAR = 5,
+  VPF_FMT_BGR = 6,
+  VPF_FMT_YCBCR = 7,
+  VPF_FMT_YUV444 = 8,
+  VPF_FMT_RGB_32F = 9,
+  VPF_FMT_RGB_32F_PLANAR = 10,
+  VPF_FMT_YUV422 = 11,
+  VPF_FMT_P10 = 12,
+  VPF_FMT_P12 = 13,
+  VPF_FMT_YUV444_10bit = 14,
+  VPF_FMT_YUV420_10bit = 15,
+  VPF_FMT_NV12_PLANAR = 16,
+  VPF_FMT_GRAY12 = 17
+} vpf_pixel_format;
+
+/* src/TC/inc/MemoryInterfaces.hpp:51-61 */
+typedef enum vpf_color_space { VPF_BT_601 = 0, VPF_BT_709 = 1, VPF_CS_UNSPEC = 2 } vpf_color_space;
+typedef enum vpf_color_range { VPF_MPEG = 0, VPF_JPEG = 1, VPF_CR_UDEF = 2 } vpf_color_range;
+
+typedef enum vpf_interp {
+  VPF_INTERP_NEAREST = 0,
+  VPF_INTERP_LINEAR = 1,
+  VPF_INTERP_LANCZOS3 = 2
+} vpf_interp;
+
+typedef enum vpf_status {
+  VPF_OK = 0,
+  VPF_ERR_UNSUPPORTED = 1, /* format pair / matrix not implemented              */
+  VPF_ERR_BAD_ARG = 2,     /* null pointer, zero size, pitch < row bytes, ...    */
+  VPF_ERR_LAUNCH = 3,      /* HIP runtime reported an error at launch            */
+  VPF_ERR_NO_DEVICE = 4    /* no usable gfx950 device                            */
+} vpf_status;
+
+/* One 2-D plane in device memory.  `pitch` is in bytes.  16 bytes, no implicit padding. */
+typedef struct vpf_plane {
+  void* ptr;
+  uint32_t pitch;
+  uint32_t reserved; /* must be 0 */
+} vpf_plane;
+
+/* Size in pixels of the full-resolution image (plane 0 for YUV formats). */
+typedef struct vpf_size {
+  uint32_t width;
+  uint32_t height;
+} vpf_size;
+
+/* Where and on which stream to run.  Replaces NppStreamContext
+ * (src/TC/src/NppCommon.cpp:10-60).  device < 0 means "current device". */
+typedef struct vpf_exec {
+  int32_t device;
+  uint32_t flags; /* reserved, 0 */
+  void* stream;   /* hipStream_t; NULL = default stream */
+} vpf_exec;
+
+/*
+ * Plane conventions for `src[]` / `dst[]` (unused entries are ignored, may be zeroed):
+ *   Y                      [0] = W x H bytes
+ *   NV12                   [0] = Y  (W x H), [1] = interleaved UV (2*ceil(W/2) bytes x ceil(H/2) rows)
+ *   YUV420, YCBCR          [0] = Y, [1] = U (ceil(W/2) x ceil(H/2)), [2] = V
+ *   YUV444, RGB_PLANAR     [0],[1],[2] = three W x H planes (the reference stacks them in one
+ *                          allocation, plane i at base + i*H*pitch: MemoryInterfaces.cpp:1593-1600;
+ *                          the caller resolves that to three pointers)
+ *   RGB, BGR               [0] = packed 3 bytes / pixel (3W bytes x H)
+ *   RGB_32F                [0] = packed 3 floats / pixel; RGB_32F_PLANAR: three float planes
+ *   P10, P12               [0] = Y 16-bit, [1] = interleaved UV 16-bit (MSB-aligned samples)
+ */
+
+/* Colour / layout conversion of one frame.  Replaces every nppi* call in TasksColorCvt.cpp. */
+VPF_API vpf_status vpf_convert(const vpf_exec* exec, int src_fmt, int dst_fmt, int color_space,
+                               int color_range, vpf_size size, const vpf_plane src[3],
+                               const vpf_plane dst[3]);
+
+typedef struct vpf_frame_io {
+  vpf_plane src[3];
+  vpf_plane dst[3];
+} vpf_frame_io;
+
+/* The same conversion over `n` independent frames of identical size/format, dispatched as few
+ * launches as possible (one per 16 frames).  `frames` is a HOST array, consumed before return.
+ * Exists because a 4K frame is ~5 us of HBM time, the same order as a kernel boundary. */
+VPF_API vpf_status vpf_convert_batch(const vpf_exec* exec, int src_fmt, int dst_fmt,
+                                     int color_space, int color_range, vpf_size size, uint32_t n,
+                                     const vpf_frame_io* frames);
+
+/* 1 if vpf_convert implements (src_fmt,dst_fmt) under (color_space,color_range), else 0.
+ * Pure host logic; callable without a GPU. */
+VPF_API int vpf_convert_supported(int src_fmt, int dst_fmt, int color_space, int color_range);
+
+/* Whole-image resize.  `fmt` in {RGB, BGR, Y, YUV420, YCBCR, YUV444, RGB_PLANAR, NV12}; every plane
+ * is resized independently (chroma planes at their own resolution).  Replaces nppiResize_8u_C3R /
+ * _C1R (Tasks.cpp:1193,1227-1253). */
+VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size src_size,
+                              const vpf_plane src[3], vpf_size dst_size, const vpf_plane dst[3]);
+
+/* Per-pixel remap with bilinear sampling, packed RGB/BGR only (Tasks.cpp:1555-1602,
+ * nppiRemap_8u_C3R + NPPI_INTER_LINEAR).  xmap/ymap are device pointers to float32 rows of
+ * dst_size.width entries, row pitch in bytes.  Destination pixels whose source coordinate lies
+ * outside [0,W-1]x[0,H-1] are left untouched. */
+VPF_API vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size src_size, const vpf_plane* src,
+                             const float* xmap, uint32_t xmap_pitch, const float* ymap,
+                             uint32_t ymap_pitch, vpf_size dst_size, const vpf_plane* dst);
+
+/* Fused NV12 -> bilinear resize -> packed RGB/BGR / RGB_PLANAR in one pass: reads only the source
+ * texels it needs (BASELINE.md config 3 "fused").  Result is defined as: convert every NV12 texel
+ * with vpf_convert's arithmetic, then vpf_resize(LINEAR) of the RGB image. */
+VPF_API vpf_status vpf_convert_resize(const vpf_exec* exec, int src_fmt, int dst_fmt,
+                                      int color_space, int color_range, vpf_size src_size,
+                                      const vpf_plane src[3], vpf_size dst_size,
+                                      const vpf_plane dst[3]);
+
+VPF_API const char* vpf_status_string(int status);
+VPF_API const char* vpf_version(void);
+/* hipGetDeviceCount; 0 when no GPU / no driver (never fails). Replaces GetNumGpus
+ * (src/PyNvCodec/src/PyNvCodec.cpp:427-429). */
+VPF_API int vpf_device_count(void);
+
+/* Tuning hook used by bench.py / tests to select a kernel variant for NV12->RGB (0 = default).
+ * Not part of the reference surface. Returns the previous value. */
+VPF_API int vpf_set_tuning(int key, int value);
+#define VPF_TUNE_NV12_RGB_VARIANT 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPF_HIP_H_ */

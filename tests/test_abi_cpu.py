@@ -1,0 +1,78 @@
+"""CPU-side checks of the drop-in boundary: libvpfhip.so loads without a GPU, exports exactly what
+include/vpf_hip.h declares, and its host-side validation / dispatch tables behave like the oracle's.
+No kernel is launched here (argument validation precedes any HIP call)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "vpf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"VPF_API\s+[\w\s\*]+?\b(vpf_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(capi):
+    names = _declared()
+    assert set(names) == set(capi.EXPORTS)
+    L = capi.lib()
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_abi_struct_layout(capi):
+    # the C header promises: vpf_plane is 16 bytes, vpf_exec 16 bytes, vpf_frame_io 96 bytes
+    assert C.sizeof(capi.Plane) == 16 and C.sizeof(capi.Exec) == 16 and C.sizeof(capi.FrameIO) == 96
+    assert C.sizeof(capi.Size) == 8
+
+
+def test_version_and_status_strings(capi):
+    assert "gfx950" in capi.version()
+    assert capi.status_string(capi.OK) == "ok"
+    assert "unsupported" in capi.status_string(capi.ERR_UNSUPPORTED)
+
+
+def test_supported_table_equals_oracle(capi, oracle):
+    for s in range(0, 18):
+        for d in range(0, 18):
+            for cs in (0, 1, 2):
+                for cr in (0, 1, 2):
+                    assert capi.convert_supported(s, d, cs, cr) == oracle.supported(s, d, cs, cr), (s, d, cs, cr)
+
+
+def test_validation_without_gpu(capi):
+    ex = capi.make_exec()
+    fake = [(0x1000, 64), (0x2000, 64)]
+    # unsupported pair / colour-space: rejected before any device work
+    assert capi.convert(ex, capi.NV12, capi.YUV444, 0, 0, 16, 16, fake, fake, check=False) == capi.ERR_UNSUPPORTED
+    assert capi.convert(ex, capi.NV12, capi.RGB, 2, 2, 16, 16, fake, fake, check=False) == capi.ERR_UNSUPPORTED
+    # bad args: zero size, null plane, pitch smaller than the row
+    assert capi.convert(ex, capi.NV12, capi.RGB, 1, 0, 0, 16, fake, [(0x3000, 64)], check=False) == capi.ERR_BAD_ARG
+    assert capi.convert(ex, capi.NV12, capi.RGB, 1, 0, 16, 16, [(0, 64), (0x2000, 64)], [(0x3000, 64)], check=False) == capi.ERR_BAD_ARG
+    assert capi.convert(ex, capi.NV12, capi.RGB, 1, 0, 16, 16, fake, [(0x3000, 47)], check=False) == capi.ERR_BAD_ARG
+    assert capi.resize(ex, capi.RGB, capi.INTERP_LANCZOS3, 16, 16, [(0x1000, 64)], 8, 8, [(0x2000, 64)], check=False) == capi.ERR_UNSUPPORTED
+    assert capi.resize(ex, capi.RGB_32F, capi.INTERP_LINEAR, 16, 16, [(0x1000, 256)], 8, 8, [(0x2000, 256)], check=False) == capi.ERR_UNSUPPORTED
+    assert capi.resize(ex, capi.RGB, capi.INTERP_LINEAR, 16, 16, [(0x1000, 47)], 8, 8, [(0x2000, 64)], check=False) == capi.ERR_BAD_ARG
+    assert capi.remap(ex, capi.NV12, 16, 16, (0x1000, 64), 0x2000, 64, 0x3000, 64, 16, 16, (0x4000, 64), check=False) == capi.ERR_UNSUPPORTED
+    assert capi.remap(ex, capi.RGB, 16, 16, (0x1000, 64), 0x2000, 60, 0x3000, 64, 16, 16, (0x4000, 64), check=False) == capi.ERR_BAD_ARG
+    with pytest.raises(capi.VpfError):
+        capi.convert(ex, capi.NV12, capi.YUV444, 0, 0, 16, 16, fake, fake)
+
+
+def test_device_count_never_fails(capi):
+    assert capi.device_count() >= 0
+
+
+def test_product_does_not_touch_oracle():
+    """The product tree must not import / include / link anything under oracle/."""
+    pkg = os.path.join(ROOT, "videoprocessingframework_amd")
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "vpf_oracle" not in txt and "libvpforacle" not in txt, f

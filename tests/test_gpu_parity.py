@@ -1,0 +1,324 @@
+"""-m gpu parity tests: HIP kernels (through the C ABI, libvpfhip.so) vs the CPU oracle.
+
+Bar: BIT-EXACT against the oracle's FP32 mode (the restatement of the kernels' operation order) —
+which tests/test_oracle_kat.py proves is within 1 LSB of exact round-half-up for every possible input —
+and therefore within north_star's +-1 LSB of the specification-level oracle (asserted directly too).
+Padding bytes of every pitched destination must come back untouched.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():  # -m gpu on a box without a GPU: fail loudly rather than pass vacuously
+    pytest.skip("no GPU visible", allow_module_level=True)
+
+from gpu_util import DevPlanes, assert_planes_equal, stream_handle  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+MATS = [(0, 0), (0, 1), (1, 0), (1, 1)]
+
+
+def _convert(capi, oracle, sf, df, cs, cr, w, h, src, align=256, extra=0, offset=0, variant=0, exact_tol=True):
+    s = DevPlanes(src, align, extra, offset)
+    d = DevPlanes(oracle.alloc(df, w, h), align, extra, offset)
+    prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+    try:
+        capi.convert(capi.make_exec(stream_handle()), sf, df, cs, cr, w, h, s.desc(), d.desc())
+    finally:
+        capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+    torch.cuda.synchronize()
+    got, intact = d.download()
+    assert intact, "kernel wrote outside the destination rows (padding clobbered)"
+    st, want = oracle.convert(sf, df, cs, cr, w, h, src, oracle.FP32)
+    assert st == 0
+    assert_planes_equal(got, want, f"convert {sf}->{df} cs{cs} cr{cr} {w}x{h} v{variant}")
+    if exact_tol:
+        st, ex = oracle.convert(sf, df, cs, cr, w, h, src, oracle.EXACT)
+        for g, e in zip(got, ex):
+            if g.dtype == np.uint8:
+                assert np.abs(g.astype(np.int16) - e.astype(np.int16)).max() <= 1  # +-1 LSB (north_star)
+    return got
+
+
+# ---------------------------------------------------------------------------------------------
+# headline path: NV12 -> RGB / BGR / RGB_PLANAR
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cs,cr", MATS)
+@pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
+def test_nv12_to_rgb_matrices(capi, oracle, cs, cr, dst):
+    w, h = 256, 64
+    for dist in "ABC":
+        src = oracle.synth(oracle.NV12, w, h, 1000, dist)
+        _convert(capi, oracle, capi.NV12, getattr(capi, dst), cs, cr, w, h, src)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
+def test_nv12_to_rgb_every_kernel_variant(capi, oracle, variant, dst):
+    """all kernel variants (p4 / p16 / LDS-transposed / non-temporal / explicit pack / generic) agree bit for bit"""
+    for (w, h) in [(1920, 32), (3840, 8), (848, 464), (1280, 18)]:
+        src = oracle.synth(oracle.NV12, w, h, 1001)
+        _convert(capi, oracle, capi.NV12, getattr(capi, dst), 1, 0, w, h, src, variant=variant, exact_tol=False)
+
+
+def test_nv12_frame_kat_on_gpu(capi, oracle):
+    """the committed golden frame (tests/golden/nv12_frame_kat.json) through the HIP path: +-1 LSB, and
+    bit-exact vs the oracle's FP32 mode"""
+    kat = json.load(open(os.path.join(G, "nv12_frame_kat.json")))
+    w, h = kat["w"], kat["h"]
+    src = [np.array(kat["y"], np.uint8), np.array(kat["uv"], np.uint8)]
+    for key, (cs, cr) in {"601_MPEG": (0, 0), "601_JPEG": (0, 1), "709_MPEG": (1, 0), "709_JPEG": (1, 1)}.items():
+        got = _convert(capi, oracle, capi.NV12, capi.RGB, cs, cr, w, h, src)
+        want = np.array(kat["rgb"][key], np.uint8)
+        assert np.abs(got[0].astype(int) - want.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("w,h", [(2, 2), (1, 1), (3, 5), (4, 2), (6, 4), (10, 6), (17, 9), (64, 2), (66, 34), (255, 3),
+                                 (1000, 10), (1022, 6), (1026, 4)])
+def test_nv12_to_rgb_ragged_sizes(capi, oracle, w, h):
+    """minimal, odd and ragged sizes (generic path) incl. width not multiple of 4/16/64"""
+    src = oracle.synth(oracle.NV12, w, h, 1002)
+    for dst in (capi.RGB, capi.BGR, capi.RGB_PLANAR):
+        _convert(capi, oracle, capi.NV12, dst, 1, 0, w, h, src, align=1)       # pitch == row bytes
+        _convert(capi, oracle, capi.NV12, dst, 0, 1, w, h, src, align=64, extra=3, offset=1)  # odd pitch, odd base
+
+
+@pytest.mark.parametrize("align,extra,offset", [(256, 0, 0), (4, 0, 0), (4, 4, 4), (16, 0, 16), (1, 0, 0), (256, 0, 2)])
+def test_nv12_to_rgb_pitch_and_alignment(capi, oracle, align, extra, offset):
+    w, h = 1280, 24
+    src = oracle.synth(oracle.NV12, w, h, 1003)
+    for variant in (0, 5):
+        _convert(capi, oracle, capi.NV12, capi.RGB, 1, 0, w, h, src, align, extra, offset, variant=variant)
+
+
+def test_saturation_corners(capi, oracle):
+    """every clamp: planes of constant extreme values"""
+    w, h = 64, 8
+    for yv in (0, 255):
+        for uv in (0, 255):
+            for vv in (0, 255):
+                y = np.full((h, w), yv, np.uint8)
+                c = np.empty((h // 2, w), np.uint8)
+                c[:, 0::2], c[:, 1::2] = uv, vv
+                for cs, cr in MATS:
+                    _convert(capi, oracle, capi.NV12, capi.RGB, cs, cr, w, h, [y, c])
+
+
+def test_exhaustive_yuv_triples_on_gpu(capi, oracle):
+    """All 2^24 (Y,U,V) triples through the real kernel, per matrix: a 4096 x 8192 NV12 frame whose 2x2
+    quads enumerate (U,V) and whose luma enumerates Y within 16 x 16 blocks of quads. Bit-exact vs FP32 oracle."""
+    w, h = 8192, 4096  # chroma grid 4096 x 2048 = 2^23 quads x 4 luma = 2^25 px >= 2 * 2^24 (each triple >= once)
+    qy, qx = np.meshgrid(np.arange(h // 2), np.arange(w // 2), indexing="ij")
+    # quad index -> (u, v, ybase): u = qx & 255, v = qy & 255, block = (qx >> 8) + 16 * (qy >> 8) in [0, 128)
+    u = (qx & 255).astype(np.uint8)
+    v = (qy & 255).astype(np.uint8)
+    blk = ((qx >> 8) + 16 * (qy >> 8)).astype(np.int32)  # 0..127
+    uv = np.empty((h // 2, w), np.uint8)
+    uv[:, 0::2], uv[:, 1::2] = u, v
+    y = np.empty((h, w), np.uint8)
+    # the 4 luma samples of quad (block b) take Y values 2b, 2b+1 (top row) and again 2b, 2b+1 (bottom) -> all 256 Y
+    y[0::2, 0::2] = (2 * blk).astype(np.uint8)
+    y[0::2, 1::2] = (2 * blk + 1).astype(np.uint8)
+    y[1::2, 0::2] = (2 * blk + 1).astype(np.uint8)
+    y[1::2, 1::2] = (2 * blk).astype(np.uint8)
+    for cs, cr in MATS:
+        _convert(capi, oracle, capi.NV12, capi.RGB, cs, cr, w, h, [y, uv], exact_tol=False)
+
+
+def test_full_size_4k_and_1080p(capi, oracle):
+    """BASELINE.json sizes, full frames, bit-exact (configs[1] 1080p NV12->RGB_PLANAR 709 limited; 4K NV12->RGB)"""
+    src = oracle.synth(oracle.NV12, 1920, 1080, 1004, "B")
+    _convert(capi, oracle, capi.NV12, capi.RGB_PLANAR, 1, 0, 1920, 1080, src)
+    src = oracle.synth(oracle.NV12, 3840, 2160, 1005, "A")
+    for variant in (0, 5):
+        _convert(capi, oracle, capi.NV12, capi.RGB, 1, 0, 3840, 2160, src, variant=variant, exact_tol=False)
+
+
+def test_batch_matches_single(capi, oracle):
+    """vpf_convert_batch over 37 frames (3 dispatches of <=16) == 37 single conversions; outputs independent"""
+    w, h, n = 640, 36, 37
+    srcs = [oracle.synth(oracle.NV12, w, h, 2000 + i) for i in range(n)]
+    S = [DevPlanes(s) for s in srcs]
+    D = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
+    batch = capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)])
+    capi.convert_batch(capi.make_exec(stream_handle()), capi.NV12, capi.RGB, 1, 0, w, h, batch)
+    torch.cuda.synchronize()
+    for i in range(n):
+        got, intact = D[i].download()
+        assert intact
+        _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, srcs[i])
+        assert_planes_equal(got, want, f"batch frame {i}")
+
+
+def test_linearity_property_full_size(capi, oracle):
+    """size-independent property at 4K: full-range luma ramp with neutral chroma maps to R=G=B=Y (JPEG matrices)"""
+    w, h = 3840, 2160
+    y = (np.arange(w, dtype=np.int64)[None, :] + np.arange(h, dtype=np.int64)[:, None]) % 256
+    y = y.astype(np.uint8)
+    uv = np.full((h // 2, w), 128, np.uint8)
+    s, d = DevPlanes([y, uv]), DevPlanes(oracle.alloc(oracle.RGB_PLANAR, w, h))
+    for cs in (0, 1):
+        capi.convert(capi.make_exec(stream_handle()), capi.NV12, capi.RGB_PLANAR, cs, capi.JPEG, w, h, s.desc(), d.desc())
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact and all(np.array_equal(p, y) for p in got)
+
+
+# ---------------------------------------------------------------------------------------------
+# the rest of the converter matrix
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src_fmt", ["YUV420", "YUV444"])
+@pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
+def test_planar_yuv_to_rgb(capi, oracle, src_fmt, dst):
+    for (w, h) in [(640, 48), (30, 14), (7, 5)]:
+        src = oracle.synth(getattr(oracle, src_fmt), w, h, 1010)
+        for cs, cr in MATS:
+            _convert(capi, oracle, getattr(capi, src_fmt), getattr(capi, dst), cs, cr, w, h, src)
+        _convert(capi, oracle, getattr(capi, src_fmt), getattr(capi, dst), 0, 0, w, h, src, align=2, extra=2, offset=2)
+
+
+RELAYOUT = [("NV12", "YUV420"), ("YUV420", "NV12"), ("RGB", "RGB_PLANAR"), ("RGB_PLANAR", "RGB"), ("RGB", "BGR"),
+            ("BGR", "RGB"), ("BGR", "RGB_PLANAR"), ("RGB_PLANAR", "BGR"), ("NV12", "Y"), ("Y", "YUV444"),
+            ("RGB", "Y"), ("BGR", "Y"), ("RGB_PLANAR", "Y"), ("P10", "NV12"), ("P12", "NV12")]
+
+
+@pytest.mark.parametrize("s,d", RELAYOUT)
+def test_relayout_converters(capi, oracle, s, d):
+    for (w, h) in [(1920, 16), (848, 464), (64, 4), (18, 10), (5, 3), (1, 1)]:
+        src = oracle.synth(getattr(oracle, s), w, h, 1020)
+        _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src)
+        _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src, align=1)
+        _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src, variant=9)  # forced generic
+
+
+def test_float_converters(capi, oracle):
+    for (w, h) in [(320, 20), (7, 3)]:
+        src = oracle.synth(oracle.RGB, w, h, 1021)
+        got = _convert(capi, oracle, capi.RGB, capi.RGB_32F, 0, 0, w, h, src)
+        assert got[0].dtype == np.float32 and got[0].max() <= 1.0
+        _convert(capi, oracle, capi.RGB_32F, capi.RGB_32F_PLANAR, 0, 0, w, h, got)
+
+
+@pytest.mark.parametrize("s", ["RGB", "BGR", "RGB_PLANAR"])
+@pytest.mark.parametrize("d", ["YUV444", "YUV420", "YCBCR"])
+def test_rgb_to_yuv(capi, oracle, s, d):
+    for (w, h) in [(640, 48), (30, 14), (7, 5), (1, 1)]:
+        src = oracle.synth(getattr(oracle, s), w, h, 1030)
+        for cr in (0, 1):
+            _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, cr, w, h, src)
+
+
+def test_roundtrip_nv12_rgb_yuv420_nv12(capi, oracle):
+    """sample chain of samples/SamplePyTorch.py:150-158 (601 MPEG): NV12->YUV420->RGB->YUV420->NV12 returns a
+    picture within 3 LSB of the original on legal-range input that is constant over 2x2 quads"""
+    w, h = 256, 64
+    rng = np.random.default_rng(5)
+    yq = rng.integers(40, 200, (h // 2, w // 2), dtype=np.uint8)
+    y = np.repeat(np.repeat(yq, 2, 0), 2, 1)
+    uv = rng.integers(100, 156, (h // 2, w), dtype=np.uint8)
+    a = _convert(capi, oracle, capi.NV12, capi.YUV420, 0, 0, w, h, [y, uv])
+    b = _convert(capi, oracle, capi.YUV420, capi.RGB, 0, 0, w, h, a)
+    c = _convert(capi, oracle, capi.RGB, capi.YUV420, 0, 0, w, h, b)
+    d = _convert(capi, oracle, capi.YUV420, capi.NV12, 0, 0, w, h, c)
+    assert np.abs(d[0].astype(int) - y.astype(int)).max() <= 3
+    assert np.abs(d[1].astype(int) - uv.astype(int)).max() <= 3
+
+
+# ---------------------------------------------------------------------------------------------
+# resize / remap / fused
+# ---------------------------------------------------------------------------------------------
+def _resize(capi, oracle, fmt, interp, sw, sh, dw, dh, seed=1040, align=256):
+    src = oracle.synth(fmt, sw, sh, seed)
+    s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(fmt, dw, dh), align)
+    capi.resize(capi.make_exec(stream_handle()), fmt, interp, sw, sh, s.desc(), dw, dh, d.desc())
+    torch.cuda.synchronize()
+    got, intact = d.download()
+    assert intact
+    _, want = oracle.resize(fmt, interp, sw, sh, src, dw, dh, oracle.FP32)
+    assert_planes_equal(got, want, f"resize fmt{fmt} {sw}x{sh}->{dw}x{dh}")
+    _, ex = oracle.resize(fmt, interp, sw, sh, src, dw, dh, oracle.EXACT)
+    for g, e in zip(got, ex):
+        assert np.abs(g.astype(int) - e.astype(int)).max() <= 1
+    return got
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "BGR", "Y", "YUV420", "YUV444", "RGB_PLANAR", "NV12"])
+def test_resize_bilinear(capi, oracle, fmt):
+    f = getattr(capi, fmt)
+    for (sw, sh, dw, dh) in [(3840, 64, 1280, 22), (640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 2, 2)]:
+        _resize(capi, oracle, f, capi.INTERP_LINEAR, sw, sh, dw, dh)
+    _resize(capi, oracle, f, capi.INTERP_LINEAR, 128, 72, 50, 30, align=1)
+    _resize(capi, oracle, f, capi.INTERP_NEAREST, 128, 72, 50, 30)
+
+
+def test_resize_4k_to_720p_full(capi, oracle):
+    """BASELINE.json configs[2]: 3840x2160 RGB -> 1280x720 bilinear, full frame"""
+    _resize(capi, oracle, capi.RGB, capi.INTERP_LINEAR, 3840, 2160, 1280, 720)
+
+
+def test_fused_convert_resize(capi, oracle):
+    for (sw, sh, dw, dh) in [(3840, 2160, 1280, 720), (640, 360, 224, 224), (100, 60, 333, 201), (18, 10, 7, 5)]:
+        for sfmt in ("NV12", "YUV420"):
+            src = oracle.synth(getattr(oracle, sfmt), sw, sh, 1050)
+            for dfmt in ("RGB", "BGR", "RGB_PLANAR"):
+                s, d = DevPlanes(src), DevPlanes(oracle.alloc(getattr(oracle, dfmt), dw, dh))
+                capi.convert_resize(capi.make_exec(stream_handle()), getattr(capi, sfmt), getattr(capi, dfmt), 1, 0, sw, sh,
+                                    s.desc(), dw, dh, d.desc())
+                torch.cuda.synchronize()
+                got, intact = d.download()
+                assert intact
+                _, want = oracle.convert_resize(getattr(oracle, sfmt), getattr(oracle, dfmt), 1, 0, sw, sh, src, dw, dh)
+                assert_planes_equal(got, want, f"fused {sfmt}->{dfmt} {sw}x{sh}->{dw}x{dh}")
+
+
+def _maps(kind, w, h):
+    xm, ym = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    if kind == "identity":
+        return xm, ym
+    if kind == "shift":
+        return xm + 0.5, ym + 0.25
+    # barrel distortion r' = r (1 + 0.1 r^2), SURVEY.md §8(d)
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    nx, ny = (xm - cx) / cx, (ym - cy) / cy
+    k = 1 + 0.1 * (nx * nx + ny * ny)
+    return (nx * k * cx + cx).astype(np.float32), (ny * k * cy + cy).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["identity", "shift", "barrel"])
+def test_remap(capi, oracle, kind):
+    for (w, h) in [(1920, 1080), (333, 77)]:
+        src = oracle.synth(oracle.RGB, w, h, 1060)
+        xm, ym = _maps(kind, w, h)
+        s = DevPlanes(src)
+        d = DevPlanes(oracle.alloc(oracle.RGB, w, h, fill=9))
+        dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+        capi.remap(capi.make_exec(stream_handle()), capi.RGB, w, h, s.desc()[0], dx.data_ptr(), 4 * w, dy.data_ptr(), 4 * w,
+                   w, h, d.desc()[0])
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact
+        _, want = oracle.remap(oracle.RGB, w, h, src, xm, ym, dst=oracle.alloc(oracle.RGB, w, h, fill=9))
+        assert_planes_equal(got, want, f"remap {kind} {w}x{h}")
+        if kind == "identity":
+            assert np.array_equal(got[0], src[0])
+
+
+def test_async_on_user_stream(capi, oracle):
+    """launches are asynchronous on the caller's stream and ordered with other work on it"""
+    w, h = 1920, 1080
+    src = oracle.synth(oracle.NV12, w, h, 1070)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        s, d = DevPlanes(src), DevPlanes(oracle.alloc(oracle.RGB, w, h))
+        ex = capi.make_exec(st.cuda_stream)
+        for _ in range(4):
+            capi.convert(ex, capi.NV12, capi.RGB, 1, 0, w, h, s.desc(), d.desc())
+        st.synchronize()
+        got, _ = d.download()
+    _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+    assert_planes_equal(got, want, "stream")

@@ -1,0 +1,239 @@
+// k_relayout.hip — pure re-layout converters for gfx950 (no arithmetic on the samples, or a single
+// scale): NV12 <-> YUV420 (reference nv12_yuv420 / yuv420_nv12, src/TC/src/TasksColorCvt.cpp:196-240,
+// 945-975), RGB <-> RGB_PLANAR (rgb8_deinterleave / rgb8_interleave :1059-1088,1102-1131), RGB <-> BGR
+// (rgb_bgr / bgr_rgb :1145-1209), NV12 -> Y (nv12_y :254-279), Y -> YUV444 (y_yuv444 :844-873),
+// RGB -> RGB_32F (rbg8_rgb32f :1222-1254), RGB_32F -> RGB_32F_PLANAR (rgb32f_deinterleave :1268-1297),
+// P10/P12 -> NV12 (p16_nv12 :990-1045), RGB/BGR -> Y (rbg8_y :293-308).
+//
+// All of it is 2-6 B/px of pure HBM streaming.  Fast paths move 12-16 B per lane with byte permutes
+// (v_perm_b32) in registers; the generic path handles any size/alignment with byte accesses.
+#include "vpf_device.h"
+
+namespace vpf {
+
+// ------------------------------------------------------------------------------------------
+// NV12 <-> YUV420: one lane = 16 luma px x 2 rows + 8 chroma pairs.
+// fast path: w % 16 == 0, h even, Y/UV planes 16-B aligned, U/V planes 8-B aligned.
+// ------------------------------------------------------------------------------------------
+template <bool TO_PLANAR>
+__global__ __launch_bounds__(256) void k_nv12_yuv420_p16(const BatchArgs args, uint32_t w, uint32_t h,
+                                                         uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t rp = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || rp >= (h >> 1)) return;
+  const uint32_t x = gx * 16;
+  const u32x4 y0 = ldg<false, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+  const u32x4 y1 = ldg<false, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+  if constexpr (TO_PLANAR) {
+    const u32x4 uv = ldg<false, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+    u32x2 u, v;  // even bytes -> U, odd bytes -> V
+    u[0] = __builtin_amdgcn_perm(uv[1], uv[0], 0x06040200u);
+    u[1] = __builtin_amdgcn_perm(uv[3], uv[2], 0x06040200u);
+    v[0] = __builtin_amdgcn_perm(uv[1], uv[0], 0x07050301u);
+    v[1] = __builtin_amdgcn_perm(uv[3], uv[2], 0x07050301u);
+    stg<false, u32x2>(f.d[1] + (size_t)rp * f.dp[1] + (x >> 1), u);
+    stg<false, u32x2>(f.d[2] + (size_t)rp * f.dp[2] + (x >> 1), v);
+  } else {
+    const u32x2 u = ldg<false, u32x2>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1));
+    const u32x2 v = ldg<false, u32x2>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
+    u32x4 uv;  // interleave: U0 V0 U1 V1 | U2 V2 U3 V3 | ...
+    uv[0] = __builtin_amdgcn_perm(v[0], u[0], 0x05010400u);
+    uv[1] = __builtin_amdgcn_perm(v[0], u[0], 0x07030602u);
+    uv[2] = __builtin_amdgcn_perm(v[1], u[1], 0x05010400u);
+    uv[3] = __builtin_amdgcn_perm(v[1], u[1], 0x07030602u);
+    stg<false, u32x4>(f.d[1] + (size_t)rp * f.dp[1] + x, uv);
+  }
+  stg<false, u32x4>(f.d[0] + (size_t)(2 * rp) * f.dp[0] + x, y0);
+  stg<false, u32x4>(f.d[0] + (size_t)(2 * rp + 1) * f.dp[0] + x, y1);
+}
+
+// ------------------------------------------------------------------------------------------
+// packed RGB <-> planar / channel swap: one lane = 4 px = 12 packed bytes.
+// fast path: w % 4 == 0, planes 4-B aligned.  MODE 0: packed->planar, 1: planar->packed, 2: swap R/B
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rgb_relayout_p4(const BatchArgs args, uint32_t w, uint32_t h,
+                                                         uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || y >= h) return;
+  const uint32_t x = gx * 4;
+  if constexpr (MODE == 1) {
+    const uint32_t r = ldg<false, uint32_t>(f.s[0] + (size_t)y * f.sp[0] + x);
+    const uint32_t g = ldg<false, uint32_t>(f.s[1] + (size_t)y * f.sp[1] + x);
+    const uint32_t b = ldg<false, uint32_t>(f.s[2] + (size_t)y * f.sp[2] + x);
+    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 ; perm(hi, lo, sel): sel 0-3 -> lo bytes, 4-7 -> hi bytes
+    const uint32_t rg_lo = __builtin_amdgcn_perm(g, r, 0x05010400u);  // R0 G0 R1 G1
+    const uint32_t rg_hi = __builtin_amdgcn_perm(g, r, 0x07030602u);  // R2 G2 R3 G3
+    const uint32_t d0 = __builtin_amdgcn_perm(b, rg_lo, 0x02040100u);  // R0 G0 B0 R1
+    const uint32_t d1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b, rg_lo, 0x00000503u) /* G1 B1 . . */,
+                                              rg_hi, 0x01000504u);    // G1 B1 R2 G2
+    const uint32_t d2 = __builtin_amdgcn_perm(b, rg_hi, 0x07030206u);  // B2 R3 G3 B3
+    stg3<false>(f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+  } else {
+    const uint8_t* p = f.s[0] + (size_t)y * f.sp[0] + 3 * (size_t)x;
+    const uint32_t d0 = ldg<false, uint32_t>(p), d1 = ldg<false, uint32_t>(p + 4), d2 = ldg<false, uint32_t>(p + 8);
+    // d0 = c0a c1a c2a c0b ; d1 = c1b c2b c0c c1c ; d2 = c2c c0d c1d c2d
+    if constexpr (MODE == 0) {
+      const uint32_t c0 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000300u) /* c0a c0b */,
+                                                __builtin_amdgcn_perm(d2, d1, 0x00000502u) /* c0c c0d */, 0x01000504u);
+      const uint32_t c1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000401u) /* c1a c1b */,
+                                                __builtin_amdgcn_perm(d2, d1, 0x00000603u) /* c1c c1d */, 0x01000504u);
+      const uint32_t c2 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000502u) /* c2a c2b */,
+                                                __builtin_amdgcn_perm(d2, d1, 0x00000704u) /* c2c c2d */, 0x01000504u);
+      stg<false, uint32_t>(f.d[0] + (size_t)y * f.dp[0] + x, c0);
+      stg<false, uint32_t>(f.d[1] + (size_t)y * f.dp[1] + x, c1);
+      stg<false, uint32_t>(f.d[2] + (size_t)y * f.dp[2] + x, c2);
+    } else {
+      // swap c0<->c2 in every pixel:
+      // o0 = c2a c1a c0a c2b ; o1 = c1b c0b c2c c1c ; o2 = c0c c2d c1d c0d
+      const uint32_t o0 = __builtin_amdgcn_perm(d1, d0, 0x05000102u);
+      const uint32_t o1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d2, d0, 0x04000003u) /* c0b . . c2c */,
+                                                d1, 0x03070400u);     // c1b c0b c2c c1c
+      const uint32_t o2 = __builtin_amdgcn_perm(d2, d1, 0x05060702u);
+      stg3<false>(f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x, o0, o1, o2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic per-pixel re-layout: any size / alignment, byte (or element) accesses.
+// ------------------------------------------------------------------------------------------
+enum GenericOp : int {
+  OP_NV12_YUV420, OP_YUV420_NV12, OP_RGB_PLANAR, OP_PLANAR_RGB, OP_SWAP_RB, OP_COPY_Y, OP_Y_YUV444,
+  OP_RGB_RGB32F, OP_RGB32F_PLANAR, OP_P16_NV12, OP_RGB_GRAY, OP_BGR_GRAY, OP_PLANAR_GRAY, OP_PLANAR_SWAP
+};
+
+VPF_DEV uint8_t p16_to_8(uint16_t v) {  // (v + 128) >> 8 saturated: nppiDivC_16u(256) round-to-nearest + Convert_16u8u
+  uint32_t r = ((uint32_t)v + 128u) >> 8;
+  return (uint8_t)(r > 255u ? 255u : r);
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_relayout_generic(const BatchArgs args, uint32_t w, uint32_t h) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const uint32_t cw = (w + 1) >> 1, ch = (h + 1) >> 1;
+  auto S = [&](int k, uint32_t yy, uint32_t xx) -> uint8_t { return f.s[k][(size_t)yy * f.sp[k] + xx]; };
+  auto D = [&](int k, uint32_t yy, uint32_t xx) -> uint8_t& { return f.d[k][(size_t)yy * f.dp[k] + xx]; };
+  if constexpr (OP == OP_NV12_YUV420) {
+    D(0, y, x) = S(0, y, x);
+    if (x < cw && y < ch) { D(1, y, x) = S(1, y, 2 * x); D(2, y, x) = S(1, y, 2 * x + 1); }
+  } else if constexpr (OP == OP_YUV420_NV12) {
+    D(0, y, x) = S(0, y, x);
+    if (x < cw && y < ch) { D(1, y, 2 * x) = S(1, y, x); D(1, y, 2 * x + 1) = S(2, y, x); }
+  } else if constexpr (OP == OP_RGB_PLANAR) {
+    for (int k = 0; k < 3; k++) D(k, y, x) = S(0, y, 3 * x + k);
+  } else if constexpr (OP == OP_PLANAR_RGB) {
+    for (int k = 0; k < 3; k++) D(0, y, 3 * x + k) = S(k, y, x);
+  } else if constexpr (OP == OP_PLANAR_SWAP) {  // RGB_PLANAR -> BGR packed
+    for (int k = 0; k < 3; k++) D(0, y, 3 * x + k) = S(2 - k, y, x);
+  } else if constexpr (OP == OP_SWAP_RB) {
+    const uint8_t a = S(0, y, 3 * x), b = S(0, y, 3 * x + 1), c = S(0, y, 3 * x + 2);
+    D(0, y, 3 * x) = c; D(0, y, 3 * x + 1) = b; D(0, y, 3 * x + 2) = a;
+  } else if constexpr (OP == OP_COPY_Y) {
+    D(0, y, x) = S(0, y, x);
+  } else if constexpr (OP == OP_Y_YUV444) {
+    D(0, y, x) = S(0, y, x); D(1, y, x) = 128; D(2, y, x) = 128;
+  } else if constexpr (OP == OP_RGB_RGB32F) {
+    float* o = reinterpret_cast<float*>(f.d[0] + (size_t)y * f.dp[0]) + 3 * (size_t)x;
+    for (int k = 0; k < 3; k++) o[k] = (float)S(0, y, 3 * x + k) / 255.0f;
+  } else if constexpr (OP == OP_RGB32F_PLANAR) {
+    const float* i = reinterpret_cast<const float*>(f.s[0] + (size_t)y * f.sp[0]) + 3 * (size_t)x;
+    for (int k = 0; k < 3; k++) reinterpret_cast<float*>(f.d[k] + (size_t)y * f.dp[k])[x] = i[k];
+  } else if constexpr (OP == OP_P16_NV12) {
+    D(0, y, x) = p16_to_8(reinterpret_cast<const uint16_t*>(f.s[0] + (size_t)y * f.sp[0])[x]);
+    if (x < cw && y < ch) {
+      const uint16_t* i = reinterpret_cast<const uint16_t*>(f.s[1] + (size_t)y * f.sp[1]);
+      D(1, y, 2 * x) = p16_to_8(i[2 * x]); D(1, y, 2 * x + 1) = p16_to_8(i[2 * x + 1]);
+    }
+  } else {  // gray: .299R + .587G + .114B, round half up
+    float r, g, b;
+    if constexpr (OP == OP_PLANAR_GRAY) { r = S(0, y, x); g = S(1, y, x); b = S(2, y, x); }
+    else { r = S(0, y, 3 * x + (OP == OP_BGR_GRAY ? 2 : 0)); g = S(0, y, 3 * x + 1); b = S(0, y, 3 * x + (OP == OP_BGR_GRAY ? 0 : 2)); }
+    D(0, y, x) = (uint8_t)sat_trunc(__builtin_fmaf(r, 0.299f, __builtin_fmaf(g, 0.587f, __builtin_fmaf(b, 0.114f, 0.5f))));
+  }
+}
+
+static bool al(const BatchArgs& a, uint32_t n, int ns, int nd, uint32_t s0, uint32_t s12, uint32_t d0, uint32_t d12) {
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < ns; k++)
+      if (((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & ((k ? s12 : s0) - 1)) return false;
+    for (int k = 0; k < nd; k++)
+      if (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & ((k ? d12 : d0) - 1)) return false;
+  }
+  return true;
+}
+
+template <int OP>
+static hipError_t go_generic(hipStream_t st, uint32_t w, uint32_t h, uint32_t n, const BatchArgs& a) {
+  dim3 grid((w + 63) / 64, (h + 3) / 4, n);
+  hipLaunchKernelGGL((k_relayout_generic<OP>), grid, dim3(256), 0, st, a, w, h);
+  return hipGetLastError();
+}
+
+hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t h, uint32_t n, const BatchArgs& a) {
+  const bool force_generic = tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9;
+  if (sf == VPF_FMT_NV12 && df == VPF_FMT_YUV420) {
+    if (!force_generic && w % 16 == 0 && h % 2 == 0 && al(a, n, 2, 3, 16, 16, 16, 8)) {
+      dim3 grid((w / 16 + 63) / 64, (h / 2 + 3) / 4, n);
+      hipLaunchKernelGGL((k_nv12_yuv420_p16<true>), grid, dim3(256), 0, st, a, w, h, w / 16);
+      return hipGetLastError();
+    }
+    return go_generic<OP_NV12_YUV420>(st, w, h, n, a);
+  }
+  if (sf == VPF_FMT_YUV420 && df == VPF_FMT_NV12) {
+    if (!force_generic && w % 16 == 0 && h % 2 == 0 && al(a, n, 3, 2, 16, 8, 16, 16)) {
+      dim3 grid((w / 16 + 63) / 64, (h / 2 + 3) / 4, n);
+      hipLaunchKernelGGL((k_nv12_yuv420_p16<false>), grid, dim3(256), 0, st, a, w, h, w / 16);
+      return hipGetLastError();
+    }
+    return go_generic<OP_YUV420_NV12>(st, w, h, n, a);
+  }
+  const bool packed_s = (sf == VPF_FMT_RGB || sf == VPF_FMT_BGR), packed_d = (df == VPF_FMT_RGB || df == VPF_FMT_BGR);
+  if (packed_s && df == VPF_FMT_RGB_PLANAR) {
+    // BGR -> RGB_PLANAR: same de-interleave with planes 0 and 2 exchanged
+    BatchArgs b = a;
+    if (sf == VPF_FMT_BGR)
+      for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].d[0], b.f[i].d[2]); std::swap(b.f[i].dp[0], b.f[i].dp[2]); }
+    if (!force_generic && w % 4 == 0 && al(b, n, 1, 3, 4, 4, 4, 4)) {
+      dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
+      hipLaunchKernelGGL((k_rgb_relayout_p4<0>), grid, dim3(256), 0, st, b, w, h, w / 4);
+      return hipGetLastError();
+    }
+    return go_generic<OP_RGB_PLANAR>(st, w, h, n, b);
+  }
+  if (sf == VPF_FMT_RGB_PLANAR && packed_d) {
+    BatchArgs b = a;
+    if (df == VPF_FMT_BGR)
+      for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].s[0], b.f[i].s[2]); std::swap(b.f[i].sp[0], b.f[i].sp[2]); }
+    if (!force_generic && w % 4 == 0 && al(b, n, 3, 1, 4, 4, 4, 4)) {
+      dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
+      hipLaunchKernelGGL((k_rgb_relayout_p4<1>), grid, dim3(256), 0, st, b, w, h, w / 4);
+      return hipGetLastError();
+    }
+    return go_generic<OP_PLANAR_RGB>(st, w, h, n, b);
+  }
+  if (packed_s && packed_d && sf != df) {
+    if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 4, 4)) {
+      dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
+      hipLaunchKernelGGL((k_rgb_relayout_p4<2>), grid, dim3(256), 0, st, a, w, h, w / 4);
+      return hipGetLastError();
+    }
+    return go_generic<OP_SWAP_RB>(st, w, h, n, a);
+  }
+  if (sf == VPF_FMT_NV12 && df == VPF_FMT_Y) return go_generic<OP_COPY_Y>(st, w, h, n, a);
+  if (sf == VPF_FMT_Y && df == VPF_FMT_YUV444) return go_generic<OP_Y_YUV444>(st, w, h, n, a);
+  if (sf == VPF_FMT_RGB && df == VPF_FMT_RGB_32F) return go_generic<OP_RGB_RGB32F>(st, w, h, n, a);
+  if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) return go_generic<OP_RGB32F_PLANAR>(st, w, h, n, a);
+  if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) return go_generic<OP_P16_NV12>(st, w, h, n, a);
+  if (sf == VPF_FMT_RGB && df == VPF_FMT_Y) return go_generic<OP_RGB_GRAY>(st, w, h, n, a);
+  if (sf == VPF_FMT_BGR && df == VPF_FMT_Y) return go_generic<OP_BGR_GRAY>(st, w, h, n, a);
+  if (sf == VPF_FMT_RGB_PLANAR && df == VPF_FMT_Y) return go_generic<OP_PLANAR_GRAY>(st, w, h, n, a);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace vpf

@@ -1,0 +1,352 @@
+// k_yuv2rgb.hip — NV12 / YUV420 / YUV444 -> RGB / BGR / RGB_PLANAR for gfx950 (MI355X).
+//
+// Replaces the NPP calls behind nv12_rgb / nv12_bgr / yuv420_rgb / yuv420_bgr / yuv444_rgb /
+// yuv444_bgr (reference: src/TC/src/TasksColorCvt.cpp:53-108,122-182,322-369,383-430,444-550) and
+// fuses nv12_rgb + rgb8_deinterleave (:1059-1088) into one pass for NV12 -> RGB_PLANAR.
+//
+// This is HBM-bound pointwise work (4.5 B/px: 1.5 read, 3 written), so the design is about memory
+// instructions, not math:
+//   * a wave owns a strip of one or more ROW PAIRS so each UV sample is read once and serves its
+//     2x2 luma quad out of registers (no second trip to memory, no LDS needed for the stencil);
+//   * p4 kernels: a lane owns 4 pixels -> 1 dword of Y per row, 1 dword of UV, and writes 12 B per
+//     row.  A wave's loads are 256 contiguous bytes, its stores 768 contiguous bytes: every memory
+//     instruction is fully coalesced with no cross-lane traffic at all;
+//   * p16 kernels: a lane owns 16 pixels -> dwordx4 loads; the 48 B/row it produces are transposed
+//     through a wave-private LDS tile so every global store is a dense 1 KiB dwordx4 wave store;
+//   * math is fp32 FMA on v_cvt_f32_ubyteN operands: 1 cvt + 3 FMA + 3 pack ops per pixel;
+//   * `BatchArgs` carries up to 16 frames in the kernarg segment, blockIdx.y selects the frame, so
+//     one dispatch streams ~600 MB and the ~2 us kernel boundary is amortised.
+#include "vpf_device.h"
+
+namespace vpf {
+
+// ---------------------------------------------------------------------------------------------
+// pixel math
+// ---------------------------------------------------------------------------------------------
+// One dword of luma (4 px) + the two chroma samples covering it -> three channel quads.
+struct Quad {
+  float r[4], g[4], b[4];
+};
+VPF_DEV Quad convert4(const Yuv2RgbCoef& c, uint32_t yd, const Chroma& k0, const Chroma& k1) {
+  Quad q;
+  float y0 = ubyte<0>(yd), y1 = ubyte<1>(yd), y2 = ubyte<2>(yd), y3 = ubyte<3>(yd);
+  q.r[0] = __builtin_fmaf(y0, c.cy, k0.rc); q.g[0] = __builtin_fmaf(y0, c.cy, k0.gc); q.b[0] = __builtin_fmaf(y0, c.cy, k0.bc);
+  q.r[1] = __builtin_fmaf(y1, c.cy, k0.rc); q.g[1] = __builtin_fmaf(y1, c.cy, k0.gc); q.b[1] = __builtin_fmaf(y1, c.cy, k0.bc);
+  q.r[2] = __builtin_fmaf(y2, c.cy, k1.rc); q.g[2] = __builtin_fmaf(y2, c.cy, k1.gc); q.b[2] = __builtin_fmaf(y2, c.cy, k1.bc);
+  q.r[3] = __builtin_fmaf(y3, c.cy, k1.rc); q.g[3] = __builtin_fmaf(y3, c.cy, k1.gc); q.b[3] = __builtin_fmaf(y3, c.cy, k1.bc);
+  return q;
+}
+// 4 px -> 12 packed bytes (3 dwords) in R,G,B or B,G,R order
+template <int DST, int PACK>
+VPF_DEV void pack_rgb12(const Quad& q, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+  const float* a = (DST == FC_BGR) ? q.b : q.r;
+  const float* c = (DST == FC_BGR) ? q.r : q.b;
+  d0 = pack4<PACK>(a[0], q.g[0], c[0], a[1]);
+  d1 = pack4<PACK>(q.g[1], c[1], a[2], q.g[2]);
+  d2 = pack4<PACK>(c[2], a[3], q.g[3], c[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// p4: 4 px per lane, RP row pairs per wave task.  Requires w % 4 == 0, h even, every plane
+// pointer/pitch 4-byte aligned (2-byte for YUV420 chroma).  SRC in {FC_NV12, FC_YUV420}.
+// ---------------------------------------------------------------------------------------------
+template <int SRC, int DST, int RP, int PACK, bool NT>
+__global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                       uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  // wave-uniform by construction; readfirstlane tells the compiler so (scalar branches, SGPR addressing)
+  const uint32_t wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t rpt = wt / chunks_x, chunk = wt - rpt * chunks_x;
+  const uint32_t x = (chunk * 64 + (threadIdx.x & 63)) * 4;
+  if (x >= w) return;
+  const uint32_t nrp = h >> 1, rp0 = rpt * RP;
+
+  uint32_t ya[RP], yb[RP], uv[RP];
+#pragma unroll
+  for (int r = 0; r < RP; r++) {
+    const uint32_t rp = rp0 + r;
+    if (rp < nrp) {
+      ya[r] = ldg<NT, uint32_t>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+      yb[r] = ldg<NT, uint32_t>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+      if constexpr (SRC == FC_NV12) {
+        uv[r] = ldg<NT, uint32_t>(f.s[1] + (size_t)rp * f.sp[1] + x);
+      } else {  // two U bytes and two V bytes -> same (U0 V0 U1 V1) byte order as NV12
+        uint32_t u2 = ldg<NT, uint16_t>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1));
+        uint32_t v2 = ldg<NT, uint16_t>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
+        uv[r] = __builtin_amdgcn_perm(v2, u2, 0x05010400u);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RP; r++) {
+    const uint32_t rp = rp0 + r;
+    if (rp < nrp) {
+      const Chroma k0 = chroma_terms(c, ubyte<0>(uv[r]), ubyte<1>(uv[r]));
+      const Chroma k1 = chroma_terms(c, ubyte<2>(uv[r]), ubyte<3>(uv[r]));
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const Quad q = convert4(c, half ? yb[r] : ya[r], k0, k1);
+        const size_t row = (size_t)(2 * rp + half);
+        if constexpr (DST == FC_PLANAR) {
+          stg<NT, uint32_t>(f.d[0] + row * f.dp[0] + x, pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]));
+          stg<NT, uint32_t>(f.d[1] + row * f.dp[1] + x, pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]));
+          stg<NT, uint32_t>(f.d[2] + row * f.dp[2] + x, pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]));
+        } else {
+          uint32_t d0, d1, d2;
+          pack_rgb12<DST, PACK>(q, d0, d1, d2);
+          stg3<NT>(f.d[0] + row * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// p16: 16 px per lane (dwordx4 loads), one row pair x 1024 px per wave task.  Packed outputs are
+// transposed through a wave-private LDS tile (LDS_T) so each global store instruction writes a
+// dense 1 KiB; LDS_T = false keeps the lane-strided 48 B stores for comparison.
+// Requires w % 16 == 0, h even, 16-byte aligned planes and pitches.  SRC = FC_NV12 only.
+//
+// LDS banking: ds_write_b128 is serviced in groups of 8 consecutive lanes; lane l writes at byte
+// 48*l + 16*j -> dword banks {12l+4j .. +3} mod 32, which tile all 32 banks exactly once per
+// group: conflict free.  The ds_read_b128 side reads 16*l: contiguous, conflict free.
+// ---------------------------------------------------------------------------------------------
+template <int DST, int PACK, bool NT, bool LDS_T>
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                      uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[(LDS_T && DST != FC_PLANAR) ? 4 * 2 * 192 : 1];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t rp = wt / chunks_x, chunk = wt - rp * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  const bool act = x < w;
+
+  u32x4 y[2], uv;
+  if (act) {
+    y[0] = ldg<NT, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+    y[1] = ldg<NT, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+    uv = ldg<NT, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+  }
+  uint32_t o[2][12];
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j]));
+      const Chroma k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const Quad q = convert4(c, y[half][j], k0, k1);
+        if constexpr (DST == FC_PLANAR) {
+          o[half][j] = pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]);
+          o[half][4 + j] = pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]);
+          o[half][8 + j] = pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]);
+        } else {
+          pack_rgb12<DST, PACK>(q, o[half][3 * j], o[half][3 * j + 1], o[half][3 * j + 2]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const size_t row = (size_t)(2 * rp + half);
+    if constexpr (DST == FC_PLANAR) {
+      if (act) {
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+          stg<NT, u32x4>(f.d[p] + row * f.dp[p] + x,
+                         u32x4{o[half][4 * p], o[half][4 * p + 1], o[half][4 * p + 2], o[half][4 * p + 3]});
+      }
+    } else if constexpr (LDS_T) {
+      u32x4* t = tile + (wv * 2 + half) * 192;
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          t[lane * 3 + j] = u32x4{o[half][4 * j], o[half][4 * j + 1], o[half][4 * j + 2], o[half][4 * j + 3]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint8_t* rowp = f.d[0] + row * f.dp[0];
+      const uint32_t row_bytes = 3 * w;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const uint32_t off = chunk * 3072 + (k * 64 + lane) * 16;
+        if (off < row_bytes) stg<NT, u32x4>(rowp + off, t[k * 64 + lane]);
+      }
+    } else {
+      if (act) {
+        uint8_t* p = f.d[0] + row * f.dp[0] + 3 * (size_t)x;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          stg<NT, u32x4>(p + 16 * j, u32x4{o[half][4 * j], o[half][4 * j + 1], o[half][4 * j + 2], o[half][4 * j + 3]});
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// YUV444 (three full planes) -> RGB/BGR/PLANAR, 4 px per lane, one row per task.
+// Requires w % 4 == 0 and 4-byte aligned planes.
+// ---------------------------------------------------------------------------------------------
+template <int DST, int PACK>
+__global__ __launch_bounds__(256) void k_yuv444_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                       uint32_t h, uint32_t groups_x) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (gx >= groups_x || y >= h) return;
+  const uint32_t x = gx * 4;
+  const uint32_t yd = ldg<false, uint32_t>(f.s[0] + (size_t)y * f.sp[0] + x);
+  const uint32_t ud = ldg<false, uint32_t>(f.s[1] + (size_t)y * f.sp[1] + x);
+  const uint32_t vd = ldg<false, uint32_t>(f.s[2] + (size_t)y * f.sp[2] + x);
+  const Chroma k0 = chroma_terms(c, ubyte<0>(ud), ubyte<0>(vd)), k1 = chroma_terms(c, ubyte<1>(ud), ubyte<1>(vd));
+  const Chroma k2 = chroma_terms(c, ubyte<2>(ud), ubyte<2>(vd)), k3 = chroma_terms(c, ubyte<3>(ud), ubyte<3>(vd));
+  Quad q;
+  const float y0 = ubyte<0>(yd), y1 = ubyte<1>(yd), y2 = ubyte<2>(yd), y3 = ubyte<3>(yd);
+  q.r[0] = __builtin_fmaf(y0, c.cy, k0.rc); q.g[0] = __builtin_fmaf(y0, c.cy, k0.gc); q.b[0] = __builtin_fmaf(y0, c.cy, k0.bc);
+  q.r[1] = __builtin_fmaf(y1, c.cy, k1.rc); q.g[1] = __builtin_fmaf(y1, c.cy, k1.gc); q.b[1] = __builtin_fmaf(y1, c.cy, k1.bc);
+  q.r[2] = __builtin_fmaf(y2, c.cy, k2.rc); q.g[2] = __builtin_fmaf(y2, c.cy, k2.gc); q.b[2] = __builtin_fmaf(y2, c.cy, k2.bc);
+  q.r[3] = __builtin_fmaf(y3, c.cy, k3.rc); q.g[3] = __builtin_fmaf(y3, c.cy, k3.gc); q.b[3] = __builtin_fmaf(y3, c.cy, k3.bc);
+  if constexpr (DST == FC_PLANAR) {
+    stg<false, uint32_t>(f.d[0] + (size_t)y * f.dp[0] + x, pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]));
+    stg<false, uint32_t>(f.d[1] + (size_t)y * f.dp[1] + x, pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]));
+    stg<false, uint32_t>(f.d[2] + (size_t)y * f.dp[2] + x, pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]));
+  } else {
+    uint32_t d0, d1, d2;
+    pack_rgb12<DST, PACK>(q, d0, d1, d2);
+    stg3<false>(f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic: any size, any alignment.  One thread per 2x2 quad, byte accesses, full bounds checks.
+// ---------------------------------------------------------------------------------------------
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void k_yuv_rgb_generic(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                         uint32_t h) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  const uint32_t qx = blockIdx.x * 64 + (threadIdx.x & 63), qy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t x0 = 2 * qx, y0 = 2 * qy;
+  if (x0 >= w || y0 >= h) return;
+  float u = 0, v = 0;
+  if constexpr (SRC == FC_NV12) {
+    const uint8_t* p = f.s[1] + (size_t)qy * f.sp[1] + x0;
+    u = p[0]; v = p[1];
+  } else if constexpr (SRC == FC_YUV420) {
+    u = f.s[1][(size_t)qy * f.sp[1] + qx]; v = f.s[2][(size_t)qy * f.sp[2] + qx];
+  }
+  Chroma k = chroma_terms(c, u, v);
+  for (uint32_t dy = 0; dy < 2; dy++)
+    for (uint32_t dx = 0; dx < 2; dx++) {
+      const uint32_t x = x0 + dx, y = y0 + dy;
+      if (x >= w || y >= h) continue;
+      if constexpr (SRC == FC_YUV444) {
+        k = chroma_terms(c, (float)f.s[1][(size_t)y * f.sp[1] + x], (float)f.s[2][(size_t)y * f.sp[2] + x]);
+      }
+      const float yf = (float)f.s[0][(size_t)y * f.sp[0] + x];
+      const uint8_t r = (uint8_t)sat_trunc(__builtin_fmaf(yf, c.cy, k.rc));
+      const uint8_t g = (uint8_t)sat_trunc(__builtin_fmaf(yf, c.cy, k.gc));
+      const uint8_t b = (uint8_t)sat_trunc(__builtin_fmaf(yf, c.cy, k.bc));
+      if constexpr (DST == FC_PLANAR) {
+        f.d[0][(size_t)y * f.dp[0] + x] = r; f.d[1][(size_t)y * f.dp[1] + x] = g; f.d[2][(size_t)y * f.dp[2] + x] = b;
+      } else {
+        uint8_t* o = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x;
+        o[0] = (DST == FC_BGR) ? b : r; o[1] = g; o[2] = (DST == FC_BGR) ? r : b;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static bool aligned_all(const BatchArgs& a, uint32_t n, int nsrc, int ndst, uint32_t src_al, uint32_t dst_al,
+                        uint32_t chroma_al) {
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < nsrc; k++) {
+      uint32_t al = (k == 0) ? src_al : chroma_al;
+      if (((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & (al - 1)) return false;
+    }
+    for (int k = 0; k < ndst; k++)
+      if (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & (dst_al - 1)) return false;
+  }
+  return true;
+}
+
+template <int SRC, int DST>
+static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t n,
+                             const BatchArgs& a, int variant) {
+  const int nsrc = (SRC == FC_NV12) ? 2 : 3, ndst = (DST == FC_PLANAR) ? 3 : 1;
+  const bool even = (w % 4 == 0) && (h % 2 == 0);
+  // variant: 0 = default; 1 p4/RP4; 2 p4/RP2; 3 p4/RP1; 4 p4/RP4 +NT; 5 p16 LDS; 6 p16 direct; 7 p16 LDS +NT;
+  //          8 p4/RP4 explicit pack; 9 generic
+  if (variant == 0) variant = 1;
+  if (SRC != FC_NV12 && variant >= 5 && variant <= 7) variant = 1;
+  if (variant != 9 && variant >= 5 && variant <= 7) {
+    if constexpr (SRC == FC_NV12) {
+      if (even && w % 16 == 0 && aligned_all(a, n, nsrc, ndst, 16, 16, 16)) {
+        const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
+        dim3 grid((tasks + 3) / 4, n);
+        if (variant == 5) hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, false, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+        else if (variant == 6) hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, false, false>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+        else hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, true, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+        return hipGetLastError();
+      }
+    }
+    variant = 1;
+  }
+  if (variant != 9 && even && aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2)) {
+    const uint32_t chunks = (w / 4 + 63) / 64;
+    auto go = [&](auto kern, int rp) {
+      const uint32_t tasks = chunks * ((h / 2 + rp - 1) / rp);
+      dim3 grid((tasks + 3) / 4, n);
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      return hipGetLastError();
+    };
+    switch (variant) {
+      case 2: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, false>, 2);
+      case 3: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, false>, 1);
+      case 4: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, true>, 4);
+      case 8: return go(k_yuv420_rgb_p4<SRC, DST, 4, 0, false>, 4);
+      default: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, false>, 4);
+    }
+  }
+  dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
+  hipLaunchKernelGGL((k_yuv_rgb_generic<SRC, DST>), grid, dim3(256), 0, st, a, c, w, h);
+  return hipGetLastError();
+}
+
+template <int DST>
+static hipError_t launch_444(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t n,
+                             const BatchArgs& a, int variant) {
+  const int ndst = (DST == FC_PLANAR) ? 3 : 1;
+  if (variant != 9 && w % 4 == 0 && aligned_all(a, n, 3, ndst, 4, 4, 4) && h <= 65535) {
+    dim3 grid((w / 4 + 255) / 256, h, n);
+    hipLaunchKernelGGL((k_yuv444_rgb_p4<DST, 1>), grid, dim3(256), 0, st, a, c, w, h, w / 4);
+    return hipGetLastError();
+  }
+  dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
+  hipLaunchKernelGGL((k_yuv_rgb_generic<FC_YUV444, DST>), grid, dim3(256), 0, st, a, c, w, h);
+  return hipGetLastError();
+}
+
+hipError_t launch_yuv_to_rgb(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t w, uint32_t h,
+                             uint32_t n, const BatchArgs& a, int variant) {
+#define VPF_DST_SWITCH(FN, ...)                                                   \
+  switch (dst_fc) {                                                               \
+    case FC_RGB: return FN<__VA_ARGS__ FC_RGB>(st, c, w, h, n, a, variant);       \
+    case FC_BGR: return FN<__VA_ARGS__ FC_BGR>(st, c, w, h, n, a, variant);       \
+    case FC_PLANAR: return FN<__VA_ARGS__ FC_PLANAR>(st, c, w, h, n, a, variant); \
+    default: return hipErrorInvalidValue;                                         \
+  }
+  switch (src_fc) {
+    case FC_NV12: VPF_DST_SWITCH(launch_420, FC_NV12, )
+    case FC_YUV420: VPF_DST_SWITCH(launch_420, FC_YUV420, )
+    case FC_YUV444: VPF_DST_SWITCH(launch_444, )
+    default: return hipErrorInvalidValue;
+  }
+#undef VPF_DST_SWITCH
+}
+
+}  // namespace vpf

@@ -1,0 +1,302 @@
+// vpf_abi.hip — the C ABI of libvpfhip (include/vpf_hip.h): argument validation, format dispatch,
+// kernarg packing.  No CPU fallback of any kind: every success path ends in a HIP kernel launch.
+#include <atomic>
+#include <cstring>
+
+#include "vpf_internal.h"
+
+namespace vpf {
+
+// ------------------------------------------------------------------------------------------
+// colour matrices.  Decimal coefficients x 1e6 as published for NPP's colour models / BT.601 /
+// BT.709.  Everything the device sees is derived from these integers by one
+// correctly rounded division and one narrowing, so host and device agree bit for bit everywhere.
+// ------------------------------------------------------------------------------------------
+struct Yuv2RgbDec {
+  int64_t cy, rv, gu, gv, bu;
+  int off;
+};
+static const Yuv2RgbDec kYuv2Rgb[2][2] = {
+    {{1164000, 1596000, -392000, -813000, 2017000, 16},   // BT.601 MPEG : NPP "YCbCr"
+     {1000000, 1140000, -394000, -581000, 2032000, 0}},   // BT.601 JPEG : NPP "YUV"
+    {{1164384, 1792741, -213249, -532909, 2112402, 16},   // BT.709 MPEG : "709CSC"
+     {1000000, 1574800, -187324, -468124, 1855600, 0}}};  // BT.709 JPEG : "709HDTV"
+
+static inline float q6(int64_t v) { return (float)((double)v / 1e6); }
+
+bool make_yuv2rgb(int cs, int cr, Yuv2RgbCoef* o) {
+  if ((cs != VPF_BT_601 && cs != VPF_BT_709) || (cr != VPF_MPEG && cr != VPF_JPEG)) return false;
+  const Yuv2RgbDec& m = kYuv2Rgb[cs][cr];
+  o->cy = q6(m.cy); o->rv = q6(m.rv); o->gu = q6(m.gu); o->gv = q6(m.gv); o->bu = q6(m.bu);
+  const int64_t yoff = -(int64_t)m.off * m.cy + 500000;  // luma offset + the 0.5 of round-half-up
+  o->br = q6(yoff - 128 * m.rv);
+  o->bg = q6(yoff - 128 * (m.gu + m.gv));
+  o->bb = q6(yoff - 128 * m.bu);
+  return true;
+}
+
+struct Rgb2YuvDec {
+  int64_t m[3][3];
+  int d[3];
+};
+static const Rgb2YuvDec kRgb2Yuv[2] = {
+    {{{257000, 504000, 98000}, {-148000, -291000, 439000}, {439000, -368000, -71000}}, {16, 128, 128}},   // MPEG "YCbCr"
+    {{{299000, 587000, 114000}, {-147108, -288804, 435912}, {614777, -514799, -99978}}, {0, 128, 128}}};  // JPEG "YUV"
+
+bool make_rgb2yuv(int cr, Rgb2YuvCoef* o) {
+  if (cr != VPF_MPEG && cr != VPF_JPEG) return false;
+  const Rgb2YuvDec& m = kRgb2Yuv[cr];
+  for (int k = 0; k < 3; k++) {
+    for (int j = 0; j < 3; j++) o->m[k][j] = q6(m.m[k][j]);
+    o->d[k] = q6((int64_t)m.d[k] * 1000000 + 500000);
+  }
+  return true;
+}
+
+static std::atomic<int> g_tune_variant{0};
+int tuning(int key) { return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : 0; }
+
+// ------------------------------------------------------------------------------------------
+// format helpers
+// ------------------------------------------------------------------------------------------
+static int num_planes(int f) {
+  switch (f) {
+    case VPF_FMT_Y: case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_RGB_32F: return 1;
+    case VPF_FMT_NV12: case VPF_FMT_P10: case VPF_FMT_P12: return 2;
+    case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
+    case VPF_FMT_RGB_32F_PLANAR: return 3;
+    default: return 0;
+  }
+}
+static uint32_t row_bytes(int f, int k, uint32_t w) {
+  const uint32_t cw = (w + 1) / 2;
+  switch (f) {
+    case VPF_FMT_Y: return w;
+    case VPF_FMT_RGB: case VPF_FMT_BGR: return 3 * w;
+    case VPF_FMT_NV12: return k == 0 ? w : 2 * cw;
+    case VPF_FMT_YUV420: case VPF_FMT_YCBCR: return k == 0 ? w : cw;
+    case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR: return w;
+    case VPF_FMT_RGB_32F: return 12 * w;
+    case VPF_FMT_RGB_32F_PLANAR: return 4 * w;
+    case VPF_FMT_P10: case VPF_FMT_P12: return k == 0 ? 2 * w : 4 * cw;
+    default: return 0;
+  }
+}
+static bool planes_ok(int f, uint32_t w, const vpf_plane* p) {
+  const int n = num_planes(f);
+  if (!n || !p) return false;
+  for (int k = 0; k < n; k++)
+    if (!p[k].ptr || p[k].pitch < row_bytes(f, k, w)) return false;
+  return true;
+}
+static int yuv_src_class(int f) {
+  switch (f) {
+    case VPF_FMT_NV12: return FC_NV12;
+    case VPF_FMT_YUV420: return FC_YUV420;
+    case VPF_FMT_YUV444: return FC_YUV444;
+    default: return -1;
+  }
+}
+static int rgb_class(int f) {
+  switch (f) {
+    case VPF_FMT_RGB: return FC_RGB;
+    case VPF_FMT_BGR: return FC_BGR;
+    case VPF_FMT_RGB_PLANAR: return FC_PLANAR;
+    default: return -1;
+  }
+}
+static bool cscr_ok(int cs, int cr) {
+  return (cs == VPF_BT_601 || cs == VPF_BT_709) && (cr == VPF_MPEG || cr == VPF_JPEG);
+}
+
+enum Family { FAM_NONE, FAM_YUV2RGB, FAM_RGB2YUV, FAM_RELAYOUT };
+static Family classify(int sf, int df, int cs, int cr) {
+  if (yuv_src_class(sf) >= 0 && rgb_class(df) >= 0) return cscr_ok(cs, cr) ? FAM_YUV2RGB : FAM_NONE;
+  if (rgb_class(sf) >= 0 && (df == VPF_FMT_YUV444 || df == VPF_FMT_YUV420 || df == VPF_FMT_YCBCR))
+    return (cs == VPF_BT_601 && (cr == VPF_MPEG || cr == VPF_JPEG)) ? FAM_RGB2YUV : FAM_NONE;
+  if (sf == VPF_FMT_NV12 && (df == VPF_FMT_YUV420 || df == VPF_FMT_Y)) return FAM_RELAYOUT;
+  if (sf == VPF_FMT_YUV420 && df == VPF_FMT_NV12) return FAM_RELAYOUT;
+  if (rgb_class(sf) >= 0 && rgb_class(df) >= 0 && sf != df) return FAM_RELAYOUT;
+  if (sf == VPF_FMT_Y && df == VPF_FMT_YUV444) return FAM_RELAYOUT;
+  if (rgb_class(sf) >= 0 && df == VPF_FMT_Y) return FAM_RELAYOUT;
+  if (sf == VPF_FMT_RGB && df == VPF_FMT_RGB_32F) return FAM_RELAYOUT;
+  if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) return FAM_RELAYOUT;
+  if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) return FAM_RELAYOUT;
+  return FAM_NONE;
+}
+
+// RAII device guard: the ABI never leaves the caller's current device changed
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (dev < 0) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+static void fill_desc(FrameDesc& d, const vpf_plane* s, int ns, const vpf_plane* o, int nd) {
+  std::memset(&d, 0, sizeof(d));
+  for (int k = 0; k < ns; k++) { d.s[k] = static_cast<const uint8_t*>(s[k].ptr); d.sp[k] = s[k].pitch; }
+  for (int k = 0; k < nd; k++) { d.d[k] = static_cast<uint8_t*>(o[k].ptr); d.dp[k] = o[k].pitch; }
+}
+
+static vpf_status status_of(hipError_t e) {
+  if (e == hipSuccess) return VPF_OK;
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return VPF_ERR_NO_DEVICE;
+  return VPF_ERR_LAUNCH;
+}
+
+}  // namespace vpf
+
+using namespace vpf;
+
+extern "C" {
+
+int vpf_convert_supported(int sf, int df, int cs, int cr) { return classify(sf, df, cs, cr) != FAM_NONE; }
+
+vpf_status vpf_convert_batch(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size size, uint32_t n,
+                             const vpf_frame_io* frames) {
+  const Family fam = classify(sf, df, cs, cr);
+  if (fam == FAM_NONE) return VPF_ERR_UNSUPPORTED;
+  if (!exec || !frames || !n || !size.width || !size.height) return VPF_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n; i++)
+    if (!planes_ok(sf, size.width, frames[i].src) || !planes_ok(df, size.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
+  DeviceGuard guard(exec->device);
+  if (guard.err != hipSuccess) return status_of(guard.err);
+  hipStream_t st = static_cast<hipStream_t>(exec->stream);
+  const int ns = num_planes(sf), nd = num_planes(df);
+  Yuv2RgbCoef yc;
+  Rgb2YuvCoef rc;
+  if (fam == FAM_YUV2RGB) make_yuv2rgb(cs, cr, &yc);
+  if (fam == FAM_RGB2YUV) make_rgb2yuv(cr, &rc);
+  for (uint32_t base = 0; base < n; base += kMaxBatch) {
+    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
+    BatchArgs a;
+    for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, ns, frames[base + i].dst, nd);
+    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    hipError_t e;
+    switch (fam) {
+      case FAM_YUV2RGB:
+        e = launch_yuv_to_rgb(st, yuv_src_class(sf), rgb_class(df), yc, size.width, size.height, m, a,
+                              tuning(VPF_TUNE_NV12_RGB_VARIANT));
+        break;
+      case FAM_RGB2YUV:
+        e = launch_rgb_to_yuv(st, rgb_class(sf), df == VPF_FMT_YUV444 ? FC_YUV444 : FC_YUV420, rc, size.width,
+                              size.height, m, a);
+        break;
+      default: e = launch_relayout(st, sf, df, size.width, size.height, m, a);
+    }
+    if (e != hipSuccess) return status_of(e);
+  }
+  return VPF_OK;
+}
+
+vpf_status vpf_convert(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size size, const vpf_plane src[3],
+                       const vpf_plane dst[3]) {
+  if (classify(sf, df, cs, cr) == FAM_NONE) return VPF_ERR_UNSUPPORTED;
+  if (!src || !dst) return VPF_ERR_BAD_ARG;
+  vpf_frame_io io;
+  std::memset(&io, 0, sizeof(io));
+  for (int k = 0; k < num_planes(sf); k++) io.src[k] = src[k];
+  for (int k = 0; k < num_planes(df); k++) io.dst[k] = dst[k];
+  return vpf_convert_batch(exec, sf, df, cs, cr, size, 1, &io);
+}
+
+vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, const vpf_plane src[3], vpf_size ds,
+                      const vpf_plane dst[3]) {
+  if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR) return VPF_ERR_UNSUPPORTED;
+  switch (fmt) {
+    case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_Y: case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
+    case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_NV12: break;
+    default: return VPF_ERR_UNSUPPORTED;
+  }
+  if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !planes_ok(fmt, ss.width, src) ||
+      !planes_ok(fmt, ds.width, dst))
+    return VPF_ERR_BAD_ARG;
+  DeviceGuard guard(exec->device);
+  if (guard.err != hipSuccess) return status_of(guard.err);
+  hipStream_t st = static_cast<hipStream_t>(exec->stream);
+  auto one = [&](int ch, int k, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
+    return launch_resize(st, ch, interp, sw, sh, static_cast<const uint8_t*>(src[k].ptr), src[k].pitch, dw, dh,
+                         static_cast<uint8_t*>(dst[k].ptr), dst[k].pitch);
+  };
+  const uint32_t scw = (ss.width + 1) / 2, sch = (ss.height + 1) / 2, dcw = (ds.width + 1) / 2, dch = (ds.height + 1) / 2;
+  hipError_t e = hipSuccess;
+  switch (fmt) {
+    case VPF_FMT_RGB: case VPF_FMT_BGR: e = one(3, 0, ss.width, ss.height, ds.width, ds.height); break;
+    case VPF_FMT_Y: e = one(1, 0, ss.width, ss.height, ds.width, ds.height); break;
+    case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
+      for (int k = 0; k < 3 && e == hipSuccess; k++) e = one(1, k, ss.width, ss.height, ds.width, ds.height);
+      break;
+    case VPF_FMT_YUV420: case VPF_FMT_YCBCR:
+      e = one(1, 0, ss.width, ss.height, ds.width, ds.height);
+      for (int k = 1; k < 3 && e == hipSuccess; k++) e = one(1, k, scw, sch, dcw, dch);
+      break;
+    default:  // NV12: luma plane + the UV plane as a 2-channel image (== C3 -> R2 -> C4 of Tasks.cpp:1303-1318)
+      e = one(1, 0, ss.width, ss.height, ds.width, ds.height);
+      if (e == hipSuccess) e = one(2, 1, scw, sch, dcw, dch);
+  }
+  return status_of(e);
+}
+
+vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane* src, const float* xmap, uint32_t xp,
+                     const float* ymap, uint32_t yp, vpf_size ds, const vpf_plane* dst) {
+  if (fmt != VPF_FMT_RGB && fmt != VPF_FMT_BGR) return VPF_ERR_UNSUPPORTED;
+  if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !xmap || !ymap || !planes_ok(fmt, ss.width, src) ||
+      !planes_ok(fmt, ds.width, dst) || xp < 4 * ds.width || yp < 4 * ds.width || (xp & 3) || (yp & 3) ||
+      ((uintptr_t)xmap & 3) || ((uintptr_t)ymap & 3))
+    return VPF_ERR_BAD_ARG;
+  DeviceGuard guard(exec->device);
+  if (guard.err != hipSuccess) return status_of(guard.err);
+  return status_of(launch_remap(static_cast<hipStream_t>(exec->stream), ss.width, ss.height,
+                                static_cast<const uint8_t*>(src->ptr), src->pitch, xmap, xp, ymap, yp, ds.width,
+                                ds.height, static_cast<uint8_t*>(dst->ptr), dst->pitch));
+}
+
+vpf_status vpf_convert_resize(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size ss, const vpf_plane src[3],
+                              vpf_size ds, const vpf_plane dst[3]) {
+  if (!(sf == VPF_FMT_NV12 || sf == VPF_FMT_YUV420) || rgb_class(df) < 0 || !cscr_ok(cs, cr)) return VPF_ERR_UNSUPPORTED;
+  if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !planes_ok(sf, ss.width, src) ||
+      !planes_ok(df, ds.width, dst))
+    return VPF_ERR_BAD_ARG;
+  DeviceGuard guard(exec->device);
+  if (guard.err != hipSuccess) return status_of(guard.err);
+  Yuv2RgbCoef c;
+  make_yuv2rgb(cs, cr, &c);
+  FrameDesc f;
+  fill_desc(f, src, num_planes(sf), dst, num_planes(df));
+  return status_of(launch_convert_resize(static_cast<hipStream_t>(exec->stream), yuv_src_class(sf), rgb_class(df), c,
+                                         ss.width, ss.height, f, ds.width, ds.height));
+}
+
+const char* vpf_status_string(int s) {
+  switch (s) {
+    case VPF_OK: return "ok";
+    case VPF_ERR_UNSUPPORTED: return "unsupported format / colour-space combination";
+    case VPF_ERR_BAD_ARG: return "bad argument";
+    case VPF_ERR_LAUNCH: return "HIP launch failed";
+    case VPF_ERR_NO_DEVICE: return "no usable HIP device";
+    default: return "unknown status";
+  }
+}
+const char* vpf_version(void) { return "vpf-hip 0.1 (gfx950)"; }
+int vpf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int vpf_set_tuning(int key, int value) {
+  if (key == VPF_TUNE_NV12_RGB_VARIANT) return g_tune_variant.exchange(value);
+  return 0;
+}
+
+}  // extern "C"

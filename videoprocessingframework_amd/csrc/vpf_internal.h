@@ -1,0 +1,65 @@
+// vpf_internal.h — shared between the translation units of libvpfhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vpf_hip.h"
+
+namespace vpf {
+
+// ------------------------------------------------------------------------------------------
+// YUV -> RGB coefficients in the form the kernels consume.  Biases fold the luma offset, the
+// chroma -128 and the +0.5 of round-half-up, so a pixel costs one FMA per channel:
+//   rc = fma(V, rv, br);  gc = fma(U, gu, fma(V, gv, bg));  bc = fma(U, bu, bb)     (per chroma sample)
+//   R = sat_trunc(fma(Y, cy, rc)); G = sat_trunc(fma(Y, cy, gc)); B = sat_trunc(fma(Y, cy, bc))
+// ------------------------------------------------------------------------------------------
+struct Yuv2RgbCoef {
+  float cy, rv, gu, gv, bu, br, bg, bb;
+};
+// RGB -> YUV: out_k = sat_trunc(fma(R, m[k][0], fma(G, m[k][1], fma(B, m[k][2], d[k]))))
+struct Rgb2YuvCoef {
+  float m[3][3];
+  float d[3];
+};
+bool make_yuv2rgb(int color_space, int color_range, Yuv2RgbCoef* out);
+bool make_rgb2yuv(int color_range, Rgb2YuvCoef* out);
+
+// Up to 16 frames per dispatch travel in the kernarg segment (no device-side table to manage).
+constexpr int kMaxBatch = 16;
+struct FrameDesc {
+  const uint8_t* s[3];
+  uint8_t* d[3];
+  uint32_t sp[3];
+  uint32_t dp[3];
+};
+struct BatchArgs {
+  FrameDesc f[kMaxBatch];
+};
+
+enum FmtClass : int {
+  FC_NV12 = 0,    // Y + interleaved UV, 4:2:0
+  FC_YUV420 = 1,  // Y + U + V planes, 4:2:0
+  FC_YUV444 = 2,  // three full planes
+  FC_RGB = 3,     // packed R,G,B
+  FC_BGR = 4,     // packed B,G,R
+  FC_PLANAR = 5,  // three full planes R,G,B
+};
+
+// launchers (one per translation unit); all asynchronous on `st`
+hipError_t launch_yuv_to_rgb(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t w,
+                             uint32_t h, uint32_t n, const BatchArgs& a, int variant);
+hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc /*FC_YUV444|FC_YUV420*/,
+                             const Rgb2YuvCoef& c, uint32_t w, uint32_t h, uint32_t n, const BatchArgs& a);
+hipError_t launch_relayout(hipStream_t st, int src_fmt, int dst_fmt, uint32_t w, uint32_t h, uint32_t n,
+                           const BatchArgs& a);
+hipError_t launch_resize(hipStream_t st, int channels, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
+                         uint32_t spitch, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dpitch);
+hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t spitch,
+                        const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch, uint32_t dw,
+                        uint32_t dh, uint8_t* dst, uint32_t dpitch);
+hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw,
+                                 uint32_t sh, const FrameDesc& f, uint32_t dw, uint32_t dh);
+
+int tuning(int key);
+
+}  // namespace vpf
