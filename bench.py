@@ -74,7 +74,7 @@ class Workload:
             self.batch = capi.make_batch(frames)
             self.px_per_step = ring * w * h
             self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
-            self.launches_per_step = (ring + 15) // 16 if mode == "batch" else ring
+            self.launches_per_step = (ring + 31) // 32 if mode == "batch" else ring
             self.kernel = "k_yuv420_rgb_p4 / k_nv12_rgb_p16 (NV12->RGB)"
         elif name in ("resize_4k_720p", "fused_4k_720p"):
             self.w, self.h, self.dw, self.dh = 3840, 2160, 1280, 720
@@ -201,7 +201,7 @@ def main():
     if a.sweep and rank == 0:
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
             for mode in ("batch", "single"):
-                for v in (1, 2, 3, 4, 5, 6, 7, 8):
+                for v in (4, 8, 11, 14, 16, 15):
                     wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, v, mode)
                     _, ev = timed(wl, a.steps, a.warmup, False)
                     gbs = wl.bytes_per_step * a.steps / ev / 1e9
@@ -232,6 +232,12 @@ def main():
         avg_launch_s = ev / n_launch  # rank 0's HIP-event time over the timed region / launches in it
         bytes_per_launch = wl.bytes_per_step / wl.launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if a.workload == "nv12_rgb_4k" and a.variant == 0 and a.mode == "batch" and os.path.exists(pmc):
+            # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated on
+            # known-byte copy kernels: tools/pmc_calib.hip, scripts_gpu_pmc.sh) — collected offline, scaled to this launch
+            traffic = int(json.load(open(pmc))["hbm_bytes_per_frame"] * wl.ring / wl.launches_per_step)
         out = {
             "metric": "Gpix/s NV12->RGB 3840x2160 + achieved %HBM-BW",
             "value": round(total_px / wall_max / 1e9, 2),
@@ -250,7 +256,7 @@ def main():
                        "mode": a.mode, "frames_per_step_per_gpu": a.ring, "variant": a.variant,
                        "sharding": "independent frame rings, one process per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": wl.kernel, "bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches": n_launch},
             "verified_vs_oracle": ok,

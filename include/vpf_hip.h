@@ -128,7 +128,7 @@ typedef struct vpf_frame_io {
 } vpf_frame_io;
 
 /* The same conversion over `n` independent frames of identical size/format, dispatched as few
- * launches as possible (one per 16 frames).  `frames` is a HOST array, consumed before return.
+ * launches as possible (one per 32 frames).  `frames` is a HOST array, consumed before return.
  * Exists because a 4K frame is ~5 us of HBM time, the same order as a kernel boundary. */
 VPF_API vpf_status vpf_convert_batch(const vpf_exec* exec, int src_fmt, int dst_fmt,
                                      int color_space, int color_range, vpf_size size, uint32_t n,

@@ -71,9 +71,11 @@ static inline void yuv2rgb_exact(const yuv2rgb_dec* m, int y, int u, int v, uint
   *b = round6(yy + m->bu * uu);
 }
 
-/* fp32 restatement of the HIP kernels' operation order (csrc/vpf_color.h, yuv2rgb_coef +
- * yuv2rgb_px): biases fold -off*cy, -128*coef and the +0.5 of round-half-up; three fused
- * multiply-adds for chroma, one per channel for luma, saturate to [0,255], truncate. */
+/* fp32 restatement of the HIP kernels' operation order (csrc/vpf_device.h chroma_terms / sat_rne,
+ * csrc/vpf_abi.hip make_yuv2rgb): biases fold -off*cy and -128*coef; three fused multiply-adds for
+ * chroma, one per channel for luma, then saturate to [0,255] with round-to-nearest-EVEN — the
+ * semantics of the one instruction the kernels use (v_cvt_pk_u8_f32, measured on gfx950 by
+ * tools/probe_cvt.hip, profiles/r01_probe_cvt_pk_u8_f32.txt). */
 typedef struct {
   float cy, rv, gu, gv, bu, br, bg, bb;
 } yuv2rgb_f32;
@@ -86,9 +88,9 @@ static yuv2rgb_f32 make_f32(const yuv2rgb_dec* m) {
   c.gv = (float)((double)m->gv / 1e6);
   c.bu = (float)((double)m->bu / 1e6);
   /* exact integers / 1e6: one correctly rounded division, one correctly rounded narrowing */
-  c.br = (float)((double)(-(int64_t)m->off * m->cy - 128 * m->rv + 500000) / 1e6);
-  c.bg = (float)((double)(-(int64_t)m->off * m->cy - 128 * (m->gu + m->gv) + 500000) / 1e6);
-  c.bb = (float)((double)(-(int64_t)m->off * m->cy - 128 * m->bu + 500000) / 1e6);
+  c.br = (float)((double)(-(int64_t)m->off * m->cy - 128 * m->rv) / 1e6);
+  c.bg = (float)((double)(-(int64_t)m->off * m->cy - 128 * (m->gu + m->gv)) / 1e6);
+  c.bb = (float)((double)(-(int64_t)m->off * m->cy - 128 * m->bu) / 1e6);
   return c;
 }
 static inline uint8_t sat_trunc(float t) {
@@ -96,15 +98,21 @@ static inline uint8_t sat_trunc(float t) {
   t = t > 255.f ? 255.f : t;
   return (uint8_t)(int)t;
 }
+/* saturate + round to nearest even (default FP environment) */
+static inline uint8_t sat_rne(float t) {
+  t = t < 0.f ? 0.f : t;
+  t = t > 255.f ? 255.f : t;
+  return (uint8_t)(int)nearbyintf(t);
+}
 static inline void yuv2rgb_fp32(const yuv2rgb_f32* c, int y, int u, int v, uint8_t* r, uint8_t* g,
                                 uint8_t* b) {
   float yf = (float)y, uf = (float)u, vf = (float)v;
   float rc = __builtin_fmaf(vf, c->rv, c->br);
   float gc = __builtin_fmaf(uf, c->gu, __builtin_fmaf(vf, c->gv, c->bg));
   float bc = __builtin_fmaf(uf, c->bu, c->bb);
-  *r = sat_trunc(__builtin_fmaf(yf, c->cy, rc));
-  *g = sat_trunc(__builtin_fmaf(yf, c->cy, gc));
-  *b = sat_trunc(__builtin_fmaf(yf, c->cy, bc));
+  *r = sat_rne(__builtin_fmaf(yf, c->cy, rc));
+  *g = sat_rne(__builtin_fmaf(yf, c->cy, gc));
+  *b = sat_rne(__builtin_fmaf(yf, c->cy, bc));
 }
 
 static int valid_cscr(int cs, int cr) { return (cs == CS_601 || cs == CS_709) && (cr == CR_MPEG || cr == CR_JPEG); }
@@ -331,9 +339,9 @@ static void nv12_to_rgb_fast(int bgr, const yuv2rgb_dec* m, uint32_t w, uint32_t
       float rc = __builtin_fmaf(vf, c.rv, c.br);
       float gc = __builtin_fmaf(uf, c.gu, __builtin_fmaf(vf, c.gv, c.bg));
       float bc = __builtin_fmaf(uf, c.bu, c.bb);
-      o[3 * x + i0] = sat_trunc(__builtin_fmaf(yf, c.cy, rc));
-      o[3 * x + 1] = sat_trunc(__builtin_fmaf(yf, c.cy, gc));
-      o[3 * x + i2] = sat_trunc(__builtin_fmaf(yf, c.cy, bc));
+      o[3 * x + i0] = sat_rne(__builtin_fmaf(yf, c.cy, rc));
+      o[3 * x + 1] = sat_rne(__builtin_fmaf(yf, c.cy, gc));
+      o[3 * x + i2] = sat_rne(__builtin_fmaf(yf, c.cy, bc));
     }
   }
 }

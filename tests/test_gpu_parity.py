@@ -57,7 +57,7 @@ def test_nv12_to_rgb_matrices(capi, oracle, cs, cr, dst):
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), cs, cr, w, h, src)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
 @pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
 def test_nv12_to_rgb_every_kernel_variant(capi, oracle, variant, dst):
     """all kernel variants (p4 / p16 / LDS-transposed / non-temporal / explicit pack / generic) agree bit for bit"""
@@ -92,7 +92,7 @@ def test_nv12_to_rgb_ragged_sizes(capi, oracle, w, h):
 def test_nv12_to_rgb_pitch_and_alignment(capi, oracle, align, extra, offset):
     w, h = 1280, 24
     src = oracle.synth(oracle.NV12, w, h, 1003)
-    for variant in (0, 5):
+    for variant in (0, 4, 8):
         _convert(capi, oracle, capi.NV12, capi.RGB, 1, 0, w, h, src, align, extra, offset, variant=variant)
 
 
@@ -135,13 +135,13 @@ def test_full_size_4k_and_1080p(capi, oracle):
     src = oracle.synth(oracle.NV12, 1920, 1080, 1004, "B")
     _convert(capi, oracle, capi.NV12, capi.RGB_PLANAR, 1, 0, 1920, 1080, src)
     src = oracle.synth(oracle.NV12, 3840, 2160, 1005, "A")
-    for variant in (0, 5):
+    for variant in (0, 4):
         _convert(capi, oracle, capi.NV12, capi.RGB, 1, 0, 3840, 2160, src, variant=variant, exact_tol=False)
 
 
 def test_batch_matches_single(capi, oracle):
-    """vpf_convert_batch over 37 frames (3 dispatches of <=16) == 37 single conversions; outputs independent"""
-    w, h, n = 640, 36, 37
+    """vpf_convert_batch over 70 frames (3 dispatches of <=32) == 37 single conversions; outputs independent"""
+    w, h, n = 640, 36, 70
     srcs = [oracle.synth(oracle.NV12, w, h, 2000 + i) for i in range(n)]
     S = [DevPlanes(s) for s in srcs]
     D = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
@@ -213,20 +213,20 @@ def test_rgb_to_yuv(capi, oracle, s, d):
             _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, cr, w, h, src)
 
 
-def test_roundtrip_nv12_rgb_yuv420_nv12(capi, oracle):
-    """sample chain of samples/SamplePyTorch.py:150-158 (601 MPEG): NV12->YUV420->RGB->YUV420->NV12 returns a
-    picture within 3 LSB of the original on legal-range input that is constant over 2x2 quads"""
+def test_roundtrip_rgb_yuv420_nv12_rgb(capi, oracle):
+    """the return path of samples/SamplePyTorch.py:150-158 (BT.601 MPEG): RGB -> YUV420 -> NV12 -> YUV420 -> RGB
+    reproduces an in-gamut picture that is constant over 2x2 quads to within 2 LSB (two roundings; measured bound
+    on the oracle).  (The JPEG / NPP "YUV" model is NOT round-trippable: V = .877(R-Y)+128 clips for saturated reds.)"""
     w, h = 256, 64
     rng = np.random.default_rng(5)
-    yq = rng.integers(40, 200, (h // 2, w // 2), dtype=np.uint8)
-    y = np.repeat(np.repeat(yq, 2, 0), 2, 1)
-    uv = rng.integers(100, 156, (h // 2, w), dtype=np.uint8)
-    a = _convert(capi, oracle, capi.NV12, capi.YUV420, 0, 0, w, h, [y, uv])
-    b = _convert(capi, oracle, capi.YUV420, capi.RGB, 0, 0, w, h, a)
-    c = _convert(capi, oracle, capi.RGB, capi.YUV420, 0, 0, w, h, b)
-    d = _convert(capi, oracle, capi.YUV420, capi.NV12, 0, 0, w, h, c)
-    assert np.abs(d[0].astype(int) - y.astype(int)).max() <= 3
-    assert np.abs(d[1].astype(int) - uv.astype(int)).max() <= 3
+    q = rng.integers(0, 256, (h // 2, w // 2, 3), dtype=np.uint8)
+    rgb = np.repeat(np.repeat(q, 2, 0), 2, 1).reshape(h, 3 * w)
+    a = _convert(capi, oracle, capi.RGB, capi.YUV420, 0, 0, w, h, [rgb])
+    b = _convert(capi, oracle, capi.YUV420, capi.NV12, 0, 0, w, h, a)
+    c = _convert(capi, oracle, capi.NV12, capi.YUV420, 0, 0, w, h, b)
+    d = _convert(capi, oracle, capi.YUV420, capi.RGB, 0, 0, w, h, c)
+    assert all(np.array_equal(x, y) for x, y in zip(a, c))
+    assert np.abs(d[0].astype(int) - rgb.astype(int)).max() <= 2
 
 
 # ---------------------------------------------------------------------------------------------

@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
     if constexpr (CH == 3) {
-      stg3<false>(out, pack4<0>(o[0], o[1], o[2], o[3]), pack4<0>(o[4], o[5], o[6], o[7]), pack4<0>(o[8], o[9], o[10], o[11]));
+      stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
     } else if constexpr (CH == 2) {
-      stg<false, u32x2>(out, u32x2{pack4<0>(o[0], o[1], o[2], o[3]), pack4<0>(o[4], o[5], o[6], o[7])});
+      stg<false, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
     } else {
-      stg<false, uint32_t>(out, pack4<0>(o[0], o[1], o[2], o[3]));
+      stg<false, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
     }
   } else {
     const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
@@ -141,9 +141,9 @@ VPF_DEV void texel_rgb(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t x, uin
     u = f.s[1][(size_t)(y >> 1) * f.sp[1] + (x >> 1)]; v = f.s[2][(size_t)(y >> 1) * f.sp[2] + (x >> 1)];
   }
   const Chroma k = chroma_terms(c, u, v);
-  rgb[0] = (float)sat_trunc(__builtin_fmaf(yf, c.cy, k.rc));
-  rgb[1] = (float)sat_trunc(__builtin_fmaf(yf, c.cy, k.gc));
-  rgb[2] = (float)sat_trunc(__builtin_fmaf(yf, c.cy, k.bc));
+  rgb[0] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.rc));
+  rgb[1] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.gc));
+  rgb[2] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.bc));
 }
 
 template <int SRC, int DST>
@@ -172,15 +172,15 @@ __global__ __launch_bounds__(256) void k_convert_resize(const FrameDesc f, const
   if constexpr (DST == FC_PLANAR) {
     for (int ch = 0; ch < 3; ch++) {
       uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
-      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4<0>(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
       else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[ch][i]);
     }
   } else {
     const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
     if (vec_ok && nv == 4) {
-      stg3<false>(out, pack4<0>(o[a][0], o[1][0], o[b][0], o[a][1]), pack4<0>(o[1][1], o[b][1], o[a][2], o[1][2]),
-                  pack4<0>(o[b][2], o[a][3], o[1][3], o[b][3]));
+      stg3<false>(out, pack4_trunc(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc(o[1][1], o[b][1], o[a][2], o[1][2]),
+                  pack4_trunc(o[b][2], o[a][3], o[1][3], o[b][3]));
     } else {
       for (uint32_t i = 0; i < nv; i++) {
         out[3 * i] = (uint8_t)sat_trunc(o[a][i]); out[3 * i + 1] = (uint8_t)sat_trunc(o[1][i]); out[3 * i + 2] = (uint8_t)sat_trunc(o[b][i]);

@@ -13,8 +13,9 @@
 //     instruction is fully coalesced with no cross-lane traffic at all;
 //   * p16 kernels: a lane owns 16 pixels -> dwordx4 loads; the 48 B/row it produces are transposed
 //     through a wave-private LDS tile so every global store is a dense 1 KiB dwordx4 wave store;
-//   * math is fp32 FMA on v_cvt_f32_ubyteN operands: 1 cvt + 3 FMA + 3 pack ops per pixel;
-//   * `BatchArgs` carries up to 16 frames in the kernarg segment, blockIdx.y selects the frame, so
+//   * math is fp32 FMA on v_cvt_f32_ubyteN operands, rounded + saturated + byte-packed by
+//     v_cvt_pk_u8_f32: 1 cvt + 3 FMA + 3 pack ops per pixel;
+//   * `BatchArgs` carries up to 32 frames in the kernarg segment, blockIdx.y selects the frame, so
 //     one dispatch streams ~600 MB and the ~2 us kernel boundary is amortised.
 #include "vpf_device.h"
 
@@ -50,7 +51,7 @@ VPF_DEV void pack_rgb12(const Quad& q, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 // p4: 4 px per lane, RP row pairs per wave task.  Requires w % 4 == 0, h even, every plane
 // pointer/pitch 4-byte aligned (2-byte for YUV420 chroma).  SRC in {FC_NV12, FC_YUV420}.
 // ---------------------------------------------------------------------------------------------
-template <int SRC, int DST, int RP, int PACK, bool NT>
+template <int SRC, int DST, int RP, int PACK, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                        uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   // wave-uniform by construction; readfirstlane tells the compiler so (scalar branches, SGPR addressing)
@@ -67,13 +68,13 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
   for (int r = 0; r < RP; r++) {
     const uint32_t rp = rp0 + r;
     if (rp < nrp) {
-      ya[r] = ldg<NT, uint32_t>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
-      yb[r] = ldg<NT, uint32_t>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+      ya[r] = ldg<NTL, uint32_t>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+      yb[r] = ldg<NTL, uint32_t>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
       if constexpr (SRC == FC_NV12) {
-        uv[r] = ldg<NT, uint32_t>(f.s[1] + (size_t)rp * f.sp[1] + x);
+        uv[r] = ldg<NTL, uint32_t>(f.s[1] + (size_t)rp * f.sp[1] + x);
       } else {  // two U bytes and two V bytes -> same (U0 V0 U1 V1) byte order as NV12
-        uint32_t u2 = ldg<NT, uint16_t>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1));
-        uint32_t v2 = ldg<NT, uint16_t>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
+        uint32_t u2 = ldg<NTL, uint16_t>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1));
+        uint32_t v2 = ldg<NTL, uint16_t>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
         uv[r] = __builtin_amdgcn_perm(v2, u2, 0x05010400u);
       }
     }
@@ -89,13 +90,13 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
         const Quad q = convert4(c, half ? yb[r] : ya[r], k0, k1);
         const size_t row = (size_t)(2 * rp + half);
         if constexpr (DST == FC_PLANAR) {
-          stg<NT, uint32_t>(f.d[0] + row * f.dp[0] + x, pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]));
-          stg<NT, uint32_t>(f.d[1] + row * f.dp[1] + x, pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]));
-          stg<NT, uint32_t>(f.d[2] + row * f.dp[2] + x, pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]));
+          stg<NTS, uint32_t>(f.d[0] + row * f.dp[0] + x, pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]));
+          stg<NTS, uint32_t>(f.d[1] + row * f.dp[1] + x, pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]));
+          stg<NTS, uint32_t>(f.d[2] + row * f.dp[2] + x, pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]));
         } else {
           uint32_t d0, d1, d2;
           pack_rgb12<DST, PACK>(q, d0, d1, d2);
-          stg3<NT>(f.d[0] + row * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+          stg3<NTS>(f.d[0] + row * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
         }
       }
     }
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
 // 48*l + 16*j -> dword banks {12l+4j .. +3} mod 32, which tile all 32 banks exactly once per
 // group: conflict free.  The ds_read_b128 side reads 16*l: contiguous, conflict free.
 // ---------------------------------------------------------------------------------------------
-template <int DST, int PACK, bool NT, bool LDS_T>
+template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH>
 __global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                       uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[(LDS_T && DST != FC_PLANAR) ? 4 * 2 * 192 : 1];
@@ -126,12 +127,17 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, cons
 
   u32x4 y[2], uv;
   if (act) {
-    y[0] = ldg<NT, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
-    y[1] = ldg<NT, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
-    uv = ldg<NT, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+    y[0] = ldg<NTL, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+    y[1] = ldg<NTL, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+    uv = ldg<NTL, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
   }
   uint32_t o[2][12];
-  if (act) {
+  if constexpr (NOMATH) {  // bandwidth-ceiling probe: same loads / LDS transpose / stores, no arithmetic (NOT a conversion)
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+      for (int j = 0; j < 12; j++) o[half][j] = y[half][j & 3] ^ uv[(j >> 2) & 3];
+  } else if (act) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j]));
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, cons
       if (act) {
 #pragma unroll
         for (int p = 0; p < 3; p++)
-          stg<NT, u32x4>(f.d[p] + row * f.dp[p] + x,
+          stg<NTS, u32x4>(f.d[p] + row * f.dp[p] + x,
                          u32x4{o[half][4 * p], o[half][4 * p + 1], o[half][4 * p + 2], o[half][4 * p + 3]});
       }
     } else if constexpr (LDS_T) {
@@ -174,14 +180,14 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, cons
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const uint32_t off = chunk * 3072 + (k * 64 + lane) * 16;
-        if (off < row_bytes) stg<NT, u32x4>(rowp + off, t[k * 64 + lane]);
+        if (off < row_bytes) stg<NTS, u32x4>(rowp + off, t[k * 64 + lane]);
       }
     } else {
       if (act) {
         uint8_t* p = f.d[0] + row * f.dp[0] + 3 * (size_t)x;
 #pragma unroll
         for (int j = 0; j < 3; j++)
-          stg<NT, u32x4>(p + 16 * j, u32x4{o[half][4 * j], o[half][4 * j + 1], o[half][4 * j + 2], o[half][4 * j + 3]});
+          stg<NTS, u32x4>(p + 16 * j, u32x4{o[half][4 * j], o[half][4 * j + 1], o[half][4 * j + 2], o[half][4 * j + 3]});
       }
     }
   }
@@ -246,9 +252,9 @@ __global__ __launch_bounds__(256) void k_yuv_rgb_generic(const BatchArgs args, c
         k = chroma_terms(c, (float)f.s[1][(size_t)y * f.sp[1] + x], (float)f.s[2][(size_t)y * f.sp[2] + x]);
       }
       const float yf = (float)f.s[0][(size_t)y * f.sp[0] + x];
-      const uint8_t r = (uint8_t)sat_trunc(__builtin_fmaf(yf, c.cy, k.rc));
-      const uint8_t g = (uint8_t)sat_trunc(__builtin_fmaf(yf, c.cy, k.gc));
-      const uint8_t b = (uint8_t)sat_trunc(__builtin_fmaf(yf, c.cy, k.bc));
+      const uint8_t r = (uint8_t)sat_rne(__builtin_fmaf(yf, c.cy, k.rc));
+      const uint8_t g = (uint8_t)sat_rne(__builtin_fmaf(yf, c.cy, k.gc));
+      const uint8_t b = (uint8_t)sat_rne(__builtin_fmaf(yf, c.cy, k.bc));
       if constexpr (DST == FC_PLANAR) {
         f.d[0][(size_t)y * f.dp[0] + x] = r; f.d[1][(size_t)y * f.dp[1] + x] = g; f.d[2][(size_t)y * f.dp[2] + x] = b;
       } else {
@@ -279,24 +285,40 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
                              const BatchArgs& a, int variant) {
   const int nsrc = (SRC == FC_NV12) ? 2 : 3, ndst = (DST == FC_PLANAR) ? 3 : 1;
   const bool even = (w % 4 == 0) && (h % 2 == 0);
-  // variant: 0 = default; 1 p4/RP4; 2 p4/RP2; 3 p4/RP1; 4 p4/RP4 +NT; 5 p16 LDS; 6 p16 direct; 7 p16 LDS +NT;
-  //          8 p4/RP4 explicit pack; 9 generic
-  if (variant == 0) variant = 1;
-  if (SRC != FC_NV12 && variant >= 5 && variant <= 7) variant = 1;
-  if (variant != 9 && variant >= 5 && variant <= 7) {
-    if constexpr (SRC == FC_NV12) {
-      if (even && w % 16 == 0 && aligned_all(a, n, nsrc, ndst, 16, 16, 16)) {
-        const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
-        dim3 grid((tasks + 3) / 4, n);
-        if (variant == 5) hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, false, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
-        else if (variant == 6) hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, false, false>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
-        else hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, true, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
-        return hipGetLastError();
+  // variant (VPF_TUNE_NV12_RGB_VARIANT): 0 = default policy
+  //   1/2/3   p4, 1/2/4 row pairs per wave task          4/5/6   the same with non-temporal loads+stores
+  //   7       p16 + LDS transpose                        8       p16 + LDS transpose, non-temporal loads+stores
+  //   9       generic byte kernel                        10      p4 RP1 NT with the explicit (non cvt_pk) pack
+  //   11/12   p16 LDS with NT stores only / NT loads only
+  //   13      p16 lane-strided stores (no LDS)           15      p16 LDS NT, arithmetic removed (ceiling probe, wrong pixels)
+  //   14/16   p4 RP1 / RP2 with NT stores only
+  const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
+  const bool p4_ok = even && aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
+  // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal
+  // stores; planar outputs (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
+  if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? 11 : 4;
+  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15));
+  if (want_p16 && !p16_ok) variant = 4;
+  if (variant != 9 && !p4_ok) variant = 9;
+  if constexpr (SRC == FC_NV12) {
+    if (want_p16 && p16_ok) {
+      const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
+      dim3 grid((tasks + 3) / 4, n);
+#define VPF_P16(NTL, NTS, LDS, NOMATH) \
+  hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, NTL, NTS, LDS, NOMATH>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks)
+      switch (variant) {
+        case 7: VPF_P16(false, false, true, false); break;
+        case 11: VPF_P16(false, true, true, false); break;
+        case 12: VPF_P16(true, false, true, false); break;
+        case 13: VPF_P16(true, true, false, false); break;
+        case 15: VPF_P16(true, true, true, true); break;
+        default: VPF_P16(true, true, true, false);
       }
+#undef VPF_P16
+      return hipGetLastError();
     }
-    variant = 1;
   }
-  if (variant != 9 && even && aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2)) {
+  if (variant != 9) {
     const uint32_t chunks = (w / 4 + 63) / 64;
     auto go = [&](auto kern, int rp) {
       const uint32_t tasks = chunks * ((h / 2 + rp - 1) / rp);
@@ -305,11 +327,15 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       return hipGetLastError();
     };
     switch (variant) {
-      case 2: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, false>, 2);
-      case 3: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, false>, 1);
-      case 4: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, true>, 4);
-      case 8: return go(k_yuv420_rgb_p4<SRC, DST, 4, 0, false>, 4);
-      default: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, false>, 4);
+      case 1: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, false, false>, 1);
+      case 2: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, false, false>, 2);
+      case 3: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, false, false>, 4);
+      case 5: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, true, true>, 2);
+      case 6: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, true, true>, 4);
+      case 10: return go(k_yuv420_rgb_p4<SRC, DST, 1, 0, true, true>, 1);
+      case 14: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, false, true>, 1);
+      case 16: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, false, true>, 2);
+      default: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true>, 1);
     }
   }
   dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);

@@ -28,7 +28,7 @@ bool make_yuv2rgb(int cs, int cr, Yuv2RgbCoef* o) {
   if ((cs != VPF_BT_601 && cs != VPF_BT_709) || (cr != VPF_MPEG && cr != VPF_JPEG)) return false;
   const Yuv2RgbDec& m = kYuv2Rgb[cs][cr];
   o->cy = q6(m.cy); o->rv = q6(m.rv); o->gu = q6(m.gu); o->gv = q6(m.gv); o->bu = q6(m.bu);
-  const int64_t yoff = -(int64_t)m.off * m.cy + 500000;  // luma offset + the 0.5 of round-half-up
+  const int64_t yoff = -(int64_t)m.off * m.cy;  // luma offset (rounding is done by v_cvt_pk_u8_f32: nearest even)
   o->br = q6(yoff - 128 * m.rv);
   o->bg = q6(yoff - 128 * (m.gu + m.gv));
   o->bb = q6(yoff - 128 * m.bu);

@@ -16,12 +16,20 @@ VPF_DEV float ubyte(uint32_t d) {
 }
 
 // saturate to [0,255] and truncate; `t` already carries the +0.5 of round-half-up
+// (used by resize / remap / RGB->YUV: round half up)
 VPF_DEV uint32_t sat_trunc(float t) { return (uint32_t)__builtin_amdgcn_fmed3f(t, 0.0f, 255.0f); }
 
-// pack four channel values into one dword, byte 0 first.
-// PACK = 0: v_med3_f32 + v_cvt_u32_f32 + shifts/ors (semantics guaranteed by the language)
-// PACK = 1: v_cvt_pk_u8_f32 (one op per byte); only bit-identical to PACK 0 if that instruction
-//           truncates and saturates — verified on hardware by tests/test_gpu_parity.py
+// saturate to [0,255] with round-to-nearest-even: ONE instruction, v_cvt_pk_u8_f32.  Its semantics
+// (saturating, ties to even, NaN -> 0) were measured on gfx950 with tools/probe_cvt.hip
+// (profiles/r01_probe_cvt_pk_u8_f32.txt): 0 mismatches against clamp(rint(x)) over a dense sweep.
+// This is the rounding of the whole YUV -> RGB family.
+VPF_DEV uint32_t sat_rne(float t) { return __builtin_amdgcn_cvt_pk_u8_f32(t, 0, 0u); }
+// the same value spelled with language-level operations (cross-check variant)
+VPF_DEV uint32_t sat_rne_explicit(float t) { return (uint32_t)__builtin_rintf(__builtin_amdgcn_fmed3f(t, 0.0f, 255.0f)); }
+
+// pack four channel values into one dword, byte 0 first, each saturated + rounded to nearest even.
+// PACK = 1: four v_cvt_pk_u8_f32 (one op per byte, writes straight into the destination byte lane)
+// PACK = 0: v_med3_f32 + v_rndne_f32 + v_cvt_u32_f32 + shifts/ors; bit-identical, kept as a cross-check
 template <int PACK>
 VPF_DEV uint32_t pack4(float a, float b, float c, float d) {
   if constexpr (PACK == 1) {
@@ -31,8 +39,12 @@ VPF_DEV uint32_t pack4(float a, float b, float c, float d) {
     o = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, o);
     return o;
   } else {
-    return sat_trunc(a) | (sat_trunc(b) << 8) | (sat_trunc(c) << 16) | (sat_trunc(d) << 24);
+    return sat_rne_explicit(a) | (sat_rne_explicit(b) << 8) | (sat_rne_explicit(c) << 16) | (sat_rne_explicit(d) << 24);
   }
+}
+// four values already carrying +0.5: saturate + truncate (round half up), for resize / remap
+VPF_DEV uint32_t pack4_trunc(float a, float b, float c, float d) {
+  return sat_trunc(a) | (sat_trunc(b) << 8) | (sat_trunc(c) << 16) | (sat_trunc(d) << 24);
 }
 
 struct Chroma {

@@ -8,10 +8,11 @@
 namespace vpf {
 
 // ------------------------------------------------------------------------------------------
-// YUV -> RGB coefficients in the form the kernels consume.  Biases fold the luma offset, the
-// chroma -128 and the +0.5 of round-half-up, so a pixel costs one FMA per channel:
+// YUV -> RGB coefficients in the form the kernels consume.  Biases fold the luma offset and the
+// chroma -128, so a pixel costs one FMA per channel:
 //   rc = fma(V, rv, br);  gc = fma(U, gu, fma(V, gv, bg));  bc = fma(U, bu, bb)     (per chroma sample)
-//   R = sat_trunc(fma(Y, cy, rc)); G = sat_trunc(fma(Y, cy, gc)); B = sat_trunc(fma(Y, cy, bc))
+//   R = sat_rne(fma(Y, cy, rc)); G = sat_rne(fma(Y, cy, gc)); B = sat_rne(fma(Y, cy, bc))
+// sat_rne = saturate to [0,255], round to nearest even (v_cvt_pk_u8_f32)
 // ------------------------------------------------------------------------------------------
 struct Yuv2RgbCoef {
   float cy, rv, gu, gv, bu, br, bg, bb;
@@ -24,8 +25,8 @@ struct Rgb2YuvCoef {
 bool make_yuv2rgb(int color_space, int color_range, Yuv2RgbCoef* out);
 bool make_rgb2yuv(int color_range, Rgb2YuvCoef* out);
 
-// Up to 16 frames per dispatch travel in the kernarg segment (no device-side table to manage).
-constexpr int kMaxBatch = 16;
+// Up to 32 frames per dispatch travel in the kernarg segment (32 x 72 B; no device-side table to manage).
+constexpr int kMaxBatch = 32;
 struct FrameDesc {
   const uint8_t* s[3];
   uint8_t* d[3];
