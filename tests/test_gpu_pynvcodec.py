@@ -1,0 +1,282 @@
+"""-m gpu tests of the drop-in Python API: the chains user code actually builds with the reference
+(samples/*.py), checked against the CPU oracle.  Everything goes PyNvCodec -> C++ Task layer ->
+C ABI -> HIP kernels."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no GPU visible", allow_module_level=True)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "videoprocessingframework_amd"))
+import PyNvCodec as nvc  # noqa: E402
+import PytorchNvCodec as pnvc  # noqa: E402
+
+PF, CS, CR = nvc.PixelFormat, nvc.ColorSpace, nvc.ColorRange
+GPU = 0
+
+
+def host_frame(planes):
+    return np.concatenate([p.reshape(-1).view(np.uint8) for p in planes])
+
+
+def upload(fmt, w, h, planes):
+    up = nvc.PyFrameUploader(w, h, fmt, GPU)
+    return up.UploadSingleFrame(host_frame(planes)).Clone(GPU)  # Clone: the uploader's surface is recycled
+
+
+def download(surf, dtype=np.uint8):
+    dl = nvc.PySurfaceDownloader(surf.Width(), surf.Height(), surf.Format(), GPU)
+    out = np.zeros(1, dtype)
+    assert dl.DownloadSingleSurface(surf, out)
+    return out
+
+
+def test_upload_download_roundtrip(oracle):
+    for name in ("NV12", "YUV420", "RGB", "BGR", "RGB_PLANAR", "YUV444", "Y", "YCBCR", "YUV422"):
+        fmt = getattr(PF, name)
+        w, h = 322, 146
+        s = nvc.Surface.Make(fmt, w, h, GPU)
+        frame = np.random.default_rng(1).integers(0, 256, s.HostSize(), dtype=np.uint8)
+        up = nvc.PyFrameUploader(w, h, fmt, GPU)
+        surf = up.UploadSingleFrame(frame)
+        assert surf.Format() == fmt and not surf.Empty() and not surf.OwnMemory()  # alias of the uploader's surface
+        assert np.array_equal(download(surf), frame), name
+    f32 = np.random.default_rng(2).random(64 * 32 * 3, dtype=np.float32)
+    s = nvc.PyFrameUploader(64, 32, PF.RGB_32F, GPU).UploadSingleFrame(f32)
+    assert np.array_equal(download(s, np.float32), f32)
+    u16 = np.random.default_rng(3).integers(0, 65536, 64 * 32 * 3 // 2, dtype=np.uint16)
+    s = nvc.PyFrameUploader(64, 32, PF.P10, GPU).UploadSingleFrame(u16)
+    assert np.array_equal(download(s, np.uint16), u16)
+
+
+def test_chain_segmentation_sample(oracle):
+    """samples/SampleTorchSegmentation.py:207-253 — NV12 -> RGB -> RGB_PLANAR -> torch tensor, BT.709 + JPEG"""
+    w, h = 848, 464  # the reference's test clip resolution (tests/test_PySurface.py:55-64)
+    src = oracle.synth(oracle.NV12, w, h, 11, "B")
+    nv12 = upload(PF.NV12, w, h, src)
+    to_rgb = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU)
+    to_pln = nvc.PySurfaceConverter(w, h, PF.RGB, PF.RGB_PLANAR, GPU)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.JPEG)
+    rgb = to_rgb.Execute(nv12, cc)
+    pln = to_pln.Execute(rgb, cc)
+    assert not rgb.Empty() and not pln.Empty() and pln.Format() == PF.RGB_PLANAR
+    _, want_rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 1, w, h, src)
+    _, want_pln = oracle.convert(oracle.RGB, oracle.RGB_PLANAR, 1, 1, w, h, want_rgb)
+    assert np.array_equal(download(pln), host_frame(want_pln))
+    # the sample's tensor hand-off: plane = W x 3H, then resize_(3, H, W)
+    p = pln.PlanePtr()
+    t = pnvc.makefromDevicePtrUint8(p.GpuMem(), p.Width(), p.Height(), p.Pitch(), p.ElemSize())
+    assert t.shape == (3 * h, w) and t.dtype == torch.uint8 and t.is_contiguous()
+    t.resize_(3, h, w)
+    assert np.array_equal(t.cpu().numpy(), np.stack(want_pln))
+    # zero-copy view of the same surface: same pixels, no copy (data_ptr inside the surface allocation)
+    v = pnvc.view_surface_planar(pln)
+    assert v.shape == (3, h, w) and v.data_ptr() == p.GpuMem() and np.array_equal(v.cpu().numpy(), np.stack(want_pln))
+    # and the additive fused converter gives the identical planar picture in one pass
+    fused = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB_PLANAR, GPU).Execute(nv12, cc)
+    assert np.array_equal(download(fused), host_frame(want_pln))
+
+
+def test_chain_resnet_sample(oracle):
+    """samples/SampleTorchResnet.py:1073-1138 — NV12 -> YUV420 -> Resize(224x224) -> RGB -> RGB_PLANAR, BT.601 + MPEG
+    (goes through YUV420 because nv12_rgb rejects 601+MPEG)"""
+    w, h, tw, th = 848, 464, 224, 224
+    src = oracle.synth(oracle.NV12, w, h, 12, "B")
+    cc = nvc.ColorspaceConversionContext(CS.BT_601, CR.MPEG)
+    nv12 = upload(PF.NV12, w, h, src)
+    yuv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.YUV420, GPU).Execute(nv12, cc)
+    small = nvc.PySurfaceResizer(tw, th, PF.YUV420, GPU).Execute(yuv)
+    rgb = nvc.PySurfaceConverter(tw, th, PF.YUV420, PF.RGB, GPU).Execute(small, cc)
+    pln = nvc.PySurfaceConverter(tw, th, PF.RGB, PF.RGB_PLANAR, GPU).Execute(rgb, cc)
+    assert (small.Width(), small.Height()) == (tw, th) and not pln.Empty()
+    _, a = oracle.convert(oracle.NV12, oracle.YUV420, 0, 0, w, h, src)
+    _, b = oracle.resize(oracle.YUV420, oracle.LINEAR, w, h, a, tw, th)
+    _, c = oracle.convert(oracle.YUV420, oracle.RGB, 0, 0, tw, th, b)
+    _, d = oracle.convert(oracle.RGB, oracle.RGB_PLANAR, 0, 0, tw, th, c)
+    assert np.array_equal(download(pln), host_frame(d))
+    # the direct route is refused exactly like the reference refuses it (TasksColorCvt.cpp:156-163) ...
+    direct = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU)
+    assert direct.Execute(nv12, cc).Empty()
+    # ... unless the caller opts into the superset the kernels implement
+    nvc.SetExtendedColorspaces(True)
+    try:
+        out = direct.Execute(nv12, cc)
+        _, want = oracle.convert(oracle.NV12, oracle.RGB, 0, 0, w, h, src)
+        assert not out.Empty() and np.array_equal(download(out), want[0].reshape(-1))
+    finally:
+        nvc.SetExtendedColorspaces(False)
+
+
+def test_chain_remap_sample(oracle):
+    """samples/SampleRemap.py:74-101 — NV12 -> RGB -> Remap(RGB) -> download, BT.709 + JPEG"""
+    w, h = 640, 360
+    src = oracle.synth(oracle.NV12, w, h, 13)
+    xm, ym = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    xm = (xm + 3.25 * np.sin(ym / 17)).astype(np.float32)
+    ym = (ym + 2.5 * np.cos(xm / 23)).astype(np.float32)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.JPEG)
+    rgb = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU).Execute(upload(PF.NV12, w, h, src), cc)
+    rm = nvc.PySurfaceRemaper(xm, ym, PF.RGB, GPU)
+    out = rm.Execute(rgb)
+    assert (out.Width(), out.Height(), out.Format()) == (w, h, PF.RGB)
+    _, want_rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 1, w, h, src)
+    _, want = oracle.remap(oracle.RGB, w, h, want_rgb, xm, ym)  # unmapped pixels stay 0 (surface starts black)
+    assert np.array_equal(download(out), want[0].reshape(-1))
+    assert rm.Execute(nvc.Surface.Make(PF.BGR, w, h, GPU)).Empty()  # format mismatch
+
+
+def test_chain_multithread_sample(oracle):
+    """samples/SampleDecodeMultiThread.py:50-152 — per-thread {stream, converter, resizer}: NV12 -> RGB -> Resize(W/2 x H/2)"""
+    w, h = 1280, 720
+    results, errors = {}, []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            ctx, s = nvc.GetContext(GPU), st.cuda_stream
+            src = oracle.synth(oracle.NV12, w, h, 100 + i)
+            up = nvc.PyFrameUploader(w, h, PF.NV12, ctx, s)
+            conv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, ctx, s)
+            rs = nvc.PySurfaceResizer(w // 2, h // 2, PF.RGB, ctx, s)
+            dl = nvc.PySurfaceDownloader(w // 2, h // 2, PF.RGB, ctx, s)
+            cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+            out = np.zeros(1, np.uint8)
+            for _ in range(3):
+                small = rs.Execute(conv.Execute(up.UploadSingleFrame(host_frame(src)), cc))
+                assert dl.DownloadSingleSurface(small, out)
+            results[i] = (src, out)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for i, (src, out) in results.items():
+        _, rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+        _, want = oracle.resize(oracle.RGB, oracle.LINEAR, w, h, rgb, w // 2, h // 2)
+        assert np.array_equal(out, want[0].reshape(-1)), i
+
+
+def test_encode_return_path(oracle):
+    """samples/SamplePyTorch.py:150-158 return path — RGB_PLANAR -> RGB -> YUV420 -> NV12 (BT.601 MPEG)"""
+    w, h = 320, 180
+    pln = oracle.synth(oracle.RGB_PLANAR, w, h, 14)
+    cc = nvc.ColorspaceConversionContext(CS.BT_601, CR.MPEG)
+    s = upload(PF.RGB_PLANAR, w, h, pln)
+    rgb = nvc.PySurfaceConverter(w, h, PF.RGB_PLANAR, PF.RGB, GPU).Execute(s, cc)
+    yuv = nvc.PySurfaceConverter(w, h, PF.RGB, PF.YUV420, GPU).Execute(rgb, cc)
+    nv12 = nvc.PySurfaceConverter(w, h, PF.YUV420, PF.NV12, GPU).Execute(yuv, cc)
+    _, a = oracle.convert(oracle.RGB_PLANAR, oracle.RGB, 0, 0, w, h, pln)
+    _, b = oracle.convert(oracle.RGB, oracle.YUV420, 0, 0, w, h, a)
+    _, c = oracle.convert(oracle.YUV420, oracle.NV12, 0, 0, w, h, b)
+    assert np.array_equal(download(nv12), host_frame(c))
+
+
+def test_converter_output_aliases_internal_surface(oracle):
+    """§3.1 consequence (a): Execute returns a non-owning alias of ONE internal surface, overwritten by the next
+    Execute; Clone() is the deep copy samples use (samples/SamplePyTorch.py:83)"""
+    w, h = 128, 64
+    a, b = oracle.synth(oracle.NV12, w, h, 15), oracle.synth(oracle.NV12, w, h, 16)
+    conv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    out_a = conv.Execute(upload(PF.NV12, w, h, a), cc)
+    keep = out_a.Clone(GPU)
+    out_b = conv.Execute(upload(PF.NV12, w, h, b), cc)
+    assert not out_a.OwnMemory() and keep.OwnMemory()
+    assert out_a.PlanePtr().GpuMem() == out_b.PlanePtr().GpuMem() != keep.PlanePtr().GpuMem()
+    _, wa = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, a)
+    _, wb = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, b)
+    assert np.array_equal(download(out_a), wb[0].reshape(-1))   # the alias now shows frame b
+    assert np.array_equal(download(keep), wa[0].reshape(-1))    # the clone kept frame a
+
+
+def test_surface_copy_clone_crop(oracle):
+    w, h = 96, 48
+    for name in ("NV12", "RGB", "YUV420", "RGB_PLANAR"):
+        fmt, ofmt = getattr(PF, name), getattr(oracle, name)
+        planes = oracle.synth(ofmt, w, h, 17)
+        s = upload(fmt, w, h, planes)
+        d = nvc.Surface.Make(fmt, w, h, GPU)
+        d.CopyFrom(s, GPU)  # other -> self (what the name says; the reference binding copies the other way round)
+        assert np.array_equal(download(d), host_frame(planes))
+        st = torch.cuda.Stream()
+        assert np.array_equal(download(s.Clone(nvc.GetContext(GPU), st.cuda_stream)), host_frame(planes))
+        assert np.array_equal(download(s.Clone()), host_frame(planes))
+        with pytest.raises(RuntimeError, match="different size"):
+            nvc.Surface.Make(fmt, w // 2, h, GPU).CopyFrom(s, GPU)
+        x, y, cw, ch = 16, 8, 32, 20
+        c = s.Crop(x, y, cw, ch, GPU)
+        assert (c.Width(), c.Height(), c.Format()) == (cw, ch, fmt)
+        got = download(c)
+        if name == "RGB":
+            want = planes[0].reshape(h, w, 3)[y:y + ch, x:x + cw].reshape(-1)
+        elif name == "NV12":
+            want = np.concatenate([planes[0][y:y + ch, x:x + cw].reshape(-1), planes[1][y // 2:(y + ch) // 2, x:x + cw].reshape(-1)])
+        elif name == "YUV420":
+            want = np.concatenate([planes[0][y:y + ch, x:x + cw].reshape(-1)] +
+                                  [planes[k][y // 2:(y + ch) // 2, x // 2:(x + cw) // 2].reshape(-1) for k in (1, 2)])
+        else:
+            want = np.concatenate([planes[k][y:y + ch, x:x + cw].reshape(-1) for k in range(3)])
+        assert np.array_equal(got, want), name
+    with pytest.raises(RuntimeError, match="different pixel formats"):
+        nvc.Surface.Make(PF.RGB, w, h, GPU).CopyFrom(nvc.Surface.Make(PF.BGR, w, h, GPU), GPU)
+
+
+def test_surface_plane_import_export():
+    w, h = 200, 50
+    s = nvc.Surface.Make(PF.Y, w, h, GPU)
+    t = torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda")
+    p = s.PlanePtr()
+    p.Import(t.data_ptr(), w, GPU)
+    back = torch.zeros_like(t)
+    p.Export(back.data_ptr(), w, GPU)
+    assert torch.equal(t, back)
+    t2 = pnvc.DptrToTensor(p.GpuMem(), p.Width(), p.Height(), p.Pitch(), p.ElemSize())
+    assert torch.equal(t, t2)
+    pnvc.TensorToDptr(255 - t, p.GpuMem(), p.Width(), p.Height(), p.Pitch(), p.ElemSize())
+    assert torch.equal(pnvc.view_plane(p.GpuMem(), w, h, p.Pitch()), 255 - t)
+    with pytest.raises(RuntimeError, match="only torch.uint8"):
+        pnvc.makefromDevicePtrUint8(p.GpuMem(), w, h, p.Pitch(), 4)
+
+
+def test_cuda_buffer_roundtrip():
+    n = 1000
+    a = np.random.default_rng(4).integers(0, 256, n * 4, dtype=np.uint8)
+    up = nvc.PyBufferUploader(4, n, GPU)
+    buf = up.UploadSingleBuffer(a)
+    assert (buf.GetElemSize(), buf.GetNumElems(), buf.GetRawMemSize()) == (4, n, 4 * n) and buf.GpuMem()
+    out = np.zeros(1, np.uint8)
+    assert nvc.PyCudaBufferDownloader(4, n, GPU).DownloadSingleCudaBuffer(buf, out) and np.array_equal(out, a)
+    other = nvc.CudaBuffer.Make(4, n, GPU)
+    other.CopyFrom(buf, GPU)
+    assert nvc.PyCudaBufferDownloader(4, n, GPU).DownloadSingleCudaBuffer(other.Clone(), out) and np.array_equal(out, a)
+    with pytest.raises(RuntimeError, match="different size"):
+        nvc.CudaBuffer.Make(4, n + 1, GPU).CopyFrom(buf, GPU)
+
+
+def test_execute_batch(oracle):
+    w, h, n = 640, 360, 40
+    conv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    srcs = [oracle.synth(oracle.NV12, w, h, 300 + i) for i in range(n)]
+    ins = [upload(PF.NV12, w, h, s) for s in srcs]
+    outs = [nvc.Surface.Make(PF.RGB, w, h, GPU) for _ in range(n)]
+    assert conv.ExecuteBatch(ins, outs, cc)
+    torch.cuda.synchronize()
+    for i in (0, 17, 31, 32, 39):
+        _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, srcs[i])
+        assert np.array_equal(download(outs[i]), want[0].reshape(-1)), i
+    assert not conv.ExecuteBatch(ins, outs[:-1], cc)
+    assert not conv.ExecuteBatch(ins, [nvc.Surface.Make(PF.BGR, w, h, GPU) for _ in range(n)], cc)
+
+
+def test_num_gpus():
+    assert nvc.GetNumGpus() == torch.cuda.device_count() >= 1

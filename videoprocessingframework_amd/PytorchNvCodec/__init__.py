@@ -1,0 +1,80 @@
+"""PytorchNvCodec — pitched device memory <-> torch.Tensor on torch-ROCm.
+
+Function surface of the reference's src/PytorchNvCodec/src/PytorchNvCodec.cpp:141-258:
+  makefromDevicePtrUint8 / DptrToTensor (ptr, width, height, pitch, elem_size[, stream]) -> torch.uint8 [height, width]
+  TensorToDptr (tensor, ptr, width, height, pitch, elem_size[, stream])
+The reference allocates a tensor and cudaMemcpy2D's into it (:36-87) — a copy.  Here the pitched plane is first
+exposed to torch as a ZERO-COPY strided view (through __cuda_array_interface__, strides = (pitch, 1)), and the
+reference-named functions are that view plus one strided D2D copy on the requested stream; `view_plane` /
+`view_surface_planar` hand out the zero-copy view itself (config 5 of BASELINE.json), removing 2 x 3 B/px of traffic.
+
+torch is plumbing here (allocation, streams); no pixel arithmetic happens in this module.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class _DevMem:
+    """Minimal __cuda_array_interface__ carrier for a pitched uint8 region that someone else owns."""
+
+    def __init__(self, ptr: int, height: int, width: int, pitch: int, owner=None):
+        self.owner = owner  # keeps the Surface alive while torch holds the view
+        self.__cuda_array_interface__ = {
+            "shape": (height, width), "typestr": "|u1", "data": (int(ptr), False), "strides": (int(pitch), 1), "version": 2,
+        }
+
+
+def _check(ptr, elem_size, fn):
+    if elem_size != 1:
+        raise RuntimeError(f"{fn}: only torch.uint8 data type is supported")  # PytorchNvCodec.cpp:40-45
+    if not ptr:
+        raise RuntimeError(f"{fn}: Video frame has void device ptr.")
+
+
+def view_plane(ptr: int, width: int, height: int, pitch: int, owner=None, device=None) -> torch.Tensor:
+    """Zero-copy torch.uint8 view [height, width] with strides (pitch, 1) of pitched device memory."""
+    _check(ptr, 1, "view_plane")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return torch.as_tensor(_DevMem(ptr, height, width, pitch, owner), device=dev)
+
+
+def view_surface_planar(surface, gpu_id: int | None = None) -> torch.Tensor:
+    """Zero-copy [3, H, W] uint8 view of an RGB_PLANAR / YUV444 Surface (one W x 3H allocation, plane i at
+    base + i*H*pitch — reference layout MemoryInterfaces.cpp:1593-1600)."""
+    p = surface.PlanePtr()
+    h3, w, pitch = p.Height(), p.Width(), p.Pitch()
+    flat = view_plane(p.GpuMem(), w, h3, pitch, owner=surface, device=None if gpu_id is None else f"cuda:{gpu_id}")
+    return flat.view(3, h3 // 3, w) if pitch == w else flat.as_strided((3, h3 // 3, w), ((h3 // 3) * pitch, pitch, 1))
+
+
+def _on_stream(stream: int):
+    if not stream:
+        return torch.cuda.stream(torch.cuda.current_stream())
+    return torch.cuda.stream(torch.cuda.ExternalStream(int(stream)))
+
+
+def DptrToTensor(ptr: int, width: int, height: int, pitch: int, elem_size: int, stream: int = 0) -> torch.Tensor:
+    """New contiguous torch.uint8 tensor [height, width] holding a copy of the pitched plane."""
+    _check(ptr, elem_size, "makefromDevicePtrUint8")
+    with _on_stream(stream):
+        out = view_plane(ptr, width, height, pitch).contiguous().clone() if pitch == width else view_plane(ptr, width, height, pitch).contiguous()
+    if not stream:
+        torch.cuda.current_stream().synchronize()  # the reference's stream-less overload is cudaMemcpy2D (blocking)
+    return out
+
+
+makefromDevicePtrUint8 = DptrToTensor
+
+
+def TensorToDptr(tensor: torch.Tensor, ptr: int, width: int, height: int, pitch: int, elem_size: int, stream: int = 0) -> None:
+    """Copy a torch.uint8 tensor of width*height elements into pitched device memory."""
+    _check(ptr, elem_size, "copytoDevicePtrUint8")
+    if tensor.dtype != torch.uint8 or not tensor.is_cuda:
+        raise RuntimeError("copytoDevicePtrUint8: need a CUDA/HIP torch.uint8 tensor")
+    if tensor.numel() != width * height:
+        raise RuntimeError("copytoDevicePtrUint8: tensor has the wrong number of elements")
+    with _on_stream(stream):
+        view_plane(ptr, width, height, pitch, device=tensor.device).copy_(tensor.reshape(height, width))
+    if not stream:
+        torch.cuda.current_stream().synchronize()

@@ -1,0 +1,448 @@
+// PyNvCodec.cpp — pybind11 module `_PyNvCodec`: the Python API of the surface path, name for name with
+// the reference's bindings (src/PyNvCodec/src/PyNvCodec.cpp:208-461 module + enums, PySurface.cpp:163-492,
+// PySurfaceConverter.cpp:80-120, PySurfaceResizer.cpp:66-102, PySurfaceRemaper.cpp:70-107,
+// PyFrameUploader.cpp:104-161, PySurfaceDownloader.cpp:119-189, PyBufferUploader.cpp:48-96,
+// PyCudaBufferDownloader.cpp:50-104) over the HIP Task layer in ../tc.
+//
+// `context` arguments are opaque device cookies on ROCm (0 = current device, see MemoryInterfaces.hpp);
+// `stream` arguments are hipStream_t values (torch.cuda.Stream().cuda_stream works).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "Tasks.hpp"
+#include "vpf_hip.h"
+
+namespace py = pybind11;
+using namespace VPF;
+
+namespace {
+constexpr auto TASK_EXEC_SUCCESS = TaskExecStatus::TASK_EXEC_SUCCESS;
+constexpr auto TASK_EXEC_FAIL = TaskExecStatus::TASK_EXEC_FAIL;
+
+HipContext ctx_of(int gpu) { return HipResMgr::Instance().GetCtx((size_t)gpu); }
+HipStream str_of(int gpu) { return HipResMgr::Instance().GetStream((size_t)gpu); }
+
+std::string plane_repr(SurfacePlane* p, int indent = 0) {
+  if (!p) return {};
+  const std::string sp(indent, ' ');
+  std::stringstream ss;
+  ss << sp << "Owns mem:  " << p->OwnMemory() << "\n" << sp << "Width:     " << p->Width() << "\n"
+     << sp << "Height:    " << p->Height() << "\n" << sp << "Pitch:     " << p->Pitch() << "\n"
+     << sp << "Elem size: " << p->ElemSize() << "\n" << sp << "HIP ctx:   " << p->GetContext() << "\n"
+     << sp << "HIP ptr:   " << p->GpuMem() << "\n";
+  return ss.str();
+}
+std::string surface_repr(Surface* s) {
+  if (!s) return {};
+  std::stringstream ss;
+  if (s->Empty()) {
+    ss << "Empty surface\nFormat:           " << PixelFormatName(s->PixelFormat()) << "\n";
+    return ss.str();
+  }
+  ss << "Width:            " << s->Width() << "\nHeight:           " << s->Height()
+     << "\nFormat:           " << PixelFormatName(s->PixelFormat()) << "\nPitch:            " << s->Pitch()
+     << "\nElem size(bytes): " << s->ElemSize() << "\n";
+  for (uint32_t i = 0; i < s->NumPlanes() && s->GetSurfacePlane(i); i++) ss << "Plane " << i << "\n" << plane_repr(s->GetSurfacePlane(i), 2) << "\n";
+  return ss.str();
+}
+
+// deep copy src -> dst, plane by plane, then wait (PySurface.cpp:54-81)
+void copy_surface(Surface& src, Surface& dst, HipContext ctx, HipStream str) {
+  if (src.Empty() || dst.Empty()) return;
+  src.Export(dst, ctx, str, 0, 0, src.Width(), src.Height(), 0, 0);
+}
+void check_same(Surface& a, Surface& b) {
+  if (a.PixelFormat() != b.PixelFormat()) throw std::runtime_error("Surfaces have different pixel formats");
+  if (a.Width() != b.Width() || a.Height() != b.Height()) throw std::runtime_error("Surfaces have different size");
+}
+std::shared_ptr<Surface> make_surface(Pixel_Format f, uint32_t w, uint32_t h, HipContext ctx) {
+  Surface* s = Surface::Make(f, w, h, ctx);
+  if (!s) throw std::invalid_argument("Surface.Make: unsupported pixel format");
+  return std::shared_ptr<Surface>(s);
+}
+std::shared_ptr<Surface> empty_surface(Pixel_Format f) { return std::shared_ptr<Surface>(Surface::Make(f)); }
+
+// host-memory "device" allocator: lets CPU-only unit tests build Surfaces (geometry, dispatch, error paths)
+void* host_alloc(size_t n, int, void*) { return std::calloc(n ? n : 1, 1); }
+void host_free(void* p, int, void*) { std::free(p); }
+
+// ------------------------------------------------------------------------------------------------
+class PySurfaceConverter {
+  std::unique_ptr<ConvertSurface> conv_;
+  std::unique_ptr<Buffer> ctx_buf_;
+  Pixel_Format out_fmt_;
+
+public:
+  PySurfaceConverter(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str) : out_fmt_(out) {
+    conv_.reset(ConvertSurface::Make(w, h, in, out, ctx, str));
+    ctx_buf_.reset(Buffer::MakeOwnMem(sizeof(ColorspaceConversionContext)));
+  }
+  Pixel_Format GetFormat() const { return out_fmt_; }
+  // PySurfaceConverter.cpp:50-74: returns a NON-OWNING alias of the task's single output surface (overwritten by
+  // the next Execute); failure of any kind = an Empty() surface
+  std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src, std::shared_ptr<ColorspaceConversionContext> cc) {
+    if (!src) return empty_surface(out_fmt_);
+    conv_->ClearInputs();
+    conv_->SetInput(src.get(), 0U);
+    if (cc) {
+      ctx_buf_->CopyFrom(sizeof(ColorspaceConversionContext), cc.get());
+      conv_->SetInput(ctx_buf_.get(), 1U);
+    }
+    if (TASK_EXEC_SUCCESS != conv_->Execute()) return empty_surface(out_fmt_);
+    auto* out = static_cast<Surface*>(conv_->GetOutput(0U));
+    return std::shared_ptr<Surface>(out ? out->Clone() : Surface::Make(out_fmt_));
+  }
+  // additive: n surfaces in, n caller-owned surfaces out, one dispatch per 32 frames
+  bool ExecuteBatch(const std::vector<std::shared_ptr<Surface>>& src, const std::vector<std::shared_ptr<Surface>>& dst,
+                    std::shared_ptr<ColorspaceConversionContext> cc) {
+    if (src.size() != dst.size() || src.empty()) return false;
+    std::vector<Surface*> a, b;
+    for (auto& s : src) a.push_back(s.get());
+    for (auto& d : dst) b.push_back(d.get());
+    return TASK_EXEC_SUCCESS == conv_->RunBatch(a.data(), b.data(), (uint32_t)a.size(), cc.get());
+  }
+};
+
+class PySurfaceResizer {
+  std::unique_ptr<ResizeSurface> rs_;
+  Pixel_Format fmt_;
+
+public:
+  PySurfaceResizer(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) : fmt_(f) {
+    rs_.reset(ResizeSurface::Make(w, h, f, ctx, str));
+  }
+  Pixel_Format GetFormat() const { return fmt_; }
+  std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src) {
+    if (!src) return empty_surface(fmt_);
+    rs_->SetInput(src.get(), 0U);
+    if (TASK_EXEC_SUCCESS != rs_->Execute()) return empty_surface(fmt_);
+    auto* out = static_cast<Surface*>(rs_->GetOutput(0U));
+    return std::shared_ptr<Surface>(out ? out->Clone() : Surface::Make(fmt_));
+  }
+};
+
+class PySurfaceRemaper {
+  std::unique_ptr<RemapSurface> rm_;
+  Pixel_Format fmt_;
+
+public:
+  PySurfaceRemaper(py::array_t<float, py::array::c_style | py::array::forcecast>& x, py::array_t<float, py::array::c_style | py::array::forcecast>& y,
+                   Pixel_Format f, HipContext ctx, HipStream str)
+      : fmt_(f) {
+    if (x.ndim() != 2 || y.ndim() != 2 || x.shape(0) != y.shape(0) || x.shape(1) != y.shape(1))
+      throw std::runtime_error("x_map and y_map must be 2-D float32 arrays of the same shape");
+    rm_.reset(RemapSurface::Make(x.data(), y.data(), (uint32_t)x.shape(1), (uint32_t)x.shape(0), f, ctx, str));
+  }
+  Pixel_Format GetFormat() const { return fmt_; }
+  std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src) {
+    if (!src) return empty_surface(fmt_);
+    rm_->SetInput(src.get(), 0U);
+    if (TASK_EXEC_SUCCESS != rm_->Execute()) return empty_surface(fmt_);
+    auto* out = static_cast<Surface*>(rm_->GetOutput(0U));
+    return std::shared_ptr<Surface>(out ? out->Clone() : Surface::Make(fmt_));
+  }
+};
+
+class PyFrameUploader {
+  std::unique_ptr<CudaUploadFrame> up_;
+  Pixel_Format fmt_;
+
+public:
+  PyFrameUploader(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) : fmt_(f) {
+    up_.reset(CudaUploadFrame::Make(str, ctx, w, h, f));
+  }
+  Pixel_Format GetFormat() const { return fmt_; }
+  std::shared_ptr<Surface> Upload(void* data, size_t bytes) {
+    std::unique_ptr<Buffer> raw(Buffer::Make(bytes, data));
+    up_->SetInput(raw.get(), 0U);
+    const auto res = up_->Execute();
+    up_->ClearInputs();
+    auto* s = static_cast<Surface*>(up_->GetOutput(0U));
+    if (TASK_EXEC_FAIL == res || !s) throw std::runtime_error("Error uploading frame to GPU");
+    return std::shared_ptr<Surface>(s->Clone());
+  }
+};
+
+class PySurfaceDownloader {
+  std::unique_ptr<CudaDownloadSurface> dl_;
+  Pixel_Format fmt_;
+
+public:
+  PySurfaceDownloader(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) : fmt_(f) {
+    dl_.reset(CudaDownloadSurface::Make(str, ctx, w, h, f));
+  }
+  Pixel_Format GetFormat() const { return fmt_; }
+  template <typename T>
+  bool Download(std::shared_ptr<Surface> s, py::array_t<T>& frame) {
+    if (!s) return false;
+    Buffer* raw = nullptr;
+    {
+      py::gil_scoped_release nogil;
+      dl_->SetInput(s.get(), 0U);
+      if (TASK_EXEC_FAIL == dl_->Execute()) return false;
+      raw = static_cast<Buffer*>(dl_->GetOutput(0U));
+    }
+    if (!raw) return false;
+    const size_t bytes = s->HostMemSize();
+    if (bytes != (size_t)frame.size() * sizeof(T)) frame.resize({(py::ssize_t)(bytes / sizeof(T))}, false);
+    std::memcpy(frame.mutable_data(), raw->GetRawMemPtr(), bytes);
+    return true;
+  }
+};
+
+class PyBufferUploader {
+  std::unique_ptr<UploadBuffer> up_;
+
+public:
+  PyBufferUploader(uint32_t e, uint32_t n, HipContext ctx, HipStream str) { up_.reset(UploadBuffer::Make(str, ctx, e, n)); }
+  std::shared_ptr<CudaBuffer> Upload(py::array_t<uint8_t>& a) {
+    std::unique_ptr<Buffer> raw(Buffer::Make((size_t)a.size(), a.mutable_data()));
+    up_->SetInput(raw.get(), 0U);
+    const auto res = up_->Execute();
+    up_->ClearInputs();
+    auto* b = static_cast<CudaBuffer*>(up_->GetOutput(0U));
+    if (TASK_EXEC_FAIL == res || !b) throw std::runtime_error("Error uploading frame to GPU");
+    return std::shared_ptr<CudaBuffer>(b->Clone());
+  }
+};
+
+class PyCudaBufferDownloader {
+  std::unique_ptr<DownloadCudaBuffer> dl_;
+
+public:
+  PyCudaBufferDownloader(uint32_t e, uint32_t n, HipContext ctx, HipStream str) { dl_.reset(DownloadCudaBuffer::Make(str, ctx, e, n)); }
+  bool Download(std::shared_ptr<CudaBuffer> b, py::array_t<uint8_t>& a) {
+    if (!b) return false;
+    dl_->SetInput(b.get(), 0U);
+    if (TASK_EXEC_FAIL == dl_->Execute()) return false;
+    auto* raw = static_cast<Buffer*>(dl_->GetOutput(0U));
+    if (!raw) return false;
+    const size_t bytes = b->GetRawMemSize();
+    if (bytes != (size_t)a.size()) a.resize({(py::ssize_t)bytes}, false);
+    std::memcpy(a.mutable_data(), raw->GetRawMemPtr(), bytes);
+    return true;
+  }
+};
+}  // namespace
+
+PYBIND11_MODULE(_PyNvCodec, m) {
+  m.doc() = "MI355X-native surface conversion behind VPF's Python API (hand-written HIP kernels via libvpfhip)";
+
+  py::enum_<Pixel_Format>(m, "PixelFormat")
+      .value("Y", Y).value("RGB", RGB).value("NV12", NV12).value("YUV420", YUV420).value("RGB_PLANAR", RGB_PLANAR)
+      .value("BGR", BGR).value("YCBCR", YCBCR).value("YUV444", YUV444).value("YUV444_10bit", YUV444_10bit)
+      .value("YUV420_10bit", YUV420_10bit).value("UNDEFINED", UNDEFINED).value("RGB_32F", RGB_32F)
+      .value("RGB_32F_PLANAR", RGB_32F_PLANAR).value("YUV422", YUV422).value("P10", P10).value("P12", P12)
+      .export_values();
+  py::enum_<ColorSpace>(m, "ColorSpace").value("BT_601", BT_601).value("BT_709", BT_709).value("UNSPEC", UNSPEC).export_values();
+  py::enum_<ColorRange>(m, "ColorRange").value("MPEG", MPEG).value("JPEG", JPEG).value("UDEF", UDEF).export_values();
+
+  py::class_<ColorspaceConversionContext, std::shared_ptr<ColorspaceConversionContext>>(m, "ColorspaceConversionContext")
+      .def(py::init<>())
+      .def(py::init<ColorSpace, ColorRange>(), py::arg("color_space"), py::arg("color_range"))
+      .def_readwrite("color_space", &ColorspaceConversionContext::color_space)
+      .def_readwrite("color_range", &ColorspaceConversionContext::color_range);
+
+  py::class_<CudaBuffer, std::shared_ptr<CudaBuffer>>(m, "CudaBuffer")
+      .def("GetRawMemSize", &CudaBuffer::GetRawMemSize)
+      .def("GetNumElems", &CudaBuffer::GetNumElems)
+      .def("GetElemSize", &CudaBuffer::GetElemSize)
+      .def("GpuMem", &CudaBuffer::GpuMem)
+      .def("Clone", [](std::shared_ptr<CudaBuffer> self) { return std::shared_ptr<CudaBuffer>(self->Clone()); })
+      .def("CopyFrom",
+           [](std::shared_ptr<CudaBuffer> self, std::shared_ptr<CudaBuffer> other, size_t ctx, size_t str) {
+             if (self->GetRawMemSize() != other->GetRawMemSize()) throw std::runtime_error("Buffers have different size.");
+             std::unique_ptr<SurfacePlane> d(new SurfacePlane((uint32_t)self->GetRawMemSize(), 1, (uint32_t)self->GetRawMemSize(), 1, self->GpuMem()));
+             d->Import(other->GpuMem(), (uint32_t)other->GetRawMemSize(), (HipContext)ctx, (HipStream)str);
+           },
+           py::arg("other"), py::arg("context"), py::arg("stream"))
+      .def("CopyFrom",
+           [](std::shared_ptr<CudaBuffer> self, std::shared_ptr<CudaBuffer> other, int gpu) {
+             if (self->GetRawMemSize() != other->GetRawMemSize()) throw std::runtime_error("Buffers have different size.");
+             std::unique_ptr<SurfacePlane> d(new SurfacePlane((uint32_t)self->GetRawMemSize(), 1, (uint32_t)self->GetRawMemSize(), 1, self->GpuMem()));
+             d->Import(other->GpuMem(), (uint32_t)other->GetRawMemSize(), ctx_of(gpu), str_of(gpu));
+           },
+           py::arg("other"), py::arg("gpu_id"))
+      .def_static("Make", [](uint32_t e, uint32_t n, int gpu) { return std::shared_ptr<CudaBuffer>(CudaBuffer::Make(e, n, ctx_of(gpu))); },
+                  py::arg("elem_size"), py::arg("num_elems"), py::arg("gpu_id"));
+
+  py::class_<SurfacePlane, std::shared_ptr<SurfacePlane>>(m, "SurfacePlane")
+      .def("Width", &SurfacePlane::Width)
+      .def("Height", &SurfacePlane::Height)
+      .def("Pitch", &SurfacePlane::Pitch)
+      .def("GpuMem", &SurfacePlane::GpuMem)
+      .def("ElemSize", &SurfacePlane::ElemSize)
+      .def("HostFrameSize", &SurfacePlane::GetHostMemSize)
+      .def("Import", [](std::shared_ptr<SurfacePlane> self, size_t src, uint32_t pitch, int gpu) { self->Import((DevicePtr)src, pitch, ctx_of(gpu), str_of(gpu)); },
+           py::arg("src"), py::arg("src_pitch"), py::arg("gpu_id"))
+      .def("Import", [](std::shared_ptr<SurfacePlane> self, size_t src, uint32_t pitch, size_t ctx, size_t str) { self->Import((DevicePtr)src, pitch, (HipContext)ctx, (HipStream)str); },
+           py::arg("src"), py::arg("src_pitch"), py::arg("context"), py::arg("stream"))
+      .def("Export", [](std::shared_ptr<SurfacePlane> self, size_t dst, uint32_t pitch, int gpu) { self->Export((DevicePtr)dst, pitch, ctx_of(gpu), str_of(gpu)); },
+           py::arg("dst"), py::arg("dst_pitch"), py::arg("gpu_id"))
+      .def("Export", [](std::shared_ptr<SurfacePlane> self, size_t dst, uint32_t pitch, size_t ctx, size_t str) { self->Export((DevicePtr)dst, pitch, (HipContext)ctx, (HipStream)str); },
+           py::arg("dst"), py::arg("dst_pitch"), py::arg("context"), py::arg("stream"))
+      .def("__repr__", [](std::shared_ptr<SurfacePlane> self) { return plane_repr(self.get()); });
+
+  py::class_<Surface, std::shared_ptr<Surface>>(m, "Surface")
+      .def("Width", &Surface::Width, py::arg("plane") = 0U)
+      .def("Height", &Surface::Height, py::arg("plane") = 0U)
+      .def("Pitch", &Surface::Pitch, py::arg("plane") = 0U)
+      .def("Format", &Surface::PixelFormat)
+      .def("Empty", &Surface::Empty)
+      .def("NumPlanes", &Surface::NumPlanes)
+      .def("HostSize", &Surface::HostMemSize)
+      .def("OwnMemory", &Surface::OwnMemory)
+      .def_static("Make", [](Pixel_Format f, uint32_t w, uint32_t h, int gpu) { return make_surface(f, w, h, ctx_of(gpu)); },
+                  py::arg("format"), py::arg("width"), py::arg("height"), py::arg("gpu_id"))
+      .def_static("Make", [](Pixel_Format f, uint32_t w, uint32_t h, size_t ctx) { return make_surface(f, w, h, (HipContext)ctx); },
+                  py::arg("format"), py::arg("width"), py::arg("height"), py::arg("context"))
+      .def("PlanePtr",
+           [](std::shared_ptr<Surface> self, int plane) {
+             SurfacePlane* p = self->GetSurfacePlane((uint32_t)plane);
+             if (!p) throw std::invalid_argument("Invalid plane number");
+             return std::make_shared<SurfacePlane>(*p);  // non-owning copy
+           },
+           py::arg("plane") = 0U)
+      // NB: the reference's binding copies self -> other (PySurface.cpp:361,382), the opposite of the method's
+      // name; this one does what the name says: other -> self.
+      .def("CopyFrom",
+           [](std::shared_ptr<Surface> self, std::shared_ptr<Surface> other, int gpu) {
+             check_same(*self, *other);
+             copy_surface(*other, *self, ctx_of(gpu), str_of(gpu));
+           },
+           py::arg("other"), py::arg("gpu_id"))
+      .def("CopyFrom",
+           [](std::shared_ptr<Surface> self, std::shared_ptr<Surface> other, size_t ctx, size_t str) {
+             check_same(*self, *other);
+             copy_surface(*other, *self, (HipContext)ctx, (HipStream)str);
+           },
+           py::arg("other"), py::arg("context"), py::arg("stream"))
+      .def("Clone",
+           [](std::shared_ptr<Surface> self) {
+             auto n = make_surface(self->PixelFormat(), self->Width(), self->Height(), self->Context());
+             copy_surface(*self, *n, self->Context(), nullptr);
+             return n;
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("Clone",
+           [](std::shared_ptr<Surface> self, int gpu) {
+             auto n = make_surface(self->PixelFormat(), self->Width(), self->Height(), ctx_of(gpu));
+             copy_surface(*self, *n, ctx_of(gpu), str_of(gpu));
+             return n;
+           },
+           py::arg("gpu_id"), py::call_guard<py::gil_scoped_release>())
+      .def("Clone",
+           [](std::shared_ptr<Surface> self, size_t ctx, size_t str) {
+             auto n = make_surface(self->PixelFormat(), self->Width(), self->Height(), (HipContext)ctx);
+             copy_surface(*self, *n, (HipContext)ctx, (HipStream)str);
+             return n;
+           },
+           py::arg("context"), py::arg("stream"), py::call_guard<py::gil_scoped_release>())
+      .def("Crop",
+           [](std::shared_ptr<Surface> self, uint32_t x, uint32_t y, uint32_t w, uint32_t h, int gpu) {
+             auto n = make_surface(self->PixelFormat(), w, h, ctx_of(gpu));
+             self->Export(*n, ctx_of(gpu), str_of(gpu), x, y, w, h, 0U, 0U);
+             return n;
+           },
+           py::arg("x"), py::arg("y"), py::arg("w"), py::arg("h"), py::arg("gpu_id"), py::call_guard<py::gil_scoped_release>())
+      .def("Crop",
+           [](std::shared_ptr<Surface> self, uint32_t x, uint32_t y, uint32_t w, uint32_t h, size_t ctx, size_t str) {
+             auto n = make_surface(self->PixelFormat(), w, h, (HipContext)ctx);
+             self->Export(*n, (HipContext)ctx, (HipStream)str, x, y, w, h, 0U, 0U);
+             return n;
+           },
+           py::arg("x"), py::arg("y"), py::arg("w"), py::arg("h"), py::arg("context"), py::arg("stream"),
+           py::call_guard<py::gil_scoped_release>())
+      .def("__repr__", [](std::shared_ptr<Surface> self) { return surface_repr(self.get()); });
+
+  py::class_<PySurfaceConverter>(m, "PySurfaceConverter")
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, uint32_t gpu) {
+             return new PySurfaceConverter(w, h, in, out, ctx_of((int)gpu), str_of((int)gpu));
+           }),
+           py::arg("width"), py::arg("height"), py::arg("src_format"), py::arg("dst_format"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, size_t ctx, size_t str) {
+             return new PySurfaceConverter(w, h, in, out, (HipContext)ctx, (HipStream)str);
+           }),
+           py::arg("width"), py::arg("height"), py::arg("src_format"), py::arg("dst_format"), py::arg("context"), py::arg("stream"))
+      .def("Format", &PySurfaceConverter::GetFormat)
+      .def("Execute", &PySurfaceConverter::Execute, py::arg("src"), py::arg("cc_ctx") = nullptr,
+           py::call_guard<py::gil_scoped_release>())
+      .def("ExecuteBatch", &PySurfaceConverter::ExecuteBatch, py::arg("src"), py::arg("dst"), py::arg("cc_ctx") = nullptr,
+           py::call_guard<py::gil_scoped_release>());
+
+  py::class_<PySurfaceResizer>(m, "PySurfaceResizer")
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, uint32_t gpu) { return new PySurfaceResizer(w, h, f, ctx_of((int)gpu), str_of((int)gpu)); }),
+           py::arg("width"), py::arg("height"), py::arg("format"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceResizer(w, h, f, (HipContext)ctx, (HipStream)str); }),
+           py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
+      .def("Format", &PySurfaceResizer::GetFormat)
+      .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::call_guard<py::gil_scoped_release>());
+
+  using FMap = py::array_t<float, py::array::c_style | py::array::forcecast>;
+  py::class_<PySurfaceRemaper>(m, "PySurfaceRemaper")
+      .def(py::init([](FMap& x, FMap& y, Pixel_Format f, uint32_t gpu) { return new PySurfaceRemaper(x, y, f, ctx_of((int)gpu), str_of((int)gpu)); }),
+           py::arg("x_map"), py::arg("y_map"), py::arg("format"), py::arg("gpu_id"))
+      .def(py::init([](FMap& x, FMap& y, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceRemaper(x, y, f, (HipContext)ctx, (HipStream)str); }),
+           py::arg("x_map"), py::arg("y_map"), py::arg("format"), py::arg("context"), py::arg("stream"))
+      .def("Format", &PySurfaceRemaper::GetFormat)
+      .def("Execute", &PySurfaceRemaper::Execute, py::arg("src"), py::call_guard<py::gil_scoped_release>());
+
+  py::class_<PyFrameUploader>(m, "PyFrameUploader")
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, uint32_t gpu) { return new PyFrameUploader(w, h, f, ctx_of((int)gpu), str_of((int)gpu)); }),
+           py::arg("width"), py::arg("height"), py::arg("format"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PyFrameUploader(w, h, f, (HipContext)ctx, (HipStream)str); }),
+           py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
+      .def("Format", &PyFrameUploader::GetFormat)
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size()); },
+           py::arg("frame").noconvert(true))
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },
+           py::arg("frame").noconvert(true))
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint16_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(uint16_t)); },
+           py::arg("frame").noconvert(true));
+
+  py::class_<PySurfaceDownloader>(m, "PySurfaceDownloader")
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, uint32_t gpu) { return new PySurfaceDownloader(w, h, f, ctx_of((int)gpu), str_of((int)gpu)); }),
+           py::arg("width"), py::arg("height"), py::arg("format"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceDownloader(w, h, f, (HipContext)ctx, (HipStream)str); }),
+           py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
+      .def("Format", &PySurfaceDownloader::GetFormat)
+      .def("DownloadSingleSurface", &PySurfaceDownloader::Download<uint8_t>, py::arg("surface"), py::arg("frame").noconvert(true))
+      .def("DownloadSingleSurface", &PySurfaceDownloader::Download<float>, py::arg("surface"), py::arg("frame").noconvert(true))
+      .def("DownloadSingleSurface", &PySurfaceDownloader::Download<uint16_t>, py::arg("surface"), py::arg("frame").noconvert(true));
+
+  py::class_<PyBufferUploader>(m, "PyBufferUploader")
+      .def(py::init([](uint32_t e, uint32_t n, uint32_t gpu) { return new PyBufferUploader(e, n, ctx_of((int)gpu), str_of((int)gpu)); }),
+           py::arg("elem_size"), py::arg("num_elems"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t e, uint32_t n, size_t ctx, size_t str) { return new PyBufferUploader(e, n, (HipContext)ctx, (HipStream)str); }),
+           py::arg("elem_size"), py::arg("num_elems"), py::arg("context"), py::arg("stream"))
+      .def("UploadSingleBuffer", &PyBufferUploader::Upload, py::arg("array"));
+
+  py::class_<PyCudaBufferDownloader>(m, "PyCudaBufferDownloader")
+      .def(py::init([](uint32_t e, uint32_t n, uint32_t gpu) { return new PyCudaBufferDownloader(e, n, ctx_of((int)gpu), str_of((int)gpu)); }),
+           py::arg("elem_size"), py::arg("num_elems"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t e, uint32_t n, size_t ctx, size_t str) { return new PyCudaBufferDownloader(e, n, (HipContext)ctx, (HipStream)str); }),
+           py::arg("elem_size"), py::arg("num_elems"), py::arg("context"), py::arg("stream"))
+      .def("DownloadSingleCudaBuffer", &PyCudaBufferDownloader::Download, py::arg("buffer"), py::arg("array"));
+
+  m.def("GetNumGpus", []() { return (int)HipResMgr::Instance().GetNumGpus(); });
+  // --- additive helpers (not in the reference) ---
+  m.def("GetContext", [](int gpu) { return (size_t)ctx_of(gpu); }, py::arg("gpu_id"), "opaque context cookie of a GPU ordinal");
+  m.def("GetStream", [](int gpu) { return (size_t)str_of(gpu); }, py::arg("gpu_id"), "the per-GPU non-blocking hipStream_t used by the gpu_id overloads");
+  m.def("SetExtendedColorspaces", &SetExtendedColorspaces, py::arg("on"),
+        "also accept colour-space/range combinations the reference's converters reject although the kernels implement them");
+  m.def("ConverterPairSupport", &ConvertSurface::PairSupport, py::arg("src_format"), py::arg("dst_format"),
+        "1: pair exists in the reference's ConvertSurface, 2: additive pair, 0: unsupported");
+  m.def("KernelLibraryVersion", []() { return std::string(vpf_version()); });
+  m.def("_UseHostAllocator", [](bool on) {
+    static const DeviceAllocator host = {host_alloc, host_free, nullptr};
+    SetDeviceAllocator(on ? &host : nullptr);
+  }, py::arg("on"), "TEST HOOK: back Surfaces with host memory so geometry/dispatch can be unit-tested without a GPU");
+}

@@ -1,0 +1,504 @@
+// Tasks.cpp — see Tasks.hpp.  The reference's 24 NPP-backed *_Impl structs (src/TC/src/TasksColorCvt.cpp)
+// become ONE implementation driven by a pair table: the table restates, per (in,out) pair, the default
+// colour context and the combinations each reference impl accepts or rejects; the pixels come from
+// vpf_convert (libvpfhip).
+#include "Tasks.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "vpf_hip.h"
+
+namespace VPF {
+
+namespace {
+constexpr auto TASK_EXEC_SUCCESS = TaskExecStatus::TASK_EXEC_SUCCESS;
+constexpr auto TASK_EXEC_FAIL = TaskExecStatus::TASK_EXEC_FAIL;
+
+std::atomic<int> g_extended{-1};
+
+struct StreamRef {  // argument of the stream-sync callback (always non-null, also for the NULL stream)
+  HipContext ctx;
+  HipStream str;
+};
+void hip_stream_sync(void* p) {
+  auto* s = static_cast<StreamRef*>(p);
+  DeviceScope scope(s->ctx);
+  (void)hipStreamSynchronize((hipStream_t)s->str);
+}
+
+vpf_exec make_exec(HipContext ctx, HipStream str) {
+  vpf_exec e;
+  e.device = DeviceOfContext(ctx);
+  e.flags = 0;
+  e.stream = str;
+  return e;
+}
+void fill_planes(Surface* s, vpf_plane out[3]) {
+  std::memset(out, 0, 3 * sizeof(vpf_plane));
+  for (uint32_t p = 0; p < s->NumPlanes() && p < 3; p++) {
+    out[p].ptr = (void*)s->PlanePtr(p);
+    out[p].pitch = s->Pitch(p);
+  }
+}
+
+// How each reference impl turns the optional ColorspaceConversionContext into a matrix, and what it rejects.
+enum CtxRule {
+  RULE_NONE,         // context ignored (pure re-layout)
+  RULE_NV12_RGB,     // nv12_rgb / nv12_bgr        TasksColorCvt.cpp:67-100,136-169
+  RULE_RANGE_ONLY,   // nv12_yuv420                :218-232
+  RULE_YUV420_RGB,   // yuv420_rgb / yuv420_bgr    :329-361,390-422
+  RULE_601_BOTH,     // yuv444_bgr, bgr_yuv444     :452-483,634-665
+  RULE_601_JPEG,     // yuv444_rgb (+ rgb planar)  :514-543,574-605
+  RULE_RGB_YUV,      // rgb_yuv444, rgb_planar_yuv444, rgb_yuv420 :734-765,789-823,891-924
+  RULE_FIXED_MPEG,   // bgr_ycbcr                  :686-712 (context ignored, YCbCr model)
+};
+struct PairInfo {
+  Pixel_Format in, out;
+  CtxRule rule;
+  int level;  // 1 = pair exists in the reference ctor (:1313-1360), 2 = additive
+  const char* name;
+};
+const PairInfo kPairs[] = {
+    {NV12, YUV420, RULE_RANGE_ONLY, 1, "nv12_yuv420"},   {YUV420, NV12, RULE_NONE, 1, "yuv420_nv12"},
+    {P10, NV12, RULE_NONE, 1, "p16_nv12"},               {P12, NV12, RULE_NONE, 1, "p16_nv12"},
+    {NV12, RGB, RULE_NV12_RGB, 1, "nv12_rgb"},           {NV12, BGR, RULE_NV12_RGB, 1, "nv12_bgr"},
+    {RGB, RGB_PLANAR, RULE_NONE, 1, "rgb8_deinterleave"}, {RGB_PLANAR, RGB, RULE_NONE, 1, "rgb8_interleave"},
+    {RGB_PLANAR, YUV444, RULE_RGB_YUV, 1, "rgb_planar_yuv444"}, {Y, YUV444, RULE_NONE, 1, "y_yuv444"},
+    {YUV420, RGB, RULE_YUV420_RGB, 1, "yuv420_rgb"},     {RGB, YUV420, RULE_RGB_YUV, 1, "rgb_yuv420"},
+    {RGB, YUV444, RULE_RGB_YUV, 1, "rgb_yuv444"},        {BGR, YCBCR, RULE_FIXED_MPEG, 1, "bgr_ycbcr"},
+    {RGB, BGR, RULE_NONE, 1, "rgb_bgr"},                 {BGR, RGB, RULE_NONE, 1, "bgr_rgb"},
+    {YUV420, BGR, RULE_YUV420_RGB, 1, "yuv420_bgr"},     {YUV444, BGR, RULE_601_BOTH, 1, "yuv444_bgr"},
+    {YUV444, RGB, RULE_601_JPEG, 1, "yuv444_rgb"},       {BGR, YUV444, RULE_601_BOTH, 1, "bgr_yuv444"},
+    {NV12, Y, RULE_NONE, 1, "nv12_y"},                   {RGB, RGB_32F, RULE_NONE, 1, "rbg8_rgb32f"},
+    {RGB, Y, RULE_NONE, 1, "rbg8_y"},                    {RGB_32F, RGB_32F_PLANAR, RULE_NONE, 1, "rgb32f_deinterleave"},
+    // additive pairs (single-pass fusions and symmetric completions the kernels provide)
+    {NV12, RGB_PLANAR, RULE_NV12_RGB, 2, "nv12_rgb_planar"},      // = nv12_rgb + rgb8_deinterleave in one pass
+    {YUV420, RGB_PLANAR, RULE_YUV420_RGB, 2, "yuv420_rgb_planar"},
+    {YUV444, RGB_PLANAR, RULE_601_JPEG, 2, "yuv444_rgb_planar"},  // defined but never dispatched in the reference (:555-615)
+    {BGR, RGB_PLANAR, RULE_NONE, 2, "bgr8_deinterleave"},         {RGB_PLANAR, BGR, RULE_NONE, 2, "bgr8_interleave"},
+    {BGR, Y, RULE_NONE, 2, "bgr8_y"},                             {RGB_PLANAR, Y, RULE_NONE, 2, "rgb8_planar_y"},
+    {BGR, YUV420, RULE_RGB_YUV, 2, "bgr_yuv420"},                 {RGB_PLANAR, YUV420, RULE_RGB_YUV, 2, "rgb_planar_yuv420"},
+};
+const PairInfo* find_pair(Pixel_Format in, Pixel_Format out) {
+  for (const auto& p : kPairs)
+    if (p.in == in && p.out == out) return &p;
+  return nullptr;
+}
+
+// -> true and (cs, cr) to hand to vpf_convert, or false after printing the reference's diagnostic
+bool resolve_ctx(const PairInfo& pi, const ColorspaceConversionContext* c, int* cs, int* cr) {
+  const bool ext = ExtendedColorspaces();
+  auto unsupported_space = [&]() { std::cerr << pi.name << ": unsupported color space." << std::endl; return false; };
+  auto unsupported_range = [&]() { std::cerr << pi.name << ": unsupported color range." << std::endl; return false; };
+  switch (pi.rule) {
+    case RULE_NONE: *cs = VPF_BT_601; *cr = VPF_MPEG; return true;
+    case RULE_FIXED_MPEG: *cs = VPF_BT_601; *cr = VPF_MPEG; return true;
+    case RULE_RANGE_ONLY: {
+      const ColorRange r = c ? c->color_range : MPEG;
+      if (r != JPEG && r != MPEG) return unsupported_range();
+      *cs = VPF_BT_601; *cr = r; return true;
+    }
+    case RULE_NV12_RGB: {
+      const ColorRange r = c ? c->color_range : MPEG;
+      const ColorSpace s = c ? c->color_space : BT_601;
+      if (s == BT_709) { *cs = VPF_BT_709; *cr = (r == JPEG) ? VPF_JPEG : VPF_MPEG; return true; }
+      if (s == BT_601) {
+        if (r == JPEG) { *cs = VPF_BT_601; *cr = VPF_JPEG; return true; }
+        if (ext && r == MPEG) { *cs = VPF_BT_601; *cr = VPF_MPEG; return true; }
+        std::cerr << "Rec. 601 NV12 -> RGB MPEG range conversion isn't supported yet." << std::endl
+                  << "Convert NV12 -> YUV first and then do Rec. 601 YUV -> RGB MPEG range conversion." << std::endl;
+        return false;
+      }
+      return unsupported_space();
+    }
+    case RULE_YUV420_RGB: {
+      const ColorRange r = c ? c->color_range : MPEG;
+      const ColorSpace s = c ? c->color_space : BT_601;
+      if (s == BT_709) {
+        if (ext) { *cs = VPF_BT_709; *cr = (r == JPEG) ? VPF_JPEG : VPF_MPEG; return true; }
+        std::cerr << "Rec.709 YUV -> RGB conversion isn't supported yet." << std::endl;
+        return false;
+      }
+      if (s != BT_601) return unsupported_space();
+      *cs = VPF_BT_601; *cr = (r == JPEG) ? VPF_JPEG : VPF_MPEG; return true;
+    }
+    case RULE_601_BOTH: {
+      const ColorRange r = c ? c->color_range : MPEG;
+      const ColorSpace s = c ? c->color_space : BT_601;
+      if (s != BT_601 && !(ext && s == BT_709 && pi.in == YUV444)) return unsupported_space();
+      if (r != JPEG && r != MPEG) return unsupported_range();
+      *cs = s; *cr = r; return true;
+    }
+    case RULE_601_JPEG: {
+      const ColorRange r = c ? c->color_range : MPEG;
+      const ColorSpace s = c ? c->color_space : BT_601;
+      if (s != BT_601 && !(ext && s == BT_709)) return unsupported_space();
+      if (r != JPEG && !(ext && r == MPEG)) return unsupported_range();
+      *cs = s; *cr = r; return true;
+    }
+    case RULE_RGB_YUV: {
+      const ColorRange r = c ? c->color_range : JPEG;
+      const ColorSpace s = c ? c->color_space : BT_601;
+      if (s != BT_601) return unsupported_space();
+      if (r != JPEG && r != MPEG) return unsupported_range();
+      *cs = VPF_BT_601; *cr = r; return true;
+    }
+  }
+  return false;
+}
+}  // namespace
+
+void SetExtendedColorspaces(bool on) { g_extended.store(on ? 1 : 0); }
+bool ExtendedColorspaces() {
+  int v = g_extended.load();
+  if (v < 0) {
+    const char* e = std::getenv("VPF_HIP_EXTENDED");
+    v = (e && e[0] && e[0] != '0') ? 1 : 0;
+    g_extended.store(v);
+  }
+  return v == 1;
+}
+
+// ------------------------------------------------------------------------------------------ ConvertSurface
+struct ConvertSurface::Impl {
+  const PairInfo* pair;
+  uint32_t w, h;
+  HipContext ctx;
+  HipStream str;
+  std::unique_ptr<Surface> out;  // allocated once, reused by every Execute (reference: nv12_rgb ctor :114-118)
+};
+
+int ConvertSurface::PairSupport(Pixel_Format in, Pixel_Format out) {
+  const PairInfo* p = find_pair(in, out);
+  return p ? p->level : 0;
+}
+
+ConvertSurface::ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str)
+    : Task("HipConvertSurface", numInputs, numOutputs, nullptr, nullptr), pImpl(nullptr) {
+  const PairInfo* p = find_pair(in, out);
+  if (!p) {
+    std::stringstream ss;
+    ss << "Unsupported pixel format conversion: " << in << " to " << out;
+    throw std::invalid_argument(ss.str());
+  }
+  pImpl = new Impl{p, w, h, ctx, str, nullptr};
+  pImpl->out.reset(Surface::Make(out, w, h, ctx));
+}
+ConvertSurface::~ConvertSurface() { delete pImpl; }
+ConvertSurface* ConvertSurface::Make(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str) {
+  return new ConvertSurface(w, h, in, out, ctx, str);
+}
+
+TaskExecStatus ConvertSurface::Run() {
+  ClearOutputs();
+  auto* in = static_cast<Surface*>(GetInput(0));
+  const ColorspaceConversionContext* cc = nullptr;
+  if (auto* b = static_cast<Buffer*>(GetInput(1))) cc = b->GetDataAs<ColorspaceConversionContext>();
+  if (!in || in->Empty() || !pImpl->out || pImpl->out->Empty()) return TASK_EXEC_SUCCESS;  // null output = failure
+  if (in->PixelFormat() != pImpl->pair->in || in->Width() != pImpl->w || in->Height() != pImpl->h) {
+    std::cerr << pImpl->pair->name << ": input surface is " << PixelFormatName(in->PixelFormat()) << " " << in->Width()
+              << "x" << in->Height() << ", converter was built for " << PixelFormatName(pImpl->pair->in) << " "
+              << pImpl->w << "x" << pImpl->h << std::endl;
+    return TASK_EXEC_SUCCESS;
+  }
+  int cs, cr;
+  if (!resolve_ctx(*pImpl->pair, cc, &cs, &cr)) return TASK_EXEC_SUCCESS;
+  vpf_plane src[3], dst[3];
+  fill_planes(in, src);
+  fill_planes(pImpl->out.get(), dst);
+  const vpf_exec ex = make_exec(pImpl->ctx, pImpl->str);
+  const vpf_status st = vpf_convert(&ex, pImpl->pair->in, pImpl->pair->out, cs, cr, vpf_size{pImpl->w, pImpl->h}, src, dst);
+  if (st != VPF_OK) {
+    std::cerr << "Failed to convert surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_SUCCESS;
+  }
+  SetOutput(pImpl->out.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+TaskExecStatus ConvertSurface::RunBatch(Surface* const* ins, Surface* const* outs, uint32_t n, const ColorspaceConversionContext* cc) {
+  if (!ins || !outs || !n) return TASK_EXEC_FAIL;
+  int cs, cr;
+  if (!resolve_ctx(*pImpl->pair, cc, &cs, &cr)) return TASK_EXEC_FAIL;
+  std::vector<vpf_frame_io> io(n);
+  for (uint32_t i = 0; i < n; i++) {
+    Surface *s = ins[i], *d = outs[i];
+    if (!s || !d || s->Empty() || d->Empty() || s->PixelFormat() != pImpl->pair->in || d->PixelFormat() != pImpl->pair->out ||
+        s->Width() != pImpl->w || s->Height() != pImpl->h || d->Width() != pImpl->w || d->Height() != pImpl->h)
+      return TASK_EXEC_FAIL;
+    fill_planes(s, io[i].src);
+    fill_planes(d, io[i].dst);
+  }
+  const vpf_exec ex = make_exec(pImpl->ctx, pImpl->str);
+  const vpf_status st = vpf_convert_batch(&ex, pImpl->pair->in, pImpl->pair->out, cs, cr, vpf_size{pImpl->w, pImpl->h}, n, io.data());
+  if (st != VPF_OK) {
+    std::cerr << "Failed to convert surfaces. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
+  return TASK_EXEC_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------ ResizeSurface
+struct ResizeSurface::Impl {
+  Pixel_Format fmt;
+  uint32_t w, h;
+  StreamRef sref;
+  std::unique_ptr<Surface> out;
+};
+static bool resize_format_ok(Pixel_Format f) {
+  switch (f) {  // reference: packed 3C, planar (YUV420/YCBCR/YUV444/RGB_PLANAR), NV12; + Y (Tasks.cpp:1458-1476)
+    case RGB: case BGR: case YUV420: case YCBCR: case YUV444: case RGB_PLANAR: case NV12: case Y: return true;
+    default: return false;
+  }
+}
+ResizeSurface::ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str)
+    : Task("HipResizeSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(nullptr) {
+  if (!resize_format_ok(f)) {
+    std::stringstream ss;
+    ss << "pixel format not supported";
+    throw std::runtime_error(ss.str());
+  }
+  pImpl = new Impl{f, w, h, StreamRef{ctx, str}, nullptr};
+  pImpl->out.reset(Surface::Make(f, w, h, ctx));
+}
+ResizeSurface::~ResizeSurface() { delete pImpl; }
+ResizeSurface* ResizeSurface::Make(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
+  return new ResizeSurface(w, h, f, ctx, str);
+}
+TaskExecStatus ResizeSurface::Run() {
+  ClearOutputs();
+  auto* in = static_cast<Surface*>(GetInput(0));
+  if (!in || in->Empty() || !pImpl->out || pImpl->out->Empty()) return TASK_EXEC_FAIL;
+  if (in->PixelFormat() != pImpl->fmt) return TASK_EXEC_FAIL;  // Tasks.cpp:1166-1168
+  vpf_plane src[3], dst[3];
+  fill_planes(in, src);
+  fill_planes(pImpl->out.get(), dst);
+  const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
+  const vpf_status st = vpf_resize(&ex, pImpl->fmt, VPF_INTERP_LINEAR, vpf_size{in->Width(), in->Height()}, src,
+                                   vpf_size{pImpl->w, pImpl->h}, dst);
+  hip_stream_sync(&pImpl->sref);  // the reference task is blocking (cuda_stream_sync callback)
+  if (st != VPF_OK) {
+    std::cerr << "Failed to resize surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
+  SetOutput(pImpl->out.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------ RemapSurface
+struct RemapSurface::Impl {
+  Pixel_Format fmt;
+  uint32_t w, h;
+  StreamRef sref;
+  std::unique_ptr<CudaBuffer> xmap, ymap;
+  std::unique_ptr<Surface> out;
+};
+RemapSurface::RemapSurface(const float* x_map, const float* y_map, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str)
+    : Task("HipRemapSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(nullptr) {
+  if (f != RGB && f != BGR) throw std::runtime_error("pixel format not supported");  // Tasks.cpp:1615-1620
+  if (!x_map || !y_map || !w || !h) throw std::runtime_error("RemapSurface: empty map");
+  pImpl = new Impl{f, w, h, StreamRef{ctx, str}, nullptr, nullptr, nullptr};
+  // maps go to the device once, synchronously, as two tight float[h*w] buffers (Tasks.cpp:1523-1526)
+  pImpl->xmap.reset(CudaBuffer::Make(x_map, sizeof(float), (size_t)w * h, ctx, str));
+  pImpl->ymap.reset(CudaBuffer::Make(y_map, sizeof(float), (size_t)w * h, ctx, str));
+  pImpl->out.reset(Surface::Make(f, w, h, ctx));
+  // destination pixels whose source falls outside the image are left untouched: start from black, not garbage
+  DeviceScope scope(ctx);
+  (void)hipMemset((void*)pImpl->out->PlanePtr(0), 0, (size_t)pImpl->out->Pitch(0) * h);
+}
+RemapSurface::~RemapSurface() { delete pImpl; }
+RemapSurface* RemapSurface::Make(const float* x, const float* y, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
+  return new RemapSurface(x, y, w, h, f, ctx, str);
+}
+TaskExecStatus RemapSurface::Run() {
+  ClearOutputs();
+  auto* in = static_cast<Surface*>(GetInput(0));
+  if (!in || in->Empty() || in->PixelFormat() != pImpl->fmt) return TASK_EXEC_FAIL;
+  vpf_plane src[3], dst[3];
+  fill_planes(in, src);
+  fill_planes(pImpl->out.get(), dst);
+  const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
+  const vpf_status st = vpf_remap(&ex, pImpl->fmt, vpf_size{in->Width(), in->Height()}, src,
+                                  (const float*)pImpl->xmap->GpuMem(), pImpl->w * 4, (const float*)pImpl->ymap->GpuMem(),
+                                  pImpl->w * 4, vpf_size{pImpl->w, pImpl->h}, dst);
+  hip_stream_sync(&pImpl->sref);
+  if (st != VPF_OK) {
+    std::cerr << "Failed to remap surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
+  SetOutput(pImpl->out.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------ CudaUploadFrame
+// MI355X-first: the host frame is staged through PINNED memory and copied on a dedicated copy stream; the
+// task's stream only waits on the copy's event.  Two slots (pinned buffer + device surface each) let the upload of
+// frame i+1 overlap the kernels still converting frame i.  The reference copies straight from the (pageable)
+// numpy buffer on the task stream and blocks (src/TC/src/Tasks.cpp:625-662).
+struct CudaUploadFrame::Impl {
+  static constexpr int kSlots = 2;
+  StreamRef sref;
+  Pixel_Format fmt;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t done[kSlots] = {nullptr, nullptr};
+  std::unique_ptr<Buffer> staging[kSlots];
+  std::unique_ptr<Surface> surf[kSlots];
+  uint64_t n = 0;
+};
+CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f)
+    : Task("HipUploadFrame", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl) {
+  pImpl->sref = StreamRef{ctx, str};
+  pImpl->fmt = f;
+  DeviceScope scope(ctx);
+  for (int i = 0; i < Impl::kSlots; i++) {
+    pImpl->surf[i].reset(Surface::Make(f, w, h, ctx));
+    if (!pImpl->surf[i]) throw std::invalid_argument("CudaUploadFrame: unsupported pixel format");
+    pImpl->staging[i].reset(Buffer::MakeOwnMem(pImpl->surf[i]->HostMemSize(), ctx ? ctx : (HipContext)-1));
+    if (hipEventCreateWithFlags(&pImpl->done[i], hipEventDisableTiming) != hipSuccess) pImpl->done[i] = nullptr;
+  }
+  if (hipStreamCreateWithFlags(&pImpl->copy_stream, hipStreamNonBlocking) != hipSuccess) pImpl->copy_stream = nullptr;
+}
+CudaUploadFrame::~CudaUploadFrame() {
+  if (pImpl) {
+    DeviceScope scope(pImpl->sref.ctx);
+    if (pImpl->copy_stream) { (void)hipStreamSynchronize(pImpl->copy_stream); (void)hipStreamDestroy(pImpl->copy_stream); }
+    for (auto& e : pImpl->done)
+      if (e) (void)hipEventDestroy(e);
+  }
+  delete pImpl;
+}
+CudaUploadFrame* CudaUploadFrame::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
+  return new CudaUploadFrame(str, ctx, w, h, f);
+}
+TaskExecStatus CudaUploadFrame::Run() {
+  auto* host = static_cast<Buffer*>(GetInput(0));
+  if (!host) return TASK_EXEC_FAIL;
+  ClearOutputs();
+  const int slot = (int)(pImpl->n++ % Impl::kSlots);
+  Surface* s = pImpl->surf[slot].get();
+  Buffer* stage = pImpl->staging[slot].get();
+  if (!s || s->Empty() || host->GetRawMemSize() < s->HostMemSize()) return TASK_EXEC_FAIL;
+  DeviceScope scope(pImpl->sref.ctx);
+  hipStream_t cs = pImpl->copy_stream ? pImpl->copy_stream : (hipStream_t)pImpl->sref.str;
+  // the slot's previous copy must have drained before its pinned buffer is overwritten
+  if (pImpl->done[slot] && hipEventSynchronize(pImpl->done[slot]) != hipSuccess) return TASK_EXEC_FAIL;
+  std::memcpy(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
+  const uint8_t* src = stage->GetDataAs<uint8_t>();
+  for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // planes concatenated at tight width (Tasks.cpp:643-658)
+    const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
+    if (hipMemcpy2DAsync((void*)s->PlanePtr(p), s->Pitch(p), src, wb, wb, rows, hipMemcpyHostToDevice, cs) != hipSuccess)
+      return TASK_EXEC_FAIL;
+    src += wb * rows;
+  }
+  if (pImpl->done[slot] && cs != (hipStream_t)pImpl->sref.str) {
+    // order the task stream behind the copy, then block the HOST on the copy alone (the reference task is blocking,
+    // Tasks.cpp:617-618) — kernels still running on the task stream keep running underneath the next upload
+    if (hipEventRecord(pImpl->done[slot], cs) != hipSuccess) return TASK_EXEC_FAIL;
+    if (hipStreamWaitEvent((hipStream_t)pImpl->sref.str, pImpl->done[slot], 0) != hipSuccess) return TASK_EXEC_FAIL;
+    if (hipEventSynchronize(pImpl->done[slot]) != hipSuccess) return TASK_EXEC_FAIL;
+  } else {
+    hip_stream_sync(&pImpl->sref);
+  }
+  SetOutput(s, 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------ CudaDownloadSurface
+struct CudaDownloadSurface::Impl {
+  StreamRef sref;
+  Pixel_Format fmt;
+  uint32_t w, h;
+  std::unique_ptr<Buffer> host;  // pinned
+};
+CudaDownloadSurface::CudaDownloadSurface(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f)
+    : Task("HipDownloadSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(nullptr) {
+  if (!Surface::Supported(f)) {
+    std::stringstream ss;
+    ss << "CudaDownloadSurface: unsupported pixel format: " << f;
+    throw std::invalid_argument(ss.str());  // Tasks.cpp:759-762
+  }
+  pImpl = new Impl{StreamRef{ctx, str}, f, w, h, nullptr};
+  pImpl->host.reset(Buffer::MakeOwnMem(Surface::HostMemSizeOf(f, w, h), ctx ? ctx : (HipContext)-1));
+}
+CudaDownloadSurface::~CudaDownloadSurface() { delete pImpl; }
+CudaDownloadSurface* CudaDownloadSurface::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
+  return new CudaDownloadSurface(str, ctx, w, h, f);
+}
+TaskExecStatus CudaDownloadSurface::Run() {
+  auto* s = static_cast<Surface*>(GetInput(0));
+  if (!s) return TASK_EXEC_FAIL;
+  ClearOutputs();
+  if (s->Empty() || s->HostMemSize() > pImpl->host->GetRawMemSize()) return TASK_EXEC_FAIL;
+  DeviceScope scope(pImpl->sref.ctx);
+  uint8_t* dst = pImpl->host->GetDataAs<uint8_t>();
+  for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // Tasks.cpp:832-849
+    const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
+    if (hipMemcpy2DAsync(dst, wb, (const void*)s->PlanePtr(p), s->Pitch(p), wb, rows, hipMemcpyDeviceToHost,
+                         (hipStream_t)pImpl->sref.str) != hipSuccess)
+      return TASK_EXEC_FAIL;
+    dst += wb * rows;
+  }
+  hip_stream_sync(&pImpl->sref);
+  SetOutput(pImpl->host.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------ buffers
+struct UploadBuffer::Impl {
+  StreamRef sref;
+  std::unique_ptr<CudaBuffer> buf;
+};
+UploadBuffer::UploadBuffer(HipStream str, HipContext ctx, uint32_t e, uint32_t n)
+    : Task("HipUploadBuffer", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl{StreamRef{ctx, str}, nullptr}) {
+  pImpl->buf.reset(CudaBuffer::Make(e, n, ctx));
+}
+UploadBuffer::~UploadBuffer() { delete pImpl; }
+UploadBuffer* UploadBuffer::Make(HipStream str, HipContext ctx, uint32_t e, uint32_t n) { return new UploadBuffer(str, ctx, e, n); }
+TaskExecStatus UploadBuffer::Run() {
+  auto* host = static_cast<Buffer*>(GetInput(0));
+  if (!host) return TASK_EXEC_FAIL;
+  ClearOutputs();
+  if (host->GetRawMemSize() < pImpl->buf->GetRawMemSize()) return TASK_EXEC_FAIL;
+  DeviceScope scope(pImpl->sref.ctx);
+  if (hipMemcpyAsync((void*)pImpl->buf->GpuMem(), host->GetRawMemPtr(), pImpl->buf->GetRawMemSize(), hipMemcpyHostToDevice,
+                     (hipStream_t)pImpl->sref.str) != hipSuccess)
+    return TASK_EXEC_FAIL;
+  hip_stream_sync(&pImpl->sref);
+  SetOutput(pImpl->buf.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+struct DownloadCudaBuffer::Impl {
+  StreamRef sref;
+  std::unique_ptr<Buffer> host;
+};
+DownloadCudaBuffer::DownloadCudaBuffer(HipStream str, HipContext ctx, uint32_t e, uint32_t n)
+    : Task("HipDownloadBuffer", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl{StreamRef{ctx, str}, nullptr}) {
+  pImpl->host.reset(Buffer::MakeOwnMem((size_t)e * n, ctx ? ctx : (HipContext)-1));
+}
+DownloadCudaBuffer::~DownloadCudaBuffer() { delete pImpl; }
+DownloadCudaBuffer* DownloadCudaBuffer::Make(HipStream str, HipContext ctx, uint32_t e, uint32_t n) { return new DownloadCudaBuffer(str, ctx, e, n); }
+TaskExecStatus DownloadCudaBuffer::Run() {
+  auto* b = static_cast<CudaBuffer*>(GetInput(0));
+  if (!b) return TASK_EXEC_FAIL;
+  ClearOutputs();
+  if (b->GetRawMemSize() > pImpl->host->GetRawMemSize()) return TASK_EXEC_FAIL;
+  DeviceScope scope(pImpl->sref.ctx);
+  if (hipMemcpyAsync(pImpl->host->GetRawMemPtr(), (const void*)b->GpuMem(), b->GetRawMemSize(), hipMemcpyDeviceToHost,
+                     (hipStream_t)pImpl->sref.str) != hipSuccess)
+    return TASK_EXEC_FAIL;
+  hip_stream_sync(&pImpl->sref);
+  SetOutput(pImpl->host.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+}  // namespace VPF

@@ -1,0 +1,120 @@
+// Tasks.hpp — the Task layer of the surface path: ConvertSurface, ResizeSurface, RemapSurface and the
+// upload / download tasks either side of it.  Class surface of the reference's src/TC/inc/Tasks.hpp
+// (:267-338 for the three hot tasks; CudaUploadFrame / CudaDownloadSurface / UploadBuffer /
+// DownloadCudaBuffer :100-200), with (HipContext, HipStream) where the reference has (CUcontext, CUstream).
+// Every pixel is produced by libvpfhip (include/vpf_hip.h); there is no CPU path.
+#pragma once
+#include "MemoryInterfaces.hpp"
+
+namespace VPF {
+
+class ConvertSurface final : public Task {
+public:
+  // throws std::invalid_argument for an unsupported (inFormat, outFormat) pair, like the reference
+  static ConvertSurface* Make(uint32_t width, uint32_t height, Pixel_Format inFormat, Pixel_Format outFormat,
+                              HipContext ctx, HipStream str);
+  ~ConvertSurface() override;
+  // input 0: Surface, input 1: Buffer holding a ColorspaceConversionContext (optional).  Asynchronous on the
+  // task's stream.  Always returns TASK_EXEC_SUCCESS; failure = null output (TasksColorCvt.cpp:1378-1391).
+  TaskExecStatus Run() final;
+  // Additive: convert n same-shape surfaces into n caller-provided surfaces with as few dispatches as possible.
+  TaskExecStatus RunBatch(Surface* const* inputs, Surface* const* outputs, uint32_t n, const ColorspaceConversionContext* ctx);
+  // 1 if the reference's ConvertSurface ctor accepts the pair (TasksColorCvt.cpp:1313-1360), 2 if it is one of
+  // our additive pairs (e.g. the fused NV12 -> RGB_PLANAR), 0 otherwise
+  static int PairSupport(Pixel_Format inFormat, Pixel_Format outFormat);
+
+private:
+  static const uint32_t numInputs = 2U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str);
+};
+
+class ResizeSurface final : public Task {
+public:
+  static ResizeSurface* Make(uint32_t width, uint32_t height, Pixel_Format format, HipContext ctx, HipStream str);
+  ~ResizeSurface() override;
+  TaskExecStatus Run() final;  // blocking: the task registers a stream-sync callback (Tasks.cpp:1455-1456)
+
+private:
+  static const uint32_t numInputs = 1U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str);
+};
+
+class RemapSurface final : public Task {
+public:
+  static RemapSurface* Make(const float* x_map, const float* y_map, uint32_t remap_w, uint32_t remap_h,
+                            Pixel_Format format, HipContext ctx, HipStream str);
+  ~RemapSurface() override;
+  TaskExecStatus Run() final;
+
+private:
+  static const uint32_t numInputs = 1U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  RemapSurface(const float* x_map, const float* y_map, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str);
+};
+
+// host frame (planes concatenated at tight width) -> device Surface
+class CudaUploadFrame final : public Task {
+public:
+  static CudaUploadFrame* Make(HipStream str, HipContext ctx, uint32_t width, uint32_t height, Pixel_Format format);
+  ~CudaUploadFrame() override;
+  TaskExecStatus Run() final;
+
+private:
+  static const uint32_t numInputs = 1U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f);
+};
+
+// device Surface -> pinned host Buffer (planes concatenated at tight width)
+class CudaDownloadSurface final : public Task {
+public:
+  static CudaDownloadSurface* Make(HipStream str, HipContext ctx, uint32_t width, uint32_t height, Pixel_Format format);
+  ~CudaDownloadSurface() override;
+  TaskExecStatus Run() final;
+
+private:
+  static const uint32_t numInputs = 1U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  CudaDownloadSurface(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f);
+};
+
+class UploadBuffer final : public Task {
+public:
+  static UploadBuffer* Make(HipStream str, HipContext ctx, uint32_t elem_size, uint32_t num_elems);
+  ~UploadBuffer() override;
+  TaskExecStatus Run() final;
+
+private:
+  static const uint32_t numInputs = 1U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  UploadBuffer(HipStream str, HipContext ctx, uint32_t elem_size, uint32_t num_elems);
+};
+
+class DownloadCudaBuffer final : public Task {
+public:
+  static DownloadCudaBuffer* Make(HipStream str, HipContext ctx, uint32_t elem_size, uint32_t num_elems);
+  ~DownloadCudaBuffer() override;
+  TaskExecStatus Run() final;
+
+private:
+  static const uint32_t numInputs = 1U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  DownloadCudaBuffer(HipStream str, HipContext ctx, uint32_t elem_size, uint32_t num_elems);
+};
+
+// When true (default false, or env VPF_HIP_EXTENDED=1) ConvertSurface also accepts the colour-space /
+// range combinations the reference's *_Impl::Execute reject although the kernels implement them
+// (e.g. BT.601 + MPEG straight from NV12, BT.709 from YUV420).
+void SetExtendedColorspaces(bool on);
+bool ExtendedColorspaces();
+
+}  // namespace VPF
