@@ -373,7 +373,8 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            }),
            py::arg("width"), py::arg("height"), py::arg("src_format"), py::arg("dst_format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceConverter::GetFormat)
-      .def("Execute", &PySurfaceConverter::Execute, py::arg("src"), py::arg("cc_ctx") = nullptr,
+      // the returned Surface aliases memory owned by the converter: keep the converter alive as long as it lives
+      .def("Execute", &PySurfaceConverter::Execute, py::arg("src"), py::arg("cc_ctx") = nullptr, py::keep_alive<0, 1>(),
            py::call_guard<py::gil_scoped_release>())
       .def("ExecuteBatch", &PySurfaceConverter::ExecuteBatch, py::arg("src"), py::arg("dst"), py::arg("cc_ctx") = nullptr,
            py::call_guard<py::gil_scoped_release>());
@@ -384,7 +385,7 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceResizer(w, h, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceResizer::GetFormat)
-      .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::call_guard<py::gil_scoped_release>());
+      .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>());
 
   using FMap = py::array_t<float, py::array::c_style | py::array::forcecast>;
   py::class_<PySurfaceRemaper>(m, "PySurfaceRemaper")
@@ -393,7 +394,7 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](FMap& x, FMap& y, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceRemaper(x, y, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("x_map"), py::arg("y_map"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceRemaper::GetFormat)
-      .def("Execute", &PySurfaceRemaper::Execute, py::arg("src"), py::call_guard<py::gil_scoped_release>());
+      .def("Execute", &PySurfaceRemaper::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>());
 
   py::class_<PyFrameUploader>(m, "PyFrameUploader")
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, uint32_t gpu) { return new PyFrameUploader(w, h, f, ctx_of((int)gpu), str_of((int)gpu)); }),
@@ -402,11 +403,11 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PyFrameUploader::GetFormat)
       .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size()); },
-           py::arg("frame").noconvert(true))
+           py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
       .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },
-           py::arg("frame").noconvert(true))
+           py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
       .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint16_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(uint16_t)); },
-           py::arg("frame").noconvert(true));
+           py::arg("frame").noconvert(true), py::keep_alive<0, 1>());
 
   py::class_<PySurfaceDownloader>(m, "PySurfaceDownloader")
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, uint32_t gpu) { return new PySurfaceDownloader(w, h, f, ctx_of((int)gpu), str_of((int)gpu)); }),

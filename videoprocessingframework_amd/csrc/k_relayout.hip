@@ -171,7 +171,7 @@ static bool al(const BatchArgs& a, uint32_t n, int ns, int nd, uint32_t s0, uint
 template <int OP>
 static hipError_t go_generic(hipStream_t st, uint32_t w, uint32_t h, uint32_t n, const BatchArgs& a) {
   dim3 grid((w + 63) / 64, (h + 3) / 4, n);
-  hipLaunchKernelGGL((k_relayout_generic<OP>), grid, dim3(256), 0, st, a, w, h);
+  VPF_LAUNCH((k_relayout_generic<OP>), grid, dim3(256), 0, st, a, w, h);
   return hipGetLastError();
 }
 
@@ -180,7 +180,7 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if (sf == VPF_FMT_NV12 && df == VPF_FMT_YUV420) {
     if (!force_generic && w % 16 == 0 && h % 2 == 0 && al(a, n, 2, 3, 16, 16, 16, 8)) {
       dim3 grid((w / 16 + 63) / 64, (h / 2 + 3) / 4, n);
-      hipLaunchKernelGGL((k_nv12_yuv420_p16<true>), grid, dim3(256), 0, st, a, w, h, w / 16);
+      VPF_LAUNCH((k_nv12_yuv420_p16<true>), grid, dim3(256), 0, st, a, w, h, w / 16);
       return hipGetLastError();
     }
     return go_generic<OP_NV12_YUV420>(st, w, h, n, a);
@@ -188,7 +188,7 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if (sf == VPF_FMT_YUV420 && df == VPF_FMT_NV12) {
     if (!force_generic && w % 16 == 0 && h % 2 == 0 && al(a, n, 3, 2, 16, 8, 16, 16)) {
       dim3 grid((w / 16 + 63) / 64, (h / 2 + 3) / 4, n);
-      hipLaunchKernelGGL((k_nv12_yuv420_p16<false>), grid, dim3(256), 0, st, a, w, h, w / 16);
+      VPF_LAUNCH((k_nv12_yuv420_p16<false>), grid, dim3(256), 0, st, a, w, h, w / 16);
       return hipGetLastError();
     }
     return go_generic<OP_YUV420_NV12>(st, w, h, n, a);
@@ -201,7 +201,7 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
       for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].d[0], b.f[i].d[2]); std::swap(b.f[i].dp[0], b.f[i].dp[2]); }
     if (!force_generic && w % 4 == 0 && al(b, n, 1, 3, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
-      hipLaunchKernelGGL((k_rgb_relayout_p4<0>), grid, dim3(256), 0, st, b, w, h, w / 4);
+      VPF_LAUNCH((k_rgb_relayout_p4<0>), grid, dim3(256), 0, st, b, w, h, w / 4);
       return hipGetLastError();
     }
     return go_generic<OP_RGB_PLANAR>(st, w, h, n, b);
@@ -212,7 +212,7 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
       for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].s[0], b.f[i].s[2]); std::swap(b.f[i].sp[0], b.f[i].sp[2]); }
     if (!force_generic && w % 4 == 0 && al(b, n, 3, 1, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
-      hipLaunchKernelGGL((k_rgb_relayout_p4<1>), grid, dim3(256), 0, st, b, w, h, w / 4);
+      VPF_LAUNCH((k_rgb_relayout_p4<1>), grid, dim3(256), 0, st, b, w, h, w / 4);
       return hipGetLastError();
     }
     return go_generic<OP_PLANAR_RGB>(st, w, h, n, b);
@@ -220,7 +220,7 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if (packed_s && packed_d && sf != df) {
     if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
-      hipLaunchKernelGGL((k_rgb_relayout_p4<2>), grid, dim3(256), 0, st, a, w, h, w / 4);
+      VPF_LAUNCH((k_rgb_relayout_p4<2>), grid, dim3(256), 0, st, a, w, h, w / 4);
       return hipGetLastError();
     }
     return go_generic<OP_SWAP_RB>(st, w, h, n, a);

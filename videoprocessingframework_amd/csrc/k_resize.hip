@@ -83,7 +83,7 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
-#define VPF_GO(C, I) hipLaunchKernelGGL((k_resize<C, I>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok)
+#define VPF_GO(C, I) VPF_LAUNCH((k_resize<C, I>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok)
   if (interp == VPF_INTERP_LINEAR) {
     if (ch == 1) VPF_GO(1, VPF_INTERP_LINEAR); else if (ch == 2) VPF_GO(2, VPF_INTERP_LINEAR); else VPF_GO(3, VPF_INTERP_LINEAR);
   } else {
@@ -120,7 +120,7 @@ hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t*
                         uint32_t xp, const float* ymap, uint32_t yp, uint32_t dw, uint32_t dh, uint8_t* dst,
                         uint32_t dp) {
   dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-  hipLaunchKernelGGL(k_remap3, grid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh);
+  VPF_LAUNCH(k_remap3, grid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh);
   return hipGetLastError();
 }
 
@@ -195,7 +195,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
   int vec_ok = 1;
   for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) vec_ok &= ((((uintptr_t)f.d[k] | f.dp[k]) & 3) == 0);
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
-#define VPF_GO(S, D) hipLaunchKernelGGL((k_convert_resize<S, D>), grid, dim3(256), 0, st, f, c, sw, sh, dw, dh, scx, scy, vec_ok)
+#define VPF_GO(S, D) VPF_LAUNCH((k_convert_resize<S, D>), grid, dim3(256), 0, st, f, c, sw, sh, dw, dh, scx, scy, vec_ok)
   if (src_fc == FC_NV12) {
     if (dst_fc == FC_RGB) VPF_GO(FC_NV12, FC_RGB); else if (dst_fc == FC_BGR) VPF_GO(FC_NV12, FC_BGR); else VPF_GO(FC_NV12, FC_PLANAR);
   } else if (src_fc == FC_YUV420) {

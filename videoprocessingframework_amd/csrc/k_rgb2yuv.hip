@@ -57,8 +57,8 @@ hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc, const Rgb2Y
   dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
   const bool sub = (dst_fc == FC_YUV420);
 #define VPF_GO(S)                                                                                            \
-  if (sub) hipLaunchKernelGGL((k_rgb_yuv_quad<S, true>), grid, dim3(256), 0, st, a, c, w, h);                 \
-  else hipLaunchKernelGGL((k_rgb_yuv_quad<S, false>), grid, dim3(256), 0, st, a, c, w, h);                    \
+  if (sub) VPF_LAUNCH((k_rgb_yuv_quad<S, true>), grid, dim3(256), 0, st, a, c, w, h);                 \
+  else VPF_LAUNCH((k_rgb_yuv_quad<S, false>), grid, dim3(256), 0, st, a, c, w, h);                    \
   return hipGetLastError();
   switch (src_fc) {
     case FC_RGB: VPF_GO(FC_RGB)

@@ -305,7 +305,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
       dim3 grid((tasks + 3) / 4, n);
 #define VPF_P16(NTL, NTS, LDS, NOMATH) \
-  hipLaunchKernelGGL((k_nv12_rgb_p16<DST, 1, NTL, NTS, LDS, NOMATH>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks)
+  VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, NTL, NTS, LDS, NOMATH>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks)
       switch (variant) {
         case 7: VPF_P16(false, false, true, false); break;
         case 11: VPF_P16(false, true, true, false); break;
@@ -323,7 +323,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
     auto go = [&](auto kern, int rp) {
       const uint32_t tasks = chunks * ((h / 2 + rp - 1) / rp);
       dim3 grid((tasks + 3) / 4, n);
-      hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      VPF_LAUNCH(kern, grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
       return hipGetLastError();
     };
     switch (variant) {
@@ -339,7 +339,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
     }
   }
   dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
-  hipLaunchKernelGGL((k_yuv_rgb_generic<SRC, DST>), grid, dim3(256), 0, st, a, c, w, h);
+  VPF_LAUNCH((k_yuv_rgb_generic<SRC, DST>), grid, dim3(256), 0, st, a, c, w, h);
   return hipGetLastError();
 }
 
@@ -349,11 +349,11 @@ static hipError_t launch_444(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   const int ndst = (DST == FC_PLANAR) ? 3 : 1;
   if (variant != 9 && w % 4 == 0 && aligned_all(a, n, 3, ndst, 4, 4, 4) && h <= 65535) {
     dim3 grid((w / 4 + 255) / 256, h, n);
-    hipLaunchKernelGGL((k_yuv444_rgb_p4<DST, 1>), grid, dim3(256), 0, st, a, c, w, h, w / 4);
+    VPF_LAUNCH((k_yuv444_rgb_p4<DST, 1>), grid, dim3(256), 0, st, a, c, w, h, w / 4);
     return hipGetLastError();
   }
   dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
-  hipLaunchKernelGGL((k_yuv_rgb_generic<FC_YUV444, DST>), grid, dim3(256), 0, st, a, c, w, h);
+  VPF_LAUNCH((k_yuv_rgb_generic<FC_YUV444, DST>), grid, dim3(256), 0, st, a, c, w, h);
   return hipGetLastError();
 }
 

@@ -35,6 +35,13 @@ void hip_stream_sync(void* p) {
   (void)hipStreamSynchronize((hipStream_t)s->str);
 }
 
+// every HIP failure is reported on stderr (the reference prints its CUDA/NPP error codes the same way)
+bool hip_ok(hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  std::cerr << what << " failed: " << hipGetErrorName(e) << " (" << hipGetErrorString(e) << ")" << std::endl;
+  return false;
+}
+
 vpf_exec make_exec(HipContext ctx, HipStream str) {
   vpf_exec e;
   e.device = DeviceOfContext(ctx);
@@ -390,21 +397,21 @@ TaskExecStatus CudaUploadFrame::Run() {
   DeviceScope scope(pImpl->sref.ctx);
   hipStream_t cs = pImpl->copy_stream ? pImpl->copy_stream : (hipStream_t)pImpl->sref.str;
   // the slot's previous copy must have drained before its pinned buffer is overwritten
-  if (pImpl->done[slot] && hipEventSynchronize(pImpl->done[slot]) != hipSuccess) return TASK_EXEC_FAIL;
+  if (pImpl->done[slot] && !hip_ok(hipEventSynchronize(pImpl->done[slot]), "CudaUploadFrame: hipEventSynchronize")) return TASK_EXEC_FAIL;
   std::memcpy(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
   const uint8_t* src = stage->GetDataAs<uint8_t>();
   for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // planes concatenated at tight width (Tasks.cpp:643-658)
     const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
-    if (hipMemcpy2DAsync((void*)s->PlanePtr(p), s->Pitch(p), src, wb, wb, rows, hipMemcpyHostToDevice, cs) != hipSuccess)
+    if (!hip_ok(hipMemcpy2DAsync((void*)s->PlanePtr(p), s->Pitch(p), src, wb, wb, rows, hipMemcpyHostToDevice, cs), "CudaUploadFrame: hipMemcpy2DAsync"))
       return TASK_EXEC_FAIL;
     src += wb * rows;
   }
   if (pImpl->done[slot] && cs != (hipStream_t)pImpl->sref.str) {
     // order the task stream behind the copy, then block the HOST on the copy alone (the reference task is blocking,
     // Tasks.cpp:617-618) — kernels still running on the task stream keep running underneath the next upload
-    if (hipEventRecord(pImpl->done[slot], cs) != hipSuccess) return TASK_EXEC_FAIL;
-    if (hipStreamWaitEvent((hipStream_t)pImpl->sref.str, pImpl->done[slot], 0) != hipSuccess) return TASK_EXEC_FAIL;
-    if (hipEventSynchronize(pImpl->done[slot]) != hipSuccess) return TASK_EXEC_FAIL;
+    if (!hip_ok(hipEventRecord(pImpl->done[slot], cs), "CudaUploadFrame: hipEventRecord")) return TASK_EXEC_FAIL;
+    if (!hip_ok(hipStreamWaitEvent((hipStream_t)pImpl->sref.str, pImpl->done[slot], 0), "CudaUploadFrame: hipStreamWaitEvent")) return TASK_EXEC_FAIL;
+    if (!hip_ok(hipEventSynchronize(pImpl->done[slot]), "CudaUploadFrame: hipEventSynchronize")) return TASK_EXEC_FAIL;
   } else {
     hip_stream_sync(&pImpl->sref);
   }
@@ -437,14 +444,21 @@ TaskExecStatus CudaDownloadSurface::Run() {
   auto* s = static_cast<Surface*>(GetInput(0));
   if (!s) return TASK_EXEC_FAIL;
   ClearOutputs();
-  if (s->Empty() || s->HostMemSize() > pImpl->host->GetRawMemSize()) return TASK_EXEC_FAIL;
+  if (s->Empty() || s->HostMemSize() > pImpl->host->GetRawMemSize()) {
+    std::cerr << "CudaDownloadSurface: surface is empty or larger (" << s->HostMemSize() << " B) than the downloader was built for ("
+              << pImpl->host->GetRawMemSize() << " B)" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
   DeviceScope scope(pImpl->sref.ctx);
   uint8_t* dst = pImpl->host->GetDataAs<uint8_t>();
   for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // Tasks.cpp:832-849
     const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
-    if (hipMemcpy2DAsync(dst, wb, (const void*)s->PlanePtr(p), s->Pitch(p), wb, rows, hipMemcpyDeviceToHost,
-                         (hipStream_t)pImpl->sref.str) != hipSuccess)
+    if (!hip_ok(hipMemcpy2DAsync(dst, wb, (const void*)s->PlanePtr(p), s->Pitch(p), wb, rows, hipMemcpyDeviceToHost,
+                                 (hipStream_t)pImpl->sref.str), "CudaDownloadSurface: hipMemcpy2DAsync")) {
+      std::cerr << "  plane " << p << " dst " << (void*)dst << " dpitch " << wb << " src " << (void*)s->PlanePtr(p) << " spitch " << s->Pitch(p)
+                << " width " << wb << " rows " << rows << " host size " << pImpl->host->GetRawMemSize() << " pinned " << pImpl->host->Pinned() << std::endl;
       return TASK_EXEC_FAIL;
+    }
     dst += wb * rows;
   }
   hip_stream_sync(&pImpl->sref);

@@ -1,6 +1,8 @@
 // vpf_abi.hip — the C ABI of libvpfhip (include/vpf_hip.h): argument validation, format dispatch,
 // kernarg packing.  No CPU fallback of any kind: every success path ends in a HIP kernel launch.
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "vpf_internal.h"
@@ -151,6 +153,7 @@ static void fill_desc(FrameDesc& d, const vpf_plane* s, int ns, const vpf_plane*
 
 static vpf_status status_of(hipError_t e) {
   if (e == hipSuccess) return VPF_OK;
+  if (std::getenv("VPF_HIP_LOG")) std::fprintf(stderr, "libvpfhip: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return VPF_ERR_NO_DEVICE;
   return VPF_ERR_LAUNCH;
 }

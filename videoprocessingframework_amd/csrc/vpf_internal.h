@@ -63,4 +63,12 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 
 int tuning(int key);
 
+// hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a caller's bad memcpy) would be
+// reported by the check that follows a launch.  Clear it first so the check sees this launch only.
+#define VPF_LAUNCH(...)          \
+  do {                           \
+    (void)hipGetLastError();     \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 }  // namespace vpf
