@@ -33,7 +33,12 @@ int vpfo_set_threads(int n) {
 }
 const char* vpfo_version(void) { return "vpf-oracle 1 (parity unpinned: NPP closed source)"; }
 
-#define VPFO_MULTIVERSION __attribute__((target_clones("default", "arch=haswell")))
+/* Hot loops are instantiated twice from one body: baseline x86-64 (fmaf = libm call, correct everywhere) and
+ * AVX2+FMA (vectorised vfmadd), chosen at run time by CPU FEATURE.  (target_clones("arch=haswell") would dispatch
+ * on the CPU *model* and never fire on EPYC / newer Xeons.)  Results are bit-identical: fmaf is exact either way. */
+#define VPFO_MULTIVERSION
+#define VPFO_TARGET_AVX2 __attribute__((target("avx2,fma")))
+static int has_avx2_fma(void) { return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"); }
 
 /* ------------------------------------------------------------------------------------------
  * YUV -> RGB matrices.  Decimal coefficients x 1e6, exactly as printed in SURVEY.md §8c:
@@ -322,27 +327,60 @@ static void yuv_to_rgb(int mode, int sf, int df, const yuv2rgb_dec* m, uint32_t 
   }
 }
 
-/* fast row-specialised NV12 -> packed RGB/BGR, FP32 mode; used for the cpu_baseline timing so the
- * CPU number is an honest scalar/auto-vectorised port rather than the generic per-pixel switch. */
-VPFO_MULTIVERSION
+/* fast row-specialised NV12 -> packed RGB/BGR, FP32 mode; used for the cpu_baseline timing so the CPU number is
+ * an honest vectorised, multi-threaded port rather than the generic per-pixel switch.  Same operation order as
+ * yuv2rgb_fp32 (bit-identical results; tests compare the two).  Stage 1 (vectorisable): per row, chroma terms per
+ * pair and three planar u8 channel rows; stage 2: interleave to packed 3 B/px. */
+static inline uint8_t rne_u8(float t) {
+  union { float f; uint32_t u; } m;
+  m.f = t + 12582912.0f;
+  return (uint8_t)(m.u & 0xffu);
+}
+/* clamp to [0,255] then round to nearest even WITHOUT a float->int instruction: adding 1.5*2^23 leaves the
+ * RNE-rounded integer in the low mantissa bits (ulp is 1 there; default rounding mode).  Vectorises to add+and. */
+#define VPFO_CLAMP_RNE(t) rne_u8((t) < 0.f ? 0.f : ((t) > 255.f ? 255.f : (t)))
+/* one chroma pair + its two luma samples per iteration; interleaved groups of 2, so the loop vectorises */
+#define VPFO_DEFINE_ROW_FAST(NAME, ATTR)                                                                          \
+  ATTR static void NAME(const yuv2rgb_f32* c, const uint8_t* restrict yr, const uint8_t* restrict uvr, uint32_t w, \
+                        uint8_t* restrict r8, uint8_t* restrict g8, uint8_t* restrict b8) {                        \
+    const uint32_t np = w >> 1;                                                                                    \
+    for (uint32_t p = 0; p < np; p++) {                                                                            \
+      const float uf = (float)uvr[2 * p], vf = (float)uvr[2 * p + 1];                                              \
+      const float rc = __builtin_fmaf(vf, c->rv, c->br);                                                           \
+      const float gc = __builtin_fmaf(uf, c->gu, __builtin_fmaf(vf, c->gv, c->bg));                                \
+      const float bc = __builtin_fmaf(uf, c->bu, c->bb);                                                           \
+      const float y0 = (float)yr[2 * p], y1 = (float)yr[2 * p + 1];                                                \
+      r8[2 * p] = VPFO_CLAMP_RNE(__builtin_fmaf(y0, c->cy, rc));                                                   \
+      r8[2 * p + 1] = VPFO_CLAMP_RNE(__builtin_fmaf(y1, c->cy, rc));                                               \
+      g8[2 * p] = VPFO_CLAMP_RNE(__builtin_fmaf(y0, c->cy, gc));                                                   \
+      g8[2 * p + 1] = VPFO_CLAMP_RNE(__builtin_fmaf(y1, c->cy, gc));                                               \
+      b8[2 * p] = VPFO_CLAMP_RNE(__builtin_fmaf(y0, c->cy, bc));                                                   \
+      b8[2 * p + 1] = VPFO_CLAMP_RNE(__builtin_fmaf(y1, c->cy, bc));                                               \
+    }                                                                                                              \
+    if (w & 1) {                                                                                                   \
+      const uint32_t x = w - 1;                                                                                    \
+      yuv2rgb_fp32(c, yr[x], uvr[x], uvr[x + 1], &r8[x], &g8[x], &b8[x]);                                          \
+    }                                                                                                              \
+  }
+VPFO_DEFINE_ROW_FAST(nv12_row_fast_base, )
+VPFO_DEFINE_ROW_FAST(nv12_row_fast_avx2, VPFO_TARGET_AVX2)
 static void nv12_to_rgb_fast(int bgr, const yuv2rgb_dec* m, uint32_t w, uint32_t h, const vpfo_plane* s,
                              const vpfo_plane* d) {
-  yuv2rgb_f32 c = make_f32(m);
-  const int i0 = bgr ? 2 : 0, i2 = bgr ? 0 : 2;
-#pragma omp parallel for num_threads(g_threads) schedule(static)
-  for (int64_t yy = 0; yy < (int64_t)h; yy++) {
-    const uint8_t* yr = prow(&s[0], (uint32_t)yy);
-    const uint8_t* uvr = prow(&s[1], (uint32_t)yy >> 1);
-    uint8_t* o = prow(&d[0], (uint32_t)yy);
-    for (uint32_t x = 0; x < w; x++) {
-      float uf = (float)uvr[2 * (x >> 1)], vf = (float)uvr[2 * (x >> 1) + 1], yf = (float)yr[x];
-      float rc = __builtin_fmaf(vf, c.rv, c.br);
-      float gc = __builtin_fmaf(uf, c.gu, __builtin_fmaf(vf, c.gv, c.bg));
-      float bc = __builtin_fmaf(uf, c.bu, c.bb);
-      o[3 * x + i0] = sat_rne(__builtin_fmaf(yf, c.cy, rc));
-      o[3 * x + 1] = sat_rne(__builtin_fmaf(yf, c.cy, gc));
-      o[3 * x + i2] = sat_rne(__builtin_fmaf(yf, c.cy, bc));
+  const yuv2rgb_f32 c = make_f32(m);
+  const int fast = has_avx2_fma();
+#pragma omp parallel num_threads(g_threads)
+  {
+    uint8_t* tmp = (uint8_t*)malloc(3 * (size_t)w + 64);
+    uint8_t *r8 = tmp, *g8 = tmp + w, *b8 = tmp + 2 * (size_t)w;
+#pragma omp for schedule(static)
+    for (int64_t yy = 0; yy < (int64_t)h; yy++) {
+      if (fast) nv12_row_fast_avx2(&c, prow(&s[0], (uint32_t)yy), prow(&s[1], (uint32_t)yy >> 1), w, r8, g8, b8);
+      else nv12_row_fast_base(&c, prow(&s[0], (uint32_t)yy), prow(&s[1], (uint32_t)yy >> 1), w, r8, g8, b8);
+      uint8_t* o = prow(&d[0], (uint32_t)yy);
+      const uint8_t *a0 = bgr ? b8 : r8, *a2 = bgr ? r8 : b8;
+      for (uint32_t x = 0; x < w; x++) { o[3 * x] = a0[x]; o[3 * x + 1] = g8[x]; o[3 * x + 2] = a2[x]; }
     }
+    free(tmp);
   }
 }
 
