@@ -234,13 +234,18 @@ def test_roundtrip_rgb_yuv420_nv12_rgb(capi, oracle):
 # ---------------------------------------------------------------------------------------------
 def _resize(capi, oracle, fmt, interp, sw, sh, dw, dh, seed=1040, align=256):
     src = oracle.synth(fmt, sw, sh, seed)
-    s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(fmt, dw, dh), align)
-    capi.resize(capi.make_exec(stream_handle()), fmt, interp, sw, sh, s.desc(), dw, dh, d.desc())
-    torch.cuda.synchronize()
-    got, intact = d.download()
-    assert intact
     _, want = oracle.resize(fmt, interp, sw, sh, src, dw, dh, oracle.FP32)
-    assert_planes_equal(got, want, f"resize fmt{fmt} {sw}x{sh}->{dw}x{dh}")
+    for variant in (0, 9):  # 0: LDS-staged kernel where it applies; 9: forced gather kernel
+        s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(fmt, dw, dh), align)
+        prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        try:
+            capi.resize(capi.make_exec(stream_handle()), fmt, interp, sw, sh, s.desc(), dw, dh, d.desc())
+        finally:
+            capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact
+        assert_planes_equal(got, want, f"resize fmt{fmt} {sw}x{sh}->{dw}x{dh} v{variant}")
     _, ex = oracle.resize(fmt, interp, sw, sh, src, dw, dh, oracle.EXACT)
     for g, e in zip(got, ex):
         assert np.abs(g.astype(int) - e.astype(int)).max() <= 1
@@ -250,7 +255,8 @@ def _resize(capi, oracle, fmt, interp, sw, sh, dw, dh, seed=1040, align=256):
 @pytest.mark.parametrize("fmt", ["RGB", "BGR", "Y", "YUV420", "YUV444", "RGB_PLANAR", "NV12"])
 def test_resize_bilinear(capi, oracle, fmt):
     f = getattr(capi, fmt)
-    for (sw, sh, dw, dh) in [(3840, 64, 1280, 22), (640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 2, 2)]:
+    for (sw, sh, dw, dh) in [(3840, 64, 1280, 22), (640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 2, 2),
+                             (1000, 40, 300, 13), (2000, 16, 260, 5), (4096, 8, 258, 2), (300, 20, 1000, 70)]:
         _resize(capi, oracle, f, capi.INTERP_LINEAR, sw, sh, dw, dh)
     _resize(capi, oracle, f, capi.INTERP_LINEAR, 128, 72, 50, 30, align=1)
     _resize(capi, oracle, f, capi.INTERP_NEAREST, 128, 72, 50, 30)
@@ -262,18 +268,41 @@ def test_resize_4k_to_720p_full(capi, oracle):
 
 
 def test_fused_convert_resize(capi, oracle):
-    for (sw, sh, dw, dh) in [(3840, 2160, 1280, 720), (640, 360, 224, 224), (100, 60, 333, 201), (18, 10, 7, 5)]:
+    for (sw, sh, dw, dh) in [(3840, 2160, 1280, 720), (640, 360, 224, 224), (100, 60, 333, 201), (18, 10, 7, 5),
+                             (1920, 64, 260, 9), (4096, 16, 258, 3), (322, 38, 1000, 111)]:
         for sfmt in ("NV12", "YUV420"):
             src = oracle.synth(getattr(oracle, sfmt), sw, sh, 1050)
             for dfmt in ("RGB", "BGR", "RGB_PLANAR"):
-                s, d = DevPlanes(src), DevPlanes(oracle.alloc(getattr(oracle, dfmt), dw, dh))
-                capi.convert_resize(capi.make_exec(stream_handle()), getattr(capi, sfmt), getattr(capi, dfmt), 1, 0, sw, sh,
-                                    s.desc(), dw, dh, d.desc())
-                torch.cuda.synchronize()
-                got, intact = d.download()
-                assert intact
                 _, want = oracle.convert_resize(getattr(oracle, sfmt), getattr(oracle, dfmt), 1, 0, sw, sh, src, dw, dh)
-                assert_planes_equal(got, want, f"fused {sfmt}->{dfmt} {sw}x{sh}->{dw}x{dh}")
+                for variant, align in ((0, 256), (9, 256), (0, 2)):  # LDS-staged, forced gather, unaligned (-> gather)
+                    s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, dfmt), dw, dh), align)
+                    prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+                    try:
+                        capi.convert_resize(capi.make_exec(stream_handle()), getattr(capi, sfmt), getattr(capi, dfmt), 1, 0,
+                                            sw, sh, s.desc(), dw, dh, d.desc())
+                    finally:
+                        capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+                    torch.cuda.synchronize()
+                    got, intact = d.download()
+                    assert intact
+                    assert_planes_equal(got, want, f"fused {sfmt}->{dfmt} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
+
+
+def test_fused_convert_resize_batch(capi, oracle):
+    """vpf_convert_resize_batch over 35 frames (2 dispatches) == the unfused two-step result per frame"""
+    sw, sh, dw, dh, n = 640, 360, 213, 120, 35
+    srcs = [oracle.synth(oracle.NV12, sw, sh, 3000 + i) for i in range(n)]
+    S = [DevPlanes(s) for s in srcs]
+    D = [DevPlanes(oracle.alloc(oracle.BGR, dw, dh)) for _ in range(n)]
+    batch = capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)])
+    capi.convert_resize_batch(capi.make_exec(stream_handle()), capi.NV12, capi.BGR, 1, 0, sw, sh, dw, dh, batch)
+    torch.cuda.synchronize()
+    for i in (0, 13, 31, 32, 34):
+        got, intact = D[i].download()
+        _, mid = oracle.convert(oracle.NV12, oracle.BGR, 1, 0, sw, sh, srcs[i])
+        _, want = oracle.resize(oracle.BGR, oracle.LINEAR, sw, sh, mid, dw, dh)
+        assert intact
+        assert_planes_equal(got, want, f"fused batch frame {i}")
 
 
 def _maps(kind, w, h):

@@ -24,6 +24,7 @@ TUNE_NV12_RGB_VARIANT = 1
 
 EXPORTS = [
     "vpf_convert", "vpf_convert_batch", "vpf_convert_supported", "vpf_resize", "vpf_remap", "vpf_convert_resize",
+    "vpf_convert_resize_batch",
     "vpf_status_string", "vpf_version", "vpf_device_count", "vpf_set_tuning",
 ]
 
@@ -69,6 +70,7 @@ def lib() -> C.CDLL:
         L.vpf_resize.argtypes = [PE, C.c_int, C.c_int, Size, PP, Size, PP]
         L.vpf_remap.argtypes = [PE, C.c_int, Size, PP, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Size, PP]
         L.vpf_convert_resize.argtypes = [PE, C.c_int, C.c_int, C.c_int, C.c_int, Size, PP, Size, PP]
+        L.vpf_convert_resize_batch.argtypes = [PE, C.c_int, C.c_int, C.c_int, C.c_int, Size, Size, C.c_uint32, PF]
         L.vpf_status_string.argtypes = [C.c_int]
         L.vpf_status_string.restype = C.c_char_p
         L.vpf_version.restype = C.c_char_p
@@ -159,4 +161,12 @@ def convert_resize(ex: Exec, src_fmt, dst_fmt, cs, cr, sw, sh, src, dw, dh, dst,
                                   planes(dst))
     if check:
         _check(st, "vpf_convert_resize")
+    return st
+
+
+def convert_resize_batch(ex: Exec, src_fmt, dst_fmt, cs, cr, sw, sh, dw, dh, batch, n=None, check=True) -> int:
+    st = lib().vpf_convert_resize_batch(C.byref(ex), src_fmt, dst_fmt, cs, cr, Size(sw, sh), Size(dw, dh),
+                                        len(batch) if n is None else n, batch)
+    if check:
+        _check(st, "vpf_convert_resize_batch")
     return st

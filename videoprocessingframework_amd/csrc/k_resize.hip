@@ -78,11 +78,106 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged variant (the default when it applies): a wave produces 256 consecutive destination pixels of one
+// row.  It first copies the two source rows' byte span it needs into a wave-private LDS strip with fully coalesced
+// dword loads (each source byte crosses the memory pipeline once, as part of a dense 256-B wave load, instead of
+// 24 scattered byte loads per lane), then every lane picks its taps out of LDS with ds_read_u8 (cheap: ~0.6 us of
+// LDS issue per 720p frame chip-wide).  Same make_tap / bilerp arithmetic => bit-identical to k_resize.
+// Requires: 16-B aligned source rows (pointer and pitch); span of a wave <= kResizeRowBytes (host checks the scale).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kResizeRowBytes = 4096;
+
+// Copy `nq` 16-byte units of a source row (starting at the 16-B aligned byte offset `base`) into an LDS strip.
+// All loads are issued before the first LDS write (MAXIT is a compile-time bound), so the wave pays ONE memory
+// latency per strip, not one per 1 KiB.
+template <int MAXIT>
+struct Span {
+  u32x4 v[MAXIT];
+  VPF_DEV void load(const uint8_t* row, uint32_t base, uint32_t nq, uint32_t lane) {
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++)
+      if (lane + 64 * k < nq) v[k] = ldg<false, u32x4>(row + base + 16 * (lane + 64 * k));
+  }
+  VPF_DEV void store(u32x4* lds, uint32_t nq, uint32_t lane) const {
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++)
+      if (lane + 64 * k < nq) lds[lane + 64 * k] = v[k];
+  }
+};
+VPF_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                    uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                    float scx, float scy, int vec_ok) {
+  __shared__ u32x4 strip[4][2][kResizeRowBytes / 16];
+  constexpr int IT = kResizeRowBytes / 1024;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t y = blockIdx.y * 4 + wv;
+  if (y >= dh) return;
+  const uint32_t xs = blockIdx.x * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;  // this wave's dst columns [xs, xe]
+  const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
+  const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
+  const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
+  Span<IT> s0, s1;
+  s0.load(src + (size_t)ty.i0 * sp, base, nq, lane);
+  s1.load(src + (size_t)ty.i1 * sp, base, nq, lane);
+  s0.store(strip[wv][0], nq, lane);
+  s1.store(strip[wv][1], nq, lane);
+  wave_lds_sync();
+  const uint32_t x0 = xs + lane * 4;
+  if (x0 >= dw) return;
+  const uint8_t* r0 = reinterpret_cast<const uint8_t*>(strip[wv][0]);
+  const uint8_t* r1 = reinterpret_cast<const uint8_t*>(strip[wv][1]);
+  float o[4 * CH];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t x = (x0 + k < dw) ? x0 + k : dw - 1;
+    const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
+    const uint32_t a = CH * tx.i0 - base, b = CH * tx.i1 - base;
+#pragma unroll
+    for (int c = 0; c < CH; c++) o[k * CH + c] = bilerp(r0[a + c], r0[b + c], r1[a + c], r1[b + c], tx.f, ty.f);
+  }
+  uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
+  if (vec_ok && x0 + 4 <= dw) {
+    if constexpr (CH == 3) {
+      stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+    } else if constexpr (CH == 2) {
+      stg<false, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+    } else {
+      stg<false, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+    }
+  } else {
+    const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
+    for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[i]);
+  }
+}
+
+// does a wave's source span fit the LDS strip?  span <= 255*scale + 3 pixels (+3 bytes of dword alignment)
+static bool lds_resize_ok(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
+  if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9) return false;  // forced generic
+  if (((uintptr_t)src | sp) & 15) return false;
+  const double scale = (double)sw / (double)dw;
+  const double span_px = 255.0 * scale + 4.0;
+  return span_px * ch + 32.0 <= (double)row_bytes_cap;
+}
+
 hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
                          uint32_t sp, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
+  if (interp == VPF_INTERP_LINEAR && lds_resize_ok(ch, sw, dw, src, sp, kResizeRowBytes)) {
+    if (ch == 1) VPF_LAUNCH((k_resize_lds<1>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);
+    else if (ch == 2) VPF_LAUNCH((k_resize_lds<2>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);
+    else VPF_LAUNCH((k_resize_lds<3>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);
+    return hipGetLastError();
+  }
 #define VPF_GO(C, I) VPF_LAUNCH((k_resize<C, I>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok)
   if (interp == VPF_INTERP_LINEAR) {
     if (ch == 1) VPF_GO(1, VPF_INTERP_LINEAR); else if (ch == 2) VPF_GO(2, VPF_INTERP_LINEAR); else VPF_GO(3, VPF_INTERP_LINEAR);
@@ -147,9 +242,10 @@ VPF_DEV void texel_rgb(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t x, uin
 }
 
 template <int SRC, int DST>
-__global__ __launch_bounds__(256) void k_convert_resize(const FrameDesc f, const Yuv2RgbCoef c, uint32_t sw,
+__global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw,
                                                         uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy,
                                                         int vec_ok) {
+  const FrameDesc f = args.f[blockIdx.z];
   const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63);
   const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const uint32_t x0 = gx * 4;
@@ -189,21 +285,118 @@ __global__ __launch_bounds__(256) void k_convert_resize(const FrameDesc f, const
   }
 }
 
+// LDS-staged fused kernel: the wave stages the luma spans of source rows y0,y1 and the chroma spans of rows y0>>1,
+// y1>>1 (4 coalesced strips), then converts the four taps of each destination pixel from LDS.  Bit-identical to
+// k_convert_resize.  NV12: chroma strip holds interleaved UV; YUV420: U strip then V strip.
+constexpr uint32_t kFusedRowBytes = 2048;
+
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
+                                                            uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok) {
+  const FrameDesc f = args.f[blockIdx.z];
+  // [wave][0,1: luma rows][...]; [wave][2,3: chroma rows (NV12: UV interleaved | YUV420: U)]; [wave][4,5: V rows, YUV420 only]
+  __shared__ u32x4 strip[4][SRC == FC_NV12 ? 4 : 6][kFusedRowBytes / 16];
+  constexpr int IT = kFusedRowBytes / 1024;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t y = blockIdx.y * 4 + wv;
+  if (y >= dh) return;
+  const uint32_t xs = blockIdx.x * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
+  const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
+  const uint32_t ybase = first & ~15u, ynq = (last + 1 - ybase + 15) / 16;
+  uint32_t cbase, cnq;
+  if constexpr (SRC == FC_NV12) {  // chroma bytes [2*(first>>1), 2*(last>>1)+2)
+    cbase = (2 * (first >> 1)) & ~15u; cnq = (2 * (last >> 1) + 2 - cbase + 15) / 16;
+  } else {                         // chroma bytes [first>>1, (last>>1)+1)
+    cbase = (first >> 1) & ~15u; cnq = ((last >> 1) + 1 - cbase + 15) / 16;
+  }
+  constexpr int NS = (SRC == FC_NV12) ? 4 : 6;
+  Span<IT> sp_[NS];  // every strip's loads are in flight before the first LDS write
+  sp_[0].load(f.s[0] + (size_t)ty.i0 * f.sp[0], ybase, ynq, lane);
+  sp_[1].load(f.s[0] + (size_t)ty.i1 * f.sp[0], ybase, ynq, lane);
+  sp_[2].load(f.s[1] + (size_t)(ty.i0 >> 1) * f.sp[1], cbase, cnq, lane);
+  sp_[3].load(f.s[1] + (size_t)(ty.i1 >> 1) * f.sp[1], cbase, cnq, lane);
+  if constexpr (SRC != FC_NV12) {
+    sp_[4].load(f.s[2] + (size_t)(ty.i0 >> 1) * f.sp[2], cbase, cnq, lane);
+    sp_[5].load(f.s[2] + (size_t)(ty.i1 >> 1) * f.sp[2], cbase, cnq, lane);
+  }
+  sp_[0].store(strip[wv][0], ynq, lane);
+  sp_[1].store(strip[wv][1], ynq, lane);
+#pragma unroll
+  for (int k = 2; k < NS; k++) sp_[k].store(strip[wv][k], cnq, lane);
+  wave_lds_sync();
+  const uint32_t x0 = xs + lane * 4;
+  if (x0 >= dw) return;
+  auto texel = [&](uint32_t x, int r, float* rgb) {  // r: 0 = row y0, 1 = row y1
+    const float yf = (float)reinterpret_cast<const uint8_t*>(strip[wv][r])[x - ybase];
+    float u, v;
+    if constexpr (SRC == FC_NV12) {
+      const uint8_t* p = reinterpret_cast<const uint8_t*>(strip[wv][2 + r]) + (2 * (x >> 1) - cbase);
+      u = p[0]; v = p[1];
+    } else {
+      u = reinterpret_cast<const uint8_t*>(strip[wv][2 + r])[(x >> 1) - cbase];
+      v = reinterpret_cast<const uint8_t*>(strip[wv][4 + r])[(x >> 1) - cbase];
+    }
+    const Chroma k = chroma_terms(c, u, v);
+    rgb[0] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.rc));
+    rgb[1] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.gc));
+    rgb[2] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.bc));
+  };
+  float o[3][4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t x = (x0 + k < dw) ? x0 + k : dw - 1;
+    const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
+    float p00[3], p01[3], p10[3], p11[3];
+    texel(tx.i0, 0, p00); texel(tx.i1, 0, p01); texel(tx.i0, 1, p10); texel(tx.i1, 1, p11);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) o[ch][k] = bilerp(p00[ch], p01[ch], p10[ch], p11[ch], tx.f, ty.f);
+  }
+  const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
+  if constexpr (DST == FC_PLANAR) {
+    for (int ch = 0; ch < 3; ch++) {
+      uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
+      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+      else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[ch][i]);
+    }
+  } else {
+    const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
+    uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
+    if (vec_ok && nv == 4) {
+      stg3<false>(out, pack4_trunc(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc(o[1][1], o[b][1], o[a][2], o[1][2]),
+                  pack4_trunc(o[b][2], o[a][3], o[1][3], o[b][3]));
+    } else {
+      for (uint32_t i = 0; i < nv; i++) {
+        out[3 * i] = (uint8_t)sat_trunc(o[a][i]); out[3 * i + 1] = (uint8_t)sat_trunc(o[1][i]); out[3 * i + 2] = (uint8_t)sat_trunc(o[b][i]);
+      }
+    }
+  }
+}
+
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh,
-                                 const FrameDesc& f, uint32_t dw, uint32_t dh) {
+                                 uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   int vec_ok = 1;
-  for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) vec_ok &= ((((uintptr_t)f.d[k] | f.dp[k]) & 3) == 0);
-  dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
-#define VPF_GO(S, D) VPF_LAUNCH((k_convert_resize<S, D>), grid, dim3(256), 0, st, f, c, sw, sh, dw, dh, scx, scy, vec_ok)
+  bool lds_ok = lds_resize_ok(1, sw, dw, a.f[0].s[0], a.f[0].sp[0], kFusedRowBytes);
+  for (uint32_t i = 0; i < n; i++) {
+    const FrameDesc& f = a.f[i];
+    for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) vec_ok &= ((((uintptr_t)f.d[k] | f.dp[k]) & 3) == 0);
+    for (int k = 0; k < (src_fc == FC_NV12 ? 2 : 3); k++) lds_ok = lds_ok && !(((uintptr_t)f.s[k] | f.sp[k]) & 15);
+  }
+  dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);
+#define VPF_GOL(S, D) VPF_LAUNCH((k_convert_resize_lds<S, D>), grid, dim3(256), 0, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok)
+#define VPF_GO(S, D) VPF_LAUNCH((k_convert_resize<S, D>), grid, dim3(256), 0, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok)
+#define VPF_PICK(S, D) do { if (lds_ok) VPF_GOL(S, D); else VPF_GO(S, D); } while (0)
   if (src_fc == FC_NV12) {
-    if (dst_fc == FC_RGB) VPF_GO(FC_NV12, FC_RGB); else if (dst_fc == FC_BGR) VPF_GO(FC_NV12, FC_BGR); else VPF_GO(FC_NV12, FC_PLANAR);
+    if (dst_fc == FC_RGB) VPF_PICK(FC_NV12, FC_RGB); else if (dst_fc == FC_BGR) VPF_PICK(FC_NV12, FC_BGR); else VPF_PICK(FC_NV12, FC_PLANAR);
   } else if (src_fc == FC_YUV420) {
-    if (dst_fc == FC_RGB) VPF_GO(FC_YUV420, FC_RGB); else if (dst_fc == FC_BGR) VPF_GO(FC_YUV420, FC_BGR); else VPF_GO(FC_YUV420, FC_PLANAR);
+    if (dst_fc == FC_RGB) VPF_PICK(FC_YUV420, FC_RGB); else if (dst_fc == FC_BGR) VPF_PICK(FC_YUV420, FC_BGR); else VPF_PICK(FC_YUV420, FC_PLANAR);
   } else {
     return hipErrorInvalidValue;
   }
+#undef VPF_PICK
 #undef VPF_GO
+#undef VPF_GOL
   return hipGetLastError();
 }
 

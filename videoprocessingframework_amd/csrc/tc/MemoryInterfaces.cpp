@@ -205,7 +205,10 @@ CudaBuffer* CudaBuffer::Make(const void* host, size_t e, size_t n, HipContext ct
 CudaBuffer* CudaBuffer::Clone() {
   std::unique_ptr<CudaBuffer> b(new CudaBuffer(elem_size_, num_elems_, ctx_));
   DeviceScope scope(ctx_);
-  ThrowOnHipError(hipMemcpy((void*)b->mem_, (const void*)mem_, GetRawMemSize(), hipMemcpyDeviceToDevice), "CudaBuffer::Clone");
+  // D2D hipMemcpy may return before the copy has finished; the clone must be complete for users on other
+  // (non-blocking) streams, so drain the null stream explicitly
+  ThrowOnHipError(hipMemcpyAsync((void*)b->mem_, (const void*)mem_, GetRawMemSize(), hipMemcpyDeviceToDevice, nullptr), "CudaBuffer::Clone");
+  ThrowOnHipError(hipStreamSynchronize(nullptr), "CudaBuffer::Clone");
   return b.release();
 }
 

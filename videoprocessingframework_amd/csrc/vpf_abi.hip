@@ -265,20 +265,37 @@ vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane
                                 ds.height, static_cast<uint8_t*>(dst->ptr), dst->pitch));
 }
 
-vpf_status vpf_convert_resize(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size ss, const vpf_plane src[3],
-                              vpf_size ds, const vpf_plane dst[3]) {
+vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size ss, vpf_size ds,
+                                    uint32_t n, const vpf_frame_io* frames) {
   if (!(sf == VPF_FMT_NV12 || sf == VPF_FMT_YUV420) || rgb_class(df) < 0 || !cscr_ok(cs, cr)) return VPF_ERR_UNSUPPORTED;
-  if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !planes_ok(sf, ss.width, src) ||
-      !planes_ok(df, ds.width, dst))
-    return VPF_ERR_BAD_ARG;
+  if (!exec || !frames || !n || !ss.width || !ss.height || !ds.width || !ds.height) return VPF_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n; i++)
+    if (!planes_ok(sf, ss.width, frames[i].src) || !planes_ok(df, ds.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
   DeviceGuard guard(exec->device);
   if (guard.err != hipSuccess) return status_of(guard.err);
   Yuv2RgbCoef c;
   make_yuv2rgb(cs, cr, &c);
-  FrameDesc f;
-  fill_desc(f, src, num_planes(sf), dst, num_planes(df));
-  return status_of(launch_convert_resize(static_cast<hipStream_t>(exec->stream), yuv_src_class(sf), rgb_class(df), c,
-                                         ss.width, ss.height, f, ds.width, ds.height));
+  for (uint32_t base = 0; base < n; base += kMaxBatch) {
+    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
+    BatchArgs a;
+    for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, num_planes(sf), frames[base + i].dst, num_planes(df));
+    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    const hipError_t e = launch_convert_resize(static_cast<hipStream_t>(exec->stream), yuv_src_class(sf), rgb_class(df), c,
+                                               ss.width, ss.height, m, a, ds.width, ds.height);
+    if (e != hipSuccess) return status_of(e);
+  }
+  return VPF_OK;
+}
+
+vpf_status vpf_convert_resize(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size ss, const vpf_plane src[3],
+                              vpf_size ds, const vpf_plane dst[3]) {
+  if (!(sf == VPF_FMT_NV12 || sf == VPF_FMT_YUV420) || rgb_class(df) < 0 || !cscr_ok(cs, cr)) return VPF_ERR_UNSUPPORTED;
+  if (!src || !dst) return VPF_ERR_BAD_ARG;
+  vpf_frame_io io;
+  std::memset(&io, 0, sizeof(io));
+  for (int k = 0; k < num_planes(sf); k++) io.src[k] = src[k];
+  for (int k = 0; k < num_planes(df); k++) io.dst[k] = dst[k];
+  return vpf_convert_resize_batch(exec, sf, df, cs, cr, ss, ds, 1, &io);
 }
 
 const char* vpf_status_string(int s) {

@@ -59,7 +59,7 @@ hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t*
                         const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch, uint32_t dw,
                         uint32_t dh, uint8_t* dst, uint32_t dpitch);
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw,
-                                 uint32_t sh, const FrameDesc& f, uint32_t dw, uint32_t dh);
+                                 uint32_t sh, uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh);
 
 int tuning(int key);
 
