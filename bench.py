@@ -260,7 +260,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 (fp32 FMA arithmetic)",
+            "dtype": "f32",  # u8 pixels in/out, fp32 FMA arithmetic, round-to-nearest-even saturating pack
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl.w}x{wl.h} NV12 -> {'RGB' if a.workload != 'nv12_planar_1080p' else 'RGB_PLANAR'}, BT.709 limited range, "
                                    f"ring of {a.ring} device-resident frames per GPU, {wl.launches_per_step} dispatch(es) per step",

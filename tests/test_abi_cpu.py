@@ -76,3 +76,26 @@ def test_product_does_not_touch_oracle():
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
                 assert "vpf_oracle" not in txt and "libvpforacle" not in txt, f
+
+
+@pytest.mark.parametrize("first", ["capi", "PyNvCodec"])
+def test_single_hip_runtime_whatever_the_import_order(first):
+    """torch-ROCm bundles its own libamdhip64.so under the same SONAME as /opt/rocm's; loading ours first must not end
+    up with two HIP runtimes in the process (the second one to initialise would report 'no device')."""
+    import subprocess
+    import sys
+
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'videoprocessingframework_amd')!r})
+if {first!r} == "capi":
+    from videoprocessingframework_amd import capi; capi.lib()
+else:
+    import PyNvCodec
+import torch
+maps = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))
+print(len(maps), maps)
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().startswith("1 "), out.stdout

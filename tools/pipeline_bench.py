@@ -1,0 +1,50 @@
+"""End-to-end feed path: host NV12 frames (what a software decoder hands over) -> PyFrameUploader
+(pinned staging + side copy stream) -> PySurfaceConverter NV12->RGB, through the drop-in Python API.  Reports frames/s for
+upload only, convert only and the pipeline, single thread and N threads (one stream + task chain per thread, the pattern of
+samples/SampleDecodeMultiThread.py).  PCIe-inclusive numbers: never the headline `value`."""
+import os, sys, threading, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "videoprocessingframework_amd"))
+import PyNvCodec as nvc
+
+W, H, N = 3840, 2160, 200
+PF = nvc.PixelFormat
+frames = [np.random.default_rng(i).integers(0, 256, W * H * 3 // 2, dtype=np.uint8) for i in range(8)]
+cc = nvc.ColorspaceConversionContext(nvc.ColorSpace.BT_709, nvc.ColorRange.MPEG)
+
+
+def run(kind, n=N, ctx=None, stream=None):
+    ctx = nvc.GetContext(0) if ctx is None else ctx
+    stream = nvc.GetStream(0) if stream is None else stream
+    up = nvc.PyFrameUploader(W, H, PF.NV12, ctx, stream)
+    conv = nvc.PySurfaceConverter(W, H, PF.NV12, PF.RGB, ctx, stream)
+    s = up.UploadSingleFrame(frames[0])
+    conv.Execute(s, cc)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        if kind != "convert":
+            s = up.UploadSingleFrame(frames[i % 8])
+        if kind != "upload":
+            conv.Execute(s, cc)
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0)
+
+
+for kind in ("upload", "convert", "pipeline"):
+    print(f"[pipeline] 1 thread  {kind:8s}: {run(kind):9.1f} frames/s", flush=True)
+for nt in (2, 4, 8, 16):
+    res = [0.0] * nt
+    streams = [torch.cuda.Stream() for _ in range(nt)]
+
+    def work(i):
+        res[i] = run("pipeline", N, nvc.GetContext(0), streams[i].cuda_stream)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    dt = time.perf_counter() - t0
+    print(f"[pipeline] {nt:2d} threads pipeline: {nt * N / dt:9.1f} frames/s aggregate = {nt * N / dt * W * H / 1e9:6.2f} Gpix/s, "
+          f"{nt * N / dt * W * H * 1.5 / 1e9:5.1f} GB/s over PCIe", flush=True)

@@ -12,6 +12,28 @@ NVDEC / NVENC classes (PyNvDecoder, PyNvEncoder) are NVIDIA fixed-function hardw
 constructing them raises with an explanation.  FFmpeg demux / software decode is a host-side feeder that needs
 libav, which this image does not ship.
 """
+import importlib.util as _ilu
+import os as _os
+
+
+def _preload_hip_runtime():
+    """See videoprocessingframework_amd/_hip_runtime.py (duplicated: this package is also importable top-level)."""
+    import ctypes
+
+    try:
+        spec = _ilu.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        lib = _os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if _os.path.exists(lib):
+            try:
+                ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+_preload_hip_runtime()
 try:
     from ._PyNvCodec import *  # noqa: F401,F403
     from ._PyNvCodec import _UseHostAllocator  # noqa: F401

@@ -62,6 +62,9 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m videoprocessingframework_amd._build` "
                 "(there is no CPU fallback for the conversion path)")
+        from ._hip_runtime import preload
+
+        preload()  # one HIP runtime per process, whatever the import order relative to torch
         L = C.CDLL(LIB_PATH)
         PP, PE, PF = C.POINTER(Plane), C.POINTER(Exec), C.POINTER(FrameIO)
         L.vpf_convert.argtypes = [PE, C.c_int, C.c_int, C.c_int, C.c_int, Size, PP, PP]

@@ -161,6 +161,7 @@ public:
   }
   Pixel_Format GetFormat() const { return fmt_; }
   std::shared_ptr<Surface> Upload(void* data, size_t bytes) {
+    py::gil_scoped_release nogil;  // the reference releases the GIL around uploads too (PyFrameUploader.cpp:118-160)
     std::unique_ptr<Buffer> raw(Buffer::Make(bytes, data));
     up_->SetInput(raw.get(), 0U);
     const auto res = up_->Execute();
