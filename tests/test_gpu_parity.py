@@ -320,19 +320,25 @@ def _maps(kind, w, h):
 
 @pytest.mark.parametrize("kind", ["identity", "shift", "barrel"])
 def test_remap(capi, oracle, kind):
-    for (w, h) in [(1920, 1080), (333, 77)]:
+    for (w, h, variant, align) in [(1920, 1080, 0, 256), (1920, 1080, 9, 256), (333, 77, 0, 256), (640, 48, 0, 1), (644, 40, 0, 4)]:
         src = oracle.synth(oracle.RGB, w, h, 1060)
         xm, ym = _maps(kind, w, h)
-        s = DevPlanes(src)
-        d = DevPlanes(oracle.alloc(oracle.RGB, w, h, fill=9))
+        if kind == "barrel":
+            xm[3, 5:9] = np.nan  # NaN coordinates are out of range too
+        s = DevPlanes(src, align)
+        d = DevPlanes(oracle.alloc(oracle.RGB, w, h, fill=9), align)
         dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
-        capi.remap(capi.make_exec(stream_handle()), capi.RGB, w, h, s.desc()[0], dx.data_ptr(), 4 * w, dy.data_ptr(), 4 * w,
-                   w, h, d.desc()[0])
+        prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        try:
+            capi.remap(capi.make_exec(stream_handle()), capi.RGB, w, h, s.desc()[0], dx.data_ptr(), 4 * w, dy.data_ptr(), 4 * w,
+                       w, h, d.desc()[0])
+        finally:
+            capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
         torch.cuda.synchronize()
         got, intact = d.download()
         assert intact
         _, want = oracle.remap(oracle.RGB, w, h, src, xm, ym, dst=oracle.alloc(oracle.RGB, w, h, fill=9))
-        assert_planes_equal(got, want, f"remap {kind} {w}x{h}")
+        assert_planes_equal(got, want, f"remap {kind} {w}x{h} v{variant} a{align}")
         if kind == "identity":
             assert np.array_equal(got[0], src[0])
 

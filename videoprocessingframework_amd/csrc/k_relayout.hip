@@ -11,6 +11,11 @@
 
 namespace vpf {
 
+VPF_DEV uint8_t p16_to_8(uint16_t v) {  // (v + 128) >> 8 saturated: nppiDivC_16u(256) round-to-nearest + Convert_16u8u
+  uint32_t r = ((uint32_t)v + 128u) >> 8;
+  return (uint8_t)(r > 255u ? 255u : r);
+}
+
 // ------------------------------------------------------------------------------------------
 // NV12 <-> YUV420: one lane = 16 luma px x 2 rows + 8 chroma pairs.
 // fast path: w % 16 == 0, h even, Y/UV planes 16-B aligned, U/V planes 8-B aligned.
@@ -106,11 +111,6 @@ enum GenericOp : int {
   OP_RGB_RGB32F, OP_RGB32F_PLANAR, OP_P16_NV12, OP_RGB_GRAY, OP_BGR_GRAY, OP_PLANAR_GRAY, OP_PLANAR_SWAP
 };
 
-VPF_DEV uint8_t p16_to_8(uint16_t v) {  // (v + 128) >> 8 saturated: nppiDivC_16u(256) round-to-nearest + Convert_16u8u
-  uint32_t r = ((uint32_t)v + 128u) >> 8;
-  return (uint8_t)(r > 255u ? 255u : r);
-}
-
 template <int OP>
 __global__ __launch_bounds__(256) void k_relayout_generic(const BatchArgs args, uint32_t w, uint32_t h) {
   const FrameDesc f = args.f[blockIdx.z];
@@ -156,6 +156,84 @@ __global__ __launch_bounds__(256) void k_relayout_generic(const BatchArgs args, 
     else { r = S(0, y, 3 * x + (OP == OP_BGR_GRAY ? 2 : 0)); g = S(0, y, 3 * x + 1); b = S(0, y, 3 * x + (OP == OP_BGR_GRAY ? 0 : 2)); }
     D(0, y, x) = (uint8_t)sat_trunc(__builtin_fmaf(r, 0.299f, __builtin_fmaf(g, 0.587f, __builtin_fmaf(b, 0.114f, 0.5f))));
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// more fast paths (all: one dense wave access per instruction)
+// ------------------------------------------------------------------------------------------
+// plane copy, 16 B per lane; FILL: also writes 128 into two more planes (Y -> YUV444, reference y_yuv444 :844-873)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_copy_plane_p16(const BatchArgs args, uint32_t wbytes, uint32_t h, uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || y >= h) return;
+  const uint32_t x = gx * 16;
+  stg<true, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, ldg<false, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x));
+  if constexpr (FILL) {
+    const u32x4 v = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    stg<true, u32x4>(f.d[1] + (size_t)y * f.dp[1] + x, v);
+    stg<true, u32x4>(f.d[2] + (size_t)y * f.dp[2] + x, v);
+  }
+}
+
+// RGB / BGR / RGB_PLANAR -> Y (gray): lane = 4 px.  SRC: 0 RGB, 1 BGR, 2 planar
+template <int SRC>
+__global__ __launch_bounds__(256) void k_gray_p4(const BatchArgs args, uint32_t w, uint32_t h, uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || y >= h) return;
+  const uint32_t x = gx * 4;
+  float r[4], g[4], b[4];
+  if constexpr (SRC == 2) {
+    const uint32_t rd = ldg<false, uint32_t>(f.s[0] + (size_t)y * f.sp[0] + x), gd = ldg<false, uint32_t>(f.s[1] + (size_t)y * f.sp[1] + x),
+                   bd = ldg<false, uint32_t>(f.s[2] + (size_t)y * f.sp[2] + x);
+    r[0] = ubyte<0>(rd); r[1] = ubyte<1>(rd); r[2] = ubyte<2>(rd); r[3] = ubyte<3>(rd);
+    g[0] = ubyte<0>(gd); g[1] = ubyte<1>(gd); g[2] = ubyte<2>(gd); g[3] = ubyte<3>(gd);
+    b[0] = ubyte<0>(bd); b[1] = ubyte<1>(bd); b[2] = ubyte<2>(bd); b[3] = ubyte<3>(bd);
+  } else {
+    const uint8_t* p = f.s[0] + (size_t)y * f.sp[0] + 3 * (size_t)x;
+    const uint32_t d0 = ldg<false, uint32_t>(p), d1 = ldg<false, uint32_t>(p + 4), d2 = ldg<false, uint32_t>(p + 8);
+    float* c0 = (SRC == 1) ? b : r;
+    float* c2 = (SRC == 1) ? r : b;
+    c0[0] = ubyte<0>(d0); g[0] = ubyte<1>(d0); c2[0] = ubyte<2>(d0);
+    c0[1] = ubyte<3>(d0); g[1] = ubyte<0>(d1); c2[1] = ubyte<1>(d1);
+    c0[2] = ubyte<2>(d1); g[2] = ubyte<3>(d1); c2[2] = ubyte<0>(d2);
+    c0[3] = ubyte<1>(d2); g[3] = ubyte<2>(d2); c2[3] = ubyte<3>(d2);
+  }
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) o[k] = __builtin_fmaf(r[k], 0.299f, __builtin_fmaf(g[k], 0.587f, __builtin_fmaf(b[k], 0.114f, 0.5f)));
+  stg<false, uint32_t>(f.d[0] + (size_t)y * f.dp[0] + x, pack4_trunc(o[0], o[1], o[2], o[3]));
+}
+
+// RGB -> RGB_32F is elementwise over the 3W bytes of a row: lane = 4 bytes in -> 16 B (4 floats) out
+__global__ __launch_bounds__(256) void k_u8_to_f32_p4(const BatchArgs args, uint32_t wbytes, uint32_t h, uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || y >= h) return;
+  const uint32_t d = ldg<false, uint32_t>(f.s[0] + (size_t)y * f.sp[0] + 4 * (size_t)gx);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 v = {ubyte<0>(d) / 255.0f, ubyte<1>(d) / 255.0f, ubyte<2>(d) / 255.0f, ubyte<3>(d) / 255.0f};
+  stg<true, f32x4>(f.d[0] + (size_t)y * f.dp[0] + 16 * (size_t)gx, v);
+}
+
+// P10 / P12 -> NV12 is elementwise over 16-bit samples of both planes: lane = 8 samples (16 B) -> 8 B.
+// Rows [0, h) are luma, rows [h, h + ceil(h/2)) chroma; both have `wsamples` samples per row.
+__global__ __launch_bounds__(256) void k_p16_to_8_p8(const BatchArgs args, uint32_t wsamples, uint32_t h, uint32_t ch, uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), row = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || row >= h + ch) return;
+  const int pl = row >= h;
+  const uint32_t y = pl ? row - h : row;
+  const u32x4 v = ldg<false, u32x4>(f.s[pl] + (size_t)y * f.sp[pl] + 16 * (size_t)gx);
+  u32x2 o;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t a = v[2 * k], b = v[2 * k + 1];
+    o[k] = (uint32_t)p16_to_8((uint16_t)(a & 0xffffu)) | ((uint32_t)p16_to_8((uint16_t)(a >> 16)) << 8) |
+           ((uint32_t)p16_to_8((uint16_t)(b & 0xffffu)) << 16) | ((uint32_t)p16_to_8((uint16_t)(b >> 16)) << 24);
+  }
+  stg<false, u32x2>(f.d[pl] + (size_t)y * f.dp[pl] + 8 * (size_t)gx, o);
 }
 
 static bool al(const BatchArgs& a, uint32_t n, int ns, int nd, uint32_t s0, uint32_t s12, uint32_t d0, uint32_t d12) {
@@ -225,14 +303,53 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     }
     return go_generic<OP_SWAP_RB>(st, w, h, n, a);
   }
-  if (sf == VPF_FMT_NV12 && df == VPF_FMT_Y) return go_generic<OP_COPY_Y>(st, w, h, n, a);
-  if (sf == VPF_FMT_Y && df == VPF_FMT_YUV444) return go_generic<OP_Y_YUV444>(st, w, h, n, a);
-  if (sf == VPF_FMT_RGB && df == VPF_FMT_RGB_32F) return go_generic<OP_RGB_RGB32F>(st, w, h, n, a);
+  if (sf == VPF_FMT_NV12 && df == VPF_FMT_Y) {
+    if (!force_generic && w % 16 == 0 && al(a, n, 1, 1, 16, 16, 16, 16)) {
+      dim3 grid((w / 16 + 63) / 64, (h + 3) / 4, n);
+      VPF_LAUNCH((k_copy_plane_p16<false>), grid, dim3(256), 0, st, a, w, h, w / 16);
+      return hipGetLastError();
+    }
+    return go_generic<OP_COPY_Y>(st, w, h, n, a);
+  }
+  if (sf == VPF_FMT_Y && df == VPF_FMT_YUV444) {
+    if (!force_generic && w % 16 == 0 && al(a, n, 1, 3, 16, 16, 16, 16)) {
+      dim3 grid((w / 16 + 63) / 64, (h + 3) / 4, n);
+      VPF_LAUNCH((k_copy_plane_p16<true>), grid, dim3(256), 0, st, a, w, h, w / 16);
+      return hipGetLastError();
+    }
+    return go_generic<OP_Y_YUV444>(st, w, h, n, a);
+  }
+  if (sf == VPF_FMT_RGB && df == VPF_FMT_RGB_32F) {
+    if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 16, 16)) {
+      dim3 grid((3 * w / 4 + 63) / 64, (h + 3) / 4, n);
+      VPF_LAUNCH(k_u8_to_f32_p4, grid, dim3(256), 0, st, a, 3 * w, h, 3 * w / 4);
+      return hipGetLastError();
+    }
+    return go_generic<OP_RGB_RGB32F>(st, w, h, n, a);
+  }
   if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) return go_generic<OP_RGB32F_PLANAR>(st, w, h, n, a);
-  if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) return go_generic<OP_P16_NV12>(st, w, h, n, a);
-  if (sf == VPF_FMT_RGB && df == VPF_FMT_Y) return go_generic<OP_RGB_GRAY>(st, w, h, n, a);
-  if (sf == VPF_FMT_BGR && df == VPF_FMT_Y) return go_generic<OP_BGR_GRAY>(st, w, h, n, a);
-  if (sf == VPF_FMT_RGB_PLANAR && df == VPF_FMT_Y) return go_generic<OP_PLANAR_GRAY>(st, w, h, n, a);
+  if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) {
+    if (!force_generic && w % 8 == 0 && al(a, n, 2, 2, 16, 16, 8, 8)) {  // luma and chroma rows both hold w 16-bit samples
+      const uint32_t ch = (h + 1) / 2;
+      dim3 grid((w / 8 + 63) / 64, (h + ch + 3) / 4, n);
+      VPF_LAUNCH(k_p16_to_8_p8, grid, dim3(256), 0, st, a, w, h, ch, w / 8);
+      return hipGetLastError();
+    }
+    return go_generic<OP_P16_NV12>(st, w, h, n, a);
+  }
+  if (df == VPF_FMT_Y && (sf == VPF_FMT_RGB || sf == VPF_FMT_BGR || sf == VPF_FMT_RGB_PLANAR)) {
+    const int ns = (sf == VPF_FMT_RGB_PLANAR) ? 3 : 1;
+    if (!force_generic && w % 4 == 0 && al(a, n, ns, 1, 4, 4, 4, 4)) {
+      dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
+      if (sf == VPF_FMT_RGB) VPF_LAUNCH((k_gray_p4<0>), grid, dim3(256), 0, st, a, w, h, w / 4);
+      else if (sf == VPF_FMT_BGR) VPF_LAUNCH((k_gray_p4<1>), grid, dim3(256), 0, st, a, w, h, w / 4);
+      else VPF_LAUNCH((k_gray_p4<2>), grid, dim3(256), 0, st, a, w, h, w / 4);
+      return hipGetLastError();
+    }
+    if (sf == VPF_FMT_RGB) return go_generic<OP_RGB_GRAY>(st, w, h, n, a);
+    if (sf == VPF_FMT_BGR) return go_generic<OP_BGR_GRAY>(st, w, h, n, a);
+    return go_generic<OP_PLANAR_GRAY>(st, w, h, n, a);
+  }
   return hipErrorInvalidValue;
 }
 

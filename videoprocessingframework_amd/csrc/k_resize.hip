@@ -211,9 +211,70 @@ __global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src,
     o[c] = (uint8_t)sat_trunc(bilerp(r0[3 * x0 + c], r0[3 * x1 + c], r1[3 * x0 + c], r1[3 * x1 + c], fx, fy));
 }
 
+// fast remap: lane = 4 consecutive destination pixels.  Maps come in as two 16-B loads, the two source texels of a
+// row (6 contiguous bytes at an arbitrary byte offset) as ONE 12-B load from the enclosing 4-B aligned address
+// (v_alignbyte_b32 extracts them), and four valid pixels leave as one 12-B store.  Same arithmetic as k_remap3.
+// Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0.
+VPF_DEV void remap_row_taps(const uint8_t* row, uint32_t x0, bool two, uint32_t pitch, float* t0, float* t1) {
+  const uint32_t o = 3 * x0, base = o & ~3u, sh = o & 3u;
+  if (base + 12 <= pitch) {
+    const uint32_t d0 = ldg<false, uint32_t>(row + base), d1 = ldg<false, uint32_t>(row + base + 4), d2 = ldg<false, uint32_t>(row + base + 8);
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
+    t1[0] = two ? ubyte<3>(lo) : t0[0]; t1[1] = two ? ubyte<0>(hi) : t0[1]; t1[2] = two ? ubyte<1>(hi) : t0[2];
+  } else {  // right edge of the row allocation: byte loads
+    const uint32_t o1 = two ? o + 3 : o;
+    for (int c = 0; c < 3; c++) { t0[c] = row[o + c]; t1[c] = row[o1 + c]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_remap3_p4(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                   const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
+                                                   uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t x = gx * 4;
+  if (x >= dw || y >= dh) return;
+  const f32x4 sx4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(xmap) + (size_t)y * xp + 4 * (size_t)x);
+  const f32x4 sy4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(ymap) + (size_t)y * yp + 4 * (size_t)x);
+  float o[12];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float sx = sx4[k], sy = sy4[k];
+    ok[k] = (sx >= 0.f && sx <= (float)(sw - 1) && sy >= 0.f && sy <= (float)(sh - 1));
+    const float cx = ok[k] ? sx : 0.f, cy = ok[k] ? sy : 0.f;
+    const uint32_t x0 = (uint32_t)(int)cx, y0 = (uint32_t)(int)cy;
+    const bool twox = x0 + 1 < sw;
+    const uint32_t y1 = (y0 + 1 < sh) ? y0 + 1 : sh - 1;
+    const float fx = cx - (float)x0, fy = cy - (float)y0;
+    float a0[3], a1[3], b0[3], b1[3];
+    remap_row_taps(src + (size_t)y0 * sp, x0, twox, sp, a0, a1);
+    remap_row_taps(src + (size_t)y1 * sp, x0, twox, sp, b0, b1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[3 * k + c] = bilerp(a0[c], a1[c], b0[c], b1[c], fx, fy);
+  }
+  uint8_t* out = dst + (size_t)y * dp + 3 * (size_t)x;
+  if (vec_ok && ok[0] && ok[1] && ok[2] && ok[3]) {
+    stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (ok[k]) { out[3 * k] = (uint8_t)sat_trunc(o[3 * k]); out[3 * k + 1] = (uint8_t)sat_trunc(o[3 * k + 1]); out[3 * k + 2] = (uint8_t)sat_trunc(o[3 * k + 2]); }
+  }
+}
+
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp, const float* xmap,
                         uint32_t xp, const float* ymap, uint32_t yp, uint32_t dw, uint32_t dh, uint8_t* dst,
                         uint32_t dp) {
+  const bool fast = tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && (dw % 4 == 0) && !(((uintptr_t)src | sp) & 3) &&
+                    !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sp >= 12;
+  if (fast) {
+    const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
+    dim3 fgrid((dw / 4 + 63) / 64, (dh + 3) / 4);
+    VPF_LAUNCH(k_remap3_p4, fgrid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh, vec_ok);
+    return hipGetLastError();
+  }
   dim3 grid((dw + 63) / 64, (dh + 3) / 4);
   VPF_LAUNCH(k_remap3, grid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh);
   return hipGetLastError();

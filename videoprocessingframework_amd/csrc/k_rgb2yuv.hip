@@ -52,10 +52,103 @@ __global__ __launch_bounds__(256) void k_rgb_yuv_quad(const BatchArgs args, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// fast path: one lane = 4 px x 2 rows.  Packed sources come in as three dwords per row (12 B, dwordx3), planar as
+// one dword per plane per row; luma (and 4:4:4 chroma) leave as one dword per row, 4:2:0 chroma as two bytes per
+// plane.  Every access of a wave is contiguous (768 B loads, 256 B / 128 B stores).
+// Requires w % 4 == 0, h even, 4-B aligned planes (2-B for subsampled chroma).  Same arithmetic as the quad kernel.
+// ------------------------------------------------------------------------------------------
+template <int SRC>
+VPF_DEV void load_rgb4(const FrameDesc& f, uint32_t x, uint32_t y, float* r, float* g, float* b) {
+  if constexpr (SRC == FC_PLANAR) {
+    const uint32_t rd = ldg<false, uint32_t>(f.s[0] + (size_t)y * f.sp[0] + x);
+    const uint32_t gd = ldg<false, uint32_t>(f.s[1] + (size_t)y * f.sp[1] + x);
+    const uint32_t bd = ldg<false, uint32_t>(f.s[2] + (size_t)y * f.sp[2] + x);
+    r[0] = ubyte<0>(rd); r[1] = ubyte<1>(rd); r[2] = ubyte<2>(rd); r[3] = ubyte<3>(rd);
+    g[0] = ubyte<0>(gd); g[1] = ubyte<1>(gd); g[2] = ubyte<2>(gd); g[3] = ubyte<3>(gd);
+    b[0] = ubyte<0>(bd); b[1] = ubyte<1>(bd); b[2] = ubyte<2>(bd); b[3] = ubyte<3>(bd);
+  } else {
+    const uint8_t* p = f.s[0] + (size_t)y * f.sp[0] + 3 * (size_t)x;
+    const uint32_t d0 = ldg<false, uint32_t>(p), d1 = ldg<false, uint32_t>(p + 4), d2 = ldg<false, uint32_t>(p + 8);
+    // d0 = c0a c1a c2a c0b ; d1 = c1b c2b c0c c1c ; d2 = c2c c0d c1d c2d
+    float* c0 = (SRC == FC_BGR) ? b : r;
+    float* c2 = (SRC == FC_BGR) ? r : b;
+    c0[0] = ubyte<0>(d0); g[0] = ubyte<1>(d0); c2[0] = ubyte<2>(d0);
+    c0[1] = ubyte<3>(d0); g[1] = ubyte<0>(d1); c2[1] = ubyte<1>(d1);
+    c0[2] = ubyte<2>(d1); g[2] = ubyte<3>(d1); c2[2] = ubyte<0>(d2);
+    c0[3] = ubyte<1>(d2); g[3] = ubyte<2>(d2); c2[3] = ubyte<3>(d2);
+  }
+}
+
+template <int SRC, bool SUB>
+__global__ __launch_bounds__(256) void k_rgb_yuv_p4(const BatchArgs args, const Rgb2YuvCoef c, uint32_t w, uint32_t h,
+                                                    uint32_t groups_x) {
+  const FrameDesc f = args.f[blockIdx.z];
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), rp = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= groups_x || rp >= (h >> 1)) return;
+  const uint32_t x = gx * 4;
+  float r[2][4], g[2][4], b[2][4];
+  load_rgb4<SRC>(f, x, 2 * rp, r[0], g[0], b[0]);
+  load_rgb4<SRC>(f, x, 2 * rp + 1, r[1], g[1], b[1]);
+#pragma unroll
+  for (int row = 0; row < 2; row++) {
+    const size_t y = 2 * rp + row;
+    stg<false, uint32_t>(f.d[0] + y * f.dp[0] + x, pack4_trunc(mrow(c, 0, r[row][0], g[row][0], b[row][0]), mrow(c, 0, r[row][1], g[row][1], b[row][1]),
+                                                               mrow(c, 0, r[row][2], g[row][2], b[row][2]), mrow(c, 0, r[row][3], g[row][3], b[row][3])));
+    if constexpr (!SUB) {
+#pragma unroll
+      for (int k = 1; k < 3; k++)
+        stg<false, uint32_t>(f.d[k] + y * f.dp[k] + x, pack4_trunc(mrow(c, k, r[row][0], g[row][0], b[row][0]), mrow(c, k, r[row][1], g[row][1], b[row][1]),
+                                                                   mrow(c, k, r[row][2], g[row][2], b[row][2]), mrow(c, k, r[row][3], g[row][3], b[row][3])));
+    }
+  }
+  if constexpr (SUB) {
+    // two quads: px {0,1} and {2,3} of both rows; sums of small integers are exact in fp32, as is the 0.25 scale
+    float qr[2], qg[2], qb[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      qr[q] = 0.25f * (r[0][2 * q] + r[0][2 * q + 1] + r[1][2 * q] + r[1][2 * q + 1]);
+      qg[q] = 0.25f * (g[0][2 * q] + g[0][2 * q + 1] + g[1][2 * q] + g[1][2 * q + 1]);
+      qb[q] = 0.25f * (b[0][2 * q] + b[0][2 * q + 1] + b[1][2 * q] + b[1][2 * q + 1]);
+    }
+#pragma unroll
+    for (int k = 1; k < 3; k++) {
+      const uint32_t v = sat_trunc(mrow(c, k, qr[0], qg[0], qb[0])) | (sat_trunc(mrow(c, k, qr[1], qg[1], qb[1])) << 8);
+      stg<false, uint16_t>(f.d[k] + (size_t)rp * f.dp[k] + (x >> 1), (uint16_t)v);
+    }
+  }
+}
+
+static bool rgb2yuv_fast_ok(const BatchArgs& a, uint32_t n, int src_fc, bool sub, uint32_t w, uint32_t h) {
+  if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9 || (w & 3) || (h & 1)) return false;
+  const int ns = (src_fc == FC_PLANAR) ? 3 : 1;
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < ns; k++)
+      if (((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & 3) return false;
+    for (int k = 0; k < 3; k++)
+      if (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & ((k && sub) ? 1 : 3)) return false;
+  }
+  return true;
+}
+
 hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc, const Rgb2YuvCoef& c, uint32_t w, uint32_t h,
                              uint32_t n, const BatchArgs& a) {
-  dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
   const bool sub = (dst_fc == FC_YUV420);
+  if (rgb2yuv_fast_ok(a, n, src_fc, sub, w, h)) {
+    dim3 fgrid((w / 4 + 63) / 64, (h / 2 + 3) / 4, n);
+#define VPF_FAST(S)                                                                                  \
+  if (sub) VPF_LAUNCH((k_rgb_yuv_p4<S, true>), fgrid, dim3(256), 0, st, a, c, w, h, w / 4);           \
+  else VPF_LAUNCH((k_rgb_yuv_p4<S, false>), fgrid, dim3(256), 0, st, a, c, w, h, w / 4);              \
+  return hipGetLastError();
+    switch (src_fc) {
+      case FC_RGB: VPF_FAST(FC_RGB)
+      case FC_BGR: VPF_FAST(FC_BGR)
+      case FC_PLANAR: VPF_FAST(FC_PLANAR)
+      default: return hipErrorInvalidValue;
+    }
+#undef VPF_FAST
+  }
+  dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
 #define VPF_GO(S)                                                                                            \
   if (sub) VPF_LAUNCH((k_rgb_yuv_quad<S, true>), grid, dim3(256), 0, st, a, c, w, h);                 \
   else VPF_LAUNCH((k_rgb_yuv_quad<S, false>), grid, dim3(256), 0, st, a, c, w, h);                    \
