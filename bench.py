@@ -20,6 +20,13 @@ fused_4k_720p}, --sweep (table of variants on stderr), --no-cpu.
 """
 from __future__ import annotations
 
+import os
+
+# idle OpenMP workers must sleep, not spin, or they steal the cores the cpu_baseline leg is timing; libgomp reads these
+# once, when it is first loaded (torch loads it), so they have to be in the environment before any other import
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import argparse
 import json
 import os
@@ -154,7 +161,6 @@ def cpu_baseline(budget_s=10.0):
     """The oracle's FP32 port of NV12->RGB (vectorised AVX2+FMA rows, OpenMP over rows) on the host cores: a bounded
     sample of the same 4K workload.  The thread count is the best of a short calibration over {1, n/8, n/4, n/2, n}
     hardware threads (more threads is not always faster on a shared/SMT host); `cores` reports the count used."""
-    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # idle OpenMP workers must sleep, not spin on the cores being timed
     import oracle as o
 
     avail = len(os.sched_getaffinity(0))
@@ -203,20 +209,23 @@ def main():
     ap.add_argument("--workload", default="nv12_rgb_4k")
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
     a = ap.parse_args()
 
     rank, world, local = sharding.env_rank()
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the conversion path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    sharding.init("nccl", dev)  # one process per GPU over RCCL; ranks only meet at the timing barriers
+    sharding.init(a.backend, dev)  # one process per GPU over RCCL; ranks only meet at the timing barriers
+    red_dev = dev if a.backend == "nccl" else None  # gloo reduces CPU tensors
 
     if a.sweep and rank == 0:
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
             for mode in ("batch", "single"):
-                for v in (4, 8, 11, 14, 16, 15):
+                for v in (4, 8, 11, 17, 18, 19, 15):
                     wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, v, mode)
                     _, ev = timed(wl, a.steps, a.warmup, False)
                     gbs = wl.bytes_per_step * a.steps / ev / 1e9
@@ -235,7 +244,7 @@ def main():
 
     wl = Workload(a.workload, dev, a.ring, a.variant, a.mode)
     wall, ev = timed(wl, a.steps, a.warmup, dist_on)
-    total_px, wall_max = sharding.aggregate(wl.px_per_step * a.steps, wall, dev)  # sum of pixels, MAX time over ranks
+    total_px, wall_max = sharding.aggregate(wl.px_per_step * a.steps, wall, red_dev)  # sum of pixels, MAX time over ranks
     ok = wl.verify()
 
     if rank == 0:

@@ -194,6 +194,68 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// p16r: p16 for packed outputs with RPW row pairs per wave task (all 3*RPW loads in flight first) and ONE 3 KiB LDS
+// row tile per wave reused for every output row (12 KiB per block -> 8 blocks/CU instead of 6).  LDS operations of a
+// wave execute in order, so the next row's ds_write cannot overtake the previous row's ds_read.
+// ---------------------------------------------------------------------------------------------
+template <int DST, int RPW, bool NTS>
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16r(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                       uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[4 * 192];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t rpg = wt / chunks_x, chunk = wt - rpg * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  const bool act = x < w;
+  const uint32_t nrp = h >> 1;
+  u32x4 y[RPW][2], uv[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; r++) {
+    const uint32_t rp = rpg * RPW + r;
+    if (act && rp < nrp) {
+      y[r][0] = ldg<false, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+      y[r][1] = ldg<false, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+      uv[r] = ldg<false, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+    }
+  }
+  u32x4* t = tile + wv * 192;
+  const uint32_t row_bytes = 3 * w;
+#pragma unroll
+  for (int r = 0; r < RPW; r++) {
+    const uint32_t rp = rpg * RPW + r;
+    if (rp >= nrp) break;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (act) {
+        uint32_t o[12];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const Chroma k0 = chroma_terms(c, ubyte<0>(uv[r][j]), ubyte<1>(uv[r][j]));
+          const Chroma k1 = chroma_terms(c, ubyte<2>(uv[r][j]), ubyte<3>(uv[r][j]));
+          const Quad q = convert4(c, y[r][half][j], k0, k1);
+          pack_rgb12<DST, 1>(q, o[3 * j], o[3 * j + 1], o[3 * j + 2]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[lane * 3 + j] = u32x4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint8_t* rowp = f.d[0] + (size_t)(2 * rp + half) * f.dp[0];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const uint32_t off = chunk * 3072 + (k * 64 + lane) * 16;
+        if (off < row_bytes) stg<NTS, u32x4>(rowp + off, t[k * 64 + lane]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // YUV444 (three full planes) -> RGB/BGR/PLANAR, 4 px per lane, one row per task.
 // Requires w % 4 == 0 and 4-byte aligned planes.
 // ---------------------------------------------------------------------------------------------
@@ -291,16 +353,27 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   //   9       generic byte kernel                        10      p4 RP1 NT with the explicit (non cvt_pk) pack
   //   11/12   p16 LDS with NT stores only / NT loads only
   //   13      p16 lane-strided stores (no LDS)           15      p16 LDS NT, arithmetic removed (ceiling probe, wrong pixels)
-  //   14/16   p4 RP1 / RP2 with NT stores only
+  //   14/16   p4 RP1 / RP2 with NT stores only          17/18/19 p16r (one LDS row tile per wave), 1/2/4 row pairs per task, NT stores
   const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
   const bool p4_ok = even && aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
   // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal
   // stores; planar outputs (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
   if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? 11 : 4;
-  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15));
+  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 19));
   if (want_p16 && !p16_ok) variant = 4;
   if (variant != 9 && !p4_ok) variant = 9;
   if constexpr (SRC == FC_NV12) {
+    if (want_p16 && p16_ok && variant >= 17 && variant <= 19 && DST != FC_PLANAR) {  // p16r: RPW = 1, 2, 4
+      const uint32_t rpw = variant == 17 ? 1 : (variant == 18 ? 2 : 4);
+      const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * ((h / 2 + rpw - 1) / rpw);
+      dim3 grid((tasks + 3) / 4, n);
+      if constexpr (DST != FC_PLANAR) {
+        if (rpw == 1) VPF_LAUNCH((k_nv12_rgb_p16r<DST, 1, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+        else if (rpw == 2) VPF_LAUNCH((k_nv12_rgb_p16r<DST, 2, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+        else VPF_LAUNCH((k_nv12_rgb_p16r<DST, 4, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      }
+      return hipGetLastError();
+    }
     if (want_p16 && p16_ok) {
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
       dim3 grid((tasks + 3) / 4, n);
