@@ -256,7 +256,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if a.workload == "nv12_rgb_4k" and a.variant == 0 and a.mode == "batch" and os.path.exists(pmc):
             # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated on
-            # known-byte copy kernels: tools/pmc_calib.hip, scripts_gpu_pmc.sh) — collected offline, scaled to this launch
+            # known-byte copy kernels: tools/pmc_calib.hip, tools/gpu_pmc.sh) — collected offline, scaled to this launch
             traffic = int(json.load(open(pmc))["hbm_bytes_per_frame"] * wl.ring / wl.launches_per_step)
         out = {
             "metric": "Gpix/s NV12->RGB 3840x2160 + achieved %HBM-BW",

@@ -390,3 +390,37 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
         variant = int(rng.choice([0, 0, 4, 8, 9, 11])) if s == "NV12" and d in ("RGB", "BGR", "RGB_PLANAR") else 0
         src = oracle.synth(getattr(oracle, s), w, h, int(rng.integers(1 << 30)), "ABC"[int(rng.integers(3))])
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), cs, cr, w, h, src, align, extra, offset, variant=variant)
+
+
+def test_large_frame_8k(capi, oracle):
+    """largest practical picture (8192 x 8192, 67 Mpx, 302 MB of traffic in one frame): 32-bit index math, grid limits"""
+    w, h = 8192, 8192
+    src = oracle.synth(oracle.NV12, w, h, 1090)
+    for variant in (0, 4):
+        _convert(capi, oracle, capi.NV12, capi.RGB, 1, 0, w, h, src, variant=variant, exact_tol=False)
+    _convert(capi, oracle, capi.NV12, capi.YUV420, 1, 0, w, h, src, exact_tol=False)
+
+
+def test_full_size_batch_checksum_of_checksums(capi, oracle):
+    """BASELINE headline shape: 32 x 3840x2160 in ONE dispatch.  Size-independent property: the batch output equals the
+    per-frame dispatch output frame by frame (checksum of checksums), and two frames are checked bit-exactly vs the oracle."""
+    w, h, n = 3840, 2160, 32
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77)
+    src = [torch.randint(0, 256, (h * 3 // 2, w), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(n)]
+    out_b = [torch.zeros((h, 3 * w), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    out_s = [torch.zeros((h, 3 * w), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    sd = [[(s.data_ptr(), w), (s.data_ptr() + h * w, w)] for s in src]
+    ex = capi.make_exec(stream_handle())
+    capi.convert_batch(ex, capi.NV12, capi.RGB, 1, 0, w, h, capi.make_batch([(sd[i], [(out_b[i].data_ptr(), 3 * w)]) for i in range(n)]))
+    for i in range(n):
+        capi.convert(ex, capi.NV12, capi.RGB, 1, 0, w, h, sd[i], [(out_s[i].data_ptr(), 3 * w)])
+    torch.cuda.synchronize()
+    sums_b = [int(o.to(torch.int64).sum().item()) ^ int(o[::7, ::13].to(torch.int64).sum().item() << 20) for o in out_b]
+    sums_s = [int(o.to(torch.int64).sum().item()) ^ int(o[::7, ::13].to(torch.int64).sum().item() << 20) for o in out_s]
+    assert sums_b == sums_s and len(set(sums_b)) == n  # identical per frame, and frames are not aliases of each other
+    assert all(torch.equal(a, b) for a, b in zip(out_b, out_s))
+    for i in (0, 31):
+        a = src[i].cpu().numpy()
+        _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, [np.ascontiguousarray(a[:h]), np.ascontiguousarray(a[h:])])
+        assert np.array_equal(out_b[i].cpu().numpy(), want[0]), i
