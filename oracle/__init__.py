@@ -22,7 +22,7 @@ Y, RGB, NV12, YUV420, RGB_PLANAR, BGR, YCBCR, YUV444, RGB_32F, RGB_32F_PLANAR = 
 P10, P12 = 12, 13
 BT_601, BT_709 = 0, 1
 MPEG, JPEG = 0, 1
-NEAREST, LINEAR = 0, 1
+NEAREST, LINEAR, LANCZOS3 = 0, 1, 2
 
 
 class Plane(C.Structure):

@@ -609,8 +609,11 @@ static void make_taps(int mode, int interp, uint32_t S, uint32_t D, tap* t) {
     }
   }
 }
+static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw, uint32_t dh,
+                                const vpfo_plane* d);
 static int resize_plane(int mode, int interp, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw,
                         uint32_t dh, const vpfo_plane* d) {
+  if (interp == 2) return resize_plane_lanczos(mode, ch, sw, sh, s, dw, dh, d);
   tap* tx = (tap*)malloc(sizeof(tap) * dw);
   tap* ty = (tap*)malloc(sizeof(tap) * dh);
   if (!tx || !ty) { free(tx); free(ty); return VPFO_BAD_ARG; }
@@ -629,9 +632,125 @@ static int resize_plane(int mode, int interp, int ch, uint32_t sw, uint32_t sh, 
   return VPFO_OK;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Lanczos-3 (interp = 2).  The reference's resizer asks NPP for NPPI_INTER_LANCZOS (Tasks.cpp:1190,1248); NPP's
+ * exact kernel support / normalisation is unpublished, so this is the textbook separable Lanczos-3:
+ *   s = (d + 0.5) * S/D - 0.5;  i0 = floor(s);  f = s - i0;  taps i0-2 .. i0+3 (indices clamped to the image),
+ *   w_k = L(f - (k - 2)),  L(t) = sinc(t) sinc(t/3),  weights normalised to sum 1, no widening when minifying.
+ * EXACT: double + libm.  FP32: the kernels' operation order — sin(pi f), sin(pi f/3), cos(pi f/3) from fixed fma
+ * polynomials (so host and device agree bit for bit), the six taps from angle-addition identities, fma accumulation.
+ * ------------------------------------------------------------------------------------------ */
+static inline float lz_sinpi_poly(float g) { /* sin(pi g), g in [0, 0.5]; odd Taylor polynomial in x = pi g, degree 11 */
+  const float x = 3.14159274f * g, x2 = x * x;
+  float p = __builtin_fmaf(x2, -2.50521084e-8f, 2.75573192e-6f);
+  p = __builtin_fmaf(x2, p, -1.98412698e-4f);
+  p = __builtin_fmaf(x2, p, 8.33333333e-3f);
+  p = __builtin_fmaf(x2, p, -1.66666667e-1f);
+  p = __builtin_fmaf(x2, p, 1.0f);
+  return x * p;
+}
+static inline float lz_cos_poly(float x) { /* cos(x), x in [0, pi/3]; even Taylor polynomial, degree 10 */
+  const float x2 = x * x;
+  float p = __builtin_fmaf(x2, -2.75573192e-7f, 2.48015873e-5f);
+  p = __builtin_fmaf(x2, p, -1.38888889e-3f);
+  p = __builtin_fmaf(x2, p, 4.16666667e-2f);
+  p = __builtin_fmaf(x2, p, -0.5f);
+  return __builtin_fmaf(x2, p, 1.0f);
+}
+static void lanczos_weights_fp32(float f, float w[6]) {
+  if (f == 0.f) { w[0] = w[1] = w[3] = w[4] = w[5] = 0.f; w[2] = 1.f; return; }
+  const float s1 = lz_sinpi_poly(f <= 0.5f ? f : 1.0f - f); /* sin(pi f) */
+  const float s3 = lz_sinpi_poly(f * 0.333333343f);           /* sin(pi f / 3), argument in [0, 1/3) */
+  const float c3 = lz_cos_poly(1.04719758f * f);              /* cos(pi f / 3) */
+  /* tap k: t = f - m, m = k - 2.  sin(pi t) = (-1)^m sin(pi f);  sin(pi t/3) = s3 cos(m pi/3) - c3 sin(m pi/3) */
+  static const float cm[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};                        /* cos(m pi/3), m=-2..3 */
+  static const float sm[6] = {-0.866025388f, -0.866025388f, 0.0f, 0.866025388f, 0.866025388f, 0.0f}; /* sin(m pi/3) */
+  static const float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};                        /* (-1)^m */
+  float sum = 0.f;
+  for (int k = 0; k < 6; k++) {
+    const float t = f - (float)(k - 2);
+    const float a = sg[k] * s1;
+    const float b = __builtin_fmaf(s3, cm[k], -(c3 * sm[k]));
+    w[k] = (0.303963542f * (a * b)) / (t * t); /* 3 / pi^2 */
+    sum += w[k];
+  }
+  const float inv = 1.0f / sum;
+  for (int k = 0; k < 6; k++) w[k] *= inv;
+}
+static void lanczos_weights_exact(double f, double w[6]) {
+  double sum = 0;
+  for (int k = 0; k < 6; k++) {
+    const double t = f - (k - 2);
+    w[k] = (t == 0.0) ? 1.0 : 3.0 * sin(M_PI * t) * sin(M_PI * t / 3.0) / (M_PI * M_PI * t * t);
+    sum += w[k];
+  }
+  for (int k = 0; k < 6; k++) w[k] /= sum;
+}
+typedef struct { int32_t idx[6]; double w[6]; float wf[6]; } ltap;
+static void make_ltaps(int mode, uint32_t S, uint32_t D, ltap* t) {
+  const double sc = (double)S / (double)D;
+  const float scf = (float)S / (float)D;
+  for (uint32_t d = 0; d < D; d++) {
+    int32_t i0;
+    if (mode == VPFO_EXACT) {
+      const double s = (d + 0.5) * sc - 0.5;
+      i0 = (int32_t)floor(s);
+      lanczos_weights_exact(s - i0, t[d].w);
+      for (int k = 0; k < 6; k++) t[d].wf[k] = (float)t[d].w[k];
+    } else {
+      const float s = __builtin_fmaf((float)d + 0.5f, scf, -0.5f);
+      const float fl = floorf(s);
+      i0 = (int32_t)fl;
+      lanczos_weights_fp32(s - fl, t[d].wf);
+      for (int k = 0; k < 6; k++) t[d].w[k] = t[d].wf[k];
+    }
+    for (int k = 0; k < 6; k++) {
+      int32_t i = i0 + k - 2;
+      t[d].idx[k] = i < 0 ? 0 : (i > (int32_t)S - 1 ? (int32_t)S - 1 : i);
+    }
+  }
+}
+static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw, uint32_t dh,
+                                const vpfo_plane* d) {
+  ltap* tx = (ltap*)malloc(sizeof(ltap) * dw);
+  ltap* ty = (ltap*)malloc(sizeof(ltap) * dh);
+  if (!tx || !ty) { free(tx); free(ty); return VPFO_BAD_ARG; }
+  make_ltaps(mode, sw, dw, tx);
+  make_ltaps(mode, sh, dh, ty);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int64_t yy = 0; yy < (int64_t)dh; yy++) {
+    uint8_t* o = prow(d, (uint32_t)yy);
+    for (uint32_t x = 0; x < dw; x++)
+      for (int c = 0; c < ch; c++) {
+        if (mode == VPFO_EXACT) {
+          double acc = 0;
+          for (int ky = 0; ky < 6; ky++) {
+            const uint8_t* r = prow(s, (uint32_t)ty[yy].idx[ky]);
+            double ra = 0;
+            for (int kx = 0; kx < 6; kx++) ra += tx[x].w[kx] * r[ch * tx[x].idx[kx] + c];
+            acc += ty[yy].w[ky] * ra;
+          }
+          const double v = floor(acc + 0.5);
+          o[ch * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        } else { /* kernel order: per source row an fma chain over x taps (tap 0 first), then an fma chain over rows */
+          float acc = 0.f;
+          for (int ky = 0; ky < 6; ky++) {
+            const uint8_t* r = prow(s, (uint32_t)ty[yy].idx[ky]);
+            float ra = 0.f;
+            for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx[x].wf[kx], (float)r[ch * tx[x].idx[kx] + c], ra);
+            acc = __builtin_fmaf(ty[yy].wf[ky], ra, acc);
+          }
+          o[ch * x + c] = sat_trunc(acc + 0.5f);
+        }
+      }
+  }
+  free(tx); free(ty);
+  return VPFO_OK;
+}
+
 int vpfo_resize(int mode, int fmt, int interp, uint32_t sw, uint32_t sh, const vpfo_plane s[3], uint32_t dw,
                 uint32_t dh, const vpfo_plane d[3]) {
-  if (interp != 0 && interp != 1) return VPFO_UNSUPPORTED;
+  if (interp != 0 && interp != 1 && interp != 2) return VPFO_UNSUPPORTED;
   if (!sw || !sh || !dw || !dh) return VPFO_BAD_ARG;
   if (!check_planes(fmt, sw, s) || !check_planes(fmt, dw, d)) return (nplanes(fmt) ? VPFO_BAD_ARG : VPFO_UNSUPPORTED);
   switch (fmt) {

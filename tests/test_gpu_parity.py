@@ -424,3 +424,24 @@ def test_full_size_batch_checksum_of_checksums(capi, oracle):
         a = src[i].cpu().numpy()
         _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, [np.ascontiguousarray(a[:h]), np.ascontiguousarray(a[h:])])
         assert np.array_equal(out_b[i].cpu().numpy(), want[0]), i
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "Y", "YUV420", "NV12", "RGB_PLANAR"])
+def test_resize_lanczos3(capi, oracle, fmt):
+    """Lanczos-3 (the filter the reference resizer requests, Tasks.cpp:1190): bit-exact vs the oracle's FP32 restatement
+    (polynomial sin/cos, identical weights), within 1 LSB of the double-precision evaluation"""
+    f = getattr(capi, fmt)
+    for (sw, sh, dw, dh) in [(640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (1920, 32, 640, 11), (9, 7, 20, 15)]:
+        src = oracle.synth(f, sw, sh, 1100)
+        s, d = DevPlanes(src), DevPlanes(oracle.alloc(f, dw, dh))
+        capi.resize(capi.make_exec(stream_handle()), f, capi.INTERP_LANCZOS3, sw, sh, s.desc(), dw, dh, d.desc())
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact
+        _, want = oracle.resize(f, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.FP32)
+        assert_planes_equal(got, want, f"lanczos fmt{fmt} {sw}x{sh}->{dw}x{dh}")
+        _, ex = oracle.resize(f, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.EXACT)
+        for g, e in zip(got, ex):
+            assert np.abs(g.astype(int) - e.astype(int)).max() <= 1
+        if (sw, sh) == (dw, dh):
+            assert_planes_equal(got, src, "lanczos identity")

@@ -120,6 +120,8 @@ public:
     rs_.reset(ResizeSurface::Make(w, h, f, ctx, str));
   }
   Pixel_Format GetFormat() const { return fmt_; }
+  void SetInterpolation(int i) { rs_->SetInterpolation(i); }
+  int GetInterpolation() const { return rs_->GetInterpolation(); }
   std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src) {
     if (!src) return empty_surface(fmt_);
     rs_->SetInput(src.get(), 0U);
@@ -386,6 +388,9 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceResizer(w, h, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceResizer::GetFormat)
+      .def("SetInterpolation", &PySurfaceResizer::SetInterpolation, py::arg("interp"),
+           "additive: 0 nearest, 1 bilinear (default), 2 Lanczos-3 (the filter the reference requests from NPP)")
+      .def("GetInterpolation", &PySurfaceResizer::GetInterpolation)
       .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>());
 
   using FMap = py::array_t<float, py::array::c_style | py::array::forcecast>;

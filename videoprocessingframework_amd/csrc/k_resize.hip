@@ -79,6 +79,97 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 }
 
 // ------------------------------------------------------------------------------------------
+// Lanczos-3 (VPF_INTERP_LANCZOS3): what the reference's resizer asks NPP for (Tasks.cpp:1190).  Textbook separable
+// 6 x 6 taps, weights normalised, indices clamped, no widening when minifying.  sin / cos come from fixed fma
+// polynomials and the six taps from angle-addition identities so the host oracle reproduces the weights bit for bit
+// (the test oracle restates the same sequence).  Gather kernel: lane = one destination pixel.
+// ------------------------------------------------------------------------------------------
+VPF_DEV float lz_sinpi_poly(float g) {  // sin(pi g), g in [0, 0.5]
+  const float x = 3.14159274f * g, x2 = x * x;
+  float p = __builtin_fmaf(x2, -2.50521084e-8f, 2.75573192e-6f);
+  p = __builtin_fmaf(x2, p, -1.98412698e-4f);
+  p = __builtin_fmaf(x2, p, 8.33333333e-3f);
+  p = __builtin_fmaf(x2, p, -1.66666667e-1f);
+  p = __builtin_fmaf(x2, p, 1.0f);
+  return x * p;
+}
+VPF_DEV float lz_cos_poly(float x) {  // cos(x), x in [0, pi/3]
+  const float x2 = x * x;
+  float p = __builtin_fmaf(x2, -2.75573192e-7f, 2.48015873e-5f);
+  p = __builtin_fmaf(x2, p, -1.38888889e-3f);
+  p = __builtin_fmaf(x2, p, 4.16666667e-2f);
+  p = __builtin_fmaf(x2, p, -0.5f);
+  return __builtin_fmaf(x2, p, 1.0f);
+}
+struct LTap {
+  int32_t i0;
+  float w[6];
+};
+VPF_DEV LTap make_ltap(uint32_t d, float scale) {
+  LTap t;
+  const float s = __builtin_fmaf((float)d + 0.5f, scale, -0.5f);
+  const float fl = __builtin_floorf(s);
+  t.i0 = (int32_t)fl;
+  const float f = s - fl;
+  if (f == 0.f) {
+    t.w[0] = t.w[1] = t.w[3] = t.w[4] = t.w[5] = 0.f; t.w[2] = 1.f;
+    return t;
+  }
+  const float s1 = lz_sinpi_poly(f <= 0.5f ? f : 1.0f - f);
+  const float s3 = lz_sinpi_poly(f * 0.333333343f);
+  const float c3 = lz_cos_poly(1.04719758f * f);
+  constexpr float cm[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};
+  constexpr float sm[6] = {-0.866025388f, -0.866025388f, 0.0f, 0.866025388f, 0.866025388f, 0.0f};
+  constexpr float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float tt = f - (float)(k - 2);
+    const float a = sg[k] * s1;
+    const float b = __builtin_fmaf(s3, cm[k], -(c3 * sm[k]));
+    t.w[k] = (0.303963542f * (a * b)) / (tt * tt);
+    sum += t.w[k];
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int k = 0; k < 6; k++) t.w[k] *= inv;
+  return t;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_resize_lanczos(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                        uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                        float scx, float scy) {
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  const LTap tx = make_ltap(x, scx), ty = make_ltap(y, scy);
+  uint32_t xi[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int32_t i = tx.i0 + k - 2;
+    xi[k] = (uint32_t)(i < 0 ? 0 : (i > (int32_t)sw - 1 ? (int32_t)sw - 1 : i)) * CH;
+  }
+  float acc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) acc[c] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 6; ky++) {
+    const int32_t j = ty.i0 + ky - 2;
+    const uint8_t* r = src + (size_t)(j < 0 ? 0 : (j > (int32_t)sh - 1 ? (int32_t)sh - 1 : j)) * sp;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      float ra = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], (float)r[xi[kx] + c], ra);
+      acc[c] = __builtin_fmaf(ty.w[ky], ra, acc[c]);
+    }
+  }
+  uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
+#pragma unroll
+  for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_trunc(acc[c] + 0.5f);
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS-staged variant (the default when it applies): a wave produces 256 consecutive destination pixels of one
 // row.  It first copies the two source rows' byte span it needs into a wave-private LDS strip with fully coalesced
 // dword loads (each source byte crosses the memory pipeline once, as part of a dense 256-B wave load, instead of
@@ -171,6 +262,13 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
                          uint32_t sp, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
+  if (interp == VPF_INTERP_LANCZOS3) {
+    dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
+    if (ch == 1) VPF_LAUNCH((k_resize_lanczos<1>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
+    else if (ch == 2) VPF_LAUNCH((k_resize_lanczos<2>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
+    else VPF_LAUNCH((k_resize_lanczos<3>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
+    return hipGetLastError();
+  }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
   if (interp == VPF_INTERP_LINEAR && lds_resize_ok(ch, sw, dw, src, sp, kResizeRowBytes)) {
     if (ch == 1) VPF_LAUNCH((k_resize_lds<1>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);

@@ -260,7 +260,13 @@ struct ResizeSurface::Impl {
   uint32_t w, h;
   StreamRef sref;
   std::unique_ptr<Surface> out;
+  int interp = VPF_INTERP_LINEAR;
 };
+void ResizeSurface::SetInterpolation(int interp) {
+  if (interp < VPF_INTERP_NEAREST || interp > VPF_INTERP_LANCZOS3) throw std::invalid_argument("ResizeSurface: unknown interpolation");
+  pImpl->interp = interp;
+}
+int ResizeSurface::GetInterpolation() const { return pImpl->interp; }
 static bool resize_format_ok(Pixel_Format f) {
   switch (f) {  // reference: packed 3C, planar (YUV420/YCBCR/YUV444/RGB_PLANAR), NV12; + Y (Tasks.cpp:1458-1476)
     case RGB: case BGR: case YUV420: case YCBCR: case YUV444: case RGB_PLANAR: case NV12: case Y: return true;
@@ -274,7 +280,11 @@ ResizeSurface::ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext 
     ss << "pixel format not supported";
     throw std::runtime_error(ss.str());
   }
-  pImpl = new Impl{f, w, h, StreamRef{ctx, str}, nullptr};
+  pImpl = new Impl{f, w, h, StreamRef{ctx, str}, nullptr, VPF_INTERP_LINEAR};
+  if (const char* e = std::getenv("VPF_HIP_RESIZE_INTERP")) {  // "lanczos" restores the reference resizer's filter
+    if (!std::strcmp(e, "lanczos") || !std::strcmp(e, "2")) pImpl->interp = VPF_INTERP_LANCZOS3;
+    else if (!std::strcmp(e, "nearest") || !std::strcmp(e, "0")) pImpl->interp = VPF_INTERP_NEAREST;
+  }
   pImpl->out.reset(Surface::Make(f, w, h, ctx));
 }
 ResizeSurface::~ResizeSurface() { delete pImpl; }
@@ -290,7 +300,7 @@ TaskExecStatus ResizeSurface::Run() {
   fill_planes(in, src);
   fill_planes(pImpl->out.get(), dst);
   const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
-  const vpf_status st = vpf_resize(&ex, pImpl->fmt, VPF_INTERP_LINEAR, vpf_size{in->Width(), in->Height()}, src,
+  const vpf_status st = vpf_resize(&ex, pImpl->fmt, pImpl->interp, vpf_size{in->Width(), in->Height()}, src,
                                    vpf_size{pImpl->w, pImpl->h}, dst);
   hip_stream_sync(&pImpl->sref);  // the reference task is blocking (cuda_stream_sync callback)
   if (st != VPF_OK) {

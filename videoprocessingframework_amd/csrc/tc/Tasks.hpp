@@ -35,6 +35,9 @@ public:
   static ResizeSurface* Make(uint32_t width, uint32_t height, Pixel_Format format, HipContext ctx, HipStream str);
   ~ResizeSurface() override;
   TaskExecStatus Run() final;  // blocking: the task registers a stream-sync callback (Tasks.cpp:1455-1456)
+  // 0 nearest, 1 bilinear (default: BASELINE.json north_star), 2 Lanczos-3 (what the reference asks NPP for, :1190)
+  void SetInterpolation(int interp);
+  int GetInterpolation() const;
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;

@@ -216,7 +216,7 @@ vpf_status vpf_convert(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf
 
 vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, const vpf_plane src[3], vpf_size ds,
                       const vpf_plane dst[3]) {
-  if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR) return VPF_ERR_UNSUPPORTED;
+  if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR && interp != VPF_INTERP_LANCZOS3) return VPF_ERR_UNSUPPORTED;
   switch (fmt) {
     case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_Y: case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
     case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_NV12: break;
