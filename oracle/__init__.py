@@ -74,6 +74,10 @@ def set_threads(n: int) -> int:
     return lib().vpfo_set_threads(n)
 
 
+def release_threads() -> None:
+    lib().vpfo_release_threads()
+
+
 # ------------------------------------------------------------------------------------------------
 # plane geometry (tight host layout); mirrors the reference's per-format plane shapes
 # (MemoryInterfaces.cpp:811-913 NV12, :915-1062 YUV420, :1361-1519 RGB/BGR, :1521-1637 planar)

@@ -31,6 +31,12 @@ int vpfo_set_threads(int n) {
   if (n >= 1) g_threads = n;
   return p;
 }
+/* tear the OpenMP thread pool down (threads left over from a larger team would otherwise idle-spin next to a smaller one) */
+void vpfo_release_threads(void) {
+#ifdef _OPENMP
+  omp_pause_resource_all(omp_pause_soft);
+#endif
+}
 const char* vpfo_version(void) { return "vpf-oracle 1 (parity unpinned: NPP closed source)"; }
 
 /* Hot loops are instantiated twice from one body: baseline x86-64 (fmaf = libm call, correct everywhere) and
