@@ -209,6 +209,28 @@ def cpu_baseline(wl: Workload, budget_s=10.0):
                       ", ".join(f"{t}t={v / 1e9:.2f}" for t, v in calib.items()) + ")"}
 
 
+def other_configs(dev, main_wl):
+    """Short (a few steps each) measurements of BASELINE.json's other configs and of the per-Execute() dispatch mode, so
+    the one JSON line also carries them.  Same ring discipline (device-resident, > Infinity Cache); informational only."""
+    res = {}
+    del main_wl.keep[:]
+    torch.cuda.empty_cache()
+    for key, name, ring, mode, steps in (
+            ("4k_nv12_rgb_one_dispatch_per_frame", "nv12_rgb_4k", 32, "single", 10),         # unmodified per-Execute() API
+            ("1080p_nv12_rgb_planar_batched", "nv12_planar_1080p", 128, "batch", 10),          # configs[1]
+            ("4k_nv12_rgb_then_resize_720p_per_frame", "resize_4k_720p", 16, "single", 4),     # configs[2], API-faithful
+            ("4k_nv12_to_720p_rgb_fused_batched", "fused_4k_720p", 32, "batch", 10)):          # configs[2], fused
+        wl = Workload(name, dev, ring, 0, mode)
+        _, ev = timed(wl, steps, 2, False)
+        res[key] = {"Gpix_s_src": round(wl.px_per_step * steps / ev / 1e9, 1),
+                    "algorithmic_GB_s": round(wl.bytes_per_step * steps / ev / 1e9, 0),
+                    "frac_of_8TB_s": round(wl.bytes_per_step * steps / ev / 1e9 / HBM_PEAK_GBS, 3),
+                    "us_per_frame": round(ev / steps / ring * 1e6, 2)}
+        del wl
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +242,8 @@ def main():
     ap.add_argument("--workload", default="nv12_rgb_4k")
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also measure the other BASELINE configs / dispatch modes (adds 'other_configs'); "
+                    "off by default so the default run launches ONE kernel shape and its rocprofv3 average is the headline's")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
     a = ap.parse_args()
 
@@ -236,7 +260,7 @@ def main():
     if a.sweep and rank == 0:
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
             for mode in ("batch", "single"):
-                for v in (4, 8, 11, 17, 18, 19, 15):
+                for v in (4, 8, 11, 20, 21, 15):
                     wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, v, mode)
                     _, ev = timed(wl, a.steps, a.warmup, False)
                     gbs = wl.bytes_per_step * a.steps / ev / 1e9
@@ -292,6 +316,8 @@ def main():
         }
         if not a.no_cpu and world == 1 and a.workload == "nv12_rgb_4k":
             out["cpu_baseline"] = cpu_baseline(wl)
+        if a.extra and world == 1 and a.workload == "nv12_rgb_4k" and a.variant == 0 and a.mode == "batch":
+            out["other_configs"] = other_configs(dev, wl)
         print(json.dumps(out), flush=True)
     if dist_on:
         sharding.barrier(dev)

@@ -113,12 +113,12 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
 // 48*l + 16*j -> dword banks {12l+4j .. +3} mod 32, which tile all 32 banks exactly once per
 // group: conflict free.  The ds_read_b128 side reads 16*l: contiguous, conflict free.
 // ---------------------------------------------------------------------------------------------
-template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH>
-__global__ __launch_bounds__(256) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
-                                                      uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
-  __shared__ u32x4 tile[(LDS_T && DST != FC_PLANAR) ? 4 * 2 * 192 : 1];
+template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                           uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[(LDS_T && DST != FC_PLANAR) ? WPB * 2 * 192 : 1];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t wt = blockIdx.x * 4 + wv;
+  const uint32_t wt = blockIdx.x * WPB + wv;
   if (wt >= n_tasks) return;
   const FrameDesc f = args.f[blockIdx.y];
   const uint32_t rp = wt / chunks_x, chunk = wt - rp * chunks_x;
@@ -356,10 +356,11 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   //   14/16   p4 RP1 / RP2 with NT stores only          17/18/19 p16r (one LDS row tile per wave), 1/2/4 row pairs per task, NT stores
   const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
   const bool p4_ok = even && aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
-  // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal
-  // stores; planar outputs (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
-  if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? 11 : 4;
-  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 19));
+  // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal loads and
+  // stores (ties with the other top variants when batched, +3 % when a launch is a single frame); planar outputs
+  // (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
+  if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? 8 : 4;
+  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21));
   if (want_p16 && !p16_ok) variant = 4;
   if (variant != 9 && !p4_ok) variant = 9;
   if constexpr (SRC == FC_NV12) {
@@ -385,6 +386,14 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
         case 12: VPF_P16(true, false, true, false); break;
         case 13: VPF_P16(true, true, false, false); break;
         case 15: VPF_P16(true, true, true, true); break;
+        case 20: {  // one wave per workgroup: 4x more, smaller workgroups -> finer balance when a launch is only one frame
+          dim3 g1(tasks, n);
+          VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, false, true, true, false, 1>), g1, dim3(64), 0, st, a, c, w, h, chunks, tasks);
+        } break;
+        case 21: {  // two waves per workgroup
+          dim3 g2((tasks + 1) / 2, n);
+          VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, false, true, true, false, 2>), g2, dim3(128), 0, st, a, c, w, h, chunks, tasks);
+        } break;
         default: VPF_P16(true, true, true, false);
       }
 #undef VPF_P16
