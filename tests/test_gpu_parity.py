@@ -86,6 +86,11 @@ def test_nv12_to_rgb_ragged_sizes(capi, oracle, w, h):
     for dst in (capi.RGB, capi.BGR, capi.RGB_PLANAR):
         _convert(capi, oracle, capi.NV12, dst, 1, 0, w, h, src, align=1)       # pitch == row bytes
         _convert(capi, oracle, capi.NV12, dst, 0, 1, w, h, src, align=64, extra=3, offset=1)  # odd pitch, odd base
+        for variant in (0, 1, 6):  # padded (4-B aligned) pitches: the ragged row end / odd last row inside the p4 kernels
+            _convert(capi, oracle, capi.NV12, dst, 1, 1, w, h, src, align=256, variant=variant)
+    ysrc = oracle.synth(oracle.YUV420, w, h, 1003)
+    _convert(capi, oracle, capi.YUV420, capi.RGB, 0, 0, w, h, ysrc, align=256)
+    _convert(capi, oracle, capi.YUV420, capi.RGB_PLANAR, 0, 1, w, h, ysrc, align=8)
 
 
 @pytest.mark.parametrize("align,extra,offset", [(256, 0, 0), (4, 0, 0), (4, 4, 4), (16, 0, 16), (1, 0, 0), (256, 0, 2)])

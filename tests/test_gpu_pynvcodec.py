@@ -280,3 +280,33 @@ def test_execute_batch(oracle):
 
 def test_num_gpus():
     assert nvc.GetNumGpus() == torch.cuda.device_count() >= 1
+
+
+def test_convert_straight_into_a_torch_tensor(oracle):
+    """BASELINE.json configs[4]: NV12 -> RGB_PLANAR written DIRECTLY into a torch tensor (true zero copy: the tensor is
+    wrapped as a non-owning Surface and handed to the converter as its output), then a remap warp of the packed picture."""
+    w, h = 1280, 720
+    src = oracle.synth(oracle.NV12, w, h, 21, "B")
+    nv12 = upload(PF.NV12, w, h, src)
+    t = torch.zeros((3, h, w), dtype=torch.uint8, device="cuda")
+    out = pnvc.surface_from_tensor(t)
+    assert out.Format() == PF.RGB_PLANAR and not out.OwnMemory() and out.PlanePtr().GpuMem() == t.data_ptr()
+    conv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB_PLANAR, GPU)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    assert conv.ExecuteBatch([nv12], [out], cc)
+    torch.cuda.synchronize()
+    _, want = oracle.convert(oracle.NV12, oracle.RGB_PLANAR, 1, 0, w, h, src)
+    assert np.array_equal(t.cpu().numpy(), np.stack(want))                 # bit-exact (FP32 oracle)
+    _, ex = oracle.convert(oracle.NV12, oracle.RGB_PLANAR, 1, 0, w, h, src, oracle.EXACT)
+    assert np.abs(t.cpu().numpy().astype(int) - np.stack(ex).astype(int)).max() <= 1   # +-1 LSB vs the specification level
+    # packed tensor as converter output + remap of it (samples/SampleRemap.py)
+    tp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    assert nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU).ExecuteBatch([nv12], [pnvc.surface_from_tensor(tp)], cc)
+    xm, ym = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    xm = xm * 0.97 + 11.5
+    warped = nvc.PySurfaceRemaper(xm, ym, PF.RGB, GPU).Execute(pnvc.surface_from_tensor(tp))
+    _, rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+    _, wantw = oracle.remap(oracle.RGB, w, h, rgb, xm, ym)
+    assert np.array_equal(download(warped), wantw[0].reshape(-1))
+    with pytest.raises(ValueError):
+        nvc.Surface.Wrap(PF.YUV420, w, h, w, t.data_ptr())               # three allocations cannot wrap one pointer

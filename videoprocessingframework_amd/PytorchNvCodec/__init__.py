@@ -78,3 +78,28 @@ def TensorToDptr(tensor: torch.Tensor, ptr: int, width: int, height: int, pitch:
         view_plane(ptr, width, height, pitch, device=tensor.device).copy_(tensor.reshape(height, width))
     if not stream:
         torch.cuda.current_stream().synchronize()
+
+
+def surface_from_tensor(tensor: torch.Tensor, fmt=None):
+    """Wrap a contiguous CUDA/HIP uint8 tensor as a non-owning PyNvCodec.Surface — the converter then writes straight into
+    the tensor (`PySurfaceConverter.ExecuteBatch([src], [surface_from_tensor(t)])`), no copy at all.
+      [3, H, W] -> RGB_PLANAR (default) or YUV444;   [H, W, 3] -> RGB (default) or BGR;   [H, W] -> Y
+    The tensor is kept alive by the returned Surface."""
+    try:
+        import PyNvCodec as nvc
+    except ImportError:  # package-relative import when used as videoprocessingframework_amd.PytorchNvCodec
+        from .. import PyNvCodec as nvc
+    if tensor.dtype != torch.uint8 or not tensor.is_cuda or not tensor.is_contiguous():
+        raise RuntimeError("surface_from_tensor: need a contiguous CUDA/HIP torch.uint8 tensor")
+    PF = nvc.PixelFormat
+    if tensor.dim() == 3 and tensor.shape[0] == 3:
+        f, (h, w), pitch = (fmt or PF.RGB_PLANAR), tensor.shape[1:], tensor.shape[2]
+    elif tensor.dim() == 3 and tensor.shape[2] == 3:
+        f, (h, w), pitch = (fmt or PF.RGB), tensor.shape[:2], 3 * tensor.shape[1]
+    elif tensor.dim() == 2:
+        f, (h, w), pitch = (fmt or PF.Y), tensor.shape, tensor.shape[1]
+    else:
+        raise RuntimeError("surface_from_tensor: expected [3,H,W], [H,W,3] or [H,W]")
+    s = nvc.Surface.Wrap(f, int(w), int(h), int(pitch), tensor.data_ptr())
+    s._owner = tensor
+    return s

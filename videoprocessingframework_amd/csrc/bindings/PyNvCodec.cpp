@@ -294,7 +294,16 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            py::arg("dst"), py::arg("dst_pitch"), py::arg("context"), py::arg("stream"))
       .def("__repr__", [](std::shared_ptr<SurfacePlane> self) { return plane_repr(self.get()); });
 
-  py::class_<Surface, std::shared_ptr<Surface>>(m, "Surface")
+  py::class_<Surface, std::shared_ptr<Surface>>(m, "Surface", py::dynamic_attr())
+      // additive: non-owning Surface over memory someone else owns (a torch tensor, a decoder's frame pool); the
+      // reference has the equivalent only in C++ (SurfaceNV12(width, height, pitch, ptr), MemoryInterfaces.cpp:822-826)
+      .def_static("Wrap",
+                  [](Pixel_Format f, uint32_t w, uint32_t h, uint32_t pitch, size_t ptr) {
+                    Surface* s = Surface::Make(f, w, h, pitch, (DevicePtr)ptr);
+                    if (!s) throw std::invalid_argument("Surface.Wrap: format must live in ONE pitched allocation (Y, NV12, P10, P12, RGB, BGR, RGB_PLANAR, YUV444, RGB_32F, RGB_32F_PLANAR)");
+                    return std::shared_ptr<Surface>(s);
+                  },
+                  py::arg("format"), py::arg("width"), py::arg("height"), py::arg("pitch"), py::arg("ptr"))
       .def("Width", &Surface::Width, py::arg("plane") = 0U)
       .def("Height", &Surface::Height, py::arg("plane") = 0U)
       .def("Pitch", &Surface::Pitch, py::arg("plane") = 0U)

@@ -48,9 +48,16 @@ VPF_DEV void pack_rgb12(const Quad& q, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 }
 
 // ---------------------------------------------------------------------------------------------
-// p4: 4 px per lane, RP row pairs per wave task.  Requires w % 4 == 0, h even, every plane
-// pointer/pitch 4-byte aligned (2-byte for YUV420 chroma).  SRC in {FC_NV12, FC_YUV420}.
+// p4: 4 px per lane, RP row pairs per wave task.  Requires every plane pointer/pitch 4-byte aligned (2-byte for
+// YUV420 chroma) — which also guarantees a whole dword can be LOADED at the ragged end of a row (pitch >= round_up(w,4)).
+// Any width / height: the last pixel group of a row stores only its valid bytes, an odd last row is a pair of one.
+// SRC in {FC_NV12, FC_YUV420}.
 // ---------------------------------------------------------------------------------------------
+VPF_DEV void store_bytes(uint8_t* p, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t nbytes) {
+  const uint32_t d[3] = {d0, d1, d2};
+  for (uint32_t i = 0; i < nbytes; i++) p[i] = (uint8_t)(d[i >> 2] >> (8 * (i & 3)));
+}
+
 template <int SRC, int DST, int RP, int PACK, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                        uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
@@ -61,7 +68,8 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
   const uint32_t rpt = wt / chunks_x, chunk = wt - rpt * chunks_x;
   const uint32_t x = (chunk * 64 + (threadIdx.x & 63)) * 4;
   if (x >= w) return;
-  const uint32_t nrp = h >> 1, rp0 = rpt * RP;
+  const uint32_t nrp = (h + 1) >> 1, rp0 = rpt * RP;
+  const uint32_t npx = (w - x < 4) ? w - x : 4;  // valid pixels of this lane's group (4 except at a ragged row end)
 
   uint32_t ya[RP], yb[RP], uv[RP];
 #pragma unroll
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
     const uint32_t rp = rp0 + r;
     if (rp < nrp) {
       ya[r] = ldg<NTL, uint32_t>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
-      yb[r] = ldg<NTL, uint32_t>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+      yb[r] = (2 * rp + 1 < h) ? ldg<NTL, uint32_t>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x) : 0u;
       if constexpr (SRC == FC_NV12) {
         uv[r] = ldg<NTL, uint32_t>(f.s[1] + (size_t)rp * f.sp[1] + x);
       } else {  // two U bytes and two V bytes -> same (U0 V0 U1 V1) byte order as NV12
@@ -87,16 +95,26 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
       const Chroma k1 = chroma_terms(c, ubyte<2>(uv[r]), ubyte<3>(uv[r]));
 #pragma unroll
       for (int half = 0; half < 2; half++) {
-        const Quad q = convert4(c, half ? yb[r] : ya[r], k0, k1);
         const size_t row = (size_t)(2 * rp + half);
+        if (row >= h) break;
+        const Quad q = convert4(c, half ? yb[r] : ya[r], k0, k1);
         if constexpr (DST == FC_PLANAR) {
-          stg<NTS, uint32_t>(f.d[0] + row * f.dp[0] + x, pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]));
-          stg<NTS, uint32_t>(f.d[1] + row * f.dp[1] + x, pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]));
-          stg<NTS, uint32_t>(f.d[2] + row * f.dp[2] + x, pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]));
+          const uint32_t pr = pack4<PACK>(q.r[0], q.r[1], q.r[2], q.r[3]), pg = pack4<PACK>(q.g[0], q.g[1], q.g[2], q.g[3]),
+                         pb = pack4<PACK>(q.b[0], q.b[1], q.b[2], q.b[3]);
+          if (npx == 4) {
+            stg<NTS, uint32_t>(f.d[0] + row * f.dp[0] + x, pr);
+            stg<NTS, uint32_t>(f.d[1] + row * f.dp[1] + x, pg);
+            stg<NTS, uint32_t>(f.d[2] + row * f.dp[2] + x, pb);
+          } else {
+            store_bytes(f.d[0] + row * f.dp[0] + x, pr, 0, 0, npx);
+            store_bytes(f.d[1] + row * f.dp[1] + x, pg, 0, 0, npx);
+            store_bytes(f.d[2] + row * f.dp[2] + x, pb, 0, 0, npx);
+          }
         } else {
           uint32_t d0, d1, d2;
           pack_rgb12<DST, PACK>(q, d0, d1, d2);
-          stg3<NTS>(f.d[0] + row * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+          if (npx == 4) stg3<NTS>(f.d[0] + row * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+          else store_bytes(f.d[0] + row * f.dp[0] + 3 * (size_t)x, d0, d1, d2, 3 * npx);
         }
       }
     }
@@ -355,7 +373,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   //   13      p16 lane-strided stores (no LDS)           15      p16 LDS NT, arithmetic removed (ceiling probe, wrong pixels)
   //   14/16   p4 RP1 / RP2 with NT stores only          17/18/19 p16r (one LDS row tile per wave), 1/2/4 row pairs per task, NT stores
   const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
-  const bool p4_ok = even && aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
+  const bool p4_ok = aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
   // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal loads and
   // stores (ties with the other top variants when batched, +3 % when a launch is a single frame); planar outputs
   // (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
@@ -401,9 +419,9 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
     }
   }
   if (variant != 9) {
-    const uint32_t chunks = (w / 4 + 63) / 64;
+    const uint32_t chunks = ((w + 3) / 4 + 63) / 64;
     auto go = [&](auto kern, int rp) {
-      const uint32_t tasks = chunks * ((h / 2 + rp - 1) / rp);
+      const uint32_t tasks = chunks * (((h + 1) / 2 + rp - 1) / rp);
       dim3 grid((tasks + 3) / 4, n);
       VPF_LAUNCH(kern, grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
       return hipGetLastError();
