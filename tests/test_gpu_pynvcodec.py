@@ -310,3 +310,17 @@ def test_convert_straight_into_a_torch_tensor(oracle):
     assert np.array_equal(download(warped), wantw[0].reshape(-1))
     with pytest.raises(ValueError):
         nvc.Surface.Wrap(PF.YUV420, w, h, w, t.data_ptr())               # three allocations cannot wrap one pointer
+
+
+def test_upload_from_pinned_memory():
+    """AllocPinned: numpy array over page-locked memory; the uploader DMAs from it directly and the result is identical"""
+    w, h = 640, 360
+    n = w * h * 3 // 2
+    a = np.random.default_rng(9).integers(0, 256, n, dtype=np.uint8)
+    p = nvc.AllocPinned(n)
+    assert p.dtype == np.uint8 and p.shape == (n,)
+    p[:] = a
+    up = nvc.PyFrameUploader(w, h, PF.NV12, GPU)
+    for _ in range(3):
+        assert np.array_equal(download(up.UploadSingleFrame(p)), a)
+        assert np.array_equal(download(up.UploadSingleFrame(a)), a)

@@ -11,6 +11,11 @@ import PyNvCodec as nvc
 W, H, N = 3840, 2160, 200
 PF = nvc.PixelFormat
 frames = [np.random.default_rng(i).integers(0, 256, W * H * 3 // 2, dtype=np.uint8) for i in range(8)]
+if "--pinned" in sys.argv:  # frames decoded straight into page-locked memory: no staging memcpy
+    pinned = [nvc.AllocPinned(f.size) for f in frames]
+    for p_, f in zip(pinned, frames):
+        p_[:] = f
+    frames = pinned
 cc = nvc.ColorspaceConversionContext(nvc.ColorSpace.BT_709, nvc.ColorRange.MPEG)
 
 

@@ -457,6 +457,14 @@ PYBIND11_MODULE(_PyNvCodec, m) {
   m.def("ConverterPairSupport", &ConvertSurface::PairSupport, py::arg("src_format"), py::arg("dst_format"),
         "1: pair exists in the reference's ConvertSurface, 2: additive pair, 0: unsupported");
   m.def("KernelLibraryVersion", []() { return std::string(vpf_version()); });
+  m.def("AllocPinned",
+        [](size_t nbytes) {
+          // numpy uint8 array over hipHostMalloc memory: PyFrameUploader DMAs from it directly (no staging memcpy)
+          Buffer* b = Buffer::MakeOwnMem(nbytes, (HipContext)-1);
+          py::capsule owner(b, [](void* p) { delete static_cast<Buffer*>(p); });
+          return py::array_t<uint8_t>({(py::ssize_t)nbytes}, {(py::ssize_t)1}, b->GetDataAs<uint8_t>(), owner);
+        },
+        py::arg("nbytes"), "additive: page-locked host buffer as a numpy uint8 array (decode straight into it)");
   m.def("_UseHostAllocator", [](bool on) {
     static const DeviceAllocator host = {host_alloc, host_free, nullptr};
     SetDeviceAllocator(on ? &host : nullptr);

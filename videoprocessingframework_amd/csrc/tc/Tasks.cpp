@@ -408,8 +408,16 @@ TaskExecStatus CudaUploadFrame::Run() {
   hipStream_t cs = pImpl->copy_stream ? pImpl->copy_stream : (hipStream_t)pImpl->sref.str;
   // the slot's previous copy must have drained before its pinned buffer is overwritten
   if (pImpl->done[slot] && !hip_ok(hipEventSynchronize(pImpl->done[slot]), "CudaUploadFrame: hipEventSynchronize")) return TASK_EXEC_FAIL;
-  std::memcpy(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
-  const uint8_t* src = stage->GetDataAs<uint8_t>();
+  // a frame that already lives in pinned (hipHostMalloc / registered) memory is DMA'd from where it is; pageable
+  // memory is staged through the slot's pinned buffer (one host memcpy, then a true async copy)
+  const uint8_t* src = host->GetDataAs<uint8_t>();
+  hipPointerAttribute_t attr;
+  const bool pinned_src = (hipPointerGetAttributes(&attr, src) == hipSuccess) && attr.type == hipMemoryTypeHost;
+  if (!pinned_src) {
+    (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error for us
+    std::memcpy(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
+    src = stage->GetDataAs<uint8_t>();
+  }
   for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // planes concatenated at tight width (Tasks.cpp:643-658)
     const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
     if (!hip_ok(hipMemcpy2DAsync((void*)s->PlanePtr(p), s->Pitch(p), src, wb, wb, rows, hipMemcpyHostToDevice, cs), "CudaUploadFrame: hipMemcpy2DAsync"))
