@@ -3,6 +3,7 @@
 # than kernel-trace), for the calibration kernels and for the headline bench.
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/pmc; export TMPDIR=/tmp
 OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc"
+[ -x tools/pmc_calib.bin ] || hipcc --offload-arch=gfx950 -O3 tools/pmc_calib.hip -o tools/pmc_calib.bin
 ./tools/pmc_calib.bin > $OUT/calib_bw.txt 2>&1
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
