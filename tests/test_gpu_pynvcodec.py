@@ -234,9 +234,10 @@ def test_surface_plane_import_export():
     w, h = 200, 50
     s = nvc.Surface.Make(PF.Y, w, h, GPU)
     t = torch.randint(0, 256, (h, w), dtype=torch.uint8, device="cuda")
+    back = torch.zeros_like(t)
+    torch.cuda.synchronize()  # torch kernels (randint / zeros) run on torch's stream, Import/Export on ours
     p = s.PlanePtr()
     p.Import(t.data_ptr(), w, GPU)
-    back = torch.zeros_like(t)
     p.Export(back.data_ptr(), w, GPU)
     assert torch.equal(t, back)
     t2 = pnvc.DptrToTensor(p.GpuMem(), p.Width(), p.Height(), p.Pitch(), p.ElemSize())
@@ -289,6 +290,7 @@ def test_convert_straight_into_a_torch_tensor(oracle):
     src = oracle.synth(oracle.NV12, w, h, 21, "B")
     nv12 = upload(PF.NV12, w, h, src)
     t = torch.zeros((3, h, w), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch's fill kernel is on torch's stream, the converter on its own: order them
     out = pnvc.surface_from_tensor(t)
     assert out.Format() == PF.RGB_PLANAR and not out.OwnMemory() and out.PlanePtr().GpuMem() == t.data_ptr()
     conv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB_PLANAR, GPU)
@@ -301,6 +303,7 @@ def test_convert_straight_into_a_torch_tensor(oracle):
     assert np.abs(t.cpu().numpy().astype(int) - np.stack(ex).astype(int)).max() <= 1   # +-1 LSB vs the specification level
     # packed tensor as converter output + remap of it (samples/SampleRemap.py)
     tp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     assert nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU).ExecuteBatch([nv12], [pnvc.surface_from_tensor(tp)], cc)
     xm, ym = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
     xm = xm * 0.97 + 11.5

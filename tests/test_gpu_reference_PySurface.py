@@ -98,6 +98,8 @@ class TestSurfaceHip(unittest.TestCase):
             src_plane = surf_src.PlanePtr()
             surface_tensor = torch.zeros(src_plane.Height(), src_plane.Width(), 1, dtype=torch.uint8,
                                          device=torch.device(f"cuda:{self.gpu_id}"))
+            torch.cuda.synchronize()  # torch's zero-fill runs on torch's stream, the copy on ours: order them (the
+            # reference test has this latent race too; it copies on a pycuda stream right after torch.zeros)
             src_plane.Export(surface_tensor.data_ptr(), self.nvDec.Width(), self.ctx, self.str)
             frame_src = np.ndarray(shape=(0), dtype=np.uint8)
             if not self.nvDwn.DownloadSingleSurface(surf_src, frame_src):

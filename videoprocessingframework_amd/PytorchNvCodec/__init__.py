@@ -84,7 +84,9 @@ def surface_from_tensor(tensor: torch.Tensor, fmt=None):
     """Wrap a contiguous CUDA/HIP uint8 tensor as a non-owning PyNvCodec.Surface — the converter then writes straight into
     the tensor (`PySurfaceConverter.ExecuteBatch([src], [surface_from_tensor(t)])`), no copy at all.
       [3, H, W] -> RGB_PLANAR (default) or YUV444;   [H, W, 3] -> RGB (default) or BGR;   [H, W] -> Y
-    The tensor is kept alive by the returned Surface."""
+    The tensor is kept alive by the returned Surface.  Stream ordering is the caller's, exactly as with the reference:
+    kernels that produced / will consume the tensor on torch's stream are not ordered against a converter running on its
+    own stream — build the converter on `torch.cuda.current_stream().cuda_stream` or synchronise in between."""
     try:
         import PyNvCodec as nvc
     except ImportError:  # package-relative import when used as videoprocessingframework_amd.PytorchNvCodec
