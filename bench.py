@@ -234,8 +234,8 @@ def other_configs(dev, main_wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ring", type=int, default=32, help="distinct frame pairs in the ring (32 x 37.3 MB = 1.19 GB)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--mode", choices=["batch", "single"], default="batch")

@@ -99,3 +99,22 @@ print(len(maps), maps)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().startswith("1 "), out.stdout
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/vpf_hip.h must be usable from C (c99, pedantic) and C++ without any HIP / torch header, and the structs must
+    have the sizes the ctypes binding assumes."""
+    import subprocess
+
+    src = tmp_path / "t.c"
+    src.write_text('#include "vpf_hip.h"\n#include <stdio.h>\nint main(void){ vpf_exec e = {0, 0, 0}; vpf_plane p = {0, 0, 0}; (void)e; (void)p;\n'
+                   ' printf("%zu %zu %zu %zu\\n", sizeof(vpf_plane), sizeof(vpf_exec), sizeof(vpf_frame_io), sizeof(vpf_size));\n'
+                   ' return (VPF_FMT_NV12 == 3 && VPF_BT_709 == 1 && VPF_JPEG == 1 && VPF_INTERP_LANCZOS3 == 2) ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{inc}", str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["16", "16", "96", "8"]
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include "vpf_hip.h"\nint main(){ vpf_size s{1, 2}; return s.width == 1 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", f"-I{inc}", str(cpp), "-o", str(tmp_path / "tpp")])
