@@ -450,3 +450,30 @@ def test_resize_lanczos3(capi, oracle, fmt):
             assert np.abs(g.astype(int) - e.astype(int)).max() <= 1
         if (sw, sh) == (dw, dh):
             assert_planes_equal(got, src, "lanczos identity")
+
+
+@pytest.mark.parametrize("cs,cr", MATS)
+def test_full_size_vs_independent_torch_float64(capi, cs, cr):
+    """A third, independent evaluation at BASELINE's full size: the published matrix in torch float64 on the GPU (chroma
+    replicated with repeat_interleave, round half up, clamp).  Tolerance: 1 LSB per channel (north_star), and the two may
+    differ on at most 1 % of samples (ties: the kernels round half to even, this reference half up)."""
+    coef = {(0, 0): (1.164, 16, 1.596, -0.392, -0.813, 2.017), (0, 1): (1.0, 0, 1.140, -0.394, -0.581, 2.032),
+            (1, 0): (1.164384, 16, 1.792741, -0.213249, -0.532909, 2.112402), (1, 1): (1.0, 0, 1.5748, -0.187324, -0.468124, 1.8556)}[(cs, cr)]
+    cy, off, rv, gu, gv, bu = coef
+    w, h = 3840, 2160
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(123 + 2 * cs + cr)
+    nv12 = torch.randint(0, 256, (h * 3 // 2, w), dtype=torch.uint8, device="cuda", generator=gen)
+    out = torch.zeros((h, 3 * w), dtype=torch.uint8, device="cuda")
+    capi.convert(capi.make_exec(stream_handle()), capi.NV12, capi.RGB, cs, cr, w, h,
+                 [(nv12.data_ptr(), w), (nv12.data_ptr() + h * w, w)], [(out.data_ptr(), 3 * w)])
+    y = nv12[:h].double() - off
+    uv = nv12[h:].view(h // 2, w // 2, 2).double() - 128.0
+    u = uv[..., 0].repeat_interleave(2, 0).repeat_interleave(2, 1)
+    v = uv[..., 1].repeat_interleave(2, 0).repeat_interleave(2, 1)
+    ref = torch.stack([cy * y + rv * v, cy * y + gu * u + gv * v, cy * y + bu * u], dim=-1)
+    ref = torch.floor(ref + 0.5).clamp_(0, 255).to(torch.int16).view(h, 3 * w)
+    torch.cuda.synchronize()
+    d = (out.to(torch.int16) - ref).abs()
+    assert int(d.max()) <= 1
+    assert float((d > 0).double().mean()) < 0.01
