@@ -58,9 +58,13 @@ VPF_DEV void store_bytes(uint8_t* p, uint32_t d0, uint32_t d1, uint32_t d2, uint
   for (uint32_t i = 0; i < nbytes; i++) p[i] = (uint8_t)(d[i >> 2] >> (8 * (i & 3)));
 }
 
-template <int SRC, int DST, int RP, int PACK, bool NTL, bool NTS>
+template <int SRC, int DST, int RP, int PACK, bool NTL, bool NTS, int BALLAST_KB = 0>
 __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                        uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  if constexpr (BALLAST_KB > 0) {  // occupancy experiment: an LDS footprint that caps resident workgroups per CU
+    __shared__ uint32_t ballast[BALLAST_KB * 256];
+    if (n_tasks == 0xffffffffu) ballast[threadIdx.x] = w;  // never true; keeps the allocation
+  }
   // wave-uniform by construction; readfirstlane tells the compiler so (scalar branches, SGPR addressing)
   const uint32_t wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wt >= n_tasks) return;
@@ -131,10 +135,11 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
 // 48*l + 16*j -> dword banks {12l+4j .. +3} mod 32, which tile all 32 banks exactly once per
 // group: conflict free.  The ds_read_b128 side reads 16*l: contiguous, conflict free.
 // ---------------------------------------------------------------------------------------------
-template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4>
+template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0>
 __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                            uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
-  __shared__ u32x4 tile[(LDS_T && DST != FC_PLANAR) ? WPB * 2 * 192 : 1];
+  // BALLAST_KB > 0 pads the LDS footprint to cap the number of resident workgroups per CU (occupancy experiment)
+  __shared__ u32x4 tile[((LDS_T && DST != FC_PLANAR) ? WPB * 2 * 192 : 1) + BALLAST_KB * 64];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * WPB + wv;
   if (wt >= n_tasks) return;
@@ -274,6 +279,93 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_p16r(const BatchArgs args, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// r4 / b4: ONE STORE INSTRUCTION PER WAVE.  tools/write_probe.hip shows the HBM write rate on gfx950 depends on how
+// many store instructions a wave issues before it retires: 1 x 1 KiB per wave 6.8 TB/s, 2 -> 5.9, 3 -> 5.7, 6 -> 5.3
+// (256-thread blocks, linear buffer).  Writes are 2/3 of this converter's traffic, so these kernels give every wave a
+// single store:
+//   r4: a lane owns 4 px of ONE row (Y dword + the UV dword it shares with the lane one row below, which another wave of
+//       the same block reads too: the second read is an L1/L2 hit, not HBM) -> one 768-B dwordx3 wave store.
+//   b4: same compute, but the block's 2 rows x 512 px (3 KiB) are gathered in LDS and leave as three dense 1-KiB dwordx4
+//       wave stores (waves 0-2; wave 3 stores nothing).
+// Require w % 4 == 0, h even, 4-B (r4) / 16-B (b4) aligned planes.  NV12 source, packed RGB/BGR destination.
+// ---------------------------------------------------------------------------------------------
+template <int DST, bool LDS_T, bool NTS>
+__global__ __launch_bounds__(256) void k_nv12_rgb_r4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                     uint32_t tiles_x, uint32_t n_tiles) {
+  __shared__ uint32_t lds[LDS_T ? 768 : 1];  // [row A: 1536 B][row B: 1536 B]
+  const uint32_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t rp = tile / tiles_x, tx = tile - rp * tiles_x;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t half = wv >> 1;                          // waves 0,1 -> row 2rp ; waves 2,3 -> row 2rp+1
+  const uint32_t px = ((wv & 1) * 64 + lane) * 4;         // pixel offset inside the 512-px tile
+  const uint32_t x = tx * 512 + px;
+  const bool act = x < w;
+  uint32_t d0 = 0, d1 = 0, d2 = 0;
+  if (act) {
+    const uint32_t yd = ldg<true, uint32_t>(f.s[0] + (size_t)(2 * rp + half) * f.sp[0] + x);
+    const uint32_t uv = ldg<false, uint32_t>(f.s[1] + (size_t)rp * f.sp[1] + x);  // read by two waves: keep it cacheable
+    const Chroma k0 = chroma_terms(c, ubyte<0>(uv), ubyte<1>(uv)), k1 = chroma_terms(c, ubyte<2>(uv), ubyte<3>(uv));
+    pack_rgb12<DST, 1>(convert4(c, yd, k0, k1), d0, d1, d2);
+  }
+  if constexpr (!LDS_T) {
+    if (act) stg3<NTS>(f.d[0] + (size_t)(2 * rp + half) * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
+  } else {
+    uint32_t* t = lds + half * 384 + (px >> 2) * 3;      // 12 B per lane, lane stride 3 dwords: conflict free
+    t[0] = d0; t[1] = d1; t[2] = d2;
+    __syncthreads();
+    if (wv < 3) {
+      const uint32_t o = (wv * 64 + lane) * 16;            // byte offset in the 3 KiB block image
+      const u32x4 v = reinterpret_cast<const u32x4*>(lds)[wv * 64 + lane];
+      const uint32_t r = o >= 1536, col = tx * 1536 + (o - r * 1536);
+      if (col < 3 * w) stg<NTS, u32x4>(f.d[0] + (size_t)(2 * rp + r) * f.dp[0] + col, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bandwidth probes with the p16 geometry (NOT conversions; reachable only through the tuning hook, used by
+// bench.py --sweep to locate the ceilings): MODE 0 = the loads only (one dword per wave stored so they are not
+// dead), MODE 1 = the stores only.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_probe_p16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t rp = wt / chunks_x, chunk = wt - rp * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  if constexpr (MODE == 0) {
+    if (x >= w) return;
+    const u32x4 a = ldg<true, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+    const u32x4 b = ldg<true, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+    const u32x4 c = ldg<true, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+    const uint32_t r = a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3];
+    if (r == 0x12345678u) f.d[0][(size_t)(2 * rp) * f.dp[0] + 3 * x] = 1;  // practically never: keeps the loads alive
+  } else if constexpr (MODE == 1 || MODE == 2) {  // the converter's store geometry; NT (1) or plain (2) stores
+    const uint32_t row_bytes = 3 * w;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      uint8_t* rowp = f.d[0] + (size_t)(2 * rp + half) * f.dp[0];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const uint32_t off = chunk * 3072 + (k * 64 + lane) * 16;
+        if (off < row_bytes) stg<MODE == 1, u32x4>(rowp + off, u32x4{off, rp, lane, (uint32_t)k});
+      }
+    }
+  } else {  // MODE 3 / 4: linear fill of the frame (needs pitch == row bytes): wave t writes 6 KiB at t * 6 KiB; NT (3) / plain (4)
+    const size_t frame_bytes = (size_t)3 * w * h;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const size_t off = (size_t)wt * 6144 + (size_t)(k * 64 + lane) * 16;
+      if (off < frame_bytes) stg<MODE == 3, u32x4>(f.d[0] + off, u32x4{(uint32_t)off, rp, lane, (uint32_t)k});
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // YUV444 (three full planes) -> RGB/BGR/PLANAR, 4 px per lane, one row per task.
 // Requires w % 4 == 0 and 4-byte aligned planes.
 // ---------------------------------------------------------------------------------------------
@@ -371,16 +463,20 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   //   9       generic byte kernel                        10      p4 RP1 NT with the explicit (non cvt_pk) pack
   //   11/12   p16 LDS with NT stores only / NT loads only
   //   13      p16 lane-strided stores (no LDS)           15      p16 LDS NT, arithmetic removed (ceiling probe, wrong pixels)
+  //   22-26   bandwidth probes (wrong pixels): loads only / stores only (NT, plain, linear NT, linear plain)
+  //   27      r4: one 768-B store per wave (lane = 4 px of one row)    28/29  b4: r4 + block LDS gather -> 1-KiB stores (NT / plain)
   //   14/16   p4 RP1 / RP2 with NT stores only          17/18/19 p16r (one LDS row tile per wave), 1/2/4 row pairs per task, NT stores
   const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
   const bool p4_ok = aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
   // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal loads and
   // stores (ties with the other top variants when batched, +3 % when a launch is a single frame); planar outputs
   // (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
-  if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? 8 : 4;
-  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21));
+  // batched launches run long enough that 4 resident workgroups per CU (variant 30: LDS-capped) beat 6 by 1-2 %
+  // (a narrower chip-wide write frontier; tools/write_probe.hip); short single-frame launches want all the waves they can get
+  if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? (n >= 4 ? 30 : 8) : 4;
+  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36);
   if (want_p16 && !p16_ok) variant = 4;
-  if (variant != 9 && !p4_ok) variant = 9;
+  if (variant != 9 && !(variant >= 22 && variant <= 29) && !p4_ok) variant = 9;
   if constexpr (SRC == FC_NV12) {
     if (want_p16 && p16_ok && variant >= 17 && variant <= 19 && DST != FC_PLANAR) {  // p16r: RPW = 1, 2, 4
       const uint32_t rpw = variant == 17 ? 1 : (variant == 18 ? 2 : 4);
@@ -391,6 +487,26 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
         else if (rpw == 2) VPF_LAUNCH((k_nv12_rgb_p16r<DST, 2, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
         else VPF_LAUNCH((k_nv12_rgb_p16r<DST, 4, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
       }
+      return hipGetLastError();
+    }
+    if ((variant == 27 || variant == 28 || variant == 29) && p16_ok && DST != FC_PLANAR) {
+      const uint32_t tiles = (w + 511) / 512, nt = tiles * (h / 2);
+      dim3 grid(nt, n);
+      if constexpr (DST != FC_PLANAR) {
+        if (variant == 27) VPF_LAUNCH((k_nv12_rgb_r4<DST, false, true>), grid, dim3(256), 0, st, a, c, w, h, tiles, nt);
+        else if (variant == 28) VPF_LAUNCH((k_nv12_rgb_r4<DST, true, true>), grid, dim3(256), 0, st, a, c, w, h, tiles, nt);
+        else VPF_LAUNCH((k_nv12_rgb_r4<DST, true, false>), grid, dim3(256), 0, st, a, c, w, h, tiles, nt);
+      }
+      return hipGetLastError();
+    }
+    if (variant >= 22 && variant <= 26 && p16_ok && DST != FC_PLANAR) {
+      const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
+      dim3 grid((tasks + 3) / 4, n);
+      if (variant == 22) VPF_LAUNCH((k_probe_p16<0>), grid, dim3(256), 0, st, a, w, h, chunks, tasks);
+      else if (variant == 23) VPF_LAUNCH((k_probe_p16<1>), grid, dim3(256), 0, st, a, w, h, chunks, tasks);
+      else if (variant == 24) VPF_LAUNCH((k_probe_p16<2>), grid, dim3(256), 0, st, a, w, h, chunks, tasks);
+      else if (variant == 25) VPF_LAUNCH((k_probe_p16<3>), grid, dim3(256), 0, st, a, w, h, chunks, tasks);
+      else VPF_LAUNCH((k_probe_p16<4>), grid, dim3(256), 0, st, a, w, h, chunks, tasks);
       return hipGetLastError();
     }
     if (want_p16 && p16_ok) {
@@ -404,6 +520,10 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
         case 12: VPF_P16(true, false, true, false); break;
         case 13: VPF_P16(true, true, false, false); break;
         case 15: VPF_P16(true, true, true, true); break;
+        case 36: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 8>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 32 KiB -> 5 blocks/CU
+        case 30: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 16>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 40 KiB -> 4 blocks/CU
+        case 31: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 29>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 53 KiB -> 3 blocks/CU
+        case 32: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 56>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 80 KiB -> 2 blocks/CU
         case 20: {  // one wave per workgroup: 4x more, smaller workgroups -> finer balance when a launch is only one frame
           dim3 g1(tasks, n);
           VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, false, true, true, false, 1>), g1, dim3(64), 0, st, a, c, w, h, chunks, tasks);
@@ -433,6 +553,9 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       case 5: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, true, true>, 2);
       case 6: return go(k_yuv420_rgb_p4<SRC, DST, 4, 1, true, true>, 4);
       case 10: return go(k_yuv420_rgb_p4<SRC, DST, 1, 0, true, true>, 1);
+      case 33: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true, 26>, 1);  // 6 blocks/CU
+      case 34: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true, 32>, 1);  // 5 blocks/CU
+      case 35: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true, 40>, 1);  // 4 blocks/CU
       case 14: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, false, true>, 1);
       case 16: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, false, true>, 2);
       default: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true>, 1);
