@@ -77,7 +77,8 @@ class Workload:
             self.px_per_step = ring * w * h
             self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
             self.launches_per_step = (ring + 31) // 32 if mode == "batch" else ring
-            self.kernel = "k_yuv420_rgb_p4 / k_nv12_rgb_p16 (NV12->RGB)"
+            self.kernel = ("k_nv12_rgb_p16 (16 px/lane, LDS-transposed 1 KiB NT stores; 4 workgroups/CU when batched)" if self.dst_fmt == capi.RGB
+                           else "k_yuv420_rgb_p4 (4 px/lane, planar dword stores)")
         elif name in ("resize_4k_720p", "fused_4k_720p"):
             self.w, self.h, self.dw, self.dh = 3840, 2160, 1280, 720
             w, h = self.w, self.h
