@@ -118,3 +118,21 @@ def test_header_is_plain_c_and_cxx(tmp_path):
     cpp = tmp_path / "t.cpp"
     cpp.write_text('#include "vpf_hip.h"\nint main(){ vpf_size s{1, 2}; return s.width == 1 ? 0 : 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", f"-I{inc}", str(cpp), "-o", str(tmp_path / "tpp")])
+
+
+def test_optional_libav_feeder_compiles_against_stub_headers():
+    """the libav-gated demux + software-decode feeder cannot be built for real here (no libav in the image),
+    so the least we can do is keep it syntactically and type-wise valid against a stub of the public libav API — both the
+    feeder itself and the PyFfmpegDecoder section of the bindings (-DVPF_WITH_LIBAV)."""
+    import subprocess
+    import sysconfig
+
+    import pybind11
+
+    csrc = os.path.join(ROOT, "videoprocessingframework_amd", "csrc")
+    inc = [f"-I{os.path.join(ROOT, 'tests', 'libav_stub')}", f"-I{os.path.join(csrc, 'tc')}", f"-I{os.path.join(csrc, 'feeder')}",
+           f"-I{os.path.join(ROOT, 'include')}"]
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", *inc, os.path.join(csrc, "feeder", "FfmpegFeeder.cpp")])
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-DVPF_WITH_LIBAV", "-D__HIP_PLATFORM_AMD__", *inc, "-I/opt/rocm/include",
+                           f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+                           os.path.join(csrc, "bindings", "PyNvCodec.cpp")])

@@ -63,5 +63,9 @@ class PyFFmpegDemuxer(_NotPortable):
     _why = "needs libavformat, which is not present in this image (host-side feeder, out of the conversion path)"
 
 
-class PyFfmpegDecoder(_NotPortable):
-    _why = "needs libavcodec, which is not present in this image (host-side feeder, out of the conversion path)"
+if getattr(_native, "HAVE_LIBAV", False):  # built where libav exists (csrc/feeder, _build_bindings.py probes for it)
+    PyFfmpegDecoder = _native.PyFfmpegDecoder
+else:
+
+    class PyFfmpegDecoder(_NotPortable):
+        _why = "needs libavcodec, which is not present in this image (host-side feeder, out of the conversion path)"

@@ -19,6 +19,11 @@
 
 #include "Tasks.hpp"
 #include "vpf_hip.h"
+#ifdef VPF_WITH_LIBAV
+#include <map>
+
+#include "FfmpegFeeder.hpp"
+#endif
 
 namespace py = pybind11;
 using namespace VPF;
@@ -234,6 +239,39 @@ public:
     return true;
   }
 };
+#ifdef VPF_WITH_LIBAV
+// PyFfmpegDecoder (reference: src/PyNvCodec/src/PyFFMpegDecoder.cpp:37-70,220-268): software decode on the host, frames
+// enter the GPU through the pinned-staging uploader.  Only compiled where libav exists.
+class PyFfmpegDecoder {
+  std::unique_ptr<FfmpegFeeder> dec_;
+  std::unique_ptr<PyFrameUploader> up_;
+  std::vector<uint8_t> host_;
+  int gpu_;
+
+public:
+  PyFfmpegDecoder(const std::string& url, const std::map<std::string, std::string>& opts, int gpu) : gpu_(gpu) {
+    dec_.reset(new FfmpegFeeder(url, opts));
+  }
+  uint32_t Width() const { return dec_->Width(); }
+  uint32_t Height() const { return dec_->Height(); }
+  double Framerate() const { return dec_->Framerate(); }
+  ColorSpace GetColorSpace() const { return dec_->GetColorSpace(); }
+  ColorRange GetColorRange() const { return dec_->GetColorRange(); }
+  Pixel_Format GetPixelFormat() const { return dec_->GetPixelFormat(); }
+  bool DecodeSingleFrame(py::array_t<uint8_t>& frame) {
+    const size_t n = dec_->FrameBytes();
+    if ((size_t)frame.size() != n) frame.resize({(py::ssize_t)n}, false);
+    return dec_->DecodeNextFrame(frame.mutable_data(), n);
+  }
+  std::shared_ptr<Surface> DecodeSingleSurface() {
+    host_.resize(dec_->FrameBytes());
+    if (!dec_->DecodeNextFrame(host_.data(), host_.size())) return empty_surface(NV12);
+    if (!up_) up_.reset(new PyFrameUploader(dec_->Width(), dec_->Height(), NV12, ctx_of(gpu_), str_of(gpu_)));
+    return up_->Upload(host_.data(), host_.size());
+  }
+};
+#endif
+
 }  // namespace
 
 PYBIND11_MODULE(_PyNvCodec, m) {
@@ -448,6 +486,22 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            py::arg("elem_size"), py::arg("num_elems"), py::arg("context"), py::arg("stream"))
       .def("DownloadSingleCudaBuffer", &PyCudaBufferDownloader::Download, py::arg("buffer"), py::arg("array"));
 
+#ifdef VPF_WITH_LIBAV
+  py::class_<PyFfmpegDecoder>(m, "PyFfmpegDecoder")
+      .def(py::init<const std::string&, const std::map<std::string, std::string>&, int>(), py::arg("input"), py::arg("opts"),
+           py::arg("gpu_id") = 0)
+      .def("Width", &PyFfmpegDecoder::Width)
+      .def("Height", &PyFfmpegDecoder::Height)
+      .def("Framerate", &PyFfmpegDecoder::Framerate)
+      .def("ColorSpace", &PyFfmpegDecoder::GetColorSpace)
+      .def("ColorRange", &PyFfmpegDecoder::GetColorRange)
+      .def("Format", &PyFfmpegDecoder::GetPixelFormat)
+      .def("DecodeSingleFrame", &PyFfmpegDecoder::DecodeSingleFrame, py::arg("frame"))
+      .def("DecodeSingleSurface", &PyFfmpegDecoder::DecodeSingleSurface, py::keep_alive<0, 1>());
+  m.attr("HAVE_LIBAV") = true;
+#else
+  m.attr("HAVE_LIBAV") = false;
+#endif
   m.def("GetNumGpus", []() { return (int)HipResMgr::Instance().GetNumGpus(); });
   // --- additive helpers (not in the reference) ---
   m.def("GetContext", [](int gpu) { return (size_t)ctx_of(gpu); }, py::arg("gpu_id"), "opaque context cookie of a GPU ordinal");

@@ -1,0 +1,46 @@
+// FfmpegFeeder.hpp — OPTIONAL host-side feeder: demux + software decode with FFmpeg's libav*, handing frames to the
+// surface path as real NV12.  SURVEY §8(f) N3; reference: src/TC/src/FfmpegSwDecoder.cpp:60-170,254-360 (open, find the
+// best video stream, send/receive loop, SaveYUV420 :141-168) and src/PyNvCodec/src/PyFFMpegDecoder.cpp:37-70.
+//
+// Built ONLY where the libav headers and libraries exist (videoprocessingframework_amd/_build_bindings.py probes for them);
+// this image has none, so here the component is compiled against tests/libav_stub (syntax only) and is otherwise UNTESTED.
+// Not on the conversion hot path: decode stays on the host, as north_star prescribes.
+//
+// Deliberate difference from the reference: its decoder stores planar YUV420P and labels it NV12
+// (FfmpegSwDecoder.cpp:405-410 vs :141-168).  This feeder emits actual NV12 (UV interleaved).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "MemoryInterfaces.hpp"
+
+namespace VPF {
+
+class FfmpegFeeder {
+public:
+  // throws std::runtime_error when the input cannot be opened / has no decodable video stream
+  FfmpegFeeder(const std::string& url, const std::map<std::string, std::string>& options);
+  ~FfmpegFeeder();
+  FfmpegFeeder(const FfmpegFeeder&) = delete;
+  FfmpegFeeder& operator=(const FfmpegFeeder&) = delete;
+
+  uint32_t Width() const;
+  uint32_t Height() const;
+  double Framerate() const;
+  ColorSpace GetColorSpace() const;   // from the stream's colorspace tag (BT.709 / BT.601 / UNSPEC)
+  ColorRange GetColorRange() const;   // MPEG (limited) / JPEG (full) / UDEF
+  Pixel_Format GetPixelFormat() const { return NV12; }
+  size_t FrameBytes() const { return (size_t)Width() * Height() * 3 / 2; }
+
+  // Decode the next frame into `nv12` (tight W x 1.5H bytes: Y plane then interleaved UV).  false at end of stream.
+  bool DecodeNextFrame(uint8_t* nv12, size_t capacity);
+
+private:
+  struct Impl;
+  std::unique_ptr<Impl> p;
+};
+
+}  // namespace VPF
