@@ -57,13 +57,24 @@ def test_nv12_to_rgb_matrices(capi, oracle, cs, cr, dst):
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), cs, cr, w, h, src)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 27, 28, 29])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 27, 28, 29, 37, 38])
 @pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
 def test_nv12_to_rgb_every_kernel_variant(capi, oracle, variant, dst):
     """all kernel variants (p4 / p16 / LDS-transposed / non-temporal / explicit pack / generic) agree bit for bit"""
     for (w, h) in [(1920, 32), (3840, 8), (848, 464), (1280, 18)]:
         src = oracle.synth(oracle.NV12, w, h, 1001)
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), 1, 0, w, h, src, variant=variant, exact_tol=False)
+
+
+@pytest.mark.parametrize("variant", [8, 17, 27, 30, 37, 38])
+def test_nv12_to_rgb_variant_falls_back_when_not_applicable(capi, oracle, variant):
+    """a 16-B-aligned-only kernel requested on ragged widths / odd bases / the other output class must silently take a
+    general kernel with identical pixels (the tuning knob is a hint, never a correctness switch)"""
+    for (w, h) in [(1002, 6), (66, 34), (17, 9), (1920, 8)]:
+        src = oracle.synth(oracle.NV12, w, h, 1003)
+        for dst in (capi.RGB, capi.RGB_PLANAR):
+            _convert(capi, oracle, capi.NV12, dst, 1, 0, w, h, src, variant=variant, align=256, exact_tol=False)
+            _convert(capi, oracle, capi.NV12, dst, 1, 0, w, h, src, variant=variant, align=64, extra=3, offset=1, exact_tol=False)
 
 
 def test_nv12_frame_kat_on_gpu(capi, oracle):

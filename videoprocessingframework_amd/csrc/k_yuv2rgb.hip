@@ -325,6 +325,80 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_r4(const BatchArgs args, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// r16 (planar outputs): a wave owns ONE row x 1024 px: lane = 16 px, Y dwordx4 + UV dwordx4 (the row below re-reads the same
+// UV line from L2, not HBM), three dense 1-KiB dwordx4 stores (R, G, B planes) — 3 stores per wave instead of the 6 a
+// row-pair wave needs for three planes (write-rate law, tools/write_probe.hip).  Requires w % 16 == 0, 16-B aligned planes.
+// ---------------------------------------------------------------------------------------------
+template <bool NTS>
+__global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                         uint32_t chunks_x, uint32_t n_tasks) {
+  const uint32_t wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  // consecutive waves of a block take rows 2rp, 2rp+1 of the same chunk, so the shared UV line is hot in L1/L2
+  const uint32_t pair = wt >> 1, half = wt & 1;
+  const uint32_t rp = pair / chunks_x, chunk = pair - rp * chunks_x;
+  const uint32_t x = chunk * 1024 + (threadIdx.x & 63) * 16;
+  const uint32_t y = 2 * rp + half;
+  if (x >= w || y >= h) return;
+  const u32x4 yq = ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x);
+  const u32x4 uv = ldg<false, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+  u32x4 r, g, b;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j])), k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+    const Quad q = convert4(c, yq[j], k0, k1);
+    r[j] = pack4<1>(q.r[0], q.r[1], q.r[2], q.r[3]);
+    g[j] = pack4<1>(q.g[0], q.g[1], q.g[2], q.g[3]);
+    b[j] = pack4<1>(q.b[0], q.b[1], q.b[2], q.b[3]);
+  }
+  stg<NTS, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, r);
+  stg<NTS, u32x4>(f.d[1] + (size_t)y * f.dp[1] + x, g);
+  stg<NTS, u32x4>(f.d[2] + (size_t)y * f.dp[2] + x, b);
+}
+
+// r16 for packed outputs: one row x 1024 px per wave (Y + the UV line it shares with its neighbour row), the 48 B/lane
+// transposed through a wave-private 3 KiB LDS tile -> three dense 1-KiB stores per wave (p16 issues six).
+template <int DST, bool NTS, int BALLAST_KB>
+__global__ __launch_bounds__(256) void k_nv12_rgb_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                      uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[4 * 192 + BALLAST_KB * 64];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t pair = wt >> 1, half = wt & 1;
+  const uint32_t rp = pair / chunks_x, chunk = pair - rp * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  const uint32_t y = 2 * rp + half;
+  if (y >= h) return;
+  const bool act = x < w;
+  u32x4* t = tile + wv * 192;
+  if (act) {
+    const u32x4 yq = ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x);
+    const u32x4 uv = ldg<false, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+    uint32_t o[12];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j])), k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+      pack_rgb12<DST, 1>(convert4(c, yq[j], k0, k1), o[3 * j], o[3 * j + 1], o[3 * j + 2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[lane * 3 + j] = u32x4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint8_t* rowp = f.d[0] + (size_t)y * f.dp[0];
+  const uint32_t row_bytes = 3 * w;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t off = chunk * 3072 + (k * 64 + lane) * 16;
+    if (off < row_bytes) stg<NTS, u32x4>(rowp + off, t[k * 64 + lane]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bandwidth probes with the p16 geometry (NOT conversions; reachable only through the tuning hook, used by
 // bench.py --sweep to locate the ceilings): MODE 0 = the loads only (one dword per wave stored so they are not
 // dead), MODE 1 = the stores only.
@@ -464,6 +538,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   //   11/12   p16 LDS with NT stores only / NT loads only
   //   13      p16 lane-strided stores (no LDS)           15      p16 LDS NT, arithmetic removed (ceiling probe, wrong pixels)
   //   22-26   bandwidth probes (wrong pixels): loads only / stores only (NT, plain, linear NT, linear plain)
+  //   37      r16 (planar outputs): one row x 1024 px per wave, 3 stores      38  r16 packed (LDS transpose; ties with 30)
   //   27      r4: one 768-B store per wave (lane = 4 px of one row)    28/29  b4: r4 + block LDS gather -> 1-KiB stores (NT / plain)
   //   14/16   p4 RP1 / RP2 with NT stores only          17/18/19 p16r (one LDS row tile per wave), 1/2/4 row pairs per task, NT stores
   const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
@@ -473,12 +548,15 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   // (no transpose needed) and anything not 16-B aligned -> p4 non-temporal
   // batched launches run long enough that 4 resident workgroups per CU (variant 30: LDS-capped) beat 6 by 1-2 %
   // (a narrower chip-wide write frontier; tools/write_probe.hip); short single-frame launches want all the waves they can get
-  if (variant == 0) variant = (p16_ok && DST != FC_PLANAR) ? (n >= 4 ? 30 : 8) : 4;
+  // planar outputs: r16 (one row per wave, three 1-KiB plane stores) beats p4's 256-B stores by ~9 % when batched
+  if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? 37 : (n >= 4 ? 30 : 8)) : 4;
   const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36);
-  if (want_p16 && !p16_ok) variant = 4;
-  if (variant != 9 && !(variant >= 22 && variant <= 29) && !p4_ok) variant = 9;
+  const bool packed_only = (variant >= 17 && variant <= 19) || (variant >= 22 && variant <= 29) || variant == 38;
+  if ((want_p16 || packed_only || variant == 37) && !p16_ok) variant = 4;
+  if ((packed_only && DST == FC_PLANAR) || (variant == 37 && DST != FC_PLANAR)) variant = 4;
+  if (variant != 9 && !p4_ok) variant = 9;  // p16_ok implies p4_ok
   if constexpr (SRC == FC_NV12) {
-    if (want_p16 && p16_ok && variant >= 17 && variant <= 19 && DST != FC_PLANAR) {  // p16r: RPW = 1, 2, 4
+    if (variant >= 17 && variant <= 19) {  // p16r: RPW = 1, 2, 4
       const uint32_t rpw = variant == 17 ? 1 : (variant == 18 ? 2 : 4);
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * ((h / 2 + rpw - 1) / rpw);
       dim3 grid((tasks + 3) / 4, n);
@@ -489,7 +567,21 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       }
       return hipGetLastError();
     }
-    if ((variant == 27 || variant == 28 || variant == 29) && p16_ok && DST != FC_PLANAR) {
+    if (variant == 38) {
+      const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;
+      dim3 grid((tasks + 3) / 4, n);
+      if constexpr (DST != FC_PLANAR) {
+        VPF_LAUNCH((k_nv12_rgb_r16<DST, true, 0>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      }
+      return hipGetLastError();
+    }
+    if (variant == 37) {
+      const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;  // one task per row per chunk (h even)
+      dim3 grid((tasks + 3) / 4, n);
+      VPF_LAUNCH((k_nv12_planar_r16<true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      return hipGetLastError();
+    }
+    if (variant >= 27 && variant <= 29) {
       const uint32_t tiles = (w + 511) / 512, nt = tiles * (h / 2);
       dim3 grid(nt, n);
       if constexpr (DST != FC_PLANAR) {
@@ -499,7 +591,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       }
       return hipGetLastError();
     }
-    if (variant >= 22 && variant <= 26 && p16_ok && DST != FC_PLANAR) {
+    if (variant >= 22 && variant <= 26) {
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
       dim3 grid((tasks + 3) / 4, n);
       if (variant == 22) VPF_LAUNCH((k_probe_p16<0>), grid, dim3(256), 0, st, a, w, h, chunks, tasks);
