@@ -205,17 +205,21 @@ RELAYOUT = [("NV12", "YUV420"), ("YUV420", "NV12"), ("RGB", "RGB_PLANAR"), ("RGB
 
 @pytest.mark.parametrize("s,d", RELAYOUT)
 def test_relayout_converters(capi, oracle, s, d):
-    for (w, h) in [(1920, 16), (848, 464), (64, 4), (18, 10), (5, 3), (1, 1)]:
+    for (w, h) in [(1920, 16), (3840, 6), (848, 464), (1040, 8), (2064, 4), (64, 4), (16, 2), (18, 10), (5, 3), (1, 1)]:
         src = oracle.synth(getattr(oracle, s), w, h, 1020)
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src)
+        _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src, variant=40)  # p4 / p16 fast paths
+        _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src, align=16, extra=16, offset=16)
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src, align=1)
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 1, w, h, src, variant=9)  # forced generic
 
 
 def test_float_converters(capi, oracle):
-    for (w, h) in [(320, 20), (7, 3)]:
+    for (w, h) in [(320, 20), (3840, 4), (1040, 6), (7, 3)]:
         src = oracle.synth(oracle.RGB, w, h, 1021)
         got = _convert(capi, oracle, capi.RGB, capi.RGB_32F, 0, 0, w, h, src)
+        for variant in (40, 9):
+            _convert(capi, oracle, capi.RGB, capi.RGB_32F, 0, 0, w, h, src, variant=variant)
         assert got[0].dtype == np.float32 and got[0].max() <= 1.0
         _convert(capi, oracle, capi.RGB_32F, capi.RGB_32F_PLANAR, 0, 0, w, h, got)
 

@@ -42,6 +42,9 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1e-3 / STEPS
 
 
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # 40 = legacy p4/p16 fast paths, 9 = generic (A/B runs)
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, VARIANT)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 N = {v: k for k, v in vars(capi).items() if k.isupper() and isinstance(v, int) and k in ("Y", "RGB", "NV12", "YUV420", "RGB_PLANAR", "BGR", "YCBCR", "YUV444", "RGB_32F", "RGB_32F_PLANAR", "P10")}
 pairs = [(capi.NV12, capi.YUV420), (capi.YUV420, capi.NV12), (capi.RGB, capi.RGB_PLANAR), (capi.RGB_PLANAR, capi.RGB), (capi.RGB, capi.BGR),
@@ -49,6 +52,8 @@ pairs = [(capi.NV12, capi.YUV420), (capi.YUV420, capi.NV12), (capi.RGB, capi.RGB
          (capi.BGR, capi.YCBCR), (capi.NV12, capi.Y), (capi.RGB, capi.Y), (capi.RGB, capi.RGB_32F), (capi.RGB_32F, capi.RGB_32F_PLANAR), (capi.P10, capi.NV12)]
 print(f"{'op':28s} {'single GB/s':>12s} {'frac':>6s} {'batch GB/s':>12s} {'frac':>6s}")
 for s, d in pairs:
+    if ONLY and f"{N[s]}->{N[d]}" not in ONLY:
+        continue
     ring = [(planes(s), planes(d)) for _ in range(RING)]
     nbytes = ring[0][0][2] + ring[0][1][2]
     cs = capi.BT_601 if s in (capi.RGB, capi.BGR, capi.RGB_PLANAR) else capi.BT_709
@@ -61,7 +66,7 @@ for s, d in pairs:
     del ring
     torch.cuda.empty_cache()
 # remap: identity + 0.5 px shift and barrel distortion, 4K RGB
-for kind in ("shift", "barrel"):
+for kind in (() if (VARIANT or ONLY) else ("shift", "barrel")):
     xm, ym = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
     if kind == "shift":
         xm = xm + 0.5

@@ -69,35 +69,21 @@ __global__ __launch_bounds__(256) void k_rgb_relayout_p4(const BatchArgs args, u
     const uint32_t r = ldg<false, uint32_t>(f.s[0] + (size_t)y * f.sp[0] + x);
     const uint32_t g = ldg<false, uint32_t>(f.s[1] + (size_t)y * f.sp[1] + x);
     const uint32_t b = ldg<false, uint32_t>(f.s[2] + (size_t)y * f.sp[2] + x);
-    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 ; perm(hi, lo, sel): sel 0-3 -> lo bytes, 4-7 -> hi bytes
-    const uint32_t rg_lo = __builtin_amdgcn_perm(g, r, 0x05010400u);  // R0 G0 R1 G1
-    const uint32_t rg_hi = __builtin_amdgcn_perm(g, r, 0x07030602u);  // R2 G2 R3 G3
-    const uint32_t d0 = __builtin_amdgcn_perm(b, rg_lo, 0x02040100u);  // R0 G0 B0 R1
-    const uint32_t d1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b, rg_lo, 0x00000503u) /* G1 B1 . . */,
-                                              rg_hi, 0x01000504u);    // G1 B1 R2 G2
-    const uint32_t d2 = __builtin_amdgcn_perm(b, rg_hi, 0x07030206u);  // B2 R3 G3 B3
+    uint32_t d0, d1, d2;
+    inter4(r, g, b, d0, d1, d2);
     stg3<false>(f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x, d0, d1, d2);
   } else {
     const uint8_t* p = f.s[0] + (size_t)y * f.sp[0] + 3 * (size_t)x;
     const uint32_t d0 = ldg<false, uint32_t>(p), d1 = ldg<false, uint32_t>(p + 4), d2 = ldg<false, uint32_t>(p + 8);
-    // d0 = c0a c1a c2a c0b ; d1 = c1b c2b c0c c1c ; d2 = c2c c0d c1d c2d
     if constexpr (MODE == 0) {
-      const uint32_t c0 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000300u) /* c0a c0b */,
-                                                __builtin_amdgcn_perm(d2, d1, 0x00000502u) /* c0c c0d */, 0x01000504u);
-      const uint32_t c1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000401u) /* c1a c1b */,
-                                                __builtin_amdgcn_perm(d2, d1, 0x00000603u) /* c1c c1d */, 0x01000504u);
-      const uint32_t c2 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000502u) /* c2a c2b */,
-                                                __builtin_amdgcn_perm(d2, d1, 0x00000704u) /* c2c c2d */, 0x01000504u);
+      uint32_t c0, c1, c2;
+      deint4(d0, d1, d2, c0, c1, c2);
       stg<false, uint32_t>(f.d[0] + (size_t)y * f.dp[0] + x, c0);
       stg<false, uint32_t>(f.d[1] + (size_t)y * f.dp[1] + x, c1);
       stg<false, uint32_t>(f.d[2] + (size_t)y * f.dp[2] + x, c2);
     } else {
-      // swap c0<->c2 in every pixel:
-      // o0 = c2a c1a c0a c2b ; o1 = c1b c0b c2c c1c ; o2 = c0c c2d c1d c0d
-      const uint32_t o0 = __builtin_amdgcn_perm(d1, d0, 0x05000102u);
-      const uint32_t o1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d2, d0, 0x04000003u) /* c0b . . c2c */,
-                                                d1, 0x03070400u);     // c1b c0b c2c c1c
-      const uint32_t o2 = __builtin_amdgcn_perm(d2, d1, 0x05060702u);
+      uint32_t o0, o1, o2;
+      swap4(d0, d1, d2, o0, o1, o2);
       stg3<false>(f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x, o0, o1, o2);
     }
   }
@@ -236,6 +222,188 @@ __global__ __launch_bounds__(256) void k_p16_to_8_p8(const BatchArgs args, uint3
   stg<false, u32x2>(f.d[pl] + (size_t)y * f.dp[pl] + 8 * (size_t)gx, o);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// r16 family: one wave = one row x 1024 px, one lane = 16 px; every global access of a wave is a dense 1-KiB
+// dwordx4 run, non-temporal (the write-rate law of DESIGN.md §4: few, large, dense stores per wave).  Packed sides go
+// through load_run48 / store_run48.  Requires w % 16 == 0 and 16-B aligned planes and pitches.
+// MODE 0: packed -> planar, 1: planar -> packed, 2: swap R/B
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rgb_relayout_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x,
+                                                          uint32_t n_tasks) {
+  __shared__ u32x4 tile[4 * 192];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  u32x4* t = tile + wv * 192;
+  uint32_t d[12];
+  if constexpr (MODE == 0) {
+    load_run48(t, f.s[0] + (size_t)y * f.sp[0], chunk * 3072, 3 * w, lane, d);
+    if (x >= w) return;
+    uint32_t c0[4], c1[4], c2[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) deint4(d[3 * g], d[3 * g + 1], d[3 * g + 2], c0[g], c1[g], c2[g]);
+    stg<true, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, u32x4{c0[0], c0[1], c0[2], c0[3]});
+    stg<true, u32x4>(f.d[1] + (size_t)y * f.dp[1] + x, u32x4{c1[0], c1[1], c1[2], c1[3]});
+    stg<true, u32x4>(f.d[2] + (size_t)y * f.dp[2] + x, u32x4{c2[0], c2[1], c2[2], c2[3]});
+  } else if constexpr (MODE == 1) {
+    const uint32_t xc = x < w ? x : w - 16;  // clamped lanes compute a duplicate that store_run48 never writes
+    const u32x4 c0 = ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + xc);
+    const u32x4 c1 = ldg<true, u32x4>(f.s[1] + (size_t)y * f.sp[1] + xc);
+    const u32x4 c2 = ldg<true, u32x4>(f.s[2] + (size_t)y * f.sp[2] + xc);
+#pragma unroll
+    for (int g = 0; g < 4; g++) inter4(c0[g], c1[g], c2[g], d[3 * g], d[3 * g + 1], d[3 * g + 2]);
+    store_run48(t, f.d[0] + (size_t)y * f.dp[0], chunk * 3072, 3 * w, lane, d);
+  } else {
+    load_run48(t, f.s[0] + (size_t)y * f.sp[0], chunk * 3072, 3 * w, lane, d);
+    uint32_t o[12];
+#pragma unroll
+    for (int g = 0; g < 4; g++) swap4(d[3 * g], d[3 * g + 1], d[3 * g + 2], o[3 * g], o[3 * g + 1], o[3 * g + 2]);
+    store_run48(t, f.d[0] + (size_t)y * f.dp[0], chunk * 3072, 3 * w, lane, o);  // each lane rewrites only its own 3 slots
+  }
+}
+
+// RGB / BGR / RGB_PLANAR -> Y, 16 px per lane -> one dense 1-KiB store per wave.  SRC: 0 RGB, 1 BGR, 2 planar
+template <int SRC>
+__global__ __launch_bounds__(256) void k_gray_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[SRC == 2 ? 1 : 4 * 192];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  uint32_t c0[4], c1[4], c2[4];
+  if constexpr (SRC == 2) {
+    if (x >= w) return;
+    const u32x4 q0 = ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x);
+    const u32x4 q1 = ldg<true, u32x4>(f.s[1] + (size_t)y * f.sp[1] + x);
+    const u32x4 q2 = ldg<true, u32x4>(f.s[2] + (size_t)y * f.sp[2] + x);
+#pragma unroll
+    for (int g = 0; g < 4; g++) { c0[g] = q0[g]; c1[g] = q1[g]; c2[g] = q2[g]; }
+  } else {
+    uint32_t d[12];
+    load_run48(tile + wv * 192, f.s[0] + (size_t)y * f.sp[0], chunk * 3072, 3 * w, lane, d);
+    if (x >= w) return;
+#pragma unroll
+    for (int g = 0; g < 4; g++) deint4(d[3 * g], d[3 * g + 1], d[3 * g + 2], c0[g], c1[g], c2[g]);
+  }
+  const uint32_t* rr = (SRC == 1) ? c2 : c0;
+  const uint32_t* bb = (SRC == 1) ? c0 : c2;
+  uint32_t o[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const uint32_t r = rr[g], gg = c1[g], b = bb[g];
+    auto gray = [](float R, float G, float B) { return __builtin_fmaf(R, 0.299f, __builtin_fmaf(G, 0.587f, __builtin_fmaf(B, 0.114f, 0.5f))); };
+    o[g] = pack4_trunc(gray(ubyte<0>(r), ubyte<0>(gg), ubyte<0>(b)), gray(ubyte<1>(r), ubyte<1>(gg), ubyte<1>(b)),
+                       gray(ubyte<2>(r), ubyte<2>(gg), ubyte<2>(b)), gray(ubyte<3>(r), ubyte<3>(gg), ubyte<3>(b)));
+  }
+  stg<true, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, u32x4{o[0], o[1], o[2], o[3]});
+}
+
+// NV12 <-> YUV420, rows split by role: a luma wave copies 1 KiB (one load, one store); a chroma wave moves 2 KiB of
+// interleaved UV <-> 1 KiB of U + 1 KiB of V.  Requires w % 32 == 0, h even, every plane and pitch 16-B aligned.
+template <bool TO_PLANAR>
+__global__ __launch_bounds__(256) void k_nv12_yuv420_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_y,
+                                                         uint32_t luma_tasks, uint32_t chunks_c, uint32_t n_tasks) {
+  __shared__ u32x4 tile[TO_PLANAR ? 1 : 4 * 128];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  if (wt < luma_tasks) {
+    const uint32_t y = wt / chunks_y, x = (wt - y * chunks_y) * 1024 + lane * 16;
+    if (x < w) stg<true, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x));
+    return;
+  }
+  const uint32_t ct = wt - luma_tasks;
+  const uint32_t rp = ct / chunks_c, chunk = ct - rp * chunks_c;
+  const uint32_t x = chunk * 2048 + lane * 32;  // byte offset in the interleaved UV row
+  if constexpr (TO_PLANAR) {
+    if (x >= w) return;
+    const uint8_t* p = f.s[1] + (size_t)rp * f.sp[1] + x;
+    const u32x4 a = ldg<true, u32x4>(p), b = ldg<true, u32x4>(p + 16);  // the lane's 32 contiguous bytes: both halves of each 128-B line are consumed by this wave
+    u32x4 u, v;  // even bytes -> U, odd bytes -> V
+    u[0] = __builtin_amdgcn_perm(a[1], a[0], 0x06040200u); u[1] = __builtin_amdgcn_perm(a[3], a[2], 0x06040200u);
+    u[2] = __builtin_amdgcn_perm(b[1], b[0], 0x06040200u); u[3] = __builtin_amdgcn_perm(b[3], b[2], 0x06040200u);
+    v[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07050301u); v[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07050301u);
+    v[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07050301u); v[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07050301u);
+    stg<true, u32x4>(f.d[1] + (size_t)rp * f.dp[1] + (x >> 1), u);
+    stg<true, u32x4>(f.d[2] + (size_t)rp * f.dp[2] + (x >> 1), v);
+  } else {
+    const uint32_t xc = x < w ? x : w - 32;
+    const u32x4 u = ldg<true, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + (xc >> 1));
+    const u32x4 v = ldg<true, u32x4>(f.s[2] + (size_t)rp * f.sp[2] + (xc >> 1));
+    u32x4* t = tile + wv * 128;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      u32x4 o;  // interleave: U0 V0 U1 V1 | U2 V2 U3 V3 | ...
+      o[0] = __builtin_amdgcn_perm(v[2 * j], u[2 * j], 0x05010400u);
+      o[1] = __builtin_amdgcn_perm(v[2 * j], u[2 * j], 0x07030602u);
+      o[2] = __builtin_amdgcn_perm(v[2 * j + 1], u[2 * j + 1], 0x05010400u);
+      o[3] = __builtin_amdgcn_perm(v[2 * j + 1], u[2 * j + 1], 0x07030602u);
+      t[lane * 2 + j] = o;
+    }
+    wave_sync();
+    uint8_t* row = f.d[1] + (size_t)rp * f.dp[1];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t off = chunk * 2048 + (k * 64 + lane) * 16;
+      if (off < w) stg<true, u32x4>(row + off, t[k * 64 + lane]);
+    }
+  }
+}
+
+// RGB -> RGB_32F, elementwise over the 3W bytes of a row: a wave takes 1 KiB of bytes as four dense 256-B dword loads
+// (all in flight before the first use) and writes four dense 1-KiB runs of floats.
+__global__ __launch_bounds__(256) void k_u8_to_f32_x4(const BatchArgs args, uint32_t wdwords, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  const uint8_t* src = f.s[0] + (size_t)y * f.sp[0];
+  uint8_t* dst = f.d[0] + (size_t)y * f.dp[0];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  uint32_t d[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = chunk * 256 + j * 64 + lane;
+    d[j] = ldg<true, uint32_t>(src + 4 * (size_t)(i < wdwords ? i : wdwords - 1));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = chunk * 256 + j * 64 + lane;
+    const f32x4 v = {ubyte<0>(d[j]) / 255.0f, ubyte<1>(d[j]) / 255.0f, ubyte<2>(d[j]) / 255.0f, ubyte<3>(d[j]) / 255.0f};
+    if (i < wdwords) stg<true, f32x4>(dst + 16 * (size_t)i, v);
+  }
+}
+
+// P10 / P12 -> NV12, 16 samples (32 B) per lane -> one dense 1-KiB store per wave; rows as in k_p16_to_8_p8.
+__global__ __launch_bounds__(256) void k_p16_to_8_x16(const BatchArgs args, uint32_t wsamples, uint32_t h, uint32_t ch, uint32_t chunks_x, uint32_t n_tasks) {
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t row = wt / chunks_x, chunk = wt - row * chunks_x;
+  const int pl = row >= h;
+  const uint32_t y = pl ? row - h : row;
+  const uint32_t xs = chunk * 1024 + lane * 16;  // first sample of the lane
+  if (xs >= wsamples) return;
+  const uint8_t* p = f.s[pl] + (size_t)y * f.sp[pl] + 2 * (size_t)xs;
+  const u32x4 a = ldg<true, u32x4>(p), b = ldg<true, u32x4>(p + 16);
+  auto two = [](uint32_t lo, uint32_t hi) {
+    return (uint32_t)p16_to_8((uint16_t)(lo & 0xffffu)) | ((uint32_t)p16_to_8((uint16_t)(lo >> 16)) << 8) |
+           ((uint32_t)p16_to_8((uint16_t)(hi & 0xffffu)) << 16) | ((uint32_t)p16_to_8((uint16_t)(hi >> 16)) << 24);
+  };
+  const u32x4 o = {two(a[0], a[1]), two(a[2], a[3]), two(b[0], b[1]), two(b[2], b[3])};
+  stg<true, u32x4>(f.d[pl] + (size_t)y * f.dp[pl] + xs, o);
+}
+
 static bool al(const BatchArgs& a, uint32_t n, int ns, int nd, uint32_t s0, uint32_t s12, uint32_t d0, uint32_t d12) {
   for (uint32_t i = 0; i < n; i++) {
     for (int k = 0; k < ns; k++)
@@ -255,6 +423,19 @@ static hipError_t go_generic(hipStream_t st, uint32_t w, uint32_t h, uint32_t n,
 
 hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t h, uint32_t n, const BatchArgs& a) {
   const bool force_generic = tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9;
+  // r16 kernels (dense 1-KiB non-temporal accesses) wherever the frame is 16-px / 16-B regular; tuning value 40 keeps
+  // the narrower p4 / p16 fast paths (A/B measurements, and so the tests still cover them on regular frames)
+  const bool r16 = !force_generic && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && w % 16 == 0;
+  auto row_tasks = [&](uint32_t chunks, uint32_t rows) { return dim3((chunks * rows + 3) / 4, n); };
+  const uint32_t cx = (w + 1023) / 1024;
+  if (r16 && w % 32 == 0 && h % 2 == 0 && ((sf == VPF_FMT_NV12 && df == VPF_FMT_YUV420 && al(a, n, 2, 3, 16, 16, 16, 16)) ||
+                                            (sf == VPF_FMT_YUV420 && df == VPF_FMT_NV12 && al(a, n, 3, 2, 16, 16, 16, 16)))) {
+    const uint32_t cc = (w + 2047) / 2048, luma = cx * h, total = luma + cc * (h / 2);
+    dim3 grid((total + 3) / 4, n);
+    if (sf == VPF_FMT_NV12) VPF_LAUNCH((k_nv12_yuv420_r16<true>), grid, dim3(256), 0, st, a, w, h, cx, luma, cc, total);
+    else VPF_LAUNCH((k_nv12_yuv420_r16<false>), grid, dim3(256), 0, st, a, w, h, cx, luma, cc, total);
+    return hipGetLastError();
+  }
   if (sf == VPF_FMT_NV12 && df == VPF_FMT_YUV420) {
     if (!force_generic && w % 16 == 0 && h % 2 == 0 && al(a, n, 2, 3, 16, 16, 16, 8)) {
       dim3 grid((w / 16 + 63) / 64, (h / 2 + 3) / 4, n);
@@ -277,6 +458,10 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     BatchArgs b = a;
     if (sf == VPF_FMT_BGR)
       for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].d[0], b.f[i].d[2]); std::swap(b.f[i].dp[0], b.f[i].dp[2]); }
+    if (r16 && al(b, n, 1, 3, 16, 16, 16, 16)) {
+      VPF_LAUNCH((k_rgb_relayout_r16<0>), row_tasks(cx, h), dim3(256), 0, st, b, w, h, cx, cx * h);
+      return hipGetLastError();
+    }
     if (!force_generic && w % 4 == 0 && al(b, n, 1, 3, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
       VPF_LAUNCH((k_rgb_relayout_p4<0>), grid, dim3(256), 0, st, b, w, h, w / 4);
@@ -288,6 +473,10 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     BatchArgs b = a;
     if (df == VPF_FMT_BGR)
       for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].s[0], b.f[i].s[2]); std::swap(b.f[i].sp[0], b.f[i].sp[2]); }
+    if (r16 && al(b, n, 3, 1, 16, 16, 16, 16)) {
+      VPF_LAUNCH((k_rgb_relayout_r16<1>), row_tasks(cx, h), dim3(256), 0, st, b, w, h, cx, cx * h);
+      return hipGetLastError();
+    }
     if (!force_generic && w % 4 == 0 && al(b, n, 3, 1, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
       VPF_LAUNCH((k_rgb_relayout_p4<1>), grid, dim3(256), 0, st, b, w, h, w / 4);
@@ -296,6 +485,10 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     return go_generic<OP_PLANAR_RGB>(st, w, h, n, b);
   }
   if (packed_s && packed_d && sf != df) {
+    if (r16 && al(a, n, 1, 1, 16, 16, 16, 16)) {
+      VPF_LAUNCH((k_rgb_relayout_r16<2>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
+      return hipGetLastError();
+    }
     if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
       VPF_LAUNCH((k_rgb_relayout_p4<2>), grid, dim3(256), 0, st, a, w, h, w / 4);
@@ -320,6 +513,11 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     return go_generic<OP_Y_YUV444>(st, w, h, n, a);
   }
   if (sf == VPF_FMT_RGB && df == VPF_FMT_RGB_32F) {
+    if (r16 && al(a, n, 1, 1, 4, 4, 16, 16)) {
+      const uint32_t wd = 3 * w / 4, c4 = (wd + 255) / 256;
+      VPF_LAUNCH(k_u8_to_f32_x4, row_tasks(c4, h), dim3(256), 0, st, a, wd, h, c4, c4 * h);
+      return hipGetLastError();
+    }
     if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 16, 16)) {
       dim3 grid((3 * w / 4 + 63) / 64, (h + 3) / 4, n);
       VPF_LAUNCH(k_u8_to_f32_p4, grid, dim3(256), 0, st, a, 3 * w, h, 3 * w / 4);
@@ -329,6 +527,11 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   }
   if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) return go_generic<OP_RGB32F_PLANAR>(st, w, h, n, a);
   if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) {
+    if (r16 && al(a, n, 2, 2, 16, 16, 16, 16)) {
+      const uint32_t ch = (h + 1) / 2;
+      VPF_LAUNCH(k_p16_to_8_x16, row_tasks(cx, h + ch), dim3(256), 0, st, a, w, h, ch, cx, cx * (h + ch));
+      return hipGetLastError();
+    }
     if (!force_generic && w % 8 == 0 && al(a, n, 2, 2, 16, 16, 8, 8)) {  // luma and chroma rows both hold w 16-bit samples
       const uint32_t ch = (h + 1) / 2;
       dim3 grid((w / 8 + 63) / 64, (h + ch + 3) / 4, n);
@@ -339,6 +542,12 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   }
   if (df == VPF_FMT_Y && (sf == VPF_FMT_RGB || sf == VPF_FMT_BGR || sf == VPF_FMT_RGB_PLANAR)) {
     const int ns = (sf == VPF_FMT_RGB_PLANAR) ? 3 : 1;
+    if (r16 && al(a, n, ns, 1, 16, 16, 16, 16)) {
+      if (sf == VPF_FMT_RGB) VPF_LAUNCH((k_gray_r16<0>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
+      else if (sf == VPF_FMT_BGR) VPF_LAUNCH((k_gray_r16<1>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
+      else VPF_LAUNCH((k_gray_r16<2>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
+      return hipGetLastError();
+    }
     if (!force_generic && w % 4 == 0 && al(a, n, ns, 1, 4, 4, 4, 4)) {
       dim3 grid((w / 4 + 63) / 64, (h + 3) / 4, n);
       if (sf == VPF_FMT_RGB) VPF_LAUNCH((k_gray_p4<0>), grid, dim3(256), 0, st, a, w, h, w / 4);

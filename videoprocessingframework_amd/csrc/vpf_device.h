@@ -78,4 +78,64 @@ VPF_DEV void stg3(void* p, uint32_t a, uint32_t b, uint32_t c) {
   stg<NT, uint32_t>(q + 2, c);
 }
 
+// make one wave's LDS writes visible to its own other lanes (wave-private tiles: no workgroup barrier needed)
+VPF_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- byte shuffles on groups of 4 packed 3-channel pixels (12 B = 3 dwords), all v_perm_b32 ----
+// d0 = c0a c1a c2a c0b ; d1 = c1b c2b c0c c1c ; d2 = c2c c0d c1d c2d   (perm(hi, lo, sel): sel 0-3 -> lo, 4-7 -> hi)
+VPF_DEV void deint4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t& c0, uint32_t& c1, uint32_t& c2) {
+  c0 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000300u), __builtin_amdgcn_perm(d2, d1, 0x00000502u), 0x01000504u);
+  c1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000401u), __builtin_amdgcn_perm(d2, d1, 0x00000603u), 0x01000504u);
+  c2 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d1, d0, 0x00000502u), __builtin_amdgcn_perm(d2, d1, 0x00000704u), 0x01000504u);
+}
+VPF_DEV void inter4(uint32_t r, uint32_t g, uint32_t b, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+  const uint32_t rg_lo = __builtin_amdgcn_perm(g, r, 0x05010400u);  // R0 G0 R1 G1
+  const uint32_t rg_hi = __builtin_amdgcn_perm(g, r, 0x07030602u);  // R2 G2 R3 G3
+  d0 = __builtin_amdgcn_perm(b, rg_lo, 0x02040100u);                // R0 G0 B0 R1
+  d1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b, rg_lo, 0x00000503u) /* G1 B1 . . */, rg_hi, 0x01000504u);  // G1 B1 R2 G2
+  d2 = __builtin_amdgcn_perm(b, rg_hi, 0x07030206u);                // B2 R3 G3 B3
+}
+VPF_DEV void swap4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t& o0, uint32_t& o1, uint32_t& o2) {
+  // o0 = c2a c1a c0a c2b ; o1 = c1b c0b c2c c1c ; o2 = c0c c2d c1d c0d
+  o0 = __builtin_amdgcn_perm(d1, d0, 0x05000102u);
+  o1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(d2, d0, 0x04000003u) /* c0b . . c2c */, d1, 0x03070400u);
+  o2 = __builtin_amdgcn_perm(d2, d1, 0x05060702u);
+}
+
+// One wave <-> one 3-KiB run of packed pixels (1024 px x 3 B) through a wave-private LDS tile of 192 x 16 B:
+// global side = three dense 1-KiB accesses (lane-contiguous 16 B), register side = 48 contiguous bytes (16 px) per lane.
+// ds_write/read_b128 at 48*lane + 16*j and 16*(64k + lane) are both bank-conflict-free (profiles/r01_pmc_sq.json).
+// `row` points at byte 0 of the run's row, `base` = byte offset of the run, `row_bytes` = 3 * width (multiple of 16).
+VPF_DEV void load_run48(u32x4* t, const uint8_t* row, uint32_t base, uint32_t row_bytes, uint32_t lane, uint32_t d[12]) {
+  u32x4 q[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {  // clamp instead of predicate: all three loads issue back to back; the clamped
+    uint32_t off = base + (k * 64 + lane) * 16;  // duplicates land in slots only out-of-range lanes would read
+    off = off < row_bytes ? off : row_bytes - 16;
+    q[k] = ldg<true, u32x4>(row + off);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) t[k * 64 + lane] = q[k];
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const u32x4 v = t[lane * 3 + j];
+    d[4 * j] = v[0]; d[4 * j + 1] = v[1]; d[4 * j + 2] = v[2]; d[4 * j + 3] = v[3];
+  }
+}
+VPF_DEV void store_run48(u32x4* t, uint8_t* row, uint32_t base, uint32_t row_bytes, uint32_t lane, const uint32_t d[12]) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) t[lane * 3 + j] = u32x4{d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]};
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t off = base + (k * 64 + lane) * 16;
+    if (off < row_bytes) stg<true, u32x4>(row + off, t[k * 64 + lane]);
+  }
+}
+
 }  // namespace vpf
