@@ -191,10 +191,12 @@ def test_linearity_property_full_size(capi, oracle):
 @pytest.mark.parametrize("src_fmt", ["YUV420", "YUV444"])
 @pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
 def test_planar_yuv_to_rgb(capi, oracle, src_fmt, dst):
-    for (w, h) in [(640, 48), (30, 14), (7, 5)]:
+    for (w, h) in [(640, 48), (3840, 4), (1040, 6), (30, 14), (7, 5)]:
         src = oracle.synth(getattr(oracle, src_fmt), w, h, 1010)
         for cs, cr in MATS:
             _convert(capi, oracle, getattr(capi, src_fmt), getattr(capi, dst), cs, cr, w, h, src)
+        for variant in (40, 9):  # 40: p4 fast path on regular frames, 9: generic
+            _convert(capi, oracle, getattr(capi, src_fmt), getattr(capi, dst), 1, 0, w, h, src, variant=variant)
         _convert(capi, oracle, getattr(capi, src_fmt), getattr(capi, dst), 0, 0, w, h, src, align=2, extra=2, offset=2)
 
 
@@ -221,16 +223,19 @@ def test_float_converters(capi, oracle):
         for variant in (40, 9):
             _convert(capi, oracle, capi.RGB, capi.RGB_32F, 0, 0, w, h, src, variant=variant)
         assert got[0].dtype == np.float32 and got[0].max() <= 1.0
-        _convert(capi, oracle, capi.RGB_32F, capi.RGB_32F_PLANAR, 0, 0, w, h, got)
+        for variant in (0, 9):
+            _convert(capi, oracle, capi.RGB_32F, capi.RGB_32F_PLANAR, 0, 0, w, h, got, variant=variant)
 
 
 @pytest.mark.parametrize("s", ["RGB", "BGR", "RGB_PLANAR"])
 @pytest.mark.parametrize("d", ["YUV444", "YUV420", "YCBCR"])
 def test_rgb_to_yuv(capi, oracle, s, d):
-    for (w, h) in [(640, 48), (30, 14), (7, 5), (1, 1)]:
+    for (w, h) in [(640, 48), (3840, 4), (1040, 6), (2064, 2), (30, 14), (7, 5), (1, 1)]:
         src = oracle.synth(getattr(oracle, s), w, h, 1030)
         for cr in (0, 1):
             _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, cr, w, h, src)
+        for variant in (40, 9):  # 40: p4 fast path on regular frames, 9: quad kernel
+            _convert(capi, oracle, getattr(capi, s), getattr(capi, d), 0, 0, w, h, src, variant=variant)
 
 
 def test_roundtrip_rgb_yuv420_nv12_rgb(capi, oracle):

@@ -229,6 +229,23 @@ __global__ __launch_bounds__(256) void k_p16_to_8_p8(const BatchArgs args, uint3
 // through load_run48 / store_run48.  Requires w % 16 == 0 and 16-B aligned planes and pitches.
 // MODE 0: packed -> planar, 1: planar -> packed, 2: swap R/B
 // ------------------------------------------------------------------------------------------
+// RGB_32F -> RGB_32F_PLANAR is the same shape one size up: a 3-KiB run is 256 px of 12 B, a lane owns 4 px and
+// de-interleaves whole dwords.  Requires w % 4 == 0, 16-B aligned planes / pitches.
+__global__ __launch_bounds__(256) void k_rgb32f_planar_r4(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[4 * 192];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  const uint32_t x = chunk * 256 + lane * 4;
+  uint32_t d[12];
+  load_run48(tile + wv * 192, f.s[0] + (size_t)y * f.sp[0], chunk * 3072, 12 * w, lane, d);
+  if (x >= w) return;
+#pragma unroll
+  for (int k = 0; k < 3; k++) stg<true, u32x4>(f.d[k] + (size_t)y * f.dp[k] + 4 * (size_t)x, u32x4{d[k], d[3 + k], d[6 + k], d[9 + k]});
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rgb_relayout_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x,
                                                           uint32_t n_tasks) {
@@ -525,7 +542,14 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     }
     return go_generic<OP_RGB_RGB32F>(st, w, h, n, a);
   }
-  if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) return go_generic<OP_RGB32F_PLANAR>(st, w, h, n, a);
+  if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) {
+    if (!force_generic && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && w % 4 == 0 && al(a, n, 1, 3, 16, 16, 16, 16)) {
+      const uint32_t c4 = (w + 255) / 256;
+      VPF_LAUNCH(k_rgb32f_planar_r4, row_tasks(c4, h), dim3(256), 0, st, a, w, h, c4, c4 * h);
+      return hipGetLastError();
+    }
+    return go_generic<OP_RGB32F_PLANAR>(st, w, h, n, a);
+  }
   if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) {
     if (r16 && al(a, n, 2, 2, 16, 16, 16, 16)) {
       const uint32_t ch = (h + 1) / 2;

@@ -119,6 +119,111 @@ __global__ __launch_bounds__(256) void k_rgb_yuv_p4(const BatchArgs args, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// r16: 16 px per lane, dense 1-KiB non-temporal accesses.  4:4:4 outputs: a wave = one row x 1024 px (3 loads, 3
+// stores).  4:2:0: a wave = one row pair (6 loads in flight, two 1-KiB luma stores + two 512-B chroma stores).
+// Packed sources arrive through the wave-private LDS transpose (load side of store_run48).  Same arithmetic as above.
+// Requires w % 16 == 0, h even for 4:2:0, 16-B aligned planes / pitches (8-B for subsampled chroma).
+// ------------------------------------------------------------------------------------------
+template <int SRC, bool SUB>
+__global__ __launch_bounds__(256) void k_rgb_yuv_r16(const BatchArgs args, const Rgb2YuvCoef c, uint32_t w, uint32_t h,
+                                                     uint32_t chunks_x, uint32_t n_tasks) {
+  constexpr int ROWS = SUB ? 2 : 1;
+  __shared__ u32x4 tile[SRC == FC_PLANAR ? 1 : 4 * 192 * ROWS];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t rg = wt / chunks_x, chunk = wt - rg * chunks_x;
+  const uint32_t y0 = rg * ROWS, x = chunk * 1024 + lane * 16;
+  uint32_t p0[ROWS][4], p1[ROWS][4], p2[ROWS][4];  // channel planes in memory order, 4 px per dword
+  if constexpr (SRC == FC_PLANAR) {
+    if (x >= w) return;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      const u32x4 a = ldg<true, u32x4>(f.s[0] + (size_t)(y0 + r) * f.sp[0] + x), b = ldg<true, u32x4>(f.s[1] + (size_t)(y0 + r) * f.sp[1] + x),
+                  d = ldg<true, u32x4>(f.s[2] + (size_t)(y0 + r) * f.sp[2] + x);
+#pragma unroll
+      for (int g = 0; g < 4; g++) { p0[r][g] = a[g]; p1[r][g] = b[g]; p2[r][g] = d[g]; }
+    }
+  } else {
+    u32x4* t = tile + wv * 192 * ROWS;
+    const uint32_t row_bytes = 3 * w;
+    u32x4 q[ROWS][3];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        uint32_t off = chunk * 3072 + (k * 64 + lane) * 16;
+        off = off < row_bytes ? off : row_bytes - 16;
+        q[r][k] = ldg<true, u32x4>(f.s[0] + (size_t)(y0 + r) * f.sp[0] + off);
+      }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) t[r * 192 + k * 64 + lane] = q[r][k];
+    wave_sync();
+    if (x >= w) return;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      uint32_t d[12];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const u32x4 v = t[r * 192 + lane * 3 + j];
+        d[4 * j] = v[0]; d[4 * j + 1] = v[1]; d[4 * j + 2] = v[2]; d[4 * j + 3] = v[3];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) deint4(d[3 * g], d[3 * g + 1], d[3 * g + 2], p0[r][g], p1[r][g], p2[r][g]);
+    }
+  }
+  auto R = [&](int r, int g) { return SRC == FC_BGR ? p2[r][g] : p0[r][g]; };
+  auto B = [&](int r, int g) { return SRC == FC_BGR ? p0[r][g] : p2[r][g]; };
+  auto row4 = [&](int k, uint32_t rd, uint32_t gd, uint32_t bd) {
+    return pack4_trunc(mrow(c, k, ubyte<0>(rd), ubyte<0>(gd), ubyte<0>(bd)), mrow(c, k, ubyte<1>(rd), ubyte<1>(gd), ubyte<1>(bd)),
+                       mrow(c, k, ubyte<2>(rd), ubyte<2>(gd), ubyte<2>(bd)), mrow(c, k, ubyte<3>(rd), ubyte<3>(gd), ubyte<3>(bd)));
+  };
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+    for (int k = 0; k < (SUB ? 1 : 3); k++) {
+      u32x4 o;
+#pragma unroll
+      for (int g = 0; g < 4; g++) o[g] = row4(k, R(r, g), p1[r][g], B(r, g));
+      stg<true, u32x4>(f.d[k] + (size_t)(y0 + r) * f.dp[k] + x, o);
+    }
+  }
+  if constexpr (SUB) {
+    uint32_t cu[2] = {0, 0}, cv[2] = {0, 0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const uint32_t r0 = R(0, g), r1 = R(1, g), g0 = p1[0][g], g1 = p1[1][g], b0 = B(0, g), b1 = B(1, g);
+      // two quads: px {0,1} and {2,3} of both rows; sums of small integers and the 0.25 scale are exact in fp32
+      const float qr0 = 0.25f * (ubyte<0>(r0) + ubyte<1>(r0) + ubyte<0>(r1) + ubyte<1>(r1)), qr1 = 0.25f * (ubyte<2>(r0) + ubyte<3>(r0) + ubyte<2>(r1) + ubyte<3>(r1));
+      const float qg0 = 0.25f * (ubyte<0>(g0) + ubyte<1>(g0) + ubyte<0>(g1) + ubyte<1>(g1)), qg1 = 0.25f * (ubyte<2>(g0) + ubyte<3>(g0) + ubyte<2>(g1) + ubyte<3>(g1));
+      const float qb0 = 0.25f * (ubyte<0>(b0) + ubyte<1>(b0) + ubyte<0>(b1) + ubyte<1>(b1)), qb1 = 0.25f * (ubyte<2>(b0) + ubyte<3>(b0) + ubyte<2>(b1) + ubyte<3>(b1));
+      const uint32_t u2 = sat_trunc(mrow(c, 1, qr0, qg0, qb0)) | (sat_trunc(mrow(c, 1, qr1, qg1, qb1)) << 8);
+      const uint32_t v2 = sat_trunc(mrow(c, 2, qr0, qg0, qb0)) | (sat_trunc(mrow(c, 2, qr1, qg1, qb1)) << 8);
+      cu[g >> 1] |= u2 << (16 * (g & 1));
+      cv[g >> 1] |= v2 << (16 * (g & 1));
+    }
+    stg<true, u32x2>(f.d[1] + (size_t)rg * f.dp[1] + (x >> 1), u32x2{cu[0], cu[1]});
+    stg<true, u32x2>(f.d[2] + (size_t)rg * f.dp[2] + (x >> 1), u32x2{cv[0], cv[1]});
+  }
+}
+
+static bool rgb2yuv_r16_ok(const BatchArgs& a, uint32_t n, int src_fc, bool sub, uint32_t w, uint32_t h) {
+  const int tv = tuning(VPF_TUNE_NV12_RGB_VARIANT);
+  if (tv == 9 || tv == 40 || (w & 15) || (sub && (h & 1))) return false;
+  const int ns = (src_fc == FC_PLANAR) ? 3 : 1;
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < ns; k++)
+      if (((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & 15) return false;
+    for (int k = 0; k < 3; k++)
+      if (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & ((k && sub) ? 7 : 15)) return false;
+  }
+  return true;
+}
+
 static bool rgb2yuv_fast_ok(const BatchArgs& a, uint32_t n, int src_fc, bool sub, uint32_t w, uint32_t h) {
   if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9 || (w & 3) || (h & 1)) return false;
   const int ns = (src_fc == FC_PLANAR) ? 3 : 1;
@@ -134,6 +239,23 @@ static bool rgb2yuv_fast_ok(const BatchArgs& a, uint32_t n, int src_fc, bool sub
 hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc, const Rgb2YuvCoef& c, uint32_t w, uint32_t h,
                              uint32_t n, const BatchArgs& a) {
   const bool sub = (dst_fc == FC_YUV420);
+  // a row-pair wave halves the wave count: on a lone 4K frame that is only ~4300 waves for 8192 slots, and the narrower
+  // p4 kernel wins by 8 % (profiles/r01_secondary_kernels.txt); batched launches have waves to spare
+  if (rgb2yuv_r16_ok(a, n, src_fc, sub, w, h) && !(sub && n < 2 && (size_t)w * h < (size_t)3840 * 2160 * 2)) {
+    const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (sub ? h / 2 : h);
+    dim3 rgrid((tasks + 3) / 4, n);
+#define VPF_R16(S)                                                                                    \
+  if (sub) VPF_LAUNCH((k_rgb_yuv_r16<S, true>), rgrid, dim3(256), 0, st, a, c, w, h, chunks, tasks);   \
+  else VPF_LAUNCH((k_rgb_yuv_r16<S, false>), rgrid, dim3(256), 0, st, a, c, w, h, chunks, tasks);      \
+  return hipGetLastError();
+    switch (src_fc) {
+      case FC_RGB: VPF_R16(FC_RGB)
+      case FC_BGR: VPF_R16(FC_BGR)
+      case FC_PLANAR: VPF_R16(FC_PLANAR)
+      default: return hipErrorInvalidValue;
+    }
+#undef VPF_R16
+  }
   if (rgb2yuv_fast_ok(a, n, src_fc, sub, w, h)) {
     dim3 fgrid((w / 4 + 63) / 64, (h / 2 + 3) / 4, n);
 #define VPF_FAST(S)                                                                                  \

@@ -472,6 +472,52 @@ __global__ __launch_bounds__(256) void k_yuv444_rgb_p4(const BatchArgs args, con
   }
 }
 
+// YUV444 -> RGB/BGR/PLANAR, r16: one row x 1024 px per wave, three dense 1-KiB plane loads, three dense 1-KiB stores
+// (packed outputs through store_run48).  Requires w % 16 == 0 and 16-B aligned planes / pitches.
+template <int DST>
+__global__ __launch_bounds__(256) void k_yuv444_rgb_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                        uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[DST == FC_PLANAR ? 1 : 4 * 192];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  const uint32_t x = chunk * 1024 + lane * 16;
+  if (DST == FC_PLANAR && x >= w) return;
+  const uint32_t xc = x < w ? x : w - 16;  // clamped lanes compute a duplicate that store_run48 never writes
+  const u32x4 yq = ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + xc);
+  const u32x4 uq = ldg<true, u32x4>(f.s[1] + (size_t)y * f.sp[1] + xc);
+  const u32x4 vq = ldg<true, u32x4>(f.s[2] + (size_t)y * f.sp[2] + xc);
+  uint32_t o[12];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t yd = yq[j], ud = uq[j], vd = vq[j];
+    const Chroma k0 = chroma_terms(c, ubyte<0>(ud), ubyte<0>(vd)), k1 = chroma_terms(c, ubyte<1>(ud), ubyte<1>(vd));
+    const Chroma k2 = chroma_terms(c, ubyte<2>(ud), ubyte<2>(vd)), k3 = chroma_terms(c, ubyte<3>(ud), ubyte<3>(vd));
+    Quad q;
+    const float y0 = ubyte<0>(yd), y1 = ubyte<1>(yd), y2 = ubyte<2>(yd), y3 = ubyte<3>(yd);
+    q.r[0] = __builtin_fmaf(y0, c.cy, k0.rc); q.g[0] = __builtin_fmaf(y0, c.cy, k0.gc); q.b[0] = __builtin_fmaf(y0, c.cy, k0.bc);
+    q.r[1] = __builtin_fmaf(y1, c.cy, k1.rc); q.g[1] = __builtin_fmaf(y1, c.cy, k1.gc); q.b[1] = __builtin_fmaf(y1, c.cy, k1.bc);
+    q.r[2] = __builtin_fmaf(y2, c.cy, k2.rc); q.g[2] = __builtin_fmaf(y2, c.cy, k2.gc); q.b[2] = __builtin_fmaf(y2, c.cy, k2.bc);
+    q.r[3] = __builtin_fmaf(y3, c.cy, k3.rc); q.g[3] = __builtin_fmaf(y3, c.cy, k3.gc); q.b[3] = __builtin_fmaf(y3, c.cy, k3.bc);
+    if constexpr (DST == FC_PLANAR) {
+      o[j] = pack4<1>(q.r[0], q.r[1], q.r[2], q.r[3]);
+      o[4 + j] = pack4<1>(q.g[0], q.g[1], q.g[2], q.g[3]);
+      o[8 + j] = pack4<1>(q.b[0], q.b[1], q.b[2], q.b[3]);
+    } else {
+      pack_rgb12<DST, 1>(q, o[3 * j], o[3 * j + 1], o[3 * j + 2]);
+    }
+  }
+  if constexpr (DST == FC_PLANAR) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      stg<true, u32x4>(f.d[k] + (size_t)y * f.dp[k] + x, u32x4{o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]});
+  } else {
+    store_run48(tile + wv * 192, f.d[0] + (size_t)y * f.dp[0], chunk * 3072, 3 * w, lane, o);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic: any size, any alignment.  One thread per 2x2 quad, byte accesses, full bounds checks.
 // ---------------------------------------------------------------------------------------------
@@ -662,6 +708,11 @@ template <int DST>
 static hipError_t launch_444(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t n,
                              const BatchArgs& a, int variant) {
   const int ndst = (DST == FC_PLANAR) ? 3 : 1;
+  if (variant != 9 && variant != 40 && w % 16 == 0 && aligned_all(a, n, 3, ndst, 16, 16, 16)) {
+    const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;
+    VPF_LAUNCH((k_yuv444_rgb_r16<DST>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, chunks, tasks);
+    return hipGetLastError();
+  }
   if (variant != 9 && w % 4 == 0 && aligned_all(a, n, 3, ndst, 4, 4, 4) && h <= 65535) {
     dim3 grid((w / 4 + 255) / 256, h, n);
     VPF_LAUNCH((k_yuv444_rgb_p4<DST, 1>), grid, dim3(256), 0, st, a, c, w, h, w / 4);
