@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256) void k_resize_lanczos(const uint8_t* __restric
 // LDS issue per 720p frame chip-wide).  Same make_tap / bilerp arithmetic => bit-identical to k_resize.
 // Requires: 16-B aligned source rows (pointer and pitch); span of a wave <= kResizeRowBytes (host checks the scale).
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kResizeRowBytes = 4096;
+constexpr uint32_t kResizeRowBytes = 4096;  // largest strip (IT = 4 dense 1-KiB loads per source row)
+// The strips live in dynamic LDS sized for THIS launch's scale factor (strip bytes = span rounded up to 256):
+// a 3x down-scale of packed RGB needs 2.5 KiB per row instead of the 4 KiB worst case, so 8 workgroups fit a CU
+// instead of 5 and the load latency of one wave hides behind the arithmetic of more neighbours.
+extern __shared__ u32x4 dyn_strip[];
 
 // Copy `nq` 16-byte units of a source row (starting at the 16-B aligned byte offset `base`) into an LDS strip.
 // All loads are issued before the first LDS write (MAXIT is a compile-time bound), so the wave pays ONE memory
@@ -202,12 +206,10 @@ VPF_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int CH>
+template <int CH, int IT /* 1-KiB loads per strip */>
 __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
-                                                    float scx, float scy, int vec_ok) {
-  __shared__ u32x4 strip[4][2][kResizeRowBytes / 16];
-  constexpr int IT = kResizeRowBytes / 1024;
+                                                    float scx, float scy, int vec_ok, uint32_t rowq /* strip size in 16-B units */) {
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t y = blockIdx.y * 4 + wv;
   if (y >= dh) return;
@@ -218,13 +220,15 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
   Span<IT> s0, s1;
   s0.load(src + (size_t)ty.i0 * sp, base, nq, lane);
   s1.load(src + (size_t)ty.i1 * sp, base, nq, lane);
-  s0.store(strip[wv][0], nq, lane);
-  s1.store(strip[wv][1], nq, lane);
+  u32x4* st0 = dyn_strip + (wv * 2) * rowq;
+  u32x4* st1 = st0 + rowq;
+  s0.store(st0, nq, lane);
+  s1.store(st1, nq, lane);
   wave_lds_sync();
   const uint32_t x0 = xs + lane * 4;
   if (x0 >= dw) return;
-  const uint8_t* r0 = reinterpret_cast<const uint8_t*>(strip[wv][0]);
-  const uint8_t* r1 = reinterpret_cast<const uint8_t*>(strip[wv][1]);
+  const uint8_t* r0 = reinterpret_cast<const uint8_t*>(st0);
+  const uint8_t* r1 = reinterpret_cast<const uint8_t*>(st1);
   float o[4 * CH];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -249,13 +253,15 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
   }
 }
 
-// does a wave's source span fit the LDS strip?  span <= 255*scale + 3 pixels (+3 bytes of dword alignment)
-static bool lds_resize_ok(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
-  if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9) return false;  // forced generic
-  if (((uintptr_t)src | sp) & 15) return false;
+// strip bytes a wave needs for its source span (<= 255*scale + 3 pixels, + 16-B alignment slack on both ends),
+// rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
+static uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
+  if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9) return 0;  // forced generic
+  if (((uintptr_t)src | sp) & 15) return 0;
   const double scale = (double)sw / (double)dw;
-  const double span_px = 255.0 * scale + 4.0;
-  return span_px * ch + 32.0 <= (double)row_bytes_cap;
+  const double need = (255.0 * scale + 4.0) * ch + 32.0;
+  if (need > (double)row_bytes_cap) return 0;
+  return ((uint32_t)need + 255u) & ~255u;
 }
 
 hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
@@ -270,10 +276,14 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
     return hipGetLastError();
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
-  if (interp == VPF_INTERP_LINEAR && lds_resize_ok(ch, sw, dw, src, sp, kResizeRowBytes)) {
-    if (ch == 1) VPF_LAUNCH((k_resize_lds<1>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);
-    else if (ch == 2) VPF_LAUNCH((k_resize_lds<2>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);
-    else VPF_LAUNCH((k_resize_lds<3>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok);
+  const uint32_t rowb = (interp == VPF_INTERP_LINEAR) ? lds_strip_bytes(ch, sw, dw, src, sp, kResizeRowBytes) : 0;
+  if (rowb) {
+    const uint32_t it = (rowb + 1023) / 1024, lds = 4 * 2 * rowb;
+#define VPF_RL(C, I) VPF_LAUNCH((k_resize_lds<C, I>), grid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok, rowb / 16)
+#define VPF_RLI(C) do { if (it == 1) VPF_RL(C, 1); else if (it == 2) VPF_RL(C, 2); else if (it == 3) VPF_RL(C, 3); else VPF_RL(C, 4); } while (0)
+    if (ch == 1) VPF_RLI(1); else if (ch == 2) VPF_RLI(2); else VPF_RLI(3);
+#undef VPF_RLI
+#undef VPF_RL
     return hipGetLastError();
   }
 #define VPF_GO(C, I) VPF_LAUNCH((k_resize<C, I>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok)
@@ -447,15 +457,17 @@ __global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, co
 // LDS-staged fused kernel: the wave stages the luma spans of source rows y0,y1 and the chroma spans of rows y0>>1,
 // y1>>1 (4 coalesced strips), then converts the four taps of each destination pixel from LDS.  Bit-identical to
 // k_convert_resize.  NV12: chroma strip holds interleaved UV; YUV420: U strip then V strip.
-constexpr uint32_t kFusedRowBytes = 2048;
+// This kernel is VALU-bound, not HBM-bound: four full conversions (incl. the u8 rounding that keeps it bit-identical to
+// convert-then-resize) per destination pixel is ~500 VALU instructions per wave of 256 px, i.e. ~2.9 us per 4K->720p
+// frame of pure issue time on 1024 SIMDs; measured 3.2 us batched.
+constexpr uint32_t kFusedRowBytes = 2048;  // cap; the launch sizes the strips for its own scale factor (dyn_strip)
 
-template <int SRC, int DST>
+template <int SRC, int DST, int IT>
 __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
-                                                            uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok) {
+                                                            uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok, uint32_t rowq) {
   const FrameDesc f = args.f[blockIdx.z];
-  // [wave][0,1: luma rows][...]; [wave][2,3: chroma rows (NV12: UV interleaved | YUV420: U)]; [wave][4,5: V rows, YUV420 only]
-  __shared__ u32x4 strip[4][SRC == FC_NV12 ? 4 : 6][kFusedRowBytes / 16];
-  constexpr int IT = kFusedRowBytes / 1024;
+  // per wave, NS strips of rowq x 16 B in dynamic LDS: 0,1 luma rows; 2,3 chroma rows (NV12: UV interleaved | YUV420: U);
+  // 4,5 V rows (YUV420 only)
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t y = blockIdx.y * 4 + wv;
   if (y >= dh) return;
@@ -470,46 +482,73 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     cbase = (first >> 1) & ~15u; cnq = ((last >> 1) + 1 - cbase + 15) / 16;
   }
   constexpr int NS = (SRC == FC_NV12) ? 4 : 6;
+  // both source rows usually sit on ONE chroma row when the upper one is even: wave-uniform, so the second chroma
+  // strip is neither loaded nor converted (its chroma terms are the first row's)
+  const bool one_crow = (ty.i0 >> 1) == (ty.i1 >> 1);
   Span<IT> sp_[NS];  // every strip's loads are in flight before the first LDS write
   sp_[0].load(f.s[0] + (size_t)ty.i0 * f.sp[0], ybase, ynq, lane);
   sp_[1].load(f.s[0] + (size_t)ty.i1 * f.sp[0], ybase, ynq, lane);
   sp_[2].load(f.s[1] + (size_t)(ty.i0 >> 1) * f.sp[1], cbase, cnq, lane);
-  sp_[3].load(f.s[1] + (size_t)(ty.i1 >> 1) * f.sp[1], cbase, cnq, lane);
+  if (!one_crow) sp_[3].load(f.s[1] + (size_t)(ty.i1 >> 1) * f.sp[1], cbase, cnq, lane);
   if constexpr (SRC != FC_NV12) {
     sp_[4].load(f.s[2] + (size_t)(ty.i0 >> 1) * f.sp[2], cbase, cnq, lane);
-    sp_[5].load(f.s[2] + (size_t)(ty.i1 >> 1) * f.sp[2], cbase, cnq, lane);
+    if (!one_crow) sp_[5].load(f.s[2] + (size_t)(ty.i1 >> 1) * f.sp[2], cbase, cnq, lane);
   }
-  sp_[0].store(strip[wv][0], ynq, lane);
-  sp_[1].store(strip[wv][1], ynq, lane);
-#pragma unroll
-  for (int k = 2; k < NS; k++) sp_[k].store(strip[wv][k], cnq, lane);
+  u32x4* const wstrip = dyn_strip + wv * NS * rowq;
+  auto strip_at = [&](int k) { return wstrip + k * rowq; };
+  sp_[0].store(strip_at(0), ynq, lane);
+  sp_[1].store(strip_at(1), ynq, lane);
+  sp_[2].store(strip_at(2), cnq, lane);
+  if (!one_crow) sp_[3].store(strip_at(3), cnq, lane);
+  if constexpr (SRC != FC_NV12) {
+    sp_[4].store(strip_at(4), cnq, lane);
+    if (!one_crow) sp_[5].store(strip_at(5), cnq, lane);
+  }
   wave_lds_sync();
   const uint32_t x0 = xs + lane * 4;
   if (x0 >= dw) return;
-  auto texel = [&](uint32_t x, int r, float* rgb) {  // r: 0 = row y0, 1 = row y1
-    const float yf = (float)reinterpret_cast<const uint8_t*>(strip[wv][r])[x - ybase];
-    float u, v;
+  // Two horizontally adjacent taps are converted together on the packed-fp32 pipe (v_pk_fma_f32: two independent
+  // IEEE fmas per instruction, so every component is bit-identical to vpf_convert's scalar fma chain).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 cy2 = {c.cy, c.cy}, rv2 = {c.rv, c.rv}, gu2 = {c.gu, c.gu}, gv2 = {c.gv, c.gv}, bu2 = {c.bu, c.bu};
+  const f32x2 br2 = {c.br, c.br}, bg2 = {c.bg, c.bg}, bb2 = {c.bb, c.bb};
+  struct Chroma2 { f32x2 rc, gc, bc; };
+  auto chroma2 = [&](uint32_t a0, uint32_t a1, int r) {  // chroma terms of taps i0, i1 on chroma strip r
+    f32x2 u, v;
     if constexpr (SRC == FC_NV12) {
-      const uint8_t* p = reinterpret_cast<const uint8_t*>(strip[wv][2 + r]) + (2 * (x >> 1) - cbase);
-      u = p[0]; v = p[1];
+      const uint8_t* p = reinterpret_cast<const uint8_t*>(strip_at(2 + r));
+      const uint32_t d0 = *reinterpret_cast<const uint16_t*>(p + a0), d1 = *reinterpret_cast<const uint16_t*>(p + a1);
+      u = f32x2{ubyte<0>(d0), ubyte<0>(d1)}; v = f32x2{ubyte<1>(d0), ubyte<1>(d1)};
     } else {
-      u = reinterpret_cast<const uint8_t*>(strip[wv][2 + r])[(x >> 1) - cbase];
-      v = reinterpret_cast<const uint8_t*>(strip[wv][4 + r])[(x >> 1) - cbase];
+      const uint8_t* pu = reinterpret_cast<const uint8_t*>(strip_at(2 + r));
+      const uint8_t* pv = reinterpret_cast<const uint8_t*>(strip_at(4 + r));
+      u = f32x2{(float)pu[a0], (float)pu[a1]}; v = f32x2{(float)pv[a0], (float)pv[a1]};
     }
-    const Chroma k = chroma_terms(c, u, v);
-    rgb[0] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.rc));
-    rgb[1] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.gc));
-    rgb[2] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.bc));
+    Chroma2 k;
+    k.rc = __builtin_elementwise_fma(v, rv2, br2);
+    k.gc = __builtin_elementwise_fma(u, gu2, __builtin_elementwise_fma(v, gv2, bg2));
+    k.bc = __builtin_elementwise_fma(u, bu2, bb2);
+    return k;
   };
+  auto rnd = [](f32x2 t) { return f32x2{(float)sat_rne(t[0]), (float)sat_rne(t[1])}; };
   float o[3][4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint32_t x = (x0 + k < dw) ? x0 + k : dw - 1;
     const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
-    float p00[3], p01[3], p10[3], p11[3];
-    texel(tx.i0, 0, p00); texel(tx.i1, 0, p01); texel(tx.i0, 1, p10); texel(tx.i1, 1, p11);
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) o[ch][k] = bilerp(p00[ch], p01[ch], p10[ch], p11[ch], tx.f, ty.f);
+    const uint32_t l0 = tx.i0 - ybase, l1 = tx.i1 - ybase;
+    const uint32_t a0 = (SRC == FC_NV12 ? (tx.i0 & ~1u) : (tx.i0 >> 1)) - cbase, a1 = (SRC == FC_NV12 ? (tx.i1 & ~1u) : (tx.i1 >> 1)) - cbase;
+    const uint8_t* y0p = reinterpret_cast<const uint8_t*>(strip_at(0));
+    const uint8_t* y1p = reinterpret_cast<const uint8_t*>(strip_at(1));
+    const f32x2 ya = {(float)y0p[l0], (float)y0p[l1]}, yb = {(float)y1p[l0], (float)y1p[l1]};
+    const Chroma2 ka = chroma2(a0, a1, 0);
+    Chroma2 kb = ka;
+    if (!one_crow) kb = chroma2(a0, a1, 1);
+    const f32x2 ra = rnd(__builtin_elementwise_fma(ya, cy2, ka.rc)), ga = rnd(__builtin_elementwise_fma(ya, cy2, ka.gc)), ba = rnd(__builtin_elementwise_fma(ya, cy2, ka.bc));
+    const f32x2 rb = rnd(__builtin_elementwise_fma(yb, cy2, kb.rc)), gb = rnd(__builtin_elementwise_fma(yb, cy2, kb.gc)), bb = rnd(__builtin_elementwise_fma(yb, cy2, kb.bc));
+    o[0][k] = bilerp(ra[0], ra[1], rb[0], rb[1], tx.f, ty.f);
+    o[1][k] = bilerp(ga[0], ga[1], gb[0], gb[1], tx.f, ty.f);
+    o[2][k] = bilerp(ba[0], ba[1], bb[0], bb[1], tx.f, ty.f);
   }
   const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
   if constexpr (DST == FC_PLANAR) {
@@ -536,14 +575,17 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
                                  uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   int vec_ok = 1;
-  bool lds_ok = lds_resize_ok(1, sw, dw, a.f[0].s[0], a.f[0].sp[0], kFusedRowBytes);
+  const uint32_t rowb = lds_strip_bytes(1, sw, dw, a.f[0].s[0], a.f[0].sp[0], kFusedRowBytes);
+  bool lds_ok = rowb != 0;
   for (uint32_t i = 0; i < n; i++) {
     const FrameDesc& f = a.f[i];
     for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) vec_ok &= ((((uintptr_t)f.d[k] | f.dp[k]) & 3) == 0);
     for (int k = 0; k < (src_fc == FC_NV12 ? 2 : 3); k++) lds_ok = lds_ok && !(((uintptr_t)f.s[k] | f.sp[k]) & 15);
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);
-#define VPF_GOL(S, D) VPF_LAUNCH((k_convert_resize_lds<S, D>), grid, dim3(256), 0, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok)
+  const uint32_t lds = 4 * (src_fc == FC_NV12 ? 4 : 6) * rowb;
+#define VPF_GOL(S, D) do { if (rowb <= 1024) VPF_LAUNCH((k_convert_resize_lds<S, D, 1>), grid, dim3(256), lds, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); \
+                           else VPF_LAUNCH((k_convert_resize_lds<S, D, 2>), grid, dim3(256), lds, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); } while (0)
 #define VPF_GO(S, D) VPF_LAUNCH((k_convert_resize<S, D>), grid, dim3(256), 0, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok)
 #define VPF_PICK(S, D) do { if (lds_ok) VPF_GOL(S, D); else VPF_GO(S, D); } while (0)
   if (src_fc == FC_NV12) {
