@@ -54,6 +54,36 @@ __global__ void k12(uint32_t* out, size_t n12) {  // 12-byte units (global_store
     if (i < n12) { uint32_t* p = out + 3 * i; __builtin_nontemporal_store((uint32_t)i, p); __builtin_nontemporal_store(1u, p + 1); __builtin_nontemporal_store(2u, p + 2); }
   }
 }
+// cache-policy bits of the store (gfx942+: sc0 / sc1 / nt), 6 KiB per wave like A
+#define ST_ASM(POL) asm volatile("global_store_dwordx4 %0, %1, off " POL :: "v"(p), "v"(v) : "memory")
+template <int POL>
+__global__ void kPol(u32x4* out, size_t n16) {
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const size_t i = wave * 384 + k * 64 + lane;
+    if (i < n16) {
+      u32x4* p = out + i; const u32x4 v = {(uint32_t)i, 1, 2, 3};
+      if constexpr (POL == 0) ST_ASM(""); else if constexpr (POL == 1) ST_ASM("sc0"); else if constexpr (POL == 2) ST_ASM("sc1");
+      else if constexpr (POL == 3) ST_ASM("sc0 sc1"); else if constexpr (POL == 4) ST_ASM("nt"); else if constexpr (POL == 5) ST_ASM("sc0 nt");
+      else if constexpr (POL == 6) ST_ASM("sc1 nt"); else ST_ASM("sc0 sc1 nt");
+    }
+  }
+}
+// XCD-aware block -> range mapping: workgroup b runs on XCD b % 8; MODE 0 gives each XCD one contiguous eighth of the
+// buffer, MODE 1 gives each XCD a contiguous 1-MiB region at a time (8 MiB super-tiles)
+template <int MODE>
+__global__ void kXcd(u32x4* out, size_t n16) {
+  const size_t nb = gridDim.x, b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  size_t tile;
+  if constexpr (MODE == 0) tile = xcd * (nb / 8) + j;
+  else { const size_t per = 1048576 / (4 * 6144); tile = ((j / per) * 8 + xcd) * per + (j % per); }
+  const size_t wave = tile * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { const size_t i = wave * 384 + k * 64 + lane; if (i < n16) __builtin_nontemporal_store(u32x4{(uint32_t)i, 1, 2, 3}, out + i); }
+}
 __global__ void kD(u32x4* out, size_t n16) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
 #pragma unroll
@@ -90,6 +120,20 @@ int main() {
   run("B  persistent 2048 blocks, contiguous ranges", [&] { hipLaunchKernelGGL((kB<true>), dim3(2048), dim3(256), 0, 0, d, n16); });
   run("C  persistent 2048 blocks, grid-strided", [&] { hipLaunchKernelGGL((kB<false>), dim3(2048), dim3(256), 0, 0, d, n16); });
   run("D  64 B per thread (ATen-like), plain", [&] { hipLaunchKernelGGL(kD, dim3((n16 / 4 + 255) / 256), dim3(256), 0, 0, d, n16); });
+  {
+    const dim3 g((n16 / 384 + 3) / 4);
+    run("pol \"\"          6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<0>), g, dim3(256), 0, 0, d, n16); });
+    run("pol sc0         6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<1>), g, dim3(256), 0, 0, d, n16); });
+    run("pol sc1         6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<2>), g, dim3(256), 0, 0, d, n16); });
+    run("pol sc0 sc1     6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<3>), g, dim3(256), 0, 0, d, n16); });
+    run("pol nt          6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<4>), g, dim3(256), 0, 0, d, n16); });
+    run("pol sc0 nt      6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<5>), g, dim3(256), 0, 0, d, n16); });
+    run("pol sc1 nt      6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<6>), g, dim3(256), 0, 0, d, n16); });
+    run("pol sc0 sc1 nt  6 KiB/wave", [&] { hipLaunchKernelGGL((kPol<7>), g, dim3(256), 0, 0, d, n16); });
+    const dim3 g8(((n16 / 384 + 3) / 4) / 8 * 8);
+    run("X0 XCD owns a contiguous eighth", [&] { hipLaunchKernelGGL((kXcd<0>), g8, dim3(256), 0, 0, d, n16); });
+    run("X1 XCD owns 1-MiB regions", [&] { hipLaunchKernelGGL((kXcd<1>), g8, dim3(256), 0, 0, d, n16); });
+  }
   run("M  hipMemsetAsync", [&] { hipMemsetAsync(d, 1, B, 0); });
   return 0;
 }

@@ -135,13 +135,18 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
 // 48*l + 16*j -> dword banks {12l+4j .. +3} mod 32, which tile all 32 banks exactly once per
 // group: conflict free.  The ds_read_b128 side reads 16*l: contiguous, conflict free.
 // ---------------------------------------------------------------------------------------------
-template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0>
+// XCD_SWZ: workgroups are dealt round-robin to the 8 XCDs (workgroup b -> XCD b % 8 when gridDim.x % 8 == 0); the
+// swizzle hands each XCD ONE contiguous eighth of every frame instead of every eighth row pair, so each XCD's L2
+// write-back stream is sequential (tools/write_probe.hip X0/X1: +6 % on pure writes).
+template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0, bool XCD_SWZ = false>
 __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                            uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   // BALLAST_KB > 0 pads the LDS footprint to cap the number of resident workgroups per CU (occupancy experiment)
   __shared__ u32x4 tile[((LDS_T && DST != FC_PLANAR) ? WPB * 2 * 192 : 1) + BALLAST_KB * 64];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t wt = blockIdx.x * WPB + wv;
+  uint32_t bx = blockIdx.x;
+  if constexpr (XCD_SWZ) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);  // host guarantees gridDim.x % 8 == 0
+  const uint32_t wt = bx * WPB + wv;
   if (wt >= n_tasks) return;
   const FrameDesc f = args.f[blockIdx.y];
   const uint32_t rp = wt / chunks_x, chunk = wt - rp * chunks_x;
@@ -596,7 +601,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   // (a narrower chip-wide write frontier; tools/write_probe.hip); short single-frame launches want all the waves they can get
   // planar outputs: r16 (one row per wave, three 1-KiB plane stores) beats p4's 256-B stores by ~9 % when batched
   if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? 37 : (n >= 4 ? 30 : 8)) : 4;
-  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36);
+  const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36 || variant == 41 || variant == 42);
   const bool packed_only = (variant >= 17 && variant <= 19) || (variant >= 22 && variant <= 29) || variant == 38;
   if ((want_p16 || packed_only || variant == 37) && !p16_ok) variant = 4;
   if ((packed_only && DST == FC_PLANAR) || (variant == 37 && DST != FC_PLANAR)) variant = 4;
@@ -650,6 +655,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
     if (want_p16 && p16_ok) {
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
       dim3 grid((tasks + 3) / 4, n);
+      if ((variant == 41 || variant == 42) && (grid.x & 7)) variant = (variant == 41) ? 30 : 8;  // swizzle needs gridDim.x % 8 == 0
 #define VPF_P16(NTL, NTS, LDS, NOMATH) \
   VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, NTL, NTS, LDS, NOMATH>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks)
       switch (variant) {
@@ -660,6 +666,8 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
         case 15: VPF_P16(true, true, true, true); break;
         case 36: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 8>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 32 KiB -> 5 blocks/CU
         case 30: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 16>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 40 KiB -> 4 blocks/CU
+        case 41: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 16, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 30 + XCD swizzle
+        case 42: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 0, true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;   // 8 + XCD swizzle
         case 31: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 29>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 53 KiB -> 3 blocks/CU
         case 32: VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 56>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks); break;  // 80 KiB -> 2 blocks/CU
         case 20: {  // one wave per workgroup: 4x more, smaller workgroups -> finer balance when a launch is only one frame
