@@ -456,15 +456,21 @@ def test_resize_lanczos3(capi, oracle, fmt):
     """Lanczos-3 (the filter the reference resizer requests, Tasks.cpp:1190): bit-exact vs the oracle's FP32 restatement
     (polynomial sin/cos, identical weights), within 1 LSB of the double-precision evaluation"""
     f = getattr(capi, fmt)
-    for (sw, sh, dw, dh) in [(640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (1920, 32, 640, 11), (9, 7, 20, 15)]:
+    for (sw, sh, dw, dh) in [(640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (1920, 32, 640, 11), (9, 7, 20, 15),
+                             (1280, 720, 427, 240), (320, 180, 1280, 720), (2000, 40, 130, 37), (1921, 70, 97, 3), (300, 1000, 150, 20)]:
         src = oracle.synth(f, sw, sh, 1100)
-        s, d = DevPlanes(src), DevPlanes(oracle.alloc(f, dw, dh))
-        capi.resize(capi.make_exec(stream_handle()), f, capi.INTERP_LANCZOS3, sw, sh, s.desc(), dw, dh, d.desc())
-        torch.cuda.synchronize()
-        got, intact = d.download()
-        assert intact
         _, want = oracle.resize(f, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.FP32)
-        assert_planes_equal(got, want, f"lanczos fmt{fmt} {sw}x{sh}->{dw}x{dh}")
+        for variant, align in ((0, 256), (9, 256), (0, 1)):  # tiled separable kernel, forced gather, unaligned (-> gather)
+            s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(f, dw, dh), align)
+            prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+            try:
+                capi.resize(capi.make_exec(stream_handle()), f, capi.INTERP_LANCZOS3, sw, sh, s.desc(), dw, dh, d.desc())
+            finally:
+                capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+            torch.cuda.synchronize()
+            got, intact = d.download()
+            assert intact
+            assert_planes_equal(got, want, f"lanczos fmt{fmt} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
         _, ex = oracle.resize(f, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.EXACT)
         for g, e in zip(got, ex):
             assert np.abs(g.astype(int) - e.astype(int)).max() <= 1

@@ -253,6 +253,92 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Lanczos-3, tiled and separable (the default when it applies; k_resize_lanczos above remains the any-input gather form).
+// The gather kernel evaluates, per destination pixel, six horizontal 6-tap dots (one per source row) and then the
+// vertical 6-tap dot.  The horizontal dot of (source row r, destination column x) does not depend on the destination
+// row, so a workgroup that owns a tile of 64 columns x TY rows computes each of them ONCE:
+//   phase 1  each wave takes source rows r, r+4, ...: stages the row's byte span in a wave-private LDS strip with dense
+//            16-B loads (the next row's load is already in flight), every lane (= one destination column) reads its
+//            6 x CH taps with ds_read_u8 and leaves the fp32 dot in LDS (H[row][channel][column]);
+//   phase 2  every lane combines six H rows per destination pixel with the vertical weights (computed once per
+//            destination row by one lane and broadcast from LDS).
+// Both dots use the gather kernel's fma order, so results are bit-identical to it (and to the oracle's FP32 mode).
+// 3x down-scale: 3.4-3.8 horizontal dots per destination pixel instead of 6; 2x up-scale: 0.6 instead of 6.
+// ------------------------------------------------------------------------------------------
+VPF_DEV int32_t ltap_i0(uint32_t d, float scale) {  // make_ltap's first expression sequence
+  return (int32_t)__builtin_floorf(__builtin_fmaf((float)d + 0.5f, scale, -0.5f));
+}
+constexpr uint32_t kLzStripQ = 128;  // 2 KiB of source bytes per wave
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_resize_lanczos_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                             uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                             float scx, float scy, uint32_t tile_rows, uint32_t nr_cap) {
+  // dynamic LDS: [4 waves][kLzStripQ x 16 B] byte strips | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats (6 weights, i0)
+  u32x4* const strip = dyn_strip + (threadIdx.x >> 6) * kLzStripQ;
+  float* const H = reinterpret_cast<float*>(dyn_strip + 4 * kLzStripQ);
+  float* const WY = H + (size_t)nr_cap * CH * 64;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t xf = blockIdx.x * 64, xl = (xf + 63 < dw - 1) ? xf + 63 : dw - 1;
+  const uint32_t x = xf + lane, xc = x < dw ? x : dw - 1;  // lanes past the right edge compute a duplicate, never stored
+  const uint32_t y0 = blockIdx.y * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
+  const int32_t R0 = ltap_i0(y0, scy) - 2, R1 = ltap_i0(yl, scy) + 3;
+  const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
+  auto clampi = [](int32_t i, int32_t hi) { return (uint32_t)(i < 0 ? 0 : (i > hi ? hi : i)); };
+  if (threadIdx.x < tile_rows) {  // vertical weights: one lane per destination row
+    const uint32_t y = y0 + threadIdx.x;
+    const LTap t = make_ltap(y < dh ? y : dh - 1, scy);
+#pragma unroll
+    for (int k = 0; k < 6; k++) WY[threadIdx.x * 8 + k] = t.w[k];
+    WY[threadIdx.x * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
+  }
+  const LTap tx = make_ltap(xc, scx);
+  const uint32_t first = clampi(ltap_i0(xf, scx) - 2, (int32_t)sw - 1), last = clampi(ltap_i0(xl, scx) + 3, (int32_t)sw - 1);
+  const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
+  uint32_t xo[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) xo[k] = clampi(tx.i0 + k - 2, (int32_t)sw - 1) * CH - base;
+  Span<2> cur, nxt;
+  if (wv < nrows) cur.load(src + (size_t)clampi(R0 + (int32_t)wv, (int32_t)sh - 1) * sp, base, nq, lane);
+  for (uint32_t r = wv; r < nrows; r += 4) {
+    if (r + 4 < nrows) nxt.load(src + (size_t)clampi(R0 + (int32_t)(r + 4), (int32_t)sh - 1) * sp, base, nq, lane);
+    cur.store(strip, nq, lane);
+    wave_lds_sync();
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(strip);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      float ra = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], (float)b[xo[kx] + c], ra);
+      H[(r * CH + c) * 64 + lane] = ra;
+    }
+    wave_lds_sync();  // the strip is rewritten next iteration
+    cur = nxt;
+  }
+  __syncthreads();
+  for (uint32_t yy = wv; yy < tile_rows; yy += 4) {
+    const uint32_t y = y0 + yy;
+    if (y >= dh) break;
+    const uint32_t r0 = (uint32_t)__float_as_int(WY[yy * 8 + 6]);
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 6; ky++) {
+      const float wy = WY[yy * 8 + ky];
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = __builtin_fmaf(wy, H[((r0 + ky) * CH + c) * 64 + lane], acc[c]);
+    }
+    // byte stores: an LDS gather into dword stores was measured and is 3-8 % SLOWER here (two more wave syncs per row)
+    if (x < dw) {
+      uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
+#pragma unroll
+      for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_trunc(acc[c] + 0.5f);
+    }
+  }
+}
+
 // strip bytes a wave needs for its source span (<= 255*scale + 3 pixels, + 16-B alignment slack on both ends),
 // rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
 static uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
@@ -269,6 +355,22 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
   if (interp == VPF_INTERP_LANCZOS3) {
+    // tiled separable kernel when the source rows are 16-B aligned and a 64-column span fits the 2-KiB strip
+    if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && !(((uintptr_t)src | sp) & 15) &&
+        ((double)scx * 63.0 + 9.0) * ch + 32.0 <= 16.0 * kLzStripQ && scy <= 48.0f) {
+      constexpr uint32_t kRowsCap = 56;  // H rows per tile: 56 x 3 x 64 floats = 42 KiB
+      uint32_t ty = (uint32_t)((double)(kRowsCap - 8) / (double)scy) + 1;
+      ty = ty > 64 ? 64 : ty;
+      // small outputs: prefer more, shorter tiles (>= ~8 workgroups per CU) over maximal row reuse
+      while (ty > 4 && (size_t)((dw + 63) / 64) * ((dh + ty - 1) / ty) < 2048) ty = (ty + 1) / 2;
+      const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + 8;
+      const uint32_t lds = 4 * kLzStripQ * 16 + nr * ch * 64 * 4 + ty * 8 * 4;
+      dim3 tgrid((dw + 63) / 64, (dh + ty - 1) / ty);
+      if (ch == 1) VPF_LAUNCH((k_resize_lanczos_tile<1>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr);
+      else if (ch == 2) VPF_LAUNCH((k_resize_lanczos_tile<2>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr);
+      else VPF_LAUNCH((k_resize_lanczos_tile<3>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr);
+      return hipGetLastError();
+    }
     dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
     if (ch == 1) VPF_LAUNCH((k_resize_lanczos<1>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
     else if (ch == 2) VPF_LAUNCH((k_resize_lanczos<2>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
