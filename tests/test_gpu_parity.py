@@ -260,7 +260,7 @@ def test_roundtrip_rgb_yuv420_nv12_rgb(capi, oracle):
 def _resize(capi, oracle, fmt, interp, sw, sh, dw, dh, seed=1040, align=256):
     src = oracle.synth(fmt, sw, sh, seed)
     _, want = oracle.resize(fmt, interp, sw, sh, src, dw, dh, oracle.FP32)
-    for variant in (0, 9):  # 0: LDS-staged kernel where it applies; 9: forced gather kernel
+    for variant in (0, 40, 9):  # 0: tiled (up-scale) or row-pair LDS kernel where they apply; 40: row-pair LDS; 9: gather
         s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(fmt, dw, dh), align)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         try:
@@ -281,7 +281,8 @@ def _resize(capi, oracle, fmt, interp, sw, sh, dw, dh, seed=1040, align=256):
 def test_resize_bilinear(capi, oracle, fmt):
     f = getattr(capi, fmt)
     for (sw, sh, dw, dh) in [(3840, 64, 1280, 22), (640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 2, 2),
-                             (1000, 40, 300, 13), (2000, 16, 260, 5), (4096, 8, 258, 2), (300, 20, 1000, 70)]:
+                             (1000, 40, 300, 13), (2000, 16, 260, 5), (4096, 8, 258, 2), (300, 20, 1000, 70),
+                             (320, 180, 1280, 720), (640, 40, 700, 333), (50, 30, 1921, 47)]:
         _resize(capi, oracle, f, capi.INTERP_LINEAR, sw, sh, dw, dh)
     _resize(capi, oracle, f, capi.INTERP_LINEAR, 128, 72, 50, 30, align=1)
     _resize(capi, oracle, f, capi.INTERP_NEAREST, 128, 72, 50, 30)

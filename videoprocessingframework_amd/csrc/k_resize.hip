@@ -271,11 +271,15 @@ VPF_DEV int32_t ltap_i0(uint32_t d, float scale) {  // make_ltap's first express
 }
 constexpr uint32_t kLzStripQ = 128;  // 2 KiB of source bytes per wave
 
-template <int CH>
-__global__ __launch_bounds__(256) void k_resize_lanczos_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
-                                                             uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
-                                                             float scx, float scy, uint32_t tile_rows, uint32_t nr_cap) {
-  // dynamic LDS: [4 waves][kLzStripQ x 16 B] byte strips | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats (6 weights, i0)
+// LZ = true: Lanczos-3 (6 taps per axis); LZ = false: bilinear (2 taps; H = the horizontal lerp fma(fx, p1 - p0, p0) of
+// k_resize's bilerp, which for an up-scale is shared by every destination row between two source rows)
+template <int CH, bool LZ>
+__global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                     float scx, float scy, uint32_t tile_rows, uint32_t nr_cap, int vec_ok) {
+  // dynamic LDS: [4 waves][kLzStripQ x 16 B] byte strips | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats
+  // (Lanczos: 6 weights + first H row; bilinear: fy, -, ..., top H row, bottom H row)
+  constexpr int NT = LZ ? 6 : 2;
   u32x4* const strip = dyn_strip + (threadIdx.x >> 6) * kLzStripQ;
   float* const H = reinterpret_cast<float*>(dyn_strip + 4 * kLzStripQ);
   float* const WY = H + (size_t)nr_cap * CH * 64;
@@ -283,22 +287,41 @@ __global__ __launch_bounds__(256) void k_resize_lanczos_tile(const uint8_t* __re
   const uint32_t xf = blockIdx.x * 64, xl = (xf + 63 < dw - 1) ? xf + 63 : dw - 1;
   const uint32_t x = xf + lane, xc = x < dw ? x : dw - 1;  // lanes past the right edge compute a duplicate, never stored
   const uint32_t y0 = blockIdx.y * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
-  const int32_t R0 = ltap_i0(y0, scy) - 2, R1 = ltap_i0(yl, scy) + 3;
-  const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
   auto clampi = [](int32_t i, int32_t hi) { return (uint32_t)(i < 0 ? 0 : (i > hi ? hi : i)); };
-  if (threadIdx.x < tile_rows) {  // vertical weights: one lane per destination row
-    const uint32_t y = y0 + threadIdx.x;
-    const LTap t = make_ltap(y < dh ? y : dh - 1, scy);
-#pragma unroll
-    for (int k = 0; k < 6; k++) WY[threadIdx.x * 8 + k] = t.w[k];
-    WY[threadIdx.x * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
+  int32_t R0, R1;
+  uint32_t first, last, xo[NT];
+  float wx[NT];
+  if constexpr (LZ) {
+    R0 = ltap_i0(y0, scy) - 2; R1 = ltap_i0(yl, scy) + 3;
+    first = clampi(ltap_i0(xf, scx) - 2, (int32_t)sw - 1); last = clampi(ltap_i0(xl, scx) + 3, (int32_t)sw - 1);
+  } else {
+    R0 = (int32_t)make_tap<VPF_INTERP_LINEAR>(y0, scy, sh).i0; R1 = (int32_t)make_tap<VPF_INTERP_LINEAR>(yl, scy, sh).i1;
+    first = make_tap<VPF_INTERP_LINEAR>(xf, scx, sw).i0; last = make_tap<VPF_INTERP_LINEAR>(xl, scx, sw).i1;
   }
-  const LTap tx = make_ltap(xc, scx);
-  const uint32_t first = clampi(ltap_i0(xf, scx) - 2, (int32_t)sw - 1), last = clampi(ltap_i0(xl, scx) + 3, (int32_t)sw - 1);
+  const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
-  uint32_t xo[6];
+  if (threadIdx.x < tile_rows) {  // vertical weights: one lane per destination row
+    const uint32_t y = y0 + threadIdx.x, yc = y < dh ? y : dh - 1;
+    if constexpr (LZ) {
+      const LTap t = make_ltap(yc, scy);
 #pragma unroll
-  for (int k = 0; k < 6; k++) xo[k] = clampi(tx.i0 + k - 2, (int32_t)sw - 1) * CH - base;
+      for (int k = 0; k < 6; k++) WY[threadIdx.x * 8 + k] = t.w[k];
+      WY[threadIdx.x * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
+    } else {
+      const Tap t = make_tap<VPF_INTERP_LINEAR>(yc, scy, sh);
+      WY[threadIdx.x * 8] = t.f;
+      WY[threadIdx.x * 8 + 6] = __int_as_float((int32_t)t.i0 - R0);
+      WY[threadIdx.x * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
+    }
+  }
+  if constexpr (LZ) {
+    const LTap tx = make_ltap(xc, scx);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { xo[k] = clampi(tx.i0 + k - 2, (int32_t)sw - 1) * CH - base; wx[k] = tx.w[k]; }
+  } else {
+    const Tap tx = make_tap<VPF_INTERP_LINEAR>(xc, scx, sw);
+    xo[0] = tx.i0 * CH - base; xo[1] = tx.i1 * CH - base; wx[0] = tx.f; wx[1] = 0.f;
+  }
   Span<2> cur, nxt;
   if (wv < nrows) cur.load(src + (size_t)clampi(R0 + (int32_t)wv, (int32_t)sh - 1) * sp, base, nq, lane);
   for (uint32_t r = wv; r < nrows; r += 4) {
@@ -308,33 +331,71 @@ __global__ __launch_bounds__(256) void k_resize_lanczos_tile(const uint8_t* __re
     const uint8_t* b = reinterpret_cast<const uint8_t*>(strip);
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-      float ra = 0.f;
+      float ra;
+      if constexpr (LZ) {
+        ra = 0.f;
 #pragma unroll
-      for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], (float)b[xo[kx] + c], ra);
+        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(wx[kx], (float)b[xo[kx] + c], ra);
+      } else {
+        const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
+        ra = __builtin_fmaf(wx[0], p1 - p0, p0);
+      }
       H[(r * CH + c) * 64 + lane] = ra;
     }
     wave_lds_sync();  // the strip is rewritten next iteration
     cur = nxt;
   }
   __syncthreads();
-  for (uint32_t yy = wv; yy < tile_rows; yy += 4) {
-    const uint32_t y = y0 + yy;
-    if (y >= dh) break;
+  // phase 2: a lane owns 4 consecutive columns of one destination row (a wave = 4 rows x 64 columns): H comes out of LDS
+  // as one ds_read_b128 per (tap, channel) and the pixels leave as one 4-12 B vector store per lane
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t cg = lane & 15, rsub = lane >> 4, x0 = xf + 4 * cg;
+  for (uint32_t yb = 0; yb < tile_rows; yb += 16) {
+    const uint32_t yy = yb + wv * 4 + rsub, y = y0 + yy;
+    if (yy >= tile_rows || y >= dh || x0 >= dw) continue;
     const uint32_t r0 = (uint32_t)__float_as_int(WY[yy * 8 + 6]);
-    float acc[CH];
+    f32x4 acc[CH];
+    if constexpr (LZ) {
 #pragma unroll
-    for (int c = 0; c < CH; c++) acc[c] = 0.f;
+      for (int c = 0; c < CH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ky = 0; ky < 6; ky++) {
-      const float wy = WY[yy * 8 + ky];
+      for (int ky = 0; ky < 6; ky++) {
+        const float wy = WY[yy * 8 + ky];
 #pragma unroll
-      for (int c = 0; c < CH; c++) acc[c] = __builtin_fmaf(wy, H[((r0 + ky) * CH + c) * 64 + lane], acc[c]);
+        for (int c = 0; c < CH; c++) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(&H[((r0 + ky) * CH + c) * 64 + 4 * cg]);
+#pragma unroll
+          for (int k = 0; k < 4; k++) acc[c][k] = __builtin_fmaf(wy, hv[k], acc[c][k]);
+        }
+      }
+    } else {
+      const uint32_t r1 = (uint32_t)__float_as_int(WY[yy * 8 + 7]);
+      const float fy = WY[yy * 8];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const f32x4 top = *reinterpret_cast<const f32x4*>(&H[(r0 * CH + c) * 64 + 4 * cg]);
+        const f32x4 bot = *reinterpret_cast<const f32x4*>(&H[(r1 * CH + c) * 64 + 4 * cg]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[c][k] = __builtin_fmaf(fy, bot[k] - top[k], top[k]);
+      }
     }
-    // byte stores: an LDS gather into dword stores was measured and is 3-8 % SLOWER here (two more wave syncs per row)
-    if (x < dw) {
-      uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
+    float o[4 * CH];  // pixel-major, + 0.5 for the truncating pack
 #pragma unroll
-      for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_trunc(acc[c] + 0.5f);
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int c = 0; c < CH; c++) o[k * CH + c] = acc[c][k] + 0.5f;
+    uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
+    if (vec_ok && x0 + 4 <= dw) {
+      if constexpr (CH == 3) {
+        stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+      } else if constexpr (CH == 2) {
+        stg<false, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+      } else {
+        stg<false, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+      }
+    } else {
+      const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
+      for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[i]);
     }
   }
 }
@@ -350,27 +411,37 @@ static uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* sr
   return ((uint32_t)need + 255u) & ~255u;
 }
 
+// tiled separable launch (Lanczos always; bilinear when up-scaling, where the horizontal lerp is shared by several
+// destination rows): needs 16-B aligned source rows and a 64-column span that fits the 2-KiB strip.  Returns false when
+// it does not apply.
+static bool launch_resize_tile(hipStream_t st, bool lz, int ch, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp,
+                               uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp, float scx, float scy) {
+  const double taps = lz ? 6.0 : 2.0;
+  if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9 || (((uintptr_t)src | sp) & 15)) return false;
+  if (((double)scx * 63.0 + taps + 3.0) * ch + 32.0 > 16.0 * kLzStripQ || scy > 48.0f) return false;
+  constexpr uint32_t kRowsCap = 56;  // H rows per tile: 56 x 3 x 64 floats = 42 KiB
+  uint32_t ty = (uint32_t)((double)(kRowsCap - taps - 2.0) / (double)scy) + 1;
+  ty = ty > 64 ? 64 : ty;
+  // small outputs: prefer more, shorter tiles (>= ~8 workgroups per CU) over maximal row reuse
+  while (ty >= 16 && (size_t)((dw + 63) / 64) * ((dh + ty - 1) / ty) < 2048) ty = (ty + 1) / 2;
+  if (ty > 4) ty &= ~3u;  // phase 2 hands out rows four per wave
+  const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
+  const uint32_t lds = 4 * kLzStripQ * 16 + nr * ch * 64 * 4 + ty * 8 * 4;
+  dim3 tgrid((dw + 63) / 64, (dh + ty - 1) / ty);
+  const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
+#define VPF_TILE(C, L) VPF_LAUNCH((k_resize_tile<C, L>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr, vec_ok)
+  if (lz) { if (ch == 1) VPF_TILE(1, true); else if (ch == 2) VPF_TILE(2, true); else VPF_TILE(3, true); }
+  else { if (ch == 1) VPF_TILE(1, false); else if (ch == 2) VPF_TILE(2, false); else VPF_TILE(3, false); }
+#undef VPF_TILE
+  return true;
+}
+
 hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
                          uint32_t sp, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
   if (interp == VPF_INTERP_LANCZOS3) {
-    // tiled separable kernel when the source rows are 16-B aligned and a 64-column span fits the 2-KiB strip
-    if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && !(((uintptr_t)src | sp) & 15) &&
-        ((double)scx * 63.0 + 9.0) * ch + 32.0 <= 16.0 * kLzStripQ && scy <= 48.0f) {
-      constexpr uint32_t kRowsCap = 56;  // H rows per tile: 56 x 3 x 64 floats = 42 KiB
-      uint32_t ty = (uint32_t)((double)(kRowsCap - 8) / (double)scy) + 1;
-      ty = ty > 64 ? 64 : ty;
-      // small outputs: prefer more, shorter tiles (>= ~8 workgroups per CU) over maximal row reuse
-      while (ty > 4 && (size_t)((dw + 63) / 64) * ((dh + ty - 1) / ty) < 2048) ty = (ty + 1) / 2;
-      const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + 8;
-      const uint32_t lds = 4 * kLzStripQ * 16 + nr * ch * 64 * 4 + ty * 8 * 4;
-      dim3 tgrid((dw + 63) / 64, (dh + ty - 1) / ty);
-      if (ch == 1) VPF_LAUNCH((k_resize_lanczos_tile<1>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr);
-      else if (ch == 2) VPF_LAUNCH((k_resize_lanczos_tile<2>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr);
-      else VPF_LAUNCH((k_resize_lanczos_tile<3>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr);
-      return hipGetLastError();
-    }
+    if (launch_resize_tile(st, true, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy)) return hipGetLastError();
     dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
     if (ch == 1) VPF_LAUNCH((k_resize_lanczos<1>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
     else if (ch == 2) VPF_LAUNCH((k_resize_lanczos<2>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
@@ -378,6 +449,10 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
     return hipGetLastError();
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
+  // up-scaling: several destination rows sit between the same two source rows -> tiled kernel (horizontal lerp once)
+  if (interp == VPF_INTERP_LINEAR && scy < 0.8f && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 &&
+      launch_resize_tile(st, false, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy))
+    return hipGetLastError();
   const uint32_t rowb = (interp == VPF_INTERP_LINEAR) ? lds_strip_bytes(ch, sw, dw, src, sp, kResizeRowBytes) : 0;
   if (rowb) {
     const uint32_t it = (rowb + 1023) / 1024, lds = 4 * 2 * rowb;
