@@ -114,6 +114,38 @@ def test_chain_resnet_sample(oracle):
         nvc.SetExtendedColorspaces(False)
 
 
+def test_fused_convert_resizer_equals_the_two_step_chain(oracle):
+    """additive PySurfaceConvertResizer: NV12 -> (bilinear) -> RGB_PLANAR in one pass must equal PySurfaceConverter followed
+    by PySurfaceResizer bit for bit (and the oracle's convert-then-resize); same refusals as the unfused converter"""
+    w, h, tw, th = 1280, 720, 416, 234
+    src = oracle.synth(oracle.NV12, w, h, 14)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    nv12 = upload(PF.NV12, w, h, src)
+    for fmt, ofmt in ((PF.RGB, oracle.RGB), (PF.RGB_PLANAR, oracle.RGB_PLANAR)):
+        fused = nvc.PySurfaceConvertResizer(w, h, PF.NV12, tw, th, fmt, GPU)
+        out = fused.Execute(nv12, cc)
+        assert not out.Empty() and (out.Width(), out.Height(), out.Format()) == (tw, th, fmt) and fused.Format() == fmt
+        conv, rs = nvc.PySurfaceConverter(w, h, PF.NV12, fmt, GPU), nvc.PySurfaceResizer(tw, th, fmt, GPU)
+        two_step = rs.Execute(conv.Execute(nv12, cc))
+        assert np.array_equal(download(out), download(two_step))
+        _, want = oracle.convert_resize(oracle.NV12, ofmt, 1, 0, w, h, src, tw, th)
+        assert np.array_equal(download(out), host_frame(want))
+        # batch: caller-owned destinations, one dispatch
+        dsts = [nvc.Surface.Make(fmt, tw, th, GPU) for _ in range(3)]
+        assert fused.ExecuteBatch([nv12] * 3, dsts, cc)
+        torch.cuda.synchronize()
+        for d in dsts:
+            assert np.array_equal(download(d), host_frame(want))
+        assert not fused.ExecuteBatch([nv12], [nvc.Surface.Make(fmt, tw + 2, th, GPU)], cc)  # wrong destination size
+    # refusals: the reference's nv12_rgb rejects BT.601 + MPEG; wrong input size / format -> Empty()
+    fused = nvc.PySurfaceConvertResizer(w, h, PF.NV12, tw, th, PF.RGB, GPU)
+    assert fused.Execute(nv12, nvc.ColorspaceConversionContext(CS.BT_601, CR.MPEG)).Empty()
+    assert fused.Execute(upload(PF.NV12, 640, 360, oracle.synth(oracle.NV12, 640, 360, 15)), cc).Empty()
+    assert fused.Execute(None, cc).Empty()
+    with pytest.raises(ValueError):
+        nvc.PySurfaceConvertResizer(w, h, PF.RGB, tw, th, PF.RGB_PLANAR, GPU)  # not a fusable pair
+
+
 def test_chain_remap_sample(oracle):
     """samples/SampleRemap.py:74-101 — NV12 -> RGB -> Remap(RGB) -> download, BT.709 + JPEG"""
     w, h = 640, 360

@@ -118,6 +118,29 @@ def test_converter_pair_table():
             nvc.PySurfaceConverter(64, 32, getattr(PF, s), getattr(PF, d), 0, 0)
 
 
+def test_fused_convert_resizer_pairs_and_host_side_checks():
+    """additive PySurfaceConvertResizer: only NV12 / YUV420 -> RGB / BGR / RGB_PLANAR are fusable; without a GPU the launch
+    fails and the result is an Empty() surface (no CPU fallback)"""
+    PF = nvc.PixelFormat
+    for s in ("NV12", "YUV420"):
+        for d in ("RGB", "BGR", "RGB_PLANAR"):
+            f = nvc.PySurfaceConvertResizer(640, 360, getattr(PF, s), 224, 224, getattr(PF, d), 0, 0)
+            assert f.Format() == getattr(PF, d)
+    for s, d in [("RGB", "RGB_PLANAR"), ("NV12", "YUV420"), ("YUV444", "RGB"), ("NV12", "Y")]:
+        with pytest.raises(ValueError, match="Unsupported fused conversion"):
+            nvc.PySurfaceConvertResizer(640, 360, getattr(PF, s), 224, 224, getattr(PF, d), 0, 0)
+    with pytest.raises(ValueError):
+        nvc.PySurfaceConvertResizer(640, 360, PF.NV12, 0, 224, PF.RGB, 0, 0)
+    f = nvc.PySurfaceConvertResizer(64, 32, PF.NV12, 32, 16, PF.RGB, 0, 0)
+    assert f.Execute(None, None).Empty()
+    assert f.Execute(nvc.Surface.Make(PF.NV12, 32, 32, context=0), None).Empty()        # wrong size
+    assert f.Execute(nvc.Surface.Make(PF.YUV420, 64, 32, context=0), None).Empty()      # wrong format
+    assert not f.ExecuteBatch([], [], None)
+    if nvc.GetNumGpus() == 0:
+        cc = nvc.ColorspaceConversionContext(nvc.ColorSpace.BT_709, nvc.ColorRange.MPEG)
+        assert f.Execute(nvc.Surface.Make(PF.NV12, 64, 32, context=0), cc).Empty()
+
+
 def test_converter_failure_is_an_empty_surface_not_a_cpu_fallback(capfd):
     """no GPU here: the HIP launch fails, Execute returns an Empty() surface of the output format
     (PySurfaceConverter.cpp:54-73) — and nothing computes the pixels on the CPU instead"""

@@ -116,6 +116,41 @@ public:
   }
 };
 
+// additive: fused conversion + bilinear resize (ConvertResizeSurface), same calling conventions as PySurfaceConverter
+class PySurfaceConvertResizer {
+  std::unique_ptr<ConvertResizeSurface> task_;
+  std::unique_ptr<Buffer> ctx_buf_;
+  Pixel_Format out_fmt_;
+
+public:
+  PySurfaceConvertResizer(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out, HipContext ctx, HipStream str)
+      : out_fmt_(out) {
+    task_.reset(ConvertResizeSurface::Make(sw, sh, in, dw, dh, out, ctx, str));
+    ctx_buf_.reset(Buffer::MakeOwnMem(sizeof(ColorspaceConversionContext)));
+  }
+  Pixel_Format GetFormat() const { return out_fmt_; }
+  std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src, std::shared_ptr<ColorspaceConversionContext> cc) {
+    if (!src) return empty_surface(out_fmt_);
+    task_->ClearInputs();
+    task_->SetInput(src.get(), 0U);
+    if (cc) {
+      ctx_buf_->CopyFrom(sizeof(ColorspaceConversionContext), cc.get());
+      task_->SetInput(ctx_buf_.get(), 1U);
+    }
+    if (TASK_EXEC_SUCCESS != task_->Execute()) return empty_surface(out_fmt_);
+    auto* out = static_cast<Surface*>(task_->GetOutput(0U));
+    return std::shared_ptr<Surface>(out ? out->Clone() : Surface::Make(out_fmt_));
+  }
+  bool ExecuteBatch(const std::vector<std::shared_ptr<Surface>>& src, const std::vector<std::shared_ptr<Surface>>& dst,
+                    std::shared_ptr<ColorspaceConversionContext> cc) {
+    if (src.size() != dst.size() || src.empty()) return false;
+    std::vector<Surface*> a, b;
+    for (auto& s : src) a.push_back(s.get());
+    for (auto& d : dst) b.push_back(d.get());
+    return TASK_EXEC_SUCCESS == task_->RunBatch(a.data(), b.data(), (uint32_t)a.size(), cc.get());
+  }
+};
+
 class PySurfaceResizer {
   std::unique_ptr<ResizeSurface> rs_;
   Pixel_Format fmt_;
@@ -427,6 +462,25 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def("Execute", &PySurfaceConverter::Execute, py::arg("src"), py::arg("cc_ctx") = nullptr, py::keep_alive<0, 1>(),
            py::call_guard<py::gil_scoped_release>())
       .def("ExecuteBatch", &PySurfaceConverter::ExecuteBatch, py::arg("src"), py::arg("dst"), py::arg("cc_ctx") = nullptr,
+           py::call_guard<py::gil_scoped_release>());
+
+  py::class_<PySurfaceConvertResizer>(m, "PySurfaceConvertResizer",
+                                      "Additive: NV12 / YUV420 -> bilinear resize -> RGB / BGR / RGB_PLANAR in one pass; bit-identical to "
+                                      "PySurfaceConverter followed by PySurfaceResizer (bilinear).")
+      .def(py::init([](uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out, uint32_t gpu) {
+             return new PySurfaceConvertResizer(sw, sh, in, dw, dh, out, ctx_of((int)gpu), str_of((int)gpu));
+           }),
+           py::arg("src_width"), py::arg("src_height"), py::arg("src_format"), py::arg("dst_width"), py::arg("dst_height"),
+           py::arg("dst_format"), py::arg("gpu_id"))
+      .def(py::init([](uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out, size_t ctx, size_t str) {
+             return new PySurfaceConvertResizer(sw, sh, in, dw, dh, out, (HipContext)ctx, (HipStream)str);
+           }),
+           py::arg("src_width"), py::arg("src_height"), py::arg("src_format"), py::arg("dst_width"), py::arg("dst_height"),
+           py::arg("dst_format"), py::arg("context"), py::arg("stream"))
+      .def("Format", &PySurfaceConvertResizer::GetFormat)
+      .def("Execute", &PySurfaceConvertResizer::Execute, py::arg("src"), py::arg("cc_ctx") = nullptr, py::keep_alive<0, 1>(),
+           py::call_guard<py::gil_scoped_release>())
+      .def("ExecuteBatch", &PySurfaceConvertResizer::ExecuteBatch, py::arg("src"), py::arg("dst"), py::arg("cc_ctx") = nullptr,
            py::call_guard<py::gil_scoped_release>());
 
   py::class_<PySurfaceResizer>(m, "PySurfaceResizer")

@@ -254,6 +254,82 @@ TaskExecStatus ConvertSurface::RunBatch(Surface* const* ins, Surface* const* out
   return TASK_EXEC_SUCCESS;
 }
 
+// ------------------------------------------------------------------------------------------ ConvertResizeSurface
+struct ConvertResizeSurface::Impl {
+  const PairInfo* pair;
+  uint32_t sw, sh, dw, dh;
+  HipContext ctx;
+  HipStream str;
+  std::unique_ptr<Surface> out;
+};
+ConvertResizeSurface::ConvertResizeSurface(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out,
+                                           HipContext ctx, HipStream str)
+    : Task("HipConvertResizeSurface", numInputs, numOutputs, nullptr, nullptr), pImpl(nullptr) {
+  const PairInfo* p = find_pair(in, out);
+  const bool fusable = p && (in == NV12 || in == YUV420) && (out == RGB || out == BGR || out == RGB_PLANAR);
+  if (!fusable || !sw || !sh || !dw || !dh) {
+    std::stringstream ss;
+    ss << "Unsupported fused conversion + resize: " << in << " to " << out;
+    throw std::invalid_argument(ss.str());
+  }
+  pImpl = new Impl{p, sw, sh, dw, dh, ctx, str, nullptr};
+  pImpl->out.reset(Surface::Make(out, dw, dh, ctx));
+}
+ConvertResizeSurface::~ConvertResizeSurface() { delete pImpl; }
+ConvertResizeSurface* ConvertResizeSurface::Make(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out,
+                                                 HipContext ctx, HipStream str) {
+  return new ConvertResizeSurface(sw, sh, in, dw, dh, out, ctx, str);
+}
+TaskExecStatus ConvertResizeSurface::Run() {
+  ClearOutputs();
+  auto* in = static_cast<Surface*>(GetInput(0));
+  const ColorspaceConversionContext* cc = nullptr;
+  if (auto* b = static_cast<Buffer*>(GetInput(1))) cc = b->GetDataAs<ColorspaceConversionContext>();
+  if (!in || in->Empty() || !pImpl->out || pImpl->out->Empty()) return TASK_EXEC_SUCCESS;
+  if (in->PixelFormat() != pImpl->pair->in || in->Width() != pImpl->sw || in->Height() != pImpl->sh) {
+    std::cerr << "fused " << pImpl->pair->name << ": input surface is " << PixelFormatName(in->PixelFormat()) << " " << in->Width()
+              << "x" << in->Height() << ", task was built for " << PixelFormatName(pImpl->pair->in) << " " << pImpl->sw << "x"
+              << pImpl->sh << std::endl;
+    return TASK_EXEC_SUCCESS;
+  }
+  int cs, cr;
+  if (!resolve_ctx(*pImpl->pair, cc, &cs, &cr)) return TASK_EXEC_SUCCESS;
+  vpf_plane src[3], dst[3];
+  fill_planes(in, src);
+  fill_planes(pImpl->out.get(), dst);
+  const vpf_exec ex = make_exec(pImpl->ctx, pImpl->str);
+  const vpf_status st = vpf_convert_resize(&ex, pImpl->pair->in, pImpl->pair->out, cs, cr, vpf_size{pImpl->sw, pImpl->sh}, src,
+                                           vpf_size{pImpl->dw, pImpl->dh}, dst);
+  if (st != VPF_OK) {
+    std::cerr << "Failed to convert + resize surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_SUCCESS;
+  }
+  SetOutput(pImpl->out.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+TaskExecStatus ConvertResizeSurface::RunBatch(Surface* const* ins, Surface* const* outs, uint32_t n, const ColorspaceConversionContext* cc) {
+  if (!ins || !outs || !n) return TASK_EXEC_FAIL;
+  int cs, cr;
+  if (!resolve_ctx(*pImpl->pair, cc, &cs, &cr)) return TASK_EXEC_FAIL;
+  std::vector<vpf_frame_io> io(n);
+  for (uint32_t i = 0; i < n; i++) {
+    Surface *s = ins[i], *d = outs[i];
+    if (!s || !d || s->Empty() || d->Empty() || s->PixelFormat() != pImpl->pair->in || d->PixelFormat() != pImpl->pair->out ||
+        s->Width() != pImpl->sw || s->Height() != pImpl->sh || d->Width() != pImpl->dw || d->Height() != pImpl->dh)
+      return TASK_EXEC_FAIL;
+    fill_planes(s, io[i].src);
+    fill_planes(d, io[i].dst);
+  }
+  const vpf_exec ex = make_exec(pImpl->ctx, pImpl->str);
+  const vpf_status st = vpf_convert_resize_batch(&ex, pImpl->pair->in, pImpl->pair->out, cs, cr, vpf_size{pImpl->sw, pImpl->sh},
+                                                 vpf_size{pImpl->dw, pImpl->dh}, n, io.data());
+  if (st != VPF_OK) {
+    std::cerr << "Failed to convert + resize surfaces. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
+  return TASK_EXEC_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------ ResizeSurface
 struct ResizeSurface::Impl {
   Pixel_Format fmt;

@@ -30,6 +30,24 @@ private:
   ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str);
 };
 
+// Additive (no reference counterpart; SURVEY §8 R1 "(ii) fused NV12 -> bilinear -> RGB"): convert and bilinear-resize in
+// one pass, bit-identical to ConvertSurface followed by ResizeSurface but without the full-size RGB intermediate.
+// Sources NV12 / YUV420, destinations RGB / BGR / RGB_PLANAR; colour-context rules are those of the unfused pair.
+class ConvertResizeSurface final : public Task {
+public:
+  static ConvertResizeSurface* Make(uint32_t src_width, uint32_t src_height, Pixel_Format inFormat, uint32_t dst_width,
+                                    uint32_t dst_height, Pixel_Format outFormat, HipContext ctx, HipStream str);
+  ~ConvertResizeSurface() override;
+  TaskExecStatus Run() final;  // asynchronous like ConvertSurface; null output = failure
+  TaskExecStatus RunBatch(Surface* const* inputs, Surface* const* outputs, uint32_t n, const ColorspaceConversionContext* ctx);
+
+private:
+  static const uint32_t numInputs = 2U, numOutputs = 1U;
+  struct Impl;
+  Impl* pImpl;
+  ConvertResizeSurface(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out, HipContext ctx, HipStream str);
+};
+
 class ResizeSurface final : public Task {
 public:
   static ResizeSurface* Make(uint32_t width, uint32_t height, Pixel_Format format, HipContext ctx, HipStream str);
