@@ -7,6 +7,8 @@ from videoprocessingframework_amd import capi
 dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 RING, STEPS = 8, 5
+if len(sys.argv) > 1:
+    capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, int(sys.argv[1]))  # 43: tiled kernel for every bilinear resize, 40: never
 for (sw, sh, dw, dh) in ((3840, 2160, 1280, 720), (1920, 1080, 1280, 720), (1920, 1080, 3840, 2160)):
     sp, dp = (3 * sw + 255) // 256 * 256, (3 * dw + 255) // 256 * 256
     src = [torch.randint(0, 256, (sh, sp), dtype=torch.uint8, device=dev) for _ in range(RING)]
