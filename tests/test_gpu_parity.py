@@ -390,21 +390,26 @@ def test_async_on_user_stream(capi, oracle):
 # ---------------------------------------------------------------------------------------------
 FUZZ_PAIRS = [("NV12", "RGB"), ("NV12", "BGR"), ("NV12", "RGB_PLANAR"), ("YUV420", "RGB"), ("YUV420", "BGR"), ("YUV444", "RGB"),
               ("NV12", "YUV420"), ("YUV420", "NV12"), ("RGB", "RGB_PLANAR"), ("RGB_PLANAR", "RGB"), ("RGB", "BGR"),
-              ("RGB", "YUV420"), ("BGR", "YUV444"), ("RGB_PLANAR", "YUV444"), ("BGR", "YCBCR"), ("RGB", "Y")]
+              ("RGB", "YUV420"), ("BGR", "YUV444"), ("RGB_PLANAR", "YUV444"), ("BGR", "YCBCR"), ("RGB", "Y"),
+              ("YUV444", "BGR"), ("YUV444", "RGB_PLANAR"), ("RGB_PLANAR", "BGR"), ("BGR", "RGB_PLANAR"), ("RGB_PLANAR", "Y"),
+              ("NV12", "Y"), ("Y", "YUV444"), ("P10", "NV12"), ("RGB", "RGB_32F"), ("RGB_PLANAR", "YUV420")]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))  # soak: VPF_FUZZ_SEEDS=500
 def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     for _ in range(12):
         s, d = FUZZ_PAIRS[int(rng.integers(len(FUZZ_PAIRS)))]
-        kind = int(rng.integers(4))
+        kind = int(rng.integers(5))
         if kind == 0:    # "video-like": multiples of 16, aligned
             w, h = 16 * int(rng.integers(1, 130)), 2 * int(rng.integers(1, 40))
             align, extra, offset = 256, 0, 0
         elif kind == 1:  # multiples of 4, dword alignment only
             w, h = 4 * int(rng.integers(1, 300)), 2 * int(rng.integers(1, 30))
             align, extra, offset = 4, 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 4))
+        elif kind == 4:  # 16-px regular but only 16-B aligned, padded pitches, shifted bases (r16 kernels off the 256-B grid)
+            w, h = 16 * int(rng.integers(1, 200)), 2 * int(rng.integers(1, 24))
+            align, extra, offset = 16, 16 * int(rng.integers(0, 4)), 16 * int(rng.integers(0, 5))
         elif kind == 2:  # anything goes
             w, h = int(rng.integers(1, 700)), int(rng.integers(1, 50))
             align, extra, offset = 1, int(rng.integers(0, 5)), int(rng.integers(0, 7))
@@ -413,7 +418,7 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
             align, extra, offset = 16, 0, 0
         cs = 0 if s in ("RGB", "BGR", "RGB_PLANAR") else int(rng.integers(2))
         cr = int(rng.integers(2))
-        variant = int(rng.choice([0, 0, 4, 8, 9, 11])) if s == "NV12" and d in ("RGB", "BGR", "RGB_PLANAR") else 0
+        variant = int(rng.choice([0, 0, 4, 8, 9, 11, 30, 37, 38])) if s == "NV12" and d in ("RGB", "BGR", "RGB_PLANAR") else int(rng.choice([0, 0, 0, 40, 9]))
         src = oracle.synth(getattr(oracle, s), w, h, int(rng.integers(1 << 30)), "ABC"[int(rng.integers(3))])
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), cs, cr, w, h, src, align, extra, offset, variant=variant)
 
