@@ -423,6 +423,51 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), cs, cr, w, h, src, align, extra, offset, variant=variant)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))
+def test_fuzz_resize_and_fused(capi, oracle, seed):
+    """random (format, filter, source size, destination size, alignment, kernel family): the tiled / row-pair / gather
+    resize kernels and the LDS / gather fused kernels against the oracle, bit for bit"""
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(6):
+        sw, sh = int(rng.integers(1, 900)), int(rng.integers(1, 120))
+        if rng.integers(3) == 0:
+            sw = 16 * int(rng.integers(1, 160))  # wide regular rows: several 64-column tiles / 256-px wave spans
+        dw, dh = max(1, int(sw * rng.uniform(0.15, 3.0))), max(1, int(sh * rng.uniform(0.15, 3.0)))
+        dw, dh = min(dw, 2600), min(dh, 300)
+        align = int(rng.choice([256, 256, 16, 4, 1]))
+        variant = int(rng.choice([0, 0, 40, 43, 9]))
+        if rng.integers(4) == 0:  # fused NV12 / YUV420 -> resize -> RGB family
+            sw, sh = sw + (sw & 1), sh + (sh & 1)
+            sf, df = str(rng.choice(["NV12", "YUV420"])), str(rng.choice(["RGB", "BGR", "RGB_PLANAR"]))
+            src = oracle.synth(getattr(oracle, sf), sw, sh, int(rng.integers(1 << 30)))
+            _, want = oracle.convert_resize(getattr(oracle, sf), getattr(oracle, df), 1, 0, sw, sh, src, dw, dh)
+            s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, df), dw, dh), align)
+            prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+            try:
+                capi.convert_resize(capi.make_exec(stream_handle()), getattr(capi, sf), getattr(capi, df), 1, 0, sw, sh, s.desc(), dw, dh, d.desc())
+            finally:
+                capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+            what = f"fused {sf}->{df}"
+        else:
+            fmt = str(rng.choice(["RGB", "BGR", "Y", "NV12", "YUV420", "RGB_PLANAR"]))
+            interp = int(rng.choice([capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_LINEAR, capi.INTERP_LANCZOS3]))
+            if fmt in ("NV12", "YUV420"):
+                sw, sh, dw, dh = sw + (sw & 1), sh + (sh & 1), dw + (dw & 1), dh + (dh & 1)
+            src = oracle.synth(getattr(oracle, fmt), sw, sh, int(rng.integers(1 << 30)))
+            _, want = oracle.resize(getattr(oracle, fmt), interp, sw, sh, src, dw, dh, oracle.FP32)
+            s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, fmt), dw, dh), align)
+            prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+            try:
+                capi.resize(capi.make_exec(stream_handle()), getattr(capi, fmt), interp, sw, sh, s.desc(), dw, dh, d.desc())
+            finally:
+                capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+            what = f"resize {fmt} interp {interp}"
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact, what
+        assert_planes_equal(got, want, f"{what} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
+
+
 def test_large_frame_8k(capi, oracle):
     """largest practical picture (8192 x 8192, 67 Mpx, 302 MB of traffic in one frame): 32-bit index math, grid limits"""
     w, h = 8192, 8192
