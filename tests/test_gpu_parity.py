@@ -468,6 +468,53 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
         assert_planes_equal(got, want, f"{what} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))
+def test_fuzz_remap(capi, oracle, seed):
+    """random source size, map size (!= source size), map family (affine / noisy / mostly out of range, with NaN and Inf
+    entries), pixel format, alignment, kernel: out-of-range destinations keep their previous content"""
+    rng = np.random.default_rng(11000 + seed)
+    for _ in range(4):
+        sw, sh = int(rng.integers(1, 700)), int(rng.integers(1, 90))
+        dw, dh = int(rng.integers(1, 700)), int(rng.integers(1, 90))
+        if rng.integers(3) == 0:
+            dw = 4 * int(rng.integers(1, 200))
+        yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
+        fam = int(rng.integers(4))
+        if fam == 0:    # affine: rotation + scale about the centre
+            a, sc = rng.uniform(-0.6, 0.6), rng.uniform(0.5, 1.8)
+            cx, cy = (dw - 1) / 2, (dh - 1) / 2
+            xm = (np.cos(a) * (xx - cx) - np.sin(a) * (yy - cy)) * sc * sw / dw + (sw - 1) / 2
+            ym = (np.sin(a) * (xx - cx) + np.cos(a) * (yy - cy)) * sc * sh / dh + (sh - 1) / 2
+        elif fam == 1:  # independent random coordinates, partly outside
+            xm, ym = rng.uniform(-3, sw + 2, (dh, dw)), rng.uniform(-3, sh + 2, (dh, dw))
+        elif fam == 2:  # stretched identity with sub-pixel noise
+            xm = xx * (sw / dw) + rng.uniform(-0.75, 0.75, (dh, dw))
+            ym = yy * (sh / dh) + rng.uniform(-0.75, 0.75, (dh, dw))
+        else:           # exact integer and half-integer coordinates, edges included
+            xm = np.round(rng.uniform(-1, sw, (dh, dw)) * 2) / 2
+            ym = np.round(rng.uniform(-1, sh, (dh, dw)) * 2) / 2
+        xm, ym = xm.astype(np.float32), ym.astype(np.float32)
+        for _ in range(int(rng.integers(0, 4))):
+            xm[int(rng.integers(dh)), int(rng.integers(dw))] = rng.choice([np.nan, np.inf, -np.inf, 1e30])
+            ym[int(rng.integers(dh)), int(rng.integers(dw))] = rng.choice([np.nan, np.inf, -np.inf, -1e30])
+        fmt = str(rng.choice(["RGB", "BGR"]))
+        align, variant = int(rng.choice([256, 16, 4, 1])), int(rng.choice([0, 0, 9]))
+        src = oracle.synth(getattr(oracle, fmt), sw, sh, int(rng.integers(1 << 30)))
+        s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, fmt), dw, dh, fill=77), align)
+        dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+        prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        try:
+            capi.remap(capi.make_exec(stream_handle()), getattr(capi, fmt), sw, sh, s.desc()[0], dx.data_ptr(), 4 * dw, dy.data_ptr(), 4 * dw,
+                       dw, dh, d.desc()[0])
+        finally:
+            capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact
+        _, want = oracle.remap(getattr(oracle, fmt), sw, sh, src, xm, ym, dst=oracle.alloc(getattr(oracle, fmt), dw, dh, fill=77))
+        assert_planes_equal(got, want, f"remap fam{fam} {fmt} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
+
+
 def test_large_frame_8k(capi, oracle):
     """largest practical picture (8192 x 8192, 67 Mpx, 302 MB of traffic in one frame): 32-bit index math, grid limits"""
     w, h = 8192, 8192
