@@ -346,7 +346,7 @@ def _maps(kind, w, h):
 
 @pytest.mark.parametrize("kind", ["identity", "shift", "barrel"])
 def test_remap(capi, oracle, kind):
-    for (w, h, variant, align) in [(1920, 1080, 0, 256), (1920, 1080, 9, 256), (333, 77, 0, 256), (640, 48, 0, 1), (644, 40, 0, 4)]:
+    for (w, h, variant, align) in [(1920, 1080, 0, 256), (1920, 1080, 40, 256), (1920, 1080, 9, 256), (333, 77, 0, 256), (640, 48, 0, 1), (644, 40, 0, 4)]:
         src = oracle.synth(oracle.RGB, w, h, 1060)
         xm, ym = _maps(kind, w, h)
         if kind == "barrel":
@@ -498,7 +498,7 @@ def test_fuzz_remap(capi, oracle, seed):
             xm[int(rng.integers(dh)), int(rng.integers(dw))] = rng.choice([np.nan, np.inf, -np.inf, 1e30])
             ym[int(rng.integers(dh)), int(rng.integers(dw))] = rng.choice([np.nan, np.inf, -np.inf, -1e30])
         fmt = str(rng.choice(["RGB", "BGR"]))
-        align, variant = int(rng.choice([256, 16, 4, 1])), int(rng.choice([0, 0, 9]))
+        align, variant = int(rng.choice([256, 16, 4, 1])), int(rng.choice([0, 0, 40, 9]))  # LDS tile / p4 gather / per-pixel
         src = oracle.synth(getattr(oracle, fmt), sw, sh, int(rng.integers(1 << 30)))
         s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, fmt), dw, dh, fill=77), align)
         dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()

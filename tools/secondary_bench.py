@@ -68,7 +68,7 @@ for s, d in pairs:
     del ring
     torch.cuda.empty_cache()
 # remap: identity + 0.5 px shift and barrel distortion, 4K RGB
-for kind in (() if (VARIANT or ONLY) else ("shift", "barrel")):
+for kind in (("shift", "barrel") if (ONLY is None or "remap" in ONLY) else ()):
     xm, ym = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
     if kind == "shift":
         xm = xm + 0.5

@@ -508,7 +508,7 @@ VPF_DEV void remap_row_taps(const uint8_t* row, uint32_t x0, bool two, uint32_t 
     const uint32_t d0 = ldg<false, uint32_t>(row + base), d1 = ldg<false, uint32_t>(row + base + 4), d2 = ldg<false, uint32_t>(row + base + 8);
     const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
     t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
-    t1[0] = two ? ubyte<3>(lo) : t0[0]; t1[1] = two ? ubyte<0>(hi) : t0[1]; t1[2] = two ? ubyte<1>(hi) : t0[2];
+    t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);  // two == false => fx == 0: the value is irrelevant
   } else {  // right edge of the row allocation: byte loads
     const uint32_t o1 = two ? o + 3 : o;
     for (int c = 0; c < 3; c++) { t0[c] = row[o + c]; t1[c] = row[o1 + c]; }
@@ -551,11 +551,134 @@ __global__ __launch_bounds__(256) void k_remap3_p4(const uint8_t* __restrict__ s
   }
 }
 
+// LDS-staged remap (default when it applies): a workgroup owns a 64 x 16 destination tile (lane = 4 consecutive pixels of
+// one row).  Smooth maps (lens undistortion, rotation, mild scaling: what PySurfaceRemaper exists for) send a tile to a
+// compact source footprint, so the workgroup reduces the footprint's bounding box (LDS atomics), stages those source rows
+// in LDS with dense 16-B loads and gathers the 2 x 2 taps from LDS with aligned dword reads + v_alignbyte_b32.  The
+// gather kernel above issues 8 scattered global loads per lane and is bound by the texture-address rate (34 us per 4K
+// frame); from LDS the same taps cost ~1/8.  Footprints that do not fit (wild maps) fall back, per workgroup, to the
+// global gathers.  Same arithmetic as k_remap3.  Requires what k_remap3_p4 requires plus 16-B aligned source rows.
+constexpr uint32_t kRemapLdsBytes = 20 * 1024;  // 8 workgroups per CU
+
+// min / max over the 64 lanes of a wave: four DPP steps inside each row of 16 lanes, then the four rows through SGPRs
+template <bool MAX>
+VPF_DEV int32_t wave_minmax(int32_t v) {
+  auto op = [](int32_t a, int32_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+  return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+            op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+VPF_DEV void lds_row_taps(const uint8_t* lrow, uint32_t o, bool two, float* t0, float* t1) {
+  const uint32_t sh = o & 3u;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(lrow + (o & ~3u));
+  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  // at the last column (two == false) the coordinate is exactly sw - 1, so fx == 0 and the second tap is multiplied by
+  // zero: whatever finite bytes follow serve as well as a replicated tap (fma(0, p1 - p0, p0) == p0)
+  (void)two;
+  t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
+  t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);
+}
+
+__global__ __launch_bounds__(256) void k_remap3_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                     const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
+                                                     uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ u32x4 L[kRemapLdsBytes / 16 + 2];
+  __shared__ int32_t bb[4][4];  // per wave: xmin, xmax, ymin, ymax of its source taps
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  const uint32_t x = blockIdx.x * 64 + 4 * (lane & 15), y = blockIdx.y * 16 + (t >> 6) * 4 + (lane >> 4);
+  const bool in = x < dw && y < dh;  // dw % 4 == 0: a lane's four pixels are inside or outside together
+  f32x4 sx4 = {-1.f, -1.f, -1.f, -1.f}, sy4 = sx4;
+  if (in) {
+    sx4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(xmap) + (size_t)y * xp + 4 * (size_t)x);
+    sy4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(ymap) + (size_t)y * yp + 4 * (size_t)x);
+  }
+  bool ok[4], twox[4];
+  uint32_t x0[4], y0[4], y1[4];
+  float fx[4], fy[4];
+  int32_t lxmin = 0x7fffffff, lxmax = -1, lymin = 0x7fffffff, lymax = -1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float sx = sx4[k], sy = sy4[k];
+    ok[k] = (sx >= 0.f && sx <= (float)(sw - 1) && sy >= 0.f && sy <= (float)(sh - 1));
+    const float cx = ok[k] ? sx : 0.f, cy = ok[k] ? sy : 0.f;
+    x0[k] = (uint32_t)(int)cx; y0[k] = (uint32_t)(int)cy;
+    twox[k] = x0[k] + 1 < sw;
+    y1[k] = (y0[k] + 1 < sh) ? y0[k] + 1 : sh - 1;
+    fx[k] = cx - (float)x0[k]; fy[k] = cy - (float)y0[k];
+    if (ok[k]) {
+      const int32_t xe = (int32_t)(twox[k] ? x0[k] + 1 : x0[k]);
+      lxmin = (int32_t)x0[k] < lxmin ? (int32_t)x0[k] : lxmin; lxmax = xe > lxmax ? xe : lxmax;
+      lymin = (int32_t)y0[k] < lymin ? (int32_t)y0[k] : lymin; lymax = (int32_t)y1[k] > lymax ? (int32_t)y1[k] : lymax;
+    }
+  }
+  {
+    const int32_t a = wave_minmax<false>(lxmin), b = wave_minmax<true>(lxmax), c = wave_minmax<false>(lymin), d = wave_minmax<true>(lymax);
+    if (lane == 0) { bb[t >> 6][0] = a; bb[t >> 6][1] = b; bb[t >> 6][2] = c; bb[t >> 6][3] = d; }
+  }
+  __syncthreads();
+  auto mn = [](int32_t a, int32_t b) { return a < b ? a : b; };
+  auto mx = [](int32_t a, int32_t b) { return a > b ? a : b; };
+  const int32_t bxmax = mx(mx(bb[0][1], bb[1][1]), mx(bb[2][1], bb[3][1]));
+  if (bxmax < 0) return;  // every pixel of the tile maps outside the source: destination untouched
+  const uint32_t xmin = (uint32_t)mn(mn(bb[0][0], bb[1][0]), mn(bb[2][0], bb[3][0])), xmax = (uint32_t)bxmax;
+  const uint32_t ymin = (uint32_t)mn(mn(bb[0][2], bb[1][2]), mn(bb[2][2], bb[3][2]));
+  const uint32_t ymax = (uint32_t)mx(mx(bb[0][3], bb[1][3]), mx(bb[2][3], bb[3][3]));
+  const uint32_t bx0 = (3 * xmin) & ~15u, pitch_l = (3 * (xmax + 1) - bx0 + 15) & ~15u, rows = ymax - ymin + 1;
+  const bool use_lds = (size_t)pitch_l * rows + 16 <= kRemapLdsBytes;
+  if (use_lds) {
+    const uint32_t upr = pitch_l >> 4, total = rows * upr;
+    for (uint32_t u = t; u < total; u += 256) {
+      const uint32_t r = u / upr, cidx = u - r * upr;
+      L[u] = ldg<false, u32x4>(src + (size_t)(ymin + r) * sp + bx0 + 16 * cidx);
+    }
+    __syncthreads();
+  }
+  if (!in) return;
+  float o[12];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float a0[3], a1[3], b0[3], b1[3];
+    if (use_lds) {
+      const uint8_t* lb = reinterpret_cast<const uint8_t*>(L);
+      const uint32_t off = 3 * x0[k] - bx0;
+      // pixels that map outside read tile-local garbage coordinates (0,0): keep the addresses inside the staged box
+      const uint32_t oc = ok[k] ? off : 3 * xmin - bx0, r0 = ok[k] ? y0[k] - ymin : 0, r1 = ok[k] ? y1[k] - ymin : 0;
+      lds_row_taps(lb + r0 * pitch_l, oc, twox[k], a0, a1);
+      lds_row_taps(lb + r1 * pitch_l, oc, twox[k], b0, b1);
+    } else {
+      remap_row_taps(src + (size_t)y0[k] * sp, x0[k], twox[k], sp, a0, a1);
+      remap_row_taps(src + (size_t)y1[k] * sp, x0[k], twox[k], sp, b0, b1);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[3 * k + c] = bilerp(a0[c], a1[c], b0[c], b1[c], fx[k], fy[k]);
+  }
+  uint8_t* out = dst + (size_t)y * dp + 3 * (size_t)x;
+  if (vec_ok && ok[0] && ok[1] && ok[2] && ok[3]) {
+    stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (ok[k]) { out[3 * k] = (uint8_t)sat_trunc(o[3 * k]); out[3 * k + 1] = (uint8_t)sat_trunc(o[3 * k + 1]); out[3 * k + 2] = (uint8_t)sat_trunc(o[3 * k + 2]); }
+  }
+}
+
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp, const float* xmap,
                         uint32_t xp, const float* ymap, uint32_t yp, uint32_t dw, uint32_t dh, uint8_t* dst,
                         uint32_t dp) {
   const bool fast = tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && (dw % 4 == 0) && !(((uintptr_t)src | sp) & 3) &&
                     !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sp >= 12;
+  if (fast && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15)) {
+    const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
+    dim3 tgrid((dw + 63) / 64, (dh + 15) / 16);
+    VPF_LAUNCH(k_remap3_tile, tgrid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh, vec_ok);
+    return hipGetLastError();
+  }
   if (fast) {
     const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
     dim3 fgrid((dw / 4 + 63) / 64, (dh + 3) / 4);
