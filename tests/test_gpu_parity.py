@@ -385,6 +385,38 @@ def test_async_on_user_stream(capi, oracle):
     assert_planes_equal(got, want, "stream")
 
 
+def test_abi_is_hip_graph_capturable(capi, oracle):
+    """the C ABI never synchronises, allocates or queries the stream, so a chain of per-frame calls can be captured into a
+    hipGraph (torch.cuda.CUDAGraph = hipStreamBeginCapture on the ABI's stream) and replayed"""
+    w, h = 640, 360
+    src = oracle.synth(oracle.NV12, w, h, 1075)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        s = DevPlanes(src)
+        mid, out = DevPlanes(oracle.alloc(oracle.RGB, w, h)), DevPlanes(oracle.alloc(oracle.RGB_PLANAR, 224, 126))
+        pl = DevPlanes(oracle.alloc(oracle.RGB_PLANAR, w, h))
+        ex = capi.make_exec(st.cuda_stream)
+
+        def chain():
+            capi.convert(ex, capi.NV12, capi.RGB, 1, 0, w, h, s.desc(), mid.desc())
+            capi.convert(ex, capi.RGB, capi.RGB_PLANAR, 1, 0, w, h, mid.desc(), pl.desc())
+            capi.resize(ex, capi.RGB_PLANAR, capi.INTERP_LINEAR, w, h, pl.desc(), 224, 126, out.desc())
+
+        chain(); st.synchronize()   # warm-up outside capture (module load)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            chain()
+        for t in mid.bufs + pl.bufs + out.bufs:
+            t.fill_(0xCD)
+        g.replay(); g.replay(); st.synchronize()
+        got, intact = out.download()
+    assert intact
+    _, a = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+    _, b = oracle.convert(oracle.RGB, oracle.RGB_PLANAR, 1, 0, w, h, a)
+    _, c = oracle.resize(oracle.RGB_PLANAR, oracle.LINEAR, w, h, b, 224, 126, oracle.FP32)
+    assert_planes_equal(got, c, "graph replay")
+
+
 # ---------------------------------------------------------------------------------------------
 # randomised shape / pitch / alignment fuzz (deterministic seeds): every converter family, bit-exact
 # ---------------------------------------------------------------------------------------------
