@@ -347,6 +347,40 @@ def test_convert_straight_into_a_torch_tensor(oracle):
         nvc.Surface.Wrap(PF.YUV420, w, h, w, t.data_ptr())               # three allocations cannot wrap one pointer
 
 
+def test_download_into_pinned_and_pageable_arrays(oracle):
+    """PySurfaceDownloader: a page-locked destination (AllocPinned) receives the DMA directly, a pageable one goes through
+    the staging buffer; wrong-size pageable arrays are resized like the reference does (PySurfaceDownloader.cpp:119-189);
+    threads download concurrently with the GIL released"""
+    w, h = 640, 360
+    src = oracle.synth(oracle.NV12, w, h, 21)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    rgb = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU).Execute(upload(PF.NV12, w, h, src), cc)
+    _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+    dl = nvc.PySurfaceDownloader(w, h, PF.RGB, GPU)
+    pinned = nvc.AllocPinned(w * h * 3)
+    pinned[:] = 0
+    assert dl.DownloadSingleSurface(rgb, pinned) and np.array_equal(pinned, want[0].reshape(-1))
+    small = np.zeros(7, np.uint8)
+    assert dl.DownloadSingleSurface(rgb, small) and small.size == w * h * 3 and np.array_equal(small, want[0].reshape(-1))
+    assert not dl.DownloadSingleSurface(nvc.Surface.Make(PF.RGB, 2 * w, 2 * h, GPU), np.zeros(1, np.uint8))  # larger than built for
+    # NV12 surface: planes concatenated at tight width
+    nv = upload(PF.NV12, w, h, src)
+    out = nvc.AllocPinned(w * h * 3 // 2)
+    assert nvc.PySurfaceDownloader(w, h, PF.NV12, GPU).DownloadSingleSurface(nv, out) and np.array_equal(out, host_frame(src))
+    res = [None] * 4
+
+    def work(i):
+        d = nvc.PySurfaceDownloader(w, h, PF.RGB, nvc.GetContext(GPU), torch.cuda.Stream().cuda_stream)
+        buf = nvc.AllocPinned(w * h * 3) if i % 2 else np.empty(w * h * 3, np.uint8)
+        ok = all(d.DownloadSingleSurface(rgb, buf) for _ in range(20))
+        res[i] = ok and np.array_equal(buf, want[0].reshape(-1))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(res)
+
+
 def test_upload_from_pinned_memory():
     """AllocPinned: numpy array over page-locked memory; the uploader DMAs from it directly and the result is identical"""
     w, h = 640, 360

@@ -37,6 +37,21 @@ def run(kind, n=N, ctx=None, stream=None):
     return n / (time.perf_counter() - t0)
 
 
+def run_download(pinned_dst, n=N, multi=1):
+    """convert -> PySurfaceDownloader into a numpy array (pageable) or an AllocPinned() array (direct DMA)"""
+    ctx, stream = nvc.GetContext(0), nvc.GetStream(0)
+    up = nvc.PyFrameUploader(W, H, PF.NV12, ctx, stream)
+    conv = nvc.PySurfaceConverter(W, H, PF.NV12, PF.RGB, ctx, stream)
+    dl = nvc.PySurfaceDownloader(W, H, PF.RGB, ctx, stream)
+    rgb = conv.Execute(up.UploadSingleFrame(frames[0]), cc)
+    out = nvc.AllocPinned(W * H * 3) if pinned_dst else np.empty(W * H * 3, np.uint8)
+    assert dl.DownloadSingleSurface(rgb, out)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dl.DownloadSingleSurface(rgb, out)
+    return n / (time.perf_counter() - t0)
+
+
 for kind in ("upload", "convert", "pipeline"):
     print(f"[pipeline] 1 thread  {kind:8s}: {run(kind):9.1f} frames/s", flush=True)
 for nt in (2, 4, 8, 16):
@@ -53,3 +68,8 @@ for nt in (2, 4, 8, 16):
     dt = time.perf_counter() - t0
     print(f"[pipeline] {nt:2d} threads pipeline: {nt * N / dt:9.1f} frames/s aggregate = {nt * N / dt * W * H / 1e9:6.2f} Gpix/s, "
           f"{nt * N / dt * W * H * 1.5 / 1e9:5.1f} GB/s over PCIe", flush=True)
+
+for pinned_dst in (False, True):
+    fps = run_download(pinned_dst)
+    print(f"[pipeline] download 4K RGB into {'AllocPinned() array (direct DMA)' if pinned_dst else 'pageable numpy array (staging + 1 copy)'}: "
+          f"{fps:8.1f} frames/s = {fps * W * H * 3 / 1e9:5.1f} GB/s", flush=True)

@@ -225,19 +225,14 @@ public:
   Pixel_Format GetFormat() const { return fmt_; }
   template <typename T>
   bool Download(std::shared_ptr<Surface> s, py::array_t<T>& frame) {
-    if (!s) return false;
-    Buffer* raw = nullptr;
-    {
-      py::gil_scoped_release nogil;
-      dl_->SetInput(s.get(), 0U);
-      if (TASK_EXEC_FAIL == dl_->Execute()) return false;
-      raw = static_cast<Buffer*>(dl_->GetOutput(0U));
-    }
-    if (!raw) return false;
+    if (!s || s->Empty()) return false;
     const size_t bytes = s->HostMemSize();
     if (bytes != (size_t)frame.size() * sizeof(T)) frame.resize({(py::ssize_t)(bytes / sizeof(T))}, false);
-    std::memcpy(frame.mutable_data(), raw->GetRawMemPtr(), bytes);
-    return true;
+    T* dst = frame.mutable_data();
+    // the DMA and (for pageable arrays) the single host copy run without the GIL; arrays from AllocPinned() receive
+    // the DMA directly
+    py::gil_scoped_release nogil;
+    return TASK_EXEC_SUCCESS == dl_->DownloadInto(s.get(), dst, bytes);
   }
 };
 

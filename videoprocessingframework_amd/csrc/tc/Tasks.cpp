@@ -534,6 +534,19 @@ CudaDownloadSurface::~CudaDownloadSurface() { delete pImpl; }
 CudaDownloadSurface* CudaDownloadSurface::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
   return new CudaDownloadSurface(str, ctx, w, h, f);
 }
+static bool download_planes(Surface* s, uint8_t* dst, hipStream_t str) {
+  for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // Tasks.cpp:832-849
+    const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
+    if (!hip_ok(hipMemcpy2DAsync(dst, wb, (const void*)s->PlanePtr(p), s->Pitch(p), wb, rows, hipMemcpyDeviceToHost, str),
+                "CudaDownloadSurface: hipMemcpy2DAsync")) {
+      std::cerr << "  plane " << p << " dst " << (void*)dst << " dpitch " << wb << " src " << (void*)s->PlanePtr(p) << " spitch "
+                << s->Pitch(p) << " width " << wb << " rows " << rows << std::endl;
+      return false;
+    }
+    dst += wb * rows;
+  }
+  return true;
+}
 TaskExecStatus CudaDownloadSurface::Run() {
   auto* s = static_cast<Surface*>(GetInput(0));
   if (!s) return TASK_EXEC_FAIL;
@@ -544,19 +557,27 @@ TaskExecStatus CudaDownloadSurface::Run() {
     return TASK_EXEC_FAIL;
   }
   DeviceScope scope(pImpl->sref.ctx);
-  uint8_t* dst = pImpl->host->GetDataAs<uint8_t>();
-  for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // Tasks.cpp:832-849
-    const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
-    if (!hip_ok(hipMemcpy2DAsync(dst, wb, (const void*)s->PlanePtr(p), s->Pitch(p), wb, rows, hipMemcpyDeviceToHost,
-                                 (hipStream_t)pImpl->sref.str), "CudaDownloadSurface: hipMemcpy2DAsync")) {
-      std::cerr << "  plane " << p << " dst " << (void*)dst << " dpitch " << wb << " src " << (void*)s->PlanePtr(p) << " spitch " << s->Pitch(p)
-                << " width " << wb << " rows " << rows << " host size " << pImpl->host->GetRawMemSize() << " pinned " << pImpl->host->Pinned() << std::endl;
-      return TASK_EXEC_FAIL;
-    }
-    dst += wb * rows;
-  }
+  if (!download_planes(s, pImpl->host->GetDataAs<uint8_t>(), (hipStream_t)pImpl->sref.str)) return TASK_EXEC_FAIL;
   hip_stream_sync(&pImpl->sref);
   SetOutput(pImpl->host.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+TaskExecStatus CudaDownloadSurface::DownloadInto(Surface* s, void* dst, size_t dst_bytes) {
+  if (!s || !dst) return TASK_EXEC_FAIL;
+  const size_t bytes = s->Empty() ? 0 : s->HostMemSize();
+  if (!bytes || bytes > pImpl->host->GetRawMemSize() || bytes > dst_bytes) {
+    std::cerr << "CudaDownloadSurface: surface is empty, larger (" << bytes << " B) than the downloader was built for ("
+              << pImpl->host->GetRawMemSize() << " B) or than the destination (" << dst_bytes << " B)" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
+  DeviceScope scope(pImpl->sref.ctx);
+  hipPointerAttribute_t attr{};
+  const bool pinned_dst = (hipPointerGetAttributes(&attr, dst) == hipSuccess) && attr.type == hipMemoryTypeHost;
+  if (!pinned_dst) (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error for us
+  uint8_t* target = pinned_dst ? static_cast<uint8_t*>(dst) : pImpl->host->GetDataAs<uint8_t>();
+  if (!download_planes(s, target, (hipStream_t)pImpl->sref.str)) return TASK_EXEC_FAIL;
+  hip_stream_sync(&pImpl->sref);
+  if (!pinned_dst) std::memcpy(dst, target, bytes);
   return TASK_EXEC_SUCCESS;
 }
 

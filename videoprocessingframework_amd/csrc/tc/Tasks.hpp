@@ -98,6 +98,10 @@ public:
   static CudaDownloadSurface* Make(HipStream str, HipContext ctx, uint32_t width, uint32_t height, Pixel_Format format);
   ~CudaDownloadSurface() override;
   TaskExecStatus Run() final;
+  // Additive: deliver the frame into caller memory (planes concatenated at tight width, like Run's output buffer).
+  // Page-locked destinations (AllocPinned) receive the DMA directly; pageable ones go through the task's pinned
+  // staging buffer and ONE host copy (the reference copies twice: PySurfaceDownloader.cpp:70).  Blocking.
+  TaskExecStatus DownloadInto(Surface* surface, void* dst, size_t dst_bytes);
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
