@@ -261,7 +261,7 @@ def main():
     if a.sweep and rank == 0:
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
             for mode in ("batch", "single"):
-                for v in (4, 8, 30, 37, 38, 41, 15, 22, 23):
+                for v in (4, 8, 30, 37, 38, 41, 43, 15, 22, 23):
                     wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, v, mode)
                     _, ev = timed(wl, a.steps, a.warmup, False)
                     nbytes = wl.bytes_per_step * (1 / 3 if v == 22 else 2 / 3 if v in (23, 24, 25, 26) else 1)  # probes move only the reads / writes

@@ -57,7 +57,7 @@ def test_nv12_to_rgb_matrices(capi, oracle, cs, cr, dst):
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), cs, cr, w, h, src)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 27, 28, 29, 37, 38, 41, 42])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 27, 28, 29, 37, 38, 41, 42, 43])
 @pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
 def test_nv12_to_rgb_every_kernel_variant(capi, oracle, variant, dst):
     """all kernel variants (p4 / p16 / LDS-transposed / non-temporal / explicit pack / generic) agree bit for bit"""
@@ -66,7 +66,7 @@ def test_nv12_to_rgb_every_kernel_variant(capi, oracle, variant, dst):
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), 1, 0, w, h, src, variant=variant, exact_tol=False)
 
 
-@pytest.mark.parametrize("variant", [8, 17, 27, 30, 37, 38])
+@pytest.mark.parametrize("variant", [8, 17, 27, 30, 37, 38, 43])
 def test_nv12_to_rgb_variant_falls_back_when_not_applicable(capi, oracle, variant):
     """a 16-B-aligned-only kernel requested on ragged widths / odd bases / the other output class must silently take a
     general kernel with identical pixels (the tuning knob is a hint, never a correctness switch)"""

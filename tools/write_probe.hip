@@ -84,6 +84,18 @@ __global__ void kXcd(u32x4* out, size_t n16) {
 #pragma unroll
   for (int k = 0; k < 6; k++) { const size_t i = wave * 384 + k * 64 + lane; if (i < n16) __builtin_nontemporal_store(u32x4{(uint32_t)i, 1, 2, 3}, out + i); }
 }
+// read:write = 1:2 like NV12->RGB.  NS = stores per wave (each 1 KiB dense); the wave first loads NS x 512 B (8 B / lane).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int NS>
+__global__ void kMix(const u32x2* in, u32x4* out, size_t n16) {
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  u32x2 v[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) { const size_t i = (wave * NS + k) * 64 + lane; v[k] = i < n16 ? __builtin_nontemporal_load(in + i) : u32x2{0, 0}; }
+#pragma unroll
+  for (int k = 0; k < NS; k++) { const size_t i = (wave * NS + k) * 64 + lane; if (i < n16) __builtin_nontemporal_store(u32x4{v[k][0], v[k][1], v[k][0] ^ 1u, v[k][1] ^ 2u}, out + i); }
+}
 __global__ void kD(u32x4* out, size_t n16) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
 #pragma unroll
@@ -133,6 +145,21 @@ int main() {
     const dim3 g8(((n16 / 384 + 3) / 4) / 8 * 8);
     run("X0 XCD owns a contiguous eighth", [&] { hipLaunchKernelGGL((kXcd<0>), g8, dim3(256), 0, 0, d, n16); });
     run("X1 XCD owns 1-MiB regions", [&] { hipLaunchKernelGGL((kXcd<1>), g8, dim3(256), 0, 0, d, n16); });
+  }
+  {
+    u32x2* src; hipMalloc(&src, B / 2); hipMemset(src, 1, B / 2); hipDeviceSynchronize();
+    auto runmix = [&](const char* name, auto launch) {
+      launch(); hipDeviceSynchronize();
+      hipEventRecord(e0, 0); for (int r = 0; r < 10; r++) launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("[wprobe] %-46s %7.0f GB/s (read + write)\n", name, 1.5 * B * 10.0 / (ms * 1e-3) / 1e9);
+    };
+    runmix("mix 1:2, 1 store/wave (512 B in, 1 KiB out)", [&] { hipLaunchKernelGGL((kMix<1>), dim3((n16 / 64 + 3) / 4), dim3(256), 0, 0, src, d, n16); });
+    runmix("mix 1:2, 2 stores/wave", [&] { hipLaunchKernelGGL((kMix<2>), dim3((n16 / 128 + 3) / 4), dim3(256), 0, 0, src, d, n16); });
+    runmix("mix 1:2, 3 stores/wave", [&] { hipLaunchKernelGGL((kMix<3>), dim3((n16 / 192 + 3) / 4), dim3(256), 0, 0, src, d, n16); });
+    runmix("mix 1:2, 6 stores/wave", [&] { hipLaunchKernelGGL((kMix<6>), dim3((n16 / 384 + 3) / 4), dim3(256), 0, 0, src, d, n16); });
+    runmix("mix 1:2, 1 store/wave, 512-thr blocks", [&] { hipLaunchKernelGGL((kMix<1>), dim3((n16 / 64 + 7) / 8), dim3(512), 0, 0, src, d, n16); });
+    runmix("mix 1:2, 1 store/wave, 1024-thr blocks", [&] { hipLaunchKernelGGL((kMix<1>), dim3((n16 / 64 + 15) / 16), dim3(1024), 0, 0, src, d, n16); });
   }
   run("M  hipMemsetAsync", [&] { hipMemsetAsync(d, 1, B, 0); });
   return 0;

@@ -403,6 +403,58 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_r16(const BatchArgs args, cons
   }
 }
 
+// s16 ("stream"): ONE 1-KiB store per wave with no LDS and no cross-lane traffic.  The packed output row is treated as a
+// byte stream: a wave owns 1 KiB of it, a lane owns 16 B = 5 1/3 pixels.  The lane converts the 8 pixels starting at the even
+// pixel that contains its first byte (Y and UV arrive as one 12-B load each from the same 4-B aligned column; v_alignbyte_b32
+// drops the 0 or 2 leading bytes), packs 24 bytes and funnels out its 16 with v_alignbyte_b32 by (byte offset mod 3-ish).
+// 1.5x the arithmetic of p16 (8 px converted per 5.33 px stored) buys the best store geometry of tools/write_probe.hip.
+// Requires w % 16 == 0, h even, 16-B aligned destination rows, 4-B aligned source rows.
+template <int DST, bool NTS>
+__global__ __launch_bounds__(256) void k_nv12_rgb_s16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                      uint32_t segs, uint32_t n_tasks) {
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t pair = wt >> 1, half = wt & 1;  // the two rows that share a UV row sit in neighbouring waves of one block
+  const uint32_t rp = pair / segs, seg = pair - rp * segs;
+  const uint32_t y = 2 * rp + half;
+  const uint32_t B = seg * 1024 + lane * 16;  // first output byte of the lane
+  if (B >= 3 * w) return;
+  const uint32_t p0 = (uint32_t)(((uint64_t)B * 0xAAAAAAABull) >> 33);  // B / 3
+  const uint32_t pe = p0 & ~1u, s = B - 3 * pe;                        // even pixel holding byte B; s in [0, 5]
+  const uint32_t col = pe & ~3u, sh = pe & 3u;                         // 4-B aligned source column, 0 or 2 bytes to drop
+  const uint8_t* yr = f.s[0] + (size_t)y * f.sp[0];
+  const uint8_t* ur = f.s[1] + (size_t)rp * f.sp[1];
+  uint32_t yd[3], ud[3];
+  if (col + 12 <= w) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { yd[i] = ldg<true, uint32_t>(yr + col + 4 * i); ud[i] = ldg<false, uint32_t>(ur + col + 4 * i); }
+  } else {  // right edge: a dword past column w belongs to pixels that do not exist; never read it (tight pitch, last row)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const uint32_t a = (col + 4 * i + 4 <= w) ? col + 4 * i : w - 4;
+      yd[i] = ldg<true, uint32_t>(yr + a); ud[i] = ldg<false, uint32_t>(ur + a);
+    }
+  }
+  const uint32_t y_lo = __builtin_amdgcn_alignbyte(yd[1], yd[0], sh), y_hi = __builtin_amdgcn_alignbyte(yd[2], yd[1], sh);
+  const uint32_t u_lo = __builtin_amdgcn_alignbyte(ud[1], ud[0], sh), u_hi = __builtin_amdgcn_alignbyte(ud[2], ud[1], sh);
+  uint32_t o[6];
+  {
+    const Chroma k0 = chroma_terms(c, ubyte<0>(u_lo), ubyte<1>(u_lo)), k1 = chroma_terms(c, ubyte<2>(u_lo), ubyte<3>(u_lo));
+    pack_rgb12<DST, 1>(convert4(c, y_lo, k0, k1), o[0], o[1], o[2]);
+    const Chroma k2 = chroma_terms(c, ubyte<0>(u_hi), ubyte<1>(u_hi)), k3 = chroma_terms(c, ubyte<2>(u_hi), ubyte<3>(u_hi));
+    pack_rgb12<DST, 1>(convert4(c, y_hi, k2, k3), o[3], o[4], o[5]);
+  }
+  const uint32_t s4 = s & 3u;
+  uint32_t a[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) a[i] = __builtin_amdgcn_alignbyte(o[i + 1], o[i], s4);
+  const bool hi = s >= 4;
+  const u32x4 v = {hi ? a[1] : a[0], hi ? a[2] : a[1], hi ? a[3] : a[2], hi ? a[4] : a[3]};
+  stg<NTS, u32x4>(f.d[0] + (size_t)y * f.dp[0] + B, v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // bandwidth probes with the p16 geometry (NOT conversions; reachable only through the tuning hook, used by
 // bench.py --sweep to locate the ceilings): MODE 0 = the loads only (one dword per wave stored so they are not
@@ -602,7 +654,7 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   // planar outputs: r16 (one row per wave, three 1-KiB plane stores) beats p4's 256-B stores by ~9 % when batched
   if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? 37 : (n >= 4 ? 30 : 8)) : 4;
   const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36 || variant == 41 || variant == 42);
-  const bool packed_only = (variant >= 17 && variant <= 19) || (variant >= 22 && variant <= 29) || variant == 38;
+  const bool packed_only = (variant >= 17 && variant <= 19) || (variant >= 22 && variant <= 29) || variant == 38 || variant == 43;
   if ((want_p16 || packed_only || variant == 37) && !p16_ok) variant = 4;
   if ((packed_only && DST == FC_PLANAR) || (variant == 37 && DST != FC_PLANAR)) variant = 4;
   if (variant != 9 && !p4_ok) variant = 9;  // p16_ok implies p4_ok
@@ -624,6 +676,11 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       if constexpr (DST != FC_PLANAR) {
         VPF_LAUNCH((k_nv12_rgb_r16<DST, true, 0>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
       }
+      return hipGetLastError();
+    }
+    if (variant == 43) {
+      const uint32_t segs = (3 * w + 1023) / 1024, tasks = segs * h;
+      if constexpr (DST != FC_PLANAR) VPF_LAUNCH((k_nv12_rgb_s16<DST, true>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, segs, tasks);
       return hipGetLastError();
     }
     if (variant == 37) {
