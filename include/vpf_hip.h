@@ -16,6 +16,7 @@
  *   (all other *_Impl in TasksColorCvt.cpp:245-1300)                                               vpf_convert
  *   NppResizeSurfacePacked3C_Impl::Run   src/TC/src/Tasks.cpp:1162-1203  nppiResize_8u_C3R         vpf_resize
  *   NppResizeSurfacePlanar_Impl::Run     Tasks.cpp:1217-1261             nppiResize_8u_C1R         vpf_resize
+ *   NppResizeSurfacePacked32F3C_Impl / NppResizeSurface32FPlanar_Impl  Tasks.cpp:1334-1445  nppiResize_32f_C3R / _C1R  vpf_resize
  *   NppRemapSurfacePacked3C_Impl::Run    Tasks.cpp:1555-1602             nppiRemap_8u_C3R          vpf_remap
  *
  * Like the NPP `_Ctx` entry points it replaces, every function here takes raw device pointers,
@@ -138,9 +139,10 @@ VPF_API vpf_status vpf_convert_batch(const vpf_exec* exec, int src_fmt, int dst_
  * Pure host logic; callable without a GPU. */
 VPF_API int vpf_convert_supported(int src_fmt, int dst_fmt, int color_space, int color_range);
 
-/* Whole-image resize.  `fmt` in {RGB, BGR, Y, YUV420, YCBCR, YUV444, RGB_PLANAR, NV12}; every plane
- * is resized independently (chroma planes at their own resolution).  Replaces nppiResize_8u_C3R /
- * _C1R (Tasks.cpp:1193,1227-1253). */
+/* Whole-image resize.  `fmt` in {RGB, BGR, Y, YUV420, YCBCR, YUV444, RGB_PLANAR, NV12, RGB_32F,
+ * RGB_32F_PLANAR}; every plane is resized independently (chroma planes at their own resolution).
+ * Replaces nppiResize_8u_C3R / _C1R (Tasks.cpp:1193,1227-1253) and nppiResize_32f_C3R / _C1R
+ * (Tasks.cpp:1376,1434; float results are neither rounded nor clamped, rows must be 4-B aligned). */
 VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size src_size,
                               const vpf_plane src[3], vpf_size dst_size, const vpf_plane dst[3]);
 

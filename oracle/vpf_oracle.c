@@ -754,6 +754,71 @@ static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, cons
   return VPFO_OK;
 }
 
+/* 32-bit float surfaces (reference: NppResizeSurfacePacked32F3C_Impl Tasks.cpp:1334-1387, nppiResize_32f_C3R;
+ * NppResizeSurface32FPlanar_Impl :1390-1445, nppiResize_32f_C1R per plane): the same taps and operation order as the 8-bit
+ * paths, on float samples, no rounding and no clamping of the result. */
+static int resize_plane_f32(int mode, int interp, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw,
+                            uint32_t dh, const vpfo_plane* d) {
+  if (interp == 2) {
+    ltap* tx = (ltap*)malloc(sizeof(ltap) * dw);
+    ltap* ty = (ltap*)malloc(sizeof(ltap) * dh);
+    if (!tx || !ty) { free(tx); free(ty); return VPFO_BAD_ARG; }
+    make_ltaps(mode, sw, dw, tx);
+    make_ltaps(mode, sh, dh, ty);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t yy = 0; yy < (int64_t)dh; yy++) {
+      float* o = (float*)prow(d, (uint32_t)yy);
+      for (uint32_t x = 0; x < dw; x++)
+        for (int c = 0; c < ch; c++) {
+          if (mode == VPFO_EXACT) {
+            double acc = 0;
+            for (int ky = 0; ky < 6; ky++) {
+              const float* r = (const float*)prow(s, (uint32_t)ty[yy].idx[ky]);
+              double ra = 0;
+              for (int kx = 0; kx < 6; kx++) ra += tx[x].w[kx] * (double)r[ch * tx[x].idx[kx] + c];
+              acc += ty[yy].w[ky] * ra;
+            }
+            o[ch * x + c] = (float)acc;
+          } else {
+            float acc = 0.f;
+            for (int ky = 0; ky < 6; ky++) {
+              const float* r = (const float*)prow(s, (uint32_t)ty[yy].idx[ky]);
+              float ra = 0.f;
+              for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx[x].wf[kx], r[ch * tx[x].idx[kx] + c], ra);
+              acc = __builtin_fmaf(ty[yy].wf[ky], ra, acc);
+            }
+            o[ch * x + c] = acc;
+          }
+        }
+    }
+    free(tx); free(ty);
+    return VPFO_OK;
+  }
+  tap* tx = (tap*)malloc(sizeof(tap) * dw);
+  tap* ty = (tap*)malloc(sizeof(tap) * dh);
+  if (!tx || !ty) { free(tx); free(ty); return VPFO_BAD_ARG; }
+  make_taps(mode, interp, sw, dw, tx);
+  make_taps(mode, interp, sh, dh, ty);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int64_t yy = 0; yy < (int64_t)dh; yy++) {
+    const float *r0 = (const float*)prow(s, ty[yy].i0), *r1 = (const float*)prow(s, ty[yy].i1);
+    float* o = (float*)prow(d, (uint32_t)yy);
+    for (uint32_t x = 0; x < dw; x++)
+      for (int k = 0; k < ch; k++) {
+        const float p00 = r0[ch * tx[x].i0 + k], p01 = r0[ch * tx[x].i1 + k], p10 = r1[ch * tx[x].i0 + k], p11 = r1[ch * tx[x].i1 + k];
+        if (mode == VPFO_EXACT) {
+          const double top = p00 + tx[x].f * ((double)p01 - p00), bot = p10 + tx[x].f * ((double)p11 - p10);
+          o[ch * x + k] = (float)(top + ty[yy].f * (bot - top));
+        } else {
+          const float top = __builtin_fmaf(tx[x].ff, p01 - p00, p00), bot = __builtin_fmaf(tx[x].ff, p11 - p10, p10);
+          o[ch * x + k] = __builtin_fmaf(ty[yy].ff, bot - top, top);
+        }
+      }
+  }
+  free(tx); free(ty);
+  return VPFO_OK;
+}
+
 int vpfo_resize(int mode, int fmt, int interp, uint32_t sw, uint32_t sh, const vpfo_plane s[3], uint32_t dw,
                 uint32_t dh, const vpfo_plane d[3]) {
   if (interp != 0 && interp != 1 && interp != 2) return VPFO_UNSUPPORTED;
@@ -770,6 +835,10 @@ int vpfo_resize(int mode, int fmt, int interp, uint32_t sw, uint32_t sh, const v
       for (int k = 1; k < 3 && !e; k++) e = resize_plane(mode, interp, 1, cdiv2(sw), cdiv2(sh), &s[k], cdiv2(dw), cdiv2(dh), &d[k]);
       return e;
     }
+    case F_RGB_32F: return resize_plane_f32(mode, interp, 3, sw, sh, &s[0], dw, dh, &d[0]);
+    case F_RGB_32F_PLANAR:
+      for (int k = 0; k < 3; k++) { int e = resize_plane_f32(mode, interp, 1, sw, sh, &s[k], dw, dh, &d[k]); if (e) return e; }
+      return VPFO_OK;
     case F_NV12: { /* = de-interleave, resize U and V planes, re-interleave (Tasks.cpp:1303-1318): ch=2 does exactly that */
       int e = resize_plane(mode, interp, 1, sw, sh, &s[0], dw, dh, &d[0]);
       if (!e) e = resize_plane(mode, interp, 2, cdiv2(sw), cdiv2(sh), &s[1], cdiv2(dw), cdiv2(dh), &d[1]);

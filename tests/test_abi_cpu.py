@@ -55,7 +55,9 @@ def test_validation_without_gpu(capi):
     assert capi.convert(ex, capi.NV12, capi.RGB, 1, 0, 16, 16, [(0, 64), (0x2000, 64)], [(0x3000, 64)], check=False) == capi.ERR_BAD_ARG
     assert capi.convert(ex, capi.NV12, capi.RGB, 1, 0, 16, 16, fake, [(0x3000, 47)], check=False) == capi.ERR_BAD_ARG
     assert capi.resize(ex, capi.RGB, 7, 16, 16, [(0x1000, 64)], 8, 8, [(0x2000, 64)], check=False) == capi.ERR_UNSUPPORTED
-    assert capi.resize(ex, capi.RGB_32F, capi.INTERP_LINEAR, 16, 16, [(0x1000, 256)], 8, 8, [(0x2000, 256)], check=False) == capi.ERR_UNSUPPORTED
+    assert capi.resize(ex, capi.P10, capi.INTERP_LINEAR, 16, 16, [(0x1000, 256), (0x5000, 256)], 8, 8, [(0x2000, 256), (0x6000, 256)], check=False) == capi.ERR_UNSUPPORTED
+    # float surfaces are resizable (reference R4 / R5), but their rows must be 4-B aligned
+    assert capi.resize(ex, capi.RGB_32F, capi.INTERP_LINEAR, 16, 16, [(0x1002, 256)], 8, 8, [(0x2000, 256)], check=False) == capi.ERR_BAD_ARG
     assert capi.resize(ex, capi.RGB, capi.INTERP_LINEAR, 16, 16, [(0x1000, 47)], 8, 8, [(0x2000, 64)], check=False) == capi.ERR_BAD_ARG
     assert capi.remap(ex, capi.NV12, 16, 16, (0x1000, 64), 0x2000, 64, 0x3000, 64, 16, 16, (0x4000, 64), check=False) == capi.ERR_UNSUPPORTED
     assert capi.remap(ex, capi.RGB, 16, 16, (0x1000, 64), 0x2000, 60, 0x3000, 64, 16, 16, (0x4000, 64), check=False) == capi.ERR_BAD_ARG

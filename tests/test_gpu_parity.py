@@ -288,6 +288,33 @@ def test_resize_bilinear(capi, oracle, fmt):
     _resize(capi, oracle, f, capi.INTERP_NEAREST, 128, 72, 50, 30)
 
 
+@pytest.mark.parametrize("fmt", ["RGB_32F", "RGB_32F_PLANAR"])
+def test_resize_float_surfaces(capi, oracle, fmt):
+    """reference R4 / R5 (Tasks.cpp:1334-1445): float surfaces through vpf_resize, every filter: bit-exact vs the oracle's
+    fp32 restatement, within float rounding of the double-precision evaluation; misaligned float rows are refused"""
+    f = getattr(capi, fmt)
+    for (sw, sh, dw, dh) in [(640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 20, 15), (1280, 30, 320, 9)]:
+        src = oracle.synth(f, sw, sh, 1045)
+        for interp in (capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_LANCZOS3):
+            _, want = oracle.resize(f, interp, sw, sh, src, dw, dh, oracle.FP32)
+            for align in (256, 4):
+                s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(f, dw, dh), align)
+                capi.resize(capi.make_exec(stream_handle()), f, interp, sw, sh, s.desc(), dw, dh, d.desc())
+                torch.cuda.synchronize()
+                got, intact = d.download()
+                assert intact
+                assert_planes_equal(got, want, f"float resize {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} a{align}")
+            _, ex = oracle.resize(f, interp, sw, sh, src, dw, dh, oracle.EXACT)
+            for g, e in zip(got, ex):  # fp32 source coordinates carry ~1e-7 * x of error; samples are in [0, 1)
+                if interp == capi.INTERP_NEAREST:  # a coordinate that rounds across a sample boundary picks a neighbour
+                    assert (g != e).mean() < 0.01
+                else:
+                    assert np.abs(g - e).max() < 3e-4
+    src = oracle.synth(f, 64, 16, 1)
+    s, d = DevPlanes(src, 256, 0, 2), DevPlanes(oracle.alloc(f, 32, 8))
+    assert capi.resize(capi.make_exec(stream_handle()), f, capi.INTERP_LINEAR, 64, 16, s.desc(), 32, 8, d.desc(), check=False) == capi.ERR_BAD_ARG
+
+
 def test_resize_4k_to_720p_full(capi, oracle):
     """BASELINE.json configs[2]: 3840x2160 RGB -> 1280x720 bilinear, full frame"""
     _resize(capi, oracle, capi.RGB, capi.INTERP_LINEAR, 3840, 2160, 1280, 720)

@@ -146,6 +146,24 @@ def test_fused_convert_resizer_equals_the_two_step_chain(oracle):
         nvc.PySurfaceConvertResizer(w, h, PF.RGB, tw, th, PF.RGB_PLANAR, GPU)  # not a fusable pair
 
 
+def test_resizer_accepts_float_surfaces_like_the_reference(oracle):
+    """ResizeSurface accepts RGB_32F and RGB_32F_PLANAR (Tasks.cpp:1458-1476): RGB -> RGB_32F -> resize -> RGB_32F_PLANAR"""
+    w, h, tw, th = 640, 360, 224, 126
+    src = oracle.synth(oracle.RGB, w, h, 16)
+    rgb = upload(PF.RGB, w, h, src)
+    f32 = nvc.PySurfaceConverter(w, h, PF.RGB, PF.RGB_32F, GPU).Execute(rgb, None)
+    small = nvc.PySurfaceResizer(tw, th, PF.RGB_32F, GPU).Execute(f32)
+    pln = nvc.PySurfaceConverter(tw, th, PF.RGB_32F, PF.RGB_32F_PLANAR, GPU).Execute(small, None)
+    small_pln = nvc.PySurfaceResizer(tw // 2, th // 2, PF.RGB_32F_PLANAR, GPU).Execute(pln)
+    assert (small.Width(), small.Height(), small.Format()) == (tw, th, PF.RGB_32F) and not small_pln.Empty()
+    _, a = oracle.convert(oracle.RGB, oracle.RGB_32F, 0, 0, w, h, src)
+    _, b = oracle.resize(oracle.RGB_32F, oracle.LINEAR, w, h, a, tw, th)
+    _, c = oracle.convert(oracle.RGB_32F, oracle.RGB_32F_PLANAR, 0, 0, tw, th, b)
+    _, d = oracle.resize(oracle.RGB_32F_PLANAR, oracle.LINEAR, tw, th, c, tw // 2, th // 2)
+    assert np.array_equal(download(small, np.float32), host_frame(b).view(np.float32))
+    assert np.array_equal(download(small_pln, np.float32), host_frame(d).view(np.float32))
+
+
 def test_chain_remap_sample(oracle):
     """samples/SampleRemap.py:74-101 — NV12 -> RGB -> Remap(RGB) -> download, BT.709 + JPEG"""
     w, h = 640, 360

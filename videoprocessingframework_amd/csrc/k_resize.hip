@@ -476,6 +476,75 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
 }
 
 // ------------------------------------------------------------------------------------------
+// 32-bit float surfaces (RGB_32F: CH = 3 interleaved, RGB_32F_PLANAR: CH = 1 per plane; reference
+// NppResizeSurfacePacked32F3C_Impl / NppResizeSurface32FPlanar_Impl, Tasks.cpp:1334-1445): the same taps and operation
+// order as the 8-bit kernels on float samples; the result is neither rounded nor clamped.  Lane = one destination pixel
+// (CH x 4 B per lane: a wave stores 256-768 contiguous bytes).
+// ------------------------------------------------------------------------------------------
+template <int CH, int INTERP>
+__global__ __launch_bounds__(256) void k_resize_f32(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                    uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                    float scx, float scy) {
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  float* o = reinterpret_cast<float*>(dst + (size_t)y * dp) + (size_t)CH * x;
+  if constexpr (INTERP == VPF_INTERP_LANCZOS3) {
+    const LTap tx = make_ltap(x, scx), ty = make_ltap(y, scy);
+    uint32_t xi[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int32_t i = tx.i0 + k - 2;
+      xi[k] = (uint32_t)(i < 0 ? 0 : (i > (int32_t)sw - 1 ? (int32_t)sw - 1 : i)) * CH;
+    }
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 6; ky++) {
+      const int32_t j = ty.i0 + ky - 2;
+      const float* r = reinterpret_cast<const float*>(src + (size_t)(j < 0 ? 0 : (j > (int32_t)sh - 1 ? (int32_t)sh - 1 : j)) * sp);
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        float ra = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], r[xi[kx] + c], ra);
+        acc[c] = __builtin_fmaf(ty.w[ky], ra, acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) o[c] = acc[c];
+  } else {
+    const Tap tx = make_tap<INTERP>(x, scx, sw), ty = make_tap<INTERP>(y, scy, sh);
+    const float* r0 = reinterpret_cast<const float*>(src + (size_t)ty.i0 * sp);
+    const float* r1 = reinterpret_cast<const float*>(src + (size_t)ty.i1 * sp);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      if constexpr (INTERP == VPF_INTERP_NEAREST) {
+        o[c] = r0[CH * tx.i0 + c];
+      } else {
+        const float p00 = r0[CH * tx.i0 + c], p01 = r0[CH * tx.i1 + c], p10 = r1[CH * tx.i0 + c], p11 = r1[CH * tx.i1 + c];
+        const float top = __builtin_fmaf(tx.f, p01 - p00, p00), bot = __builtin_fmaf(tx.f, p11 - p10, p10);
+        o[c] = __builtin_fmaf(ty.f, bot - top, top);
+      }
+    }
+  }
+}
+
+hipError_t launch_resize_f32(hipStream_t st, int ch, int interp, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp,
+                             uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp) {
+  const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
+  dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+#define VPF_F32(C, I) VPF_LAUNCH((k_resize_f32<C, I>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy)
+  if (ch == 3) {
+    if (interp == VPF_INTERP_LANCZOS3) VPF_F32(3, VPF_INTERP_LANCZOS3); else if (interp == VPF_INTERP_LINEAR) VPF_F32(3, VPF_INTERP_LINEAR); else VPF_F32(3, VPF_INTERP_NEAREST);
+  } else {
+    if (interp == VPF_INTERP_LANCZOS3) VPF_F32(1, VPF_INTERP_LANCZOS3); else if (interp == VPF_INTERP_LINEAR) VPF_F32(1, VPF_INTERP_LINEAR); else VPF_F32(1, VPF_INTERP_NEAREST);
+  }
+#undef VPF_F32
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // remap: dst(x,y) = bilinear(src, xmap[y][x], ymap[y][x]); out-of-range -> dst untouched [A9].
 // One lane per destination pixel: the map reads (8 B/px) are coalesced, texels are gathers.
 // ------------------------------------------------------------------------------------------

@@ -344,8 +344,8 @@ void ResizeSurface::SetInterpolation(int interp) {
 }
 int ResizeSurface::GetInterpolation() const { return pImpl->interp; }
 static bool resize_format_ok(Pixel_Format f) {
-  switch (f) {  // reference: packed 3C, planar (YUV420/YCBCR/YUV444/RGB_PLANAR), NV12; + Y (Tasks.cpp:1458-1476)
-    case RGB: case BGR: case YUV420: case YCBCR: case YUV444: case RGB_PLANAR: case NV12: case Y: return true;
+  switch (f) {  // reference: packed 3C, planar (YUV420/YCBCR/YUV444/RGB_PLANAR), RGB_32F, RGB_32F_PLANAR, NV12; + Y (Tasks.cpp:1458-1476)
+    case RGB: case BGR: case YUV420: case YCBCR: case YUV444: case RGB_PLANAR: case NV12: case Y: case RGB_32F: case RGB_32F_PLANAR: return true;
     default: return false;
   }
 }

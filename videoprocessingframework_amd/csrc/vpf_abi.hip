@@ -219,12 +219,15 @@ vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, co
   if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR && interp != VPF_INTERP_LANCZOS3) return VPF_ERR_UNSUPPORTED;
   switch (fmt) {
     case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_Y: case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
-    case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_NV12: break;
+    case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_NV12: case VPF_FMT_RGB_32F: case VPF_FMT_RGB_32F_PLANAR: break;
     default: return VPF_ERR_UNSUPPORTED;
   }
   if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !planes_ok(fmt, ss.width, src) ||
       !planes_ok(fmt, ds.width, dst))
     return VPF_ERR_BAD_ARG;
+  if (fmt == VPF_FMT_RGB_32F || fmt == VPF_FMT_RGB_32F_PLANAR)  // float samples: rows must be 4-B aligned
+    for (int k = 0; k < num_planes(fmt); k++)
+      if ((((uintptr_t)src[k].ptr | src[k].pitch | (uintptr_t)dst[k].ptr | dst[k].pitch) & 3)) return VPF_ERR_BAD_ARG;
   DeviceGuard guard(exec->device);
   if (guard.err != hipSuccess) return status_of(guard.err);
   hipStream_t st = static_cast<hipStream_t>(exec->stream);
@@ -234,7 +237,15 @@ vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, co
   };
   const uint32_t scw = (ss.width + 1) / 2, sch = (ss.height + 1) / 2, dcw = (ds.width + 1) / 2, dch = (ds.height + 1) / 2;
   hipError_t e = hipSuccess;
+  auto onef = [&](int ch, int k) {
+    return launch_resize_f32(st, ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(src[k].ptr), src[k].pitch, ds.width,
+                             ds.height, static_cast<uint8_t*>(dst[k].ptr), dst[k].pitch);
+  };
   switch (fmt) {
+    case VPF_FMT_RGB_32F: e = onef(3, 0); break;
+    case VPF_FMT_RGB_32F_PLANAR:
+      for (int k = 0; k < 3 && e == hipSuccess; k++) e = onef(1, k);
+      break;
     case VPF_FMT_RGB: case VPF_FMT_BGR: e = one(3, 0, ss.width, ss.height, ds.width, ds.height); break;
     case VPF_FMT_Y: e = one(1, 0, ss.width, ss.height, ds.width, ds.height); break;
     case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:

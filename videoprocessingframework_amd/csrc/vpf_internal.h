@@ -55,6 +55,8 @@ hipError_t launch_relayout(hipStream_t st, int src_fmt, int dst_fmt, uint32_t w,
                            const BatchArgs& a);
 hipError_t launch_resize(hipStream_t st, int channels, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
                          uint32_t spitch, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dpitch);
+hipError_t launch_resize_f32(hipStream_t st, int channels, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
+                             uint32_t spitch, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dpitch);
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t spitch,
                         const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch, uint32_t dw,
                         uint32_t dh, uint8_t* dst, uint32_t dpitch);
