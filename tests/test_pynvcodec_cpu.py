@@ -179,8 +179,11 @@ def test_nv12_rgb_601_mpeg_is_rejected_like_the_reference(capfd):
 
 def test_resizer_and_remaper_argument_errors():
     PF = nvc.PixelFormat
-    with pytest.raises(RuntimeError):
-        nvc.PySurfaceResizer(64, 32, PF.RGB_32F, 0, 0)  # Tasks.cpp:1470-1475
+    for bad in (PF.P10, PF.YUV422, PF.UNDEFINED):
+        with pytest.raises(RuntimeError):
+            nvc.PySurfaceResizer(64, 32, bad, 0, 0)  # Tasks.cpp:1470-1475
+    for ok in (PF.RGB, PF.BGR, PF.YUV420, PF.YCBCR, PF.YUV444, PF.RGB_PLANAR, PF.RGB_32F, PF.RGB_32F_PLANAR, PF.NV12):
+        assert nvc.PySurfaceResizer(64, 32, ok, 0, 0).Format() == ok  # the reference ctor's list (:1458-1469)
     rs = nvc.PySurfaceResizer(64, 32, PF.RGB, 0, 0)
     assert rs.Format() == PF.RGB
     assert rs.Execute(nvc.Surface.Make(PF.BGR, 128, 64, context=0)).Empty()  # format mismatch -> TASK_EXEC_FAIL (:1166-1168)
