@@ -34,10 +34,13 @@ def build(force: bool = False) -> str:
     src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("vpf_oracle.c", "vpf_oracle.h", "Makefile"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.check_call(["make", "-C", _HERE, "libvpforacle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src/TC/TC_CORE/src") and (
-        force or not os.path.exists(os.path.join(_HERE, "_ref", "libtc_core_ref.so"))
-    ):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src/TC/TC_CORE/src"):
+        ref = os.path.join(_HERE, "_ref")
+        shim_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_shim.cpp", "ref_tc_shim.cpp", "Makefile"))
+        for target, so in (("ref", "libtc_core_ref.so"), ("ref_tc", "libtc_ref.so")):  # the reference's own sources
+            so = os.path.join(ref, so)
+            if force or not os.path.exists(so) or os.path.getmtime(so) < shim_m:
+                subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -1,0 +1,2 @@
+#pragma once
+#include "fake_npp.h"

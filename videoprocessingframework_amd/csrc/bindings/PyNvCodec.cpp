@@ -559,6 +559,14 @@ PYBIND11_MODULE(_PyNvCodec, m) {
         "also accept colour-space/range combinations the reference's converters reject although the kernels implement them");
   m.def("ConverterPairSupport", &ConvertSurface::PairSupport, py::arg("src_format"), py::arg("dst_format"),
         "1: pair exists in the reference's ConvertSurface, 2: additive pair, 0: unsupported");
+  m.def("ConverterResolve",
+        [](Pixel_Format in, Pixel_Format out, std::shared_ptr<ColorspaceConversionContext> cc) -> py::object {
+          int cs = 0, cr = 0;
+          if (!ConvertSurface::ResolveContext(in, out, cc.get(), &cs, &cr)) return py::none();
+          return py::make_tuple(cs, cr);
+        },
+        py::arg("src_format"), py::arg("dst_format"), py::arg("cc_ctx") = nullptr,
+        "(color_space, color_range) the converter would use for this pair and context, or None if it refuses the combination");
   m.def("KernelLibraryVersion", []() { return std::string(vpf_version()); });
   m.def("AllocPinned",
         [](size_t nbytes) {

@@ -49,7 +49,7 @@ Traits traits(Pixel_Format f) {
     case P12: return {K_SEMI, 2, "P12"};
     case YUV420: return {K_420, 1, "YUV420"};
     case YCBCR: return {K_420, 1, "YCBCR"};
-    case YUV420_10bit: return {K_420, 2, "YUV420_10bit"};
+    case YUV420_10bit: return {K_SEMI, 2, "YUV420_10bit"};  // the reference factory builds a SurfaceP12 for it (MemoryInterfaces.cpp:662-664)
     case YUV422: return {K_422, 1, "YUV422"};
     case RGB: return {K_PACKED3, 1, "RGB"};
     case BGR: return {K_PACKED3, 1, "BGR"};

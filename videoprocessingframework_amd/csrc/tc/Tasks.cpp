@@ -189,6 +189,15 @@ int ConvertSurface::PairSupport(Pixel_Format in, Pixel_Format out) {
   return p ? p->level : 0;
 }
 
+bool ConvertSurface::ResolveContext(Pixel_Format in, Pixel_Format out, const ColorspaceConversionContext* c, int* cs, int* cr) {
+  const PairInfo* p = find_pair(in, out);
+  int a = 0, b = 0;
+  const bool ok = p && resolve_ctx(*p, c, &a, &b);
+  if (ok && cs) *cs = a;
+  if (ok && cr) *cr = b;
+  return ok;
+}
+
 ConvertSurface::ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str)
     : Task("HipConvertSurface", numInputs, numOutputs, nullptr, nullptr), pImpl(nullptr) {
   const PairInfo* p = find_pair(in, out);

@@ -22,6 +22,10 @@ public:
   // 1 if the reference's ConvertSurface ctor accepts the pair (TasksColorCvt.cpp:1313-1360), 2 if it is one of
   // our additive pairs (e.g. the fused NV12 -> RGB_PLANAR), 0 otherwise
   static int PairSupport(Pixel_Format inFormat, Pixel_Format outFormat);
+  // Which colour model Run() would use for this pair under `ctx` (nullptr = no context input): true + (*cs, *cr) in
+  // vpf_hip.h values, or false when the combination is refused like the reference refuses it.  Host logic only
+  // (tests/test_reference_tc_pin.py compares it with the reference's own dispatch code).
+  static bool ResolveContext(Pixel_Format inFormat, Pixel_Format outFormat, const ColorspaceConversionContext* ctx, int* cs, int* cr);
 
 private:
   static const uint32_t numInputs = 2U, numOutputs = 1U;
