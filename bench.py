@@ -47,6 +47,17 @@ def _pitched(rows, row_bytes, dev, gen=None, align=256):
     return t, pitch
 
 
+def _rows_touched(S: int, D: int):
+    """source rows a D-row bilinear resize of S rows reads, in the kernels' fp32 arithmetic: tap i0 always, tap i1 only when
+    its weight is non-zero (4K -> 720p is exactly 3x: every centre falls on a source row, so one row per output row)"""
+    d = np.arange(D, dtype=np.float32)
+    s_ = np.clip((d + np.float32(0.5)) * np.float32(np.float32(S) / np.float32(D)) - np.float32(0.5), 0, S - 1).astype(np.float32)
+    i0 = s_.astype(np.int64)
+    i1 = np.minimum(i0 + 1, S - 1)
+    rows = set(i0.tolist()) | set(i1[(s_ - i0.astype(np.float32)) != 0].tolist())
+    return rows
+
+
 class Workload:
     """Device-resident ring of frames + the launch closure for one step."""
 
@@ -90,12 +101,14 @@ class Workload:
                 self.keep += [src, mid, dst]
                 self.items.append(([(src.data_ptr(), sp), (src.data_ptr() + h * sp, sp)], [(mid.data_ptr(), mp)], [(dst.data_ptr(), dp)]))
             self.px_per_step = ring * w * h
+            luma_rows = _rows_touched(h, self.dh)  # algorithmic bytes at row granularity: only the rows the taps touch
+            chroma_rows = {r >> 1 for r in luma_rows}
             if name == "fused_4k_720p":
-                self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * self.dw * self.dh)
+                self.bytes_per_step = ring * (len(luma_rows) * w + len(chroma_rows) * w + 3 * self.dw * self.dh)
                 self.launches_per_step = ring if mode == "single" else (ring + 31) // 32
                 self.fbatch = capi.make_batch([(s_, d_) for s_, _, d_ in self.items])
             else:
-                self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h + 3 * w * h + 3 * self.dw * self.dh)
+                self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h + len(luma_rows) * 3 * w + 3 * self.dw * self.dh)
                 self.launches_per_step = 2 * ring
             self.kernel = "k_convert_resize" if name == "fused_4k_720p" else "k_yuv420_rgb_p4 + k_resize"
         else:

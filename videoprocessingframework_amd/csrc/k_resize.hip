@@ -217,13 +217,16 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
   const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
+  // exact-alignment shortcuts (bit-identical: fma(0, finite, t) == t): fy == 0 for the whole row (odd integer vertical
+  // scale, e.g. 4K -> 720p) -> the second source row is neither loaded nor read; fx == 0 in every lane -> one tap per row
+  const bool row1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ty.f)) != 0u;
   Span<IT> s0, s1;
   s0.load(src + (size_t)ty.i0 * sp, base, nq, lane);
-  s1.load(src + (size_t)ty.i1 * sp, base, nq, lane);
+  if (row1) s1.load(src + (size_t)ty.i1 * sp, base, nq, lane);
   u32x4* st0 = dyn_strip + (wv * 2) * rowq;
   u32x4* st1 = st0 + rowq;
   s0.store(st0, nq, lane);
-  s1.store(st1, nq, lane);
+  if (row1) s1.store(st1, nq, lane);
   wave_lds_sync();
   const uint32_t x0 = xs + lane * 4;
   if (x0 >= dw) return;
@@ -235,8 +238,19 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
     const uint32_t x = (x0 + k < dw) ? x0 + k : dw - 1;
     const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
     const uint32_t a = CH * tx.i0 - base, b = CH * tx.i1 - base;
+    const bool tap1 = __builtin_amdgcn_ballot_w64(tx.f != 0.f) != 0;  // wave-uniform
 #pragma unroll
-    for (int c = 0; c < CH; c++) o[k * CH + c] = bilerp(r0[a + c], r0[b + c], r1[a + c], r1[b + c], tx.f, ty.f);
+    for (int c = 0; c < CH; c++) {
+      const float p00 = (float)r0[a + c];
+      const float top = tap1 ? __builtin_fmaf(tx.f, (float)r0[b + c] - p00, p00) : p00;
+      if (row1) {
+        const float p10 = (float)r1[a + c];
+        const float bot = tap1 ? __builtin_fmaf(tx.f, (float)r1[b + c] - p10, p10) : p10;
+        o[k * CH + c] = __builtin_fmaf(ty.f, bot - top, top) + 0.5f;
+      } else {
+        o[k * CH + c] = top + 0.5f;
+      }
+    }
   }
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
@@ -855,10 +869,15 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
   constexpr int NS = (SRC == FC_NV12) ? 4 : 6;
   // both source rows usually sit on ONE chroma row when the upper one is even: wave-uniform, so the second chroma
   // strip is neither loaded nor converted (its chroma terms are the first row's)
-  const bool one_crow = (ty.i0 >> 1) == (ty.i1 >> 1);
+  // Exact-alignment shortcuts (bit-identical: fma(0, anything finite, t) == t).  With an odd integer scale factor (4K ->
+  // 720p is 3x) every destination pixel centre falls on a source pixel centre: fy == 0 for the whole row (wave-uniform:
+  // the second source row is neither loaded nor converted) and fx == 0 in every lane (checked per pixel with a wave
+  // vote: the second tap is not converted).  That is 4 instead of 16 conversions per lane and half the source rows.
+  const bool row1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ty.f)) != 0u;
+  const bool one_crow = !row1 || (ty.i0 >> 1) == (ty.i1 >> 1);
   Span<IT> sp_[NS];  // every strip's loads are in flight before the first LDS write
   sp_[0].load(f.s[0] + (size_t)ty.i0 * f.sp[0], ybase, ynq, lane);
-  sp_[1].load(f.s[0] + (size_t)ty.i1 * f.sp[0], ybase, ynq, lane);
+  if (row1) sp_[1].load(f.s[0] + (size_t)ty.i1 * f.sp[0], ybase, ynq, lane);
   sp_[2].load(f.s[1] + (size_t)(ty.i0 >> 1) * f.sp[1], cbase, cnq, lane);
   if (!one_crow) sp_[3].load(f.s[1] + (size_t)(ty.i1 >> 1) * f.sp[1], cbase, cnq, lane);
   if constexpr (SRC != FC_NV12) {
@@ -868,7 +887,7 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
   u32x4* const wstrip = dyn_strip + wv * NS * rowq;
   auto strip_at = [&](int k) { return wstrip + k * rowq; };
   sp_[0].store(strip_at(0), ynq, lane);
-  sp_[1].store(strip_at(1), ynq, lane);
+  if (row1) sp_[1].store(strip_at(1), ynq, lane);
   sp_[2].store(strip_at(2), cnq, lane);
   if (!one_crow) sp_[3].store(strip_at(3), cnq, lane);
   if constexpr (SRC != FC_NV12) {
@@ -902,6 +921,26 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     return k;
   };
   auto rnd = [](f32x2 t) { return f32x2{(float)sat_rne(t[0]), (float)sat_rne(t[1])}; };
+  // horizontal lerp of one source row: top[c] = fma(fx, p1[c] - p0[c], p0[c]) on the converted + rounded taps
+  auto row_pair = [&](int r, int cr, uint32_t l0, uint32_t l1, uint32_t a0, uint32_t a1, float fx, float t3[3]) {
+    const uint8_t* yp = reinterpret_cast<const uint8_t*>(strip_at(r));
+    const f32x2 yv = {(float)yp[l0], (float)yp[l1]};
+    const Chroma2 kk = chroma2(a0, a1, cr);
+    const f32x2 rr = rnd(__builtin_elementwise_fma(yv, cy2, kk.rc)), gg = rnd(__builtin_elementwise_fma(yv, cy2, kk.gc)), bb = rnd(__builtin_elementwise_fma(yv, cy2, kk.bc));
+    t3[0] = __builtin_fmaf(fx, rr[1] - rr[0], rr[0]); t3[1] = __builtin_fmaf(fx, gg[1] - gg[0], gg[0]); t3[2] = __builtin_fmaf(fx, bb[1] - bb[0], bb[0]);
+  };
+  auto row_single = [&](int r, int cr, uint32_t l0, uint32_t a0, float t3[3]) {  // fx == 0 in every lane: top == first tap
+    const float yv = (float)reinterpret_cast<const uint8_t*>(strip_at(r))[l0];
+    float u, v;
+    if constexpr (SRC == FC_NV12) {
+      const uint32_t d0 = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(strip_at(2 + cr)) + a0);
+      u = ubyte<0>(d0); v = ubyte<1>(d0);
+    } else {
+      u = (float)reinterpret_cast<const uint8_t*>(strip_at(2 + cr))[a0]; v = (float)reinterpret_cast<const uint8_t*>(strip_at(4 + cr))[a0];
+    }
+    const Chroma kk = chroma_terms(c, u, v);
+    t3[0] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.rc)); t3[1] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.gc)); t3[2] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.bc));
+  };
   float o[3][4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -909,17 +948,18 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
     const uint32_t l0 = tx.i0 - ybase, l1 = tx.i1 - ybase;
     const uint32_t a0 = (SRC == FC_NV12 ? (tx.i0 & ~1u) : (tx.i0 >> 1)) - cbase, a1 = (SRC == FC_NV12 ? (tx.i1 & ~1u) : (tx.i1 >> 1)) - cbase;
-    const uint8_t* y0p = reinterpret_cast<const uint8_t*>(strip_at(0));
-    const uint8_t* y1p = reinterpret_cast<const uint8_t*>(strip_at(1));
-    const f32x2 ya = {(float)y0p[l0], (float)y0p[l1]}, yb = {(float)y1p[l0], (float)y1p[l1]};
-    const Chroma2 ka = chroma2(a0, a1, 0);
-    Chroma2 kb = ka;
-    if (!one_crow) kb = chroma2(a0, a1, 1);
-    const f32x2 ra = rnd(__builtin_elementwise_fma(ya, cy2, ka.rc)), ga = rnd(__builtin_elementwise_fma(ya, cy2, ka.gc)), ba = rnd(__builtin_elementwise_fma(ya, cy2, ka.bc));
-    const f32x2 rb = rnd(__builtin_elementwise_fma(yb, cy2, kb.rc)), gb = rnd(__builtin_elementwise_fma(yb, cy2, kb.gc)), bb = rnd(__builtin_elementwise_fma(yb, cy2, kb.bc));
-    o[0][k] = bilerp(ra[0], ra[1], rb[0], rb[1], tx.f, ty.f);
-    o[1][k] = bilerp(ga[0], ga[1], gb[0], gb[1], tx.f, ty.f);
-    o[2][k] = bilerp(ba[0], ba[1], bb[0], bb[1], tx.f, ty.f);
+    const bool tap1 = __builtin_amdgcn_ballot_w64(tx.f != 0.f) != 0;  // wave-uniform
+    float top[3], bot[3];
+    if (tap1) row_pair(0, 0, l0, l1, a0, a1, tx.f, top); else row_single(0, 0, l0, a0, top);
+    if (row1) {
+      const int cr = one_crow ? 0 : 1;
+      if (tap1) row_pair(1, cr, l0, l1, a0, a1, tx.f, bot); else row_single(1, cr, l0, a0, bot);
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) o[ch][k] = __builtin_fmaf(ty.f, bot[ch] - top[ch], top[ch]) + 0.5f;
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) o[ch][k] = top[ch] + 0.5f;
+    }
   }
   const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
   if constexpr (DST == FC_PLANAR) {
