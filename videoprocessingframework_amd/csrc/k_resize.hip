@@ -922,15 +922,13 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
   };
   auto rnd = [](f32x2 t) { return f32x2{(float)sat_rne(t[0]), (float)sat_rne(t[1])}; };
   // horizontal lerp of one source row: top[c] = fma(fx, p1[c] - p0[c], p0[c]) on the converted + rounded taps
-  auto row_pair = [&](int r, int cr, uint32_t l0, uint32_t l1, uint32_t a0, uint32_t a1, float fx, float t3[3]) {
+  auto row_pair = [&](int r, const Chroma2& kk, uint32_t l0, uint32_t l1, float fx, float t3[3]) {
     const uint8_t* yp = reinterpret_cast<const uint8_t*>(strip_at(r));
     const f32x2 yv = {(float)yp[l0], (float)yp[l1]};
-    const Chroma2 kk = chroma2(a0, a1, cr);
     const f32x2 rr = rnd(__builtin_elementwise_fma(yv, cy2, kk.rc)), gg = rnd(__builtin_elementwise_fma(yv, cy2, kk.gc)), bb = rnd(__builtin_elementwise_fma(yv, cy2, kk.bc));
     t3[0] = __builtin_fmaf(fx, rr[1] - rr[0], rr[0]); t3[1] = __builtin_fmaf(fx, gg[1] - gg[0], gg[0]); t3[2] = __builtin_fmaf(fx, bb[1] - bb[0], bb[0]);
   };
-  auto row_single = [&](int r, int cr, uint32_t l0, uint32_t a0, float t3[3]) {  // fx == 0 in every lane: top == first tap
-    const float yv = (float)reinterpret_cast<const uint8_t*>(strip_at(r))[l0];
+  auto chroma1 = [&](uint32_t a0, int cr) {  // chroma terms of the first tap only
     float u, v;
     if constexpr (SRC == FC_NV12) {
       const uint32_t d0 = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(strip_at(2 + cr)) + a0);
@@ -938,7 +936,10 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     } else {
       u = (float)reinterpret_cast<const uint8_t*>(strip_at(2 + cr))[a0]; v = (float)reinterpret_cast<const uint8_t*>(strip_at(4 + cr))[a0];
     }
-    const Chroma kk = chroma_terms(c, u, v);
+    return chroma_terms(c, u, v);
+  };
+  auto row_single = [&](int r, const Chroma& kk, uint32_t l0, float t3[3]) {  // fx == 0 in every lane: top == first tap
+    const float yv = (float)reinterpret_cast<const uint8_t*>(strip_at(r))[l0];
     t3[0] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.rc)); t3[1] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.gc)); t3[2] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.bc));
   };
   float o[3][4];
@@ -950,10 +951,22 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     const uint32_t a0 = (SRC == FC_NV12 ? (tx.i0 & ~1u) : (tx.i0 >> 1)) - cbase, a1 = (SRC == FC_NV12 ? (tx.i1 & ~1u) : (tx.i1 >> 1)) - cbase;
     const bool tap1 = __builtin_amdgcn_ballot_w64(tx.f != 0.f) != 0;  // wave-uniform
     float top[3], bot[3];
-    if (tap1) row_pair(0, 0, l0, l1, a0, a1, tx.f, top); else row_single(0, 0, l0, a0, top);
+    if (tap1) {
+      const Chroma2 ka = chroma2(a0, a1, 0);
+      row_pair(0, ka, l0, l1, tx.f, top);
+      if (row1) {
+        if (one_crow) row_pair(1, ka, l0, l1, tx.f, bot);  // both rows sit on one chroma row: its terms are reused
+        else row_pair(1, chroma2(a0, a1, 1), l0, l1, tx.f, bot);
+      }
+    } else {
+      const Chroma ka = chroma1(a0, 0);
+      row_single(0, ka, l0, top);
+      if (row1) {
+        if (one_crow) row_single(1, ka, l0, bot);
+        else row_single(1, chroma1(a0, 1), l0, bot);
+      }
+    }
     if (row1) {
-      const int cr = one_crow ? 0 : 1;
-      if (tap1) row_pair(1, cr, l0, l1, a0, a1, tx.f, bot); else row_single(1, cr, l0, a0, bot);
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) o[ch][k] = __builtin_fmaf(ty.f, bot[ch] - top[ch], top[ch]) + 0.5f;
     } else {
