@@ -322,12 +322,14 @@ def test_resize_4k_to_720p_full(capi, oracle):
 
 def test_fused_convert_resize(capi, oracle):
     for (sw, sh, dw, dh) in [(3840, 2160, 1280, 720), (640, 360, 224, 224), (100, 60, 333, 201), (18, 10, 7, 5),
-                             (1920, 64, 260, 9), (4096, 16, 258, 3), (322, 38, 1000, 111)]:
+                             (1920, 64, 260, 9), (4096, 16, 258, 3), (322, 38, 1000, 111),
+                             (1920, 64, 960, 32), (3840, 32, 1920, 16), (64, 36, 32, 18), (2000, 16, 1000, 8), (1936, 8, 968, 4),  # exact 2x
+                             (1920, 48, 640, 16), (960, 30, 320, 10), (1280, 50, 256, 10)]:                                      # exact 3x / 5x
         for sfmt in ("NV12", "YUV420"):
             src = oracle.synth(getattr(oracle, sfmt), sw, sh, 1050)
             for dfmt in ("RGB", "BGR", "RGB_PLANAR"):
                 _, want = oracle.convert_resize(getattr(oracle, sfmt), getattr(oracle, dfmt), 1, 0, sw, sh, src, dw, dh)
-                for variant, align in ((0, 256), (9, 256), (0, 2)):  # LDS-staged, forced gather, unaligned (-> gather)
+                for variant, align in ((0, 256), (40, 256), (9, 256), (0, 2)):  # fast paths, general LDS kernel, forced gather, unaligned (-> gather)
                     s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, dfmt), dw, dh), align)
                     prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
                     try:
@@ -493,6 +495,10 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
             sw = 16 * int(rng.integers(1, 160))  # wide regular rows: several 64-column tiles / 256-px wave spans
         dw, dh = max(1, int(sw * rng.uniform(0.15, 3.0))), max(1, int(sh * rng.uniform(0.15, 3.0)))
         dw, dh = min(dw, 2600), min(dh, 300)
+        if rng.integers(4) == 0:  # exact integer ratios (2x: quad kernel; odd: exact-alignment shortcuts), per axis
+            kx, ky = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+            dw, dh = max(1, min(dw, 600)), max(1, min(dh, 40))
+            sw, sh = dw * kx, dh * ky
         align = int(rng.choice([256, 256, 16, 4, 1]))
         variant = int(rng.choice([0, 0, 40, 43, 9]))
         if rng.integers(4) == 0:  # fused NV12 / YUV420 -> resize -> RGB family

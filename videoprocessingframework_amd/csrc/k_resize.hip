@@ -995,6 +995,75 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact 2x down-scale (4K -> 1080p, 1080p -> 540p ...): s = (d + 0.5) * 2 - 0.5 = 2d + 0.5 exactly, so every destination
+// pixel is the bilerp with fx = fy = 0.5 of the 2 x 2 block (2x..2x+1, 2y..2y+1), which shares ONE chroma sample.  That
+// structure needs no tap arithmetic, no LDS gathers and one chroma evaluation per destination pixel: a lane converts
+// 16 x 2 source pixels exactly like the NV12 -> RGB kernels (dwordx4 loads, convert4) and averages them; ~70 VALU per
+// destination pixel instead of ~120 in the general kernel.  Bit-identical to it (same fma order on the same values).
+// Requires NV12, sw == 2 dw, sh == 2 dh, sw % 16 == 0 (% 32 for packed outputs), 16-B aligned source rows, 8-B (planar) / 16-B
+// (packed) aligned destination rows.
+// ------------------------------------------------------------------------------------------
+template <int DST>
+__global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t dh,
+                                                      uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[DST == FC_PLANAR ? 1 : 4 * 96];  // 1.5 KiB per wave: 64 lanes x 24 packed bytes
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const FrameDesc f = args.f[blockIdx.y];
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  const uint32_t xs = chunk * 1024 + lane * 16;  // first source pixel of the lane; destination pixel xs / 2
+  const bool act = xs < sw;
+  float o[3][8];
+  if (act) {
+    const u32x4 ya = ldg<true, u32x4>(f.s[0] + (size_t)(2 * y) * f.sp[0] + xs);
+    const u32x4 yb = ldg<true, u32x4>(f.s[0] + (size_t)(2 * y + 1) * f.sp[0] + xs);
+    const u32x4 uv = ldg<true, u32x4>(f.s[1] + (size_t)y * f.sp[1] + xs);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j])), k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+      const Quad qa = convert4(c, ya[j], k0, k1), qb = convert4(c, yb[j], k0, k1);
+      auto half2 = [](const float* t, const float* b, int i) {  // bilerp(p00, p01, p10, p11, 0.5, 0.5) on rounded taps
+        const float p00 = (float)sat_rne(t[i]), p01 = (float)sat_rne(t[i + 1]), p10 = (float)sat_rne(b[i]), p11 = (float)sat_rne(b[i + 1]);
+        const float top = __builtin_fmaf(0.5f, p01 - p00, p00), bot = __builtin_fmaf(0.5f, p11 - p10, p10);
+        return __builtin_fmaf(0.5f, bot - top, top) + 0.5f;
+      };
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        o[0][2 * j + e] = half2(qa.r, qb.r, 2 * e); o[1][2 * j + e] = half2(qa.g, qb.g, 2 * e); o[2][2 * j + e] = half2(qa.b, qb.b, 2 * e);
+      }
+    }
+  }
+  const uint32_t xd = xs >> 1;
+  if constexpr (DST == FC_PLANAR) {
+    if (!act) return;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+      stg<true, u32x2>(f.d[ch] + (size_t)y * f.dp[ch] + xd, u32x2{pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]), pack4_trunc(o[ch][4], o[ch][5], o[ch][6], o[ch][7])});
+  } else {
+    constexpr int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
+    uint32_t* t = reinterpret_cast<uint32_t*>(tile + wv * 96);
+    if (act) {
+#pragma unroll
+      for (int g = 0; g < 2; g++) {  // 4 px -> 3 dwords, twice
+        const int q = 4 * g;
+        t[lane * 6 + 3 * g] = pack4_trunc(o[a][q], o[1][q], o[b][q], o[a][q + 1]);
+        t[lane * 6 + 3 * g + 1] = pack4_trunc(o[1][q + 1], o[b][q + 1], o[a][q + 2], o[1][q + 2]);
+        t[lane * 6 + 3 * g + 2] = pack4_trunc(o[b][q + 2], o[a][q + 3], o[1][q + 3], o[b][q + 3]);
+      }
+    }
+    wave_lds_sync();
+    uint8_t* row = f.d[0] + (size_t)y * f.dp[0];
+    const uint32_t row_bytes = 3 * (sw >> 1);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {  // the wave's 1536 B leave as one dense 1-KiB store and one 512-B store
+      const uint32_t idx = k * 64 + lane, off = chunk * 1536 + idx * 16;
+      if (idx < 96 && off < row_bytes) stg<true, u32x4>(row + off, (tile + wv * 96)[idx]);
+    }
+  }
+}
+
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh,
                                  uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
@@ -1005,6 +1074,21 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
     const FrameDesc& f = a.f[i];
     for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) vec_ok &= ((((uintptr_t)f.d[k] | f.dp[k]) & 3) == 0);
     for (int k = 0; k < (src_fc == FC_NV12 ? 2 : 3); k++) lds_ok = lds_ok && !(((uintptr_t)f.s[k] | f.sp[k]) & 15);
+  }
+  // exact 2x from NV12: the quad-structured kernel (no taps, no gathers); tuning 40 / 9 keep the general kernels
+  // (packed rows leave as 16-B stores: 3 * dw must be a multiple of 16)
+  if (src_fc == FC_NV12 && sw == 2 * dw && sh == 2 * dh && sw % (dst_fc == FC_PLANAR ? 16 : 32) == 0 && lds_ok && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40) {
+    bool ok16 = true;
+    for (uint32_t i = 0; i < n; i++)
+      for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) ok16 = ok16 && !(((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & (dst_fc == FC_PLANAR ? 7 : 15));
+    if (ok16) {
+      const uint32_t chunks = (sw + 1023) / 1024, tasks = chunks * dh;
+      dim3 hgrid((tasks + 3) / 4, n);
+      if (dst_fc == FC_RGB) VPF_LAUNCH((k_convert_half<FC_RGB>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks);
+      else if (dst_fc == FC_BGR) VPF_LAUNCH((k_convert_half<FC_BGR>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks);
+      else VPF_LAUNCH((k_convert_half<FC_PLANAR>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks);
+      return hipGetLastError();
+    }
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);
   const uint32_t lds = 4 * (src_fc == FC_NV12 ? 4 : 6) * rowb;

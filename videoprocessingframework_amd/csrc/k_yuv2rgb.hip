@@ -24,19 +24,6 @@ namespace vpf {
 // ---------------------------------------------------------------------------------------------
 // pixel math
 // ---------------------------------------------------------------------------------------------
-// One dword of luma (4 px) + the two chroma samples covering it -> three channel quads.
-struct Quad {
-  float r[4], g[4], b[4];
-};
-VPF_DEV Quad convert4(const Yuv2RgbCoef& c, uint32_t yd, const Chroma& k0, const Chroma& k1) {
-  Quad q;
-  float y0 = ubyte<0>(yd), y1 = ubyte<1>(yd), y2 = ubyte<2>(yd), y3 = ubyte<3>(yd);
-  q.r[0] = __builtin_fmaf(y0, c.cy, k0.rc); q.g[0] = __builtin_fmaf(y0, c.cy, k0.gc); q.b[0] = __builtin_fmaf(y0, c.cy, k0.bc);
-  q.r[1] = __builtin_fmaf(y1, c.cy, k0.rc); q.g[1] = __builtin_fmaf(y1, c.cy, k0.gc); q.b[1] = __builtin_fmaf(y1, c.cy, k0.bc);
-  q.r[2] = __builtin_fmaf(y2, c.cy, k1.rc); q.g[2] = __builtin_fmaf(y2, c.cy, k1.gc); q.b[2] = __builtin_fmaf(y2, c.cy, k1.bc);
-  q.r[3] = __builtin_fmaf(y3, c.cy, k1.rc); q.g[3] = __builtin_fmaf(y3, c.cy, k1.gc); q.b[3] = __builtin_fmaf(y3, c.cy, k1.bc);
-  return q;
-}
 // 4 px -> 12 packed bytes (3 dwords) in R,G,B or B,G,R order
 template <int DST, int PACK>
 VPF_DEV void pack_rgb12(const Quad& q, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
