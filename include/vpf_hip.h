@@ -174,8 +174,14 @@ VPF_API const char* vpf_version(void);
  * (src/PyNvCodec/src/PyNvCodec.cpp:427-429). */
 VPF_API int vpf_device_count(void);
 
-/* Tuning hook used by bench.py / tests to select a kernel variant for NV12->RGB (0 = default).
- * Not part of the reference surface. Returns the previous value. */
+/* Tuning hook used by bench.py / tests to select a kernel family (process-wide; 0 = default policy).  A hint, never a
+ * correctness switch: every value produces identical pixels and silently falls back where it does not apply.
+ *   0        default policy (fastest applicable kernel per call)
+ *   9        the any-size / any-alignment generic kernels everywhere (byte accesses, gather resize / remap)
+ *   40       the narrower fast paths instead of the 16-px "r16" / tiled / quad kernels (A/B runs, test coverage)
+ *   1..43    individual NV12 -> RGB kernels and bandwidth probes (k_yuv2rgb.hip launch_420; probes 15, 22-26 write
+ *            wrong pixels on purpose and are for bench.py --sweep only)
+ * Not part of the reference surface.  Returns the previous value. */
 VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_NV12_RGB_VARIANT 1
 
