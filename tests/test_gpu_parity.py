@@ -293,7 +293,8 @@ def test_resize_float_surfaces(capi, oracle, fmt):
     """reference R4 / R5 (Tasks.cpp:1334-1445): float surfaces through vpf_resize, every filter: bit-exact vs the oracle's
     fp32 restatement, within float rounding of the double-precision evaluation; misaligned float rows are refused"""
     f = getattr(capi, fmt)
-    for (sw, sh, dw, dh) in [(640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 20, 15), (1280, 30, 320, 9)]:
+    for (sw, sh, dw, dh) in [(640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 20, 15), (1280, 30, 320, 9),
+                             (960, 45, 320, 15), (300, 35, 100, 7)]:  # the last two: odd integer factors (centre-sample shortcut)
         src = oracle.synth(f, sw, sh, 1045)
         for interp in (capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_LANCZOS3):
             _, want = oracle.resize(f, interp, sw, sh, src, dw, dh, oracle.FP32)
