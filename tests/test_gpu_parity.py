@@ -415,6 +415,26 @@ def test_async_on_user_stream(capi, oracle):
     assert_planes_equal(got, want, "stream")
 
 
+def test_plain_c_client_of_the_abi(oracle, tmp_path):
+    """include/vpf_hip.h from a plain C99 program (gcc, no C++ / Python / torch in the process): the drop-in boundary as
+    any FFI would use it.  tests/c/abi_smoke.c converts a constant frame and reports the pixel; compare with the oracle."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "abi_smoke")
+    pkg = os.path.join(root, "videoprocessingframework_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
+                           "-I/opt/rocm/include", os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L" + pkg, "-lvpfhip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    for (y, u, v) in [(16, 128, 128), (235, 128, 128), (81, 90, 240), (145, 54, 34), (0, 0, 0), (255, 255, 255), (120, 200, 30)]:
+        r = subprocess.run([exe, str(y), str(u), str(v)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        lines = r.stdout.strip().split("\n")
+        assert lines[-1] == "ok"
+        assert tuple(int(t) for t in lines[0].split()) == oracle.yuv2rgb_px(1, 0, y, u, v, oracle.FP32), (y, u, v, lines[0])
+
+
 def test_abi_is_hip_graph_capturable(capi, oracle):
     """the C ABI never synchronises, allocates or queries the stream, so a chain of per-frame calls can be captured into a
     hipGraph (torch.cuda.CUDAGraph = hipStreamBeginCapture on the ABI's stream) and replayed"""
