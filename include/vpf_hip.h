@@ -91,7 +91,8 @@ typedef struct vpf_plane {
   uint32_t reserved; /* must be 0 */
 } vpf_plane;
 
-/* Size in pixels of the full-resolution image (plane 0 for YUV formats). */
+/* Size in pixels of the full-resolution image (plane 0 for YUV formats).  1 .. 65536 per dimension; anything else is
+ * VPF_ERR_BAD_ARG (row-byte and offset arithmetic is 32-bit). */
 typedef struct vpf_size {
   uint32_t width;
   uint32_t height;

@@ -56,6 +56,9 @@ def test_validation_without_gpu(capi):
     assert capi.convert(ex, capi.NV12, capi.RGB, 1, 0, 16, 16, fake, [(0x3000, 47)], check=False) == capi.ERR_BAD_ARG
     assert capi.resize(ex, capi.RGB, 7, 16, 16, [(0x1000, 64)], 8, 8, [(0x2000, 64)], check=False) == capi.ERR_UNSUPPORTED
     assert capi.resize(ex, capi.P10, capi.INTERP_LINEAR, 16, 16, [(0x1000, 256), (0x5000, 256)], 8, 8, [(0x2000, 256), (0x6000, 256)], check=False) == capi.ERR_UNSUPPORTED
+    # dimensions beyond 65536 are refused before any byte arithmetic can wrap (12 * width for RGB_32F)
+    assert capi.convert(ex, capi.RGB, capi.RGB_32F, 0, 0, 0x20000000, 16, [(0x1000, 64)], [(0x3000, 64)], check=False) == capi.ERR_BAD_ARG
+    assert capi.resize(ex, capi.RGB, capi.INTERP_LINEAR, 16, 16, [(0x1000, 64)], 70000, 8, [(0x2000, 0xFFFFFFF0)], check=False) == capi.ERR_BAD_ARG
     # float surfaces are resizable (reference R4 / R5), but their rows must be 4-B aligned
     assert capi.resize(ex, capi.RGB_32F, capi.INTERP_LINEAR, 16, 16, [(0x1002, 256)], 8, 8, [(0x2000, 256)], check=False) == capi.ERR_BAD_ARG
     assert capi.resize(ex, capi.RGB, capi.INTERP_LINEAR, 16, 16, [(0x1000, 47)], 8, 8, [(0x2000, 64)], check=False) == capi.ERR_BAD_ARG

@@ -84,6 +84,9 @@ static uint32_t row_bytes(int f, int k, uint32_t w) {
     default: return 0;
   }
 }
+// Pictures larger than 65536 in either dimension are refused: beyond that 12 * width (RGB_32F row bytes) and the kernels'
+// 32-bit in-row offsets could wrap, and no video surface is that large.
+static bool dims_ok(vpf_size s) { return s.width && s.height && s.width <= 65536u && s.height <= 65536u; }
 static bool planes_ok(int f, uint32_t w, const vpf_plane* p) {
   const int n = num_planes(f);
   if (!n || !p) return false;
@@ -170,7 +173,7 @@ vpf_status vpf_convert_batch(const vpf_exec* exec, int sf, int df, int cs, int c
                              const vpf_frame_io* frames) {
   const Family fam = classify(sf, df, cs, cr);
   if (fam == FAM_NONE) return VPF_ERR_UNSUPPORTED;
-  if (!exec || !frames || !n || !size.width || !size.height) return VPF_ERR_BAD_ARG;
+  if (!exec || !frames || !n || !dims_ok(size)) return VPF_ERR_BAD_ARG;
   for (uint32_t i = 0; i < n; i++)
     if (!planes_ok(sf, size.width, frames[i].src) || !planes_ok(df, size.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
   DeviceGuard guard(exec->device);
@@ -222,7 +225,7 @@ vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, co
     case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_NV12: case VPF_FMT_RGB_32F: case VPF_FMT_RGB_32F_PLANAR: break;
     default: return VPF_ERR_UNSUPPORTED;
   }
-  if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !planes_ok(fmt, ss.width, src) ||
+  if (!exec || !dims_ok(ss) || !dims_ok(ds) || !planes_ok(fmt, ss.width, src) ||
       !planes_ok(fmt, ds.width, dst))
     return VPF_ERR_BAD_ARG;
   if (fmt == VPF_FMT_RGB_32F || fmt == VPF_FMT_RGB_32F_PLANAR)  // float samples: rows must be 4-B aligned
@@ -265,7 +268,7 @@ vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, co
 vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane* src, const float* xmap, uint32_t xp,
                      const float* ymap, uint32_t yp, vpf_size ds, const vpf_plane* dst) {
   if (fmt != VPF_FMT_RGB && fmt != VPF_FMT_BGR) return VPF_ERR_UNSUPPORTED;
-  if (!exec || !ss.width || !ss.height || !ds.width || !ds.height || !xmap || !ymap || !planes_ok(fmt, ss.width, src) ||
+  if (!exec || !dims_ok(ss) || !dims_ok(ds) || !xmap || !ymap || !planes_ok(fmt, ss.width, src) ||
       !planes_ok(fmt, ds.width, dst) || xp < 4 * ds.width || yp < 4 * ds.width || (xp & 3) || (yp & 3) ||
       ((uintptr_t)xmap & 3) || ((uintptr_t)ymap & 3))
     return VPF_ERR_BAD_ARG;
@@ -279,7 +282,7 @@ vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane
 vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size ss, vpf_size ds,
                                     uint32_t n, const vpf_frame_io* frames) {
   if (!(sf == VPF_FMT_NV12 || sf == VPF_FMT_YUV420) || rgb_class(df) < 0 || !cscr_ok(cs, cr)) return VPF_ERR_UNSUPPORTED;
-  if (!exec || !frames || !n || !ss.width || !ss.height || !ds.width || !ds.height) return VPF_ERR_BAD_ARG;
+  if (!exec || !frames || !n || !dims_ok(ss) || !dims_ok(ds)) return VPF_ERR_BAD_ARG;
   for (uint32_t i = 0; i < n; i++)
     if (!planes_ok(sf, ss.width, frames[i].src) || !planes_ok(df, ds.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
   DeviceGuard guard(exec->device);
