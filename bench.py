@@ -89,7 +89,7 @@ class Workload:
             self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
             self.launches_per_step = (ring + 31) // 32 if mode == "batch" else ring
             self.kernel = ("k_nv12_rgb_p16 (16 px/lane, LDS-transposed 1 KiB NT stores; 4 workgroups/CU when batched)" if self.dst_fmt == capi.RGB
-                           else "k_yuv420_rgb_p4 (4 px/lane, planar dword stores)")
+                           else "k_nv12_planar_r16 (one row x 1024 px per wave, 16 px/lane, three 1-KiB non-temporal plane stores)")
         elif name in ("resize_4k_720p", "fused_4k_720p"):
             self.w, self.h, self.dw, self.dh = 3840, 2160, 1280, 720
             w, h = self.w, self.h
@@ -110,7 +110,8 @@ class Workload:
             else:
                 self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h + len(luma_rows) * 3 * w + 3 * self.dw * self.dh)
                 self.launches_per_step = 2 * ring
-            self.kernel = "k_convert_resize" if name == "fused_4k_720p" else "k_yuv420_rgb_p4 + k_resize"
+            self.kernel = ("k_convert_resize_lds (exact-alignment shortcuts at 3x)" if name == "fused_4k_720p"
+                           else "k_nv12_rgb_p16 + k_resize (odd integer factor: centre-sample kernel)")
         else:
             raise SystemExit(f"unknown workload {name}")
 
