@@ -666,6 +666,22 @@ VPF_DEV int32_t wave_minmax(int32_t v) {
             op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// the same reduction on two unsigned 16-bit fields at once (v_pk_min_u16 / v_pk_max_u16): (x | y << 16)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <bool MAX>
+VPF_DEV uint32_t wave_minmax_u16x2(uint32_t v) {
+  auto op = [](uint32_t a, uint32_t b) {
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
+  };
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+  return op(op((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+            op((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
 VPF_DEV void lds_row_taps(const uint8_t* lrow, uint32_t o, bool two, float* t0, float* t1) {
   const uint32_t sh = o & 3u;
   const uint32_t* p = reinterpret_cast<const uint32_t*>(lrow + (o & ~3u));
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(256) void k_remap3_tile(const uint8_t* __restrict__
                                                      uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   __shared__ u32x4 L[kRemapLdsBytes / 16 + 2];
-  __shared__ int32_t bb[4][4];  // per wave: xmin, xmax, ymin, ymax of its source taps
+  __shared__ uint32_t bb[4][2];  // per wave: (xmin | ymin << 16), (xmax | ymax << 16) of its source taps
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t x = blockIdx.x * 64 + 4 * (lane & 15), y = blockIdx.y * 16 + (t >> 6) * 4 + (lane >> 4);
   const bool in = x < dw && y < dh;  // dw % 4 == 0: a lane's four pixels are inside or outside together
@@ -695,7 +711,11 @@ __global__ __launch_bounds__(256) void k_remap3_tile(const uint8_t* __restrict__
   bool ok[4], twox[4];
   uint32_t x0[4], y0[4], y1[4];
   float fx[4], fy[4];
-  int32_t lxmin = 0x7fffffff, lxmax = -1, lymin = 0x7fffffff, lymax = -1;
+  uint32_t kmin = 0xffffffffu, kmax = 0u;  // packed (x | y << 16); source dimensions are <= 65536 (vpf_abi dims_ok), coordinates < 65536
+  auto pk = [](uint32_t a, uint32_t b, bool mx) {
+    const u16x2 p = __builtin_bit_cast(u16x2, a), q = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, mx ? __builtin_elementwise_max(p, q) : __builtin_elementwise_min(p, q));
+  };
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const float sx = sx4[k], sy = sy4[k];
@@ -705,24 +725,19 @@ __global__ __launch_bounds__(256) void k_remap3_tile(const uint8_t* __restrict__
     twox[k] = x0[k] + 1 < sw;
     y1[k] = (y0[k] + 1 < sh) ? y0[k] + 1 : sh - 1;
     fx[k] = cx - (float)x0[k]; fy[k] = cy - (float)y0[k];
-    if (ok[k]) {
-      const int32_t xe = (int32_t)(twox[k] ? x0[k] + 1 : x0[k]);
-      lxmin = (int32_t)x0[k] < lxmin ? (int32_t)x0[k] : lxmin; lxmax = xe > lxmax ? xe : lxmax;
-      lymin = (int32_t)y0[k] < lymin ? (int32_t)y0[k] : lymin; lymax = (int32_t)y1[k] > lymax ? (int32_t)y1[k] : lymax;
-    }
+    const uint32_t lo = x0[k] | (y0[k] << 16), hi = (twox[k] ? x0[k] + 1 : x0[k]) | (y1[k] << 16);
+    kmin = pk(kmin, ok[k] ? lo : 0xffffffffu, false);
+    kmax = pk(kmax, ok[k] ? hi : 0u, true);
   }
   {
-    const int32_t a = wave_minmax<false>(lxmin), b = wave_minmax<true>(lxmax), c = wave_minmax<false>(lymin), d = wave_minmax<true>(lymax);
-    if (lane == 0) { bb[t >> 6][0] = a; bb[t >> 6][1] = b; bb[t >> 6][2] = c; bb[t >> 6][3] = d; }
+    const uint32_t a = wave_minmax_u16x2<false>(kmin), b = wave_minmax_u16x2<true>(kmax);
+    if (lane == 0) { bb[t >> 6][0] = a; bb[t >> 6][1] = b; }
   }
   __syncthreads();
-  auto mn = [](int32_t a, int32_t b) { return a < b ? a : b; };
-  auto mx = [](int32_t a, int32_t b) { return a > b ? a : b; };
-  const int32_t bxmax = mx(mx(bb[0][1], bb[1][1]), mx(bb[2][1], bb[3][1]));
-  if (bxmax < 0) return;  // every pixel of the tile maps outside the source: destination untouched
-  const uint32_t xmin = (uint32_t)mn(mn(bb[0][0], bb[1][0]), mn(bb[2][0], bb[3][0])), xmax = (uint32_t)bxmax;
-  const uint32_t ymin = (uint32_t)mn(mn(bb[0][2], bb[1][2]), mn(bb[2][2], bb[3][2]));
-  const uint32_t ymax = (uint32_t)mx(mx(bb[0][3], bb[1][3]), mx(bb[2][3], bb[3][3]));
+  const uint32_t bmin = pk(pk(bb[0][0], bb[1][0], false), pk(bb[2][0], bb[3][0], false), false);
+  const uint32_t bmax = pk(pk(bb[0][1], bb[1][1], true), pk(bb[2][1], bb[3][1], true), true);
+  if (bmin == 0xffffffffu) return;  // every pixel of the tile maps outside the source: destination untouched
+  const uint32_t xmin = bmin & 0xffffu, ymin = bmin >> 16, xmax = bmax & 0xffffu, ymax = bmax >> 16;
   const uint32_t bx0 = (3 * xmin) & ~15u, pitch_l = (3 * (xmax + 1) - bx0 + 15) & ~15u, rows = ymax - ymin + 1;
   const bool use_lds = (size_t)pitch_l * rows + 16 <= kRemapLdsBytes;
   if (use_lds) {
@@ -740,9 +755,10 @@ __global__ __launch_bounds__(256) void k_remap3_tile(const uint8_t* __restrict__
     float a0[3], a1[3], b0[3], b1[3];
     if (use_lds) {
       const uint8_t* lb = reinterpret_cast<const uint8_t*>(L);
-      const uint32_t off = 3 * x0[k] - bx0;
-      // pixels that map outside read tile-local garbage coordinates (0,0): keep the addresses inside the staged box
-      const uint32_t oc = ok[k] ? off : 3 * xmin - bx0, r0 = ok[k] ? y0[k] - ymin : 0, r1 = ok[k] ? y1[k] - ymin : 0;
+      // pixels that map outside carry the placeholder coordinate (0, 0): clamping to the box minimum keeps their (unused)
+      // reads inside the staged box and leaves every valid coordinate unchanged
+      const uint32_t xc = x0[k] > xmin ? x0[k] : xmin, r0 = (y0[k] > ymin ? y0[k] : ymin) - ymin, r1 = (y1[k] > ymin ? y1[k] : ymin) - ymin;
+      const uint32_t oc = 3 * xc - bx0;
       lds_row_taps(lb + r0 * pitch_l, oc, twox[k], a0, a1);
       lds_row_taps(lb + r1 * pitch_l, oc, twox[k], b0, b1);
     } else {
@@ -767,7 +783,7 @@ hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t*
                         uint32_t dp) {
   const bool fast = tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && (dw % 4 == 0) && !(((uintptr_t)src | sp) & 3) &&
                     !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sp >= 12;
-  if (fast && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15)) {
+  if (fast && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15) && sw < 65536 && sh < 65536) {  // tap coordinates travel as u16 pairs
     const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
     dim3 tgrid((dw + 63) / 64, (dh + 15) / 16);
     VPF_LAUNCH(k_remap3_tile, tgrid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh, vec_ok);
