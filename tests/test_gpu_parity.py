@@ -282,7 +282,8 @@ def test_resize_bilinear(capi, oracle, fmt):
     f = getattr(capi, fmt)
     for (sw, sh, dw, dh) in [(3840, 64, 1280, 22), (640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 2, 2),
                              (1000, 40, 300, 13), (2000, 16, 260, 5), (4096, 8, 258, 2), (300, 20, 1000, 70),
-                             (320, 180, 1280, 720), (640, 40, 700, 333), (50, 30, 1921, 47)]:
+                             (320, 180, 1280, 720), (640, 40, 700, 333), (50, 30, 1921, 47),
+                             (1920, 64, 960, 32), (72, 20, 36, 10), (1000, 8, 500, 4), (2056, 6, 1028, 3)]:  # last four: exact 2x
         _resize(capi, oracle, f, capi.INTERP_LINEAR, sw, sh, dw, dh)
     _resize(capi, oracle, f, capi.INTERP_LINEAR, 128, 72, 50, 30, align=1)
     _resize(capi, oracle, f, capi.INTERP_NEAREST, 128, 72, 50, 30)

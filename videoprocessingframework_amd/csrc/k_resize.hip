@@ -414,6 +414,45 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact 2x bilinear down-scale (4K -> 1080p ...): s = 2 d + 0.5 exactly, so every destination pixel is the fx = fy = 0.5
+// bilerp of one 2 x 2 block: no tap arithmetic, no LDS, pure streaming.  Lane = 4 destination pixels = 8 source pixels x 2
+// rows (CH x 8 contiguous bytes per row, loaded as 8-B units), one CH x 4-B store.  Bit-identical to the general kernels.
+// Requires dw % 4 == 0, 8-B aligned source rows, 4-B (8-B for CH == 2) aligned destination rows.
+// ------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256) void k_resize_half(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
+                                                     uint32_t dw, uint32_t dh) {
+  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t x0 = gx * 4;
+  if (x0 >= dw || y >= dh) return;
+  uint32_t ra[2 * CH], rb[2 * CH];  // 8 source pixels of rows 2y and 2y + 1
+  const uint8_t* pa = src + (size_t)(2 * y) * sp + (size_t)CH * 2 * x0;
+  const uint8_t* pb = pa + sp;
+#pragma unroll
+  for (int j = 0; j < CH; j++) {
+    const u32x2 a = ldg<true, u32x2>(pa + 8 * j), b = ldg<true, u32x2>(pb + 8 * j);
+    ra[2 * j] = a[0]; ra[2 * j + 1] = a[1]; rb[2 * j] = b[0]; rb[2 * j + 1] = b[1];
+  }
+  float o[4 * CH];
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const int i0 = CH * 2 * e + c, i1 = i0 + CH;  // byte index of the two horizontal taps inside the lane's run
+      auto byte = [](const uint32_t* d, int i) { return (float)((d[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+      o[e * CH + c] = bilerp(byte(ra, i0), byte(ra, i1), byte(rb, i0), byte(rb, i1), 0.5f, 0.5f);
+    }
+  uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
+  if constexpr (CH == 3) {
+    stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+  } else if constexpr (CH == 2) {
+    stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+  } else {
+    stg<true, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+  }
+}
+
 // strip bytes a wave needs for its source span (<= 255*scale + 3 pixels, + 16-B alignment slack on both ends),
 // rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
 static uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
@@ -462,6 +501,15 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
   if (interp != VPF_INTERP_NEAREST && sw % dw == 0 && sh % dh == 0 && ((sw / dw) & 1) && ((sh / dh) & 1) && sw < (1u << 22) && sh < (1u << 22) &&
       tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9)
     interp = VPF_INTERP_NEAREST;
+  // exact 2x bilinear: the quad-structured streaming kernel
+  if (interp == VPF_INTERP_LINEAR && sw == 2 * dw && sh == 2 * dh && dw % 4 == 0 && !(((uintptr_t)src | sp) & 7) &&
+      !(((uintptr_t)dst | dp) & (ch == 2 ? 7 : 3)) && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9) {
+    dim3 hgrid((dw / 4 + 63) / 64, (dh + 3) / 4);
+    if (ch == 1) VPF_LAUNCH((k_resize_half<1>), hgrid, dim3(256), 0, st, src, sp, dst, dp, dw, dh);
+    else if (ch == 2) VPF_LAUNCH((k_resize_half<2>), hgrid, dim3(256), 0, st, src, sp, dst, dp, dw, dh);
+    else VPF_LAUNCH((k_resize_half<3>), hgrid, dim3(256), 0, st, src, sp, dst, dp, dw, dh);
+    return hipGetLastError();
+  }
   if (interp == VPF_INTERP_LANCZOS3) {
     if (launch_resize_tile(st, true, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy)) return hipGetLastError();
     dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
