@@ -83,7 +83,7 @@ class Workload:
                     dd = [(dst.data_ptr() + i * h * dp, dp) for i in range(3)]
                 self.keep += [src, dst]
                 frames.append(([(src.data_ptr(), sp), (src.data_ptr() + h * sp, sp)], dd))
-            self.frames = frames
+            self.frames = [(capi.planes(s_), capi.planes(d_)) for s_, d_ in frames]  # descriptors built once, like a C caller
             self.batch = capi.make_batch(frames)
             self.px_per_step = ring * w * h
             self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
@@ -99,7 +99,7 @@ class Workload:
                 mid, mp = _pitched(h, 3 * w, dev)
                 dst, dp = _pitched(self.dh, 3 * self.dw, dev)
                 self.keep += [src, mid, dst]
-                self.items.append(([(src.data_ptr(), sp), (src.data_ptr() + h * sp, sp)], [(mid.data_ptr(), mp)], [(dst.data_ptr(), dp)]))
+                self.items.append((capi.planes([(src.data_ptr(), sp), (src.data_ptr() + h * sp, sp)]), capi.planes([(mid.data_ptr(), mp)]), capi.planes([(dst.data_ptr(), dp)])))
             self.px_per_step = ring * w * h
             luma_rows = _rows_touched(h, self.dh)  # algorithmic bytes at row granularity: only the rows the taps touch
             chroma_rows = {r >> 1 for r in luma_rows}

@@ -107,7 +107,10 @@ def make_exec(stream: int = 0, device: int = -1) -> Exec:
 
 
 def planes(desc) -> "C.Array[Plane]":
-    """desc: iterable of (device_ptr, pitch_bytes), at most 3."""
+    """desc: iterable of (device_ptr, pitch_bytes), at most 3; an array built earlier is passed through (callers in a
+    per-frame loop build their descriptors once)."""
+    if isinstance(desc, Plane * 3):
+        return desc
     p = (Plane * 3)()
     for i, (ptr, pitch) in enumerate(desc):
         p[i].ptr, p[i].pitch = ptr, pitch
@@ -130,10 +133,10 @@ def make_batch(frames) -> "C.Array[FrameIO]":
     """frames: list of (src_desc, dst_desc) with desc as in planes()."""
     arr = (FrameIO * len(frames))()
     for i, (s, d) in enumerate(frames):
-        for k, (ptr, pitch) in enumerate(s):
-            arr[i].src[k].ptr, arr[i].src[k].pitch = ptr, pitch
-        for k, (ptr, pitch) in enumerate(d):
-            arr[i].dst[k].ptr, arr[i].dst[k].pitch = ptr, pitch
+        s, d = planes(s), planes(d)  # accepts (ptr, pitch) lists and prebuilt Plane arrays alike
+        for k in range(3):
+            arr[i].src[k].ptr, arr[i].src[k].pitch = s[k].ptr, s[k].pitch
+            arr[i].dst[k].ptr, arr[i].dst[k].pitch = d[k].ptr, d[k].pitch
     return arr
 
 
