@@ -5,8 +5,10 @@
 // RGB -> RGB_32F (rbg8_rgb32f :1222-1254), RGB_32F -> RGB_32F_PLANAR (rgb32f_deinterleave :1268-1297),
 // P10/P12 -> NV12 (p16_nv12 :990-1045), RGB/BGR -> Y (rbg8_y :293-308).
 //
-// All of it is 2-6 B/px of pure HBM streaming.  Fast paths move 12-16 B per lane with byte permutes
-// (v_perm_b32) in registers; the generic path handles any size/alignment with byte accesses.
+// All of it is 2-24 B/px of pure HBM streaming.  Three tiers per converter, bit-identical: the r16 kernels (a wave = one row x
+// 1024 px, every global access a dense non-temporal 1-KiB run, packed sides through a wave-private LDS transpose) for
+// 16-px / 16-B regular frames; p4 / p16 kernels (4-16 B per lane, v_perm_b32 shuffles in registers) for 4-B aligned ones;
+// a generic per-pixel kernel for everything else.
 #include "vpf_device.h"
 
 namespace vpf {

@@ -1,16 +1,24 @@
-// k_resize.hip — bilinear / nearest resize, per-pixel remap, and fused NV12 -> resize -> RGB (gfx950).
+// k_resize.hip — nearest / bilinear / Lanczos-3 resize (8-bit and float surfaces), per-pixel remap, and the fused
+// NV12 / YUV420 -> bilinear -> RGB kernels (gfx950).
 //
-// Replaces nppiResize_8u_C3R / _C1R (reference: NppResizeSurfacePacked3C_Impl::Run and
-// NppResizeSurfacePlanar_Impl::Run, src/TC/src/Tasks.cpp:1162-1203,1217-1261) and nppiRemap_8u_C3R
-// (NppRemapSurfacePacked3C_Impl::Run, Tasks.cpp:1555-1602).  The reference resizer asks NPP for
-// Lanczos (:1190); north_star specifies bilinear, which is what is implemented (interp enum kept).
+// Replaces nppiResize_8u_C3R / _C1R (reference: NppResizeSurfacePacked3C_Impl::Run and NppResizeSurfacePlanar_Impl::Run,
+// src/TC/src/Tasks.cpp:1162-1203,1217-1261), nppiResize_32f_C3R / _C1R (:1334-1445) and nppiRemap_8u_C3R
+// (NppRemapSurfacePacked3C_Impl::Run, :1555-1602).  The reference resizer asks NPP for Lanczos (:1190); north_star
+// specifies bilinear, which is the default here (VPF_INTERP_LANCZOS3 selects Lanczos-3).
 //
 // Sampling convention (SURVEY.md §8c [A8]): s = (d + 0.5) * (S / D) - 0.5 clamped to [0, S-1];
 // i0 = floor(s), i1 = min(i0 + 1, S - 1), f = s - i0;
 //   top = fma(fx, p01 - p00, p00); bot = fma(fx, p11 - p10, p10); out = sat_trunc(fma(fy, bot - top, top) + 0.5)
-// One lane produces 4 consecutive destination pixels so packed RGB goes out as one 12-byte store and
-// single-channel planes as one dword.  Source texels are gathers served by L2 (a 4K RGB source row is
-// 11.5 KB; a wave touches <= 2 source rows).
+//
+// Kernel families, all bit-identical to one another (launch_resize / launch_convert_resize / launch_remap pick):
+//   k_resize, k_resize_lanczos, k_resize_f32, k_convert_resize, k_remap3   gather forms: any size / alignment
+//   k_resize_lds, k_convert_resize_lds    a wave stages the source rows it needs in wave-private LDS strips (dynamic LDS
+//                                         sized per scale factor) and picks taps from LDS; taps with weight exactly 0 are skipped
+//   k_resize_tile<CH, LZ>                 tiled + separable: horizontal pass once per (source row, column) into LDS, then
+//                                         the vertical pass (Lanczos-3 always; bilinear when the vertical scale is < 2)
+//   k_resize_half, k_convert_half         exact 2x: quad-structured streaming kernels (no taps, no gathers)
+//   k_remap3_tile, k_remap3_p4            remap with / without an LDS-staged source footprint
+//   odd integer factors on both axes      every filter returns the centre sample -> nearest kernel
 #include "vpf_device.h"
 
 namespace vpf {
