@@ -411,3 +411,62 @@ def test_upload_from_pinned_memory():
     for _ in range(3):
         assert np.array_equal(download(up.UploadSingleFrame(p)), a)
         assert np.array_equal(download(up.UploadSingleFrame(a)), a)
+
+
+def test_concurrent_threads_mixed_operations(oracle):
+    """8 threads, each with its own stream and task objects, hammer converters / fused resize / resizer / remaper /
+    uploader / downloader concurrently (GIL released inside the calls): every result must stay bit-exact.  Guards the
+    process-wide pieces (device guard, pair table, HIP error clearing, pinned staging) against races."""
+    w, h, tw, th = 640, 360, 320, 120
+    src = oracle.synth(oracle.NV12, w, h, 31)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    _, rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+    _, pln = oracle.convert(oracle.NV12, oracle.RGB_PLANAR, 1, 0, w, h, src)
+    _, yuv = oracle.convert(oracle.NV12, oracle.YUV420, 1, 0, w, h, src)
+    _, small = oracle.resize(oracle.RGB, oracle.LINEAR, w, h, rgb, tw, th)
+    _, fused = oracle.convert_resize(oracle.NV12, oracle.RGB_PLANAR, 1, 0, w, h, src, tw, th)
+    xm, ym = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    xm, ym = (xm + 2.5 * np.sin(ym / 11)).astype(np.float32), (ym + 1.5 * np.cos(xm / 13)).astype(np.float32)
+    _, warped = oracle.remap(oracle.RGB, w, h, rgb, xm, ym, dst=oracle.alloc(oracle.RGB, w, h))
+    frame = host_frame(src)
+    errors = []
+
+    def work(tid):
+        try:
+            stream = torch.cuda.Stream()
+            ctx, st = nvc.GetContext(GPU), stream.cuda_stream
+            up = nvc.PyFrameUploader(w, h, PF.NV12, ctx, st)
+            to_rgb = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, ctx, st)
+            to_pln = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB_PLANAR, ctx, st)
+            to_yuv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.YUV420, ctx, st)
+            rs = nvc.PySurfaceResizer(tw, th, PF.RGB, ctx, st)
+            fz = nvc.PySurfaceConvertResizer(w, h, PF.NV12, tw, th, PF.RGB_PLANAR, ctx, st)
+            rm = nvc.PySurfaceRemaper(xm, ym, PF.RGB, ctx, st)
+            dls = {f: nvc.PySurfaceDownloader(w, h, f, ctx, st) for f in (PF.RGB, PF.RGB_PLANAR, PF.YUV420)}
+            dl_small = nvc.PySurfaceDownloader(tw, th, PF.RGB, ctx, st)
+            dl_small_pln = nvc.PySurfaceDownloader(tw, th, PF.RGB_PLANAR, ctx, st)
+            out = np.empty(1, np.uint8)
+            for it in range(25):
+                nv12 = up.UploadSingleFrame(frame)
+                op = (it + tid) % 6
+                if op == 0:
+                    got, want, d = to_rgb.Execute(nv12, cc), host_frame(rgb), dls[PF.RGB]
+                elif op == 1:
+                    got, want, d = to_pln.Execute(nv12, cc), host_frame(pln), dls[PF.RGB_PLANAR]
+                elif op == 2:
+                    got, want, d = to_yuv.Execute(nv12, cc), host_frame(yuv), dls[PF.YUV420]
+                elif op == 3:
+                    got, want, d = rs.Execute(to_rgb.Execute(nv12, cc)), host_frame(small), dl_small
+                elif op == 4:
+                    got, want, d = fz.Execute(nv12, cc), host_frame(fused), dl_small_pln
+                else:
+                    got, want, d = rm.Execute(to_rgb.Execute(nv12, cc)), host_frame(warped), dls[PF.RGB]
+                assert not got.Empty(), (tid, it, op)
+                assert d.DownloadSingleSurface(got, out) and np.array_equal(out, want), (tid, it, op)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:3]
