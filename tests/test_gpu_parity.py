@@ -416,6 +416,22 @@ def test_async_on_user_stream(capi, oracle):
     assert_planes_equal(got, want, "stream")
 
 
+@pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
+def test_dst_reused_hint_changes_the_store_policy_not_the_pixels(capi, oracle, dst):
+    """VPF_EXEC_DST_REUSED (allocating instead of non-temporal stores on single-frame launches): identical bytes, padding
+    intact, also where the hinted kernel does not apply (ragged width -> general kernel)"""
+    for (w, h) in [(1920, 32), (848, 464), (1002, 6)]:
+        src = oracle.synth(oracle.NV12, w, h, 1077)
+        s, d = DevPlanes(src), DevPlanes(oracle.alloc(getattr(oracle, dst), w, h))
+        ex = capi.make_exec(stream_handle(), flags=capi.EXEC_DST_REUSED)
+        capi.convert(ex, capi.NV12, getattr(capi, dst), 1, 0, w, h, s.desc(), d.desc())
+        torch.cuda.synchronize()
+        got, intact = d.download()
+        assert intact
+        _, want = oracle.convert(oracle.NV12, getattr(oracle, dst), 1, 0, w, h, src, oracle.FP32)
+        assert_planes_equal(got, want, f"dst_reused {dst} {w}x{h}")
+
+
 def test_plain_c_client_of_the_abi(oracle, tmp_path):
     """include/vpf_hip.h from a plain C99 program (gcc, no C++ / Python / torch in the process): the drop-in boundary as
     any FFI would use it.  tests/c/abi_smoke.c converts a constant frame and reports the pixel; compare with the oracle."""

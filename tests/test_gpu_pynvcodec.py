@@ -164,6 +164,21 @@ def test_resizer_accepts_float_surfaces_like_the_reference(oracle):
     assert np.array_equal(download(small_pln, np.float32), host_frame(d).view(np.float32))
 
 
+def test_output_reuse_hint(oracle):
+    """additive PySurfaceConverter.SetOutputReuseHint: same pixels, the flag sticks"""
+    w, h = 1280, 720
+    src = oracle.synth(oracle.NV12, w, h, 17)
+    cc = nvc.ColorspaceConversionContext(CS.BT_709, CR.MPEG)
+    conv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.RGB, GPU)
+    assert conv.GetOutputReuseHint() is False
+    a = download(conv.Execute(upload(PF.NV12, w, h, src), cc)).copy()
+    conv.SetOutputReuseHint(True)
+    assert conv.GetOutputReuseHint() is True
+    b = download(conv.Execute(upload(PF.NV12, w, h, src), cc))
+    _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
+    assert np.array_equal(a, b) and np.array_equal(a, host_frame(want))
+
+
 def test_chain_remap_sample(oracle):
     """samples/SampleRemap.py:74-101 — NV12 -> RGB -> Remap(RGB) -> download, BT.709 + JPEG"""
     w, h = 640, 360

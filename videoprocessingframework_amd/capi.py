@@ -102,8 +102,11 @@ def convert_supported(src_fmt, dst_fmt, cs, cr) -> bool:
     return bool(lib().vpf_convert_supported(src_fmt, dst_fmt, cs, cr))
 
 
-def make_exec(stream: int = 0, device: int = -1) -> Exec:
-    return Exec(device, 0, stream or None)
+EXEC_DST_REUSED = 1
+
+
+def make_exec(stream: int = 0, device: int = -1, flags: int = 0) -> Exec:
+    return Exec(device, flags, stream or None)
 
 
 def planes(desc) -> "C.Array[Plane]":

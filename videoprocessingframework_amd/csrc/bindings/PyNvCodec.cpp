@@ -91,6 +91,8 @@ public:
     ctx_buf_.reset(Buffer::MakeOwnMem(sizeof(ColorspaceConversionContext)));
   }
   Pixel_Format GetFormat() const { return out_fmt_; }
+  void SetOutputReuseHint(bool on) { conv_->SetOutputReused(on); }
+  bool GetOutputReuseHint() const { return conv_->GetOutputReused(); }
   // PySurfaceConverter.cpp:50-74: returns a NON-OWNING alias of the task's single output surface (overwritten by
   // the next Execute); failure of any kind = an Empty() surface
   std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src, std::shared_ptr<ColorspaceConversionContext> cc) {
@@ -453,6 +455,9 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            }),
            py::arg("width"), py::arg("height"), py::arg("src_format"), py::arg("dst_format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceConverter::GetFormat)
+      .def("SetOutputReuseHint", &PySurfaceConverter::SetOutputReuseHint, py::arg("on"),
+           "additive: the result is consumed by the next kernel of a per-frame chain -> keep it in the Infinity Cache (identical pixels)")
+      .def("GetOutputReuseHint", &PySurfaceConverter::GetOutputReuseHint)
       // the returned Surface aliases memory owned by the converter: keep the converter alive as long as it lives
       .def("Execute", &PySurfaceConverter::Execute, py::arg("src"), py::arg("cc_ctx") = nullptr, py::keep_alive<0, 1>(),
            py::call_guard<py::gil_scoped_release>())

@@ -642,8 +642,8 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? 37 : (n >= 4 ? 30 : 8)) : 4;
   const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36 || variant == 41 || variant == 42);
   const bool packed_only = (variant >= 17 && variant <= 19) || (variant >= 22 && variant <= 29) || variant == 38 || variant == 43;
-  if ((want_p16 || packed_only || variant == 37) && !p16_ok) variant = 4;
-  if ((packed_only && DST == FC_PLANAR) || (variant == 37 && DST != FC_PLANAR)) variant = 4;
+  if ((want_p16 || packed_only || variant == 37 || variant == 44) && !p16_ok) variant = 4;
+  if ((packed_only && DST == FC_PLANAR) || ((variant == 37 || variant == 44) && DST != FC_PLANAR)) variant = 4;
   if (variant != 9 && !p4_ok) variant = 9;  // p16_ok implies p4_ok
   if constexpr (SRC == FC_NV12) {
     if (variant >= 17 && variant <= 19) {  // p16r: RPW = 1, 2, 4
@@ -670,10 +670,11 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       if constexpr (DST != FC_PLANAR) VPF_LAUNCH((k_nv12_rgb_s16<DST, true>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, segs, tasks);
       return hipGetLastError();
     }
-    if (variant == 37) {
+    if (variant == 37 || variant == 44) {
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;  // one task per row per chunk (h even)
       dim3 grid((tasks + 3) / 4, n);
-      VPF_LAUNCH((k_nv12_planar_r16<true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      if (variant == 37) VPF_LAUNCH((k_nv12_planar_r16<true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      else VPF_LAUNCH((k_nv12_planar_r16<false>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);  // allocating stores
       return hipGetLastError();
     }
     if (variant >= 27 && variant <= 29) {
@@ -776,7 +777,10 @@ static hipError_t launch_444(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
 }
 
 hipError_t launch_yuv_to_rgb(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t w, uint32_t h,
-                             uint32_t n, const BatchArgs& a, int variant) {
+                             uint32_t n, const BatchArgs& a, int variant, bool dst_reused) {
+  // VPF_EXEC_DST_REUSED: single-frame launches keep their output in the Infinity Cache (allocating stores) for the next
+  // kernel of the chain: variant 12 = p16 with non-temporal loads only, 44 = planar r16 with plain stores
+  if (variant == 0 && dst_reused && n < 4 && src_fc == FC_NV12) variant = (dst_fc == FC_PLANAR) ? 44 : 12;
 #define VPF_DST_SWITCH(FN, ...)                                                   \
   switch (dst_fc) {                                                               \
     case FC_RGB: return FN<__VA_ARGS__ FC_RGB>(st, c, w, h, n, a, variant);       \

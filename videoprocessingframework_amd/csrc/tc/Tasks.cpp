@@ -182,7 +182,10 @@ struct ConvertSurface::Impl {
   HipContext ctx;
   HipStream str;
   std::unique_ptr<Surface> out;  // allocated once, reused by every Execute (reference: nv12_rgb ctor :114-118)
+  bool out_reused = false;
 };
+void ConvertSurface::SetOutputReused(bool reused) { pImpl->out_reused = reused; }
+bool ConvertSurface::GetOutputReused() const { return pImpl->out_reused; }
 
 int ConvertSurface::PairSupport(Pixel_Format in, Pixel_Format out) {
   const PairInfo* p = find_pair(in, out);
@@ -206,7 +209,7 @@ ConvertSurface::ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Fo
     ss << "Unsupported pixel format conversion: " << in << " to " << out;
     throw std::invalid_argument(ss.str());
   }
-  pImpl = new Impl{p, w, h, ctx, str, nullptr};
+  pImpl = new Impl{p, w, h, ctx, str, nullptr, false};
   pImpl->out.reset(Surface::Make(out, w, h, ctx));
 }
 ConvertSurface::~ConvertSurface() { delete pImpl; }
@@ -231,7 +234,8 @@ TaskExecStatus ConvertSurface::Run() {
   vpf_plane src[3], dst[3];
   fill_planes(in, src);
   fill_planes(pImpl->out.get(), dst);
-  const vpf_exec ex = make_exec(pImpl->ctx, pImpl->str);
+  vpf_exec ex = make_exec(pImpl->ctx, pImpl->str);
+  if (pImpl->out_reused) ex.flags |= VPF_EXEC_DST_REUSED;
   const vpf_status st = vpf_convert(&ex, pImpl->pair->in, pImpl->pair->out, cs, cr, vpf_size{pImpl->w, pImpl->h}, src, dst);
   if (st != VPF_OK) {
     std::cerr << "Failed to convert surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;

@@ -26,6 +26,10 @@ public:
   // vpf_hip.h values, or false when the combination is refused like the reference refuses it.  Host logic only
   // (tests/test_reference_tc_pin.py compares it with the reference's own dispatch code).
   static bool ResolveContext(Pixel_Format inFormat, Pixel_Format outFormat, const ColorspaceConversionContext* ctx, int* cs, int* cr);
+  // Additive hint (VPF_EXEC_DST_REUSED): the output surface is consumed by the next kernel of a per-frame chain, keep
+  // it in the 256 MiB Infinity Cache instead of streaming it past.  Pixels are identical either way.
+  void SetOutputReused(bool reused);
+  bool GetOutputReused() const;
 
 private:
   static const uint32_t numInputs = 2U, numOutputs = 1U;

@@ -193,7 +193,7 @@ vpf_status vpf_convert_batch(const vpf_exec* exec, int sf, int df, int cs, int c
     switch (fam) {
       case FAM_YUV2RGB:
         e = launch_yuv_to_rgb(st, yuv_src_class(sf), rgb_class(df), yc, size.width, size.height, m, a,
-                              tuning(VPF_TUNE_NV12_RGB_VARIANT));
+                              tuning(VPF_TUNE_NV12_RGB_VARIANT), (exec->flags & VPF_EXEC_DST_REUSED) != 0);
         break;
       case FAM_RGB2YUV:
         e = launch_rgb_to_yuv(st, rgb_class(sf), df == VPF_FMT_YUV444 ? FC_YUV444 : FC_YUV420, rc, size.width,

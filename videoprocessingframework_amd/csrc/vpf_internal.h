@@ -48,7 +48,7 @@ enum FmtClass : int {
 
 // launchers (one per translation unit); all asynchronous on `st`
 hipError_t launch_yuv_to_rgb(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t w,
-                             uint32_t h, uint32_t n, const BatchArgs& a, int variant);
+                             uint32_t h, uint32_t n, const BatchArgs& a, int variant, bool dst_reused = false);
 hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc /*FC_YUV444|FC_YUV420*/,
                              const Rgb2YuvCoef& c, uint32_t w, uint32_t h, uint32_t n, const BatchArgs& a);
 hipError_t launch_relayout(hipStream_t st, int src_fmt, int dst_fmt, uint32_t w, uint32_t h, uint32_t n,
