@@ -491,7 +491,7 @@ FUZZ_PAIRS = [("NV12", "RGB"), ("NV12", "BGR"), ("NV12", "RGB_PLANAR"), ("YUV420
               ("NV12", "YUV420"), ("YUV420", "NV12"), ("RGB", "RGB_PLANAR"), ("RGB_PLANAR", "RGB"), ("RGB", "BGR"),
               ("RGB", "YUV420"), ("BGR", "YUV444"), ("RGB_PLANAR", "YUV444"), ("BGR", "YCBCR"), ("RGB", "Y"),
               ("YUV444", "BGR"), ("YUV444", "RGB_PLANAR"), ("RGB_PLANAR", "BGR"), ("BGR", "RGB_PLANAR"), ("RGB_PLANAR", "Y"),
-              ("NV12", "Y"), ("Y", "YUV444"), ("P10", "NV12"), ("RGB", "RGB_32F"), ("RGB_PLANAR", "YUV420")]
+              ("NV12", "Y"), ("Y", "YUV444"), ("P10", "NV12"), ("RGB", "RGB_32F"), ("RGB_PLANAR", "YUV420"), ("YUV420", "RGB_PLANAR")]
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))  # soak: VPF_FUZZ_SEEDS=500
@@ -517,7 +517,12 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
             align, extra, offset = 16, 0, 0
         cs = 0 if s in ("RGB", "BGR", "RGB_PLANAR") else int(rng.integers(2))
         cr = int(rng.integers(2))
-        variant = int(rng.choice([0, 0, 4, 8, 9, 11, 30, 37, 38])) if s == "NV12" and d in ("RGB", "BGR", "RGB_PLANAR") else int(rng.choice([0, 0, 0, 40, 9]))
+        if s == "NV12" and d in ("RGB", "BGR", "RGB_PLANAR"):
+            variant = int(rng.choice([0, 0, 4, 8, 9, 11, 30, 37, 38]))
+        elif s == "YUV420" and d in ("RGB", "BGR", "RGB_PLANAR"):
+            variant = int(rng.choice([0, 0, 8, 12, 30, 37, 44, 4, 40, 9]))
+        else:
+            variant = int(rng.choice([0, 0, 0, 40, 9]))
         src = oracle.synth(getattr(oracle, s), w, h, int(rng.integers(1 << 30)), "ABC"[int(rng.integers(3))])
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), cs, cr, w, h, src, align, extra, offset, variant=variant)
 

@@ -24,6 +24,19 @@ namespace vpf {
 // ---------------------------------------------------------------------------------------------
 // pixel math
 // ---------------------------------------------------------------------------------------------
+// The chroma of 16 luma pixels as four dwords of interleaved U V U V (NV12's native form).  YUV420 (I420, what software
+// decoders hand over) has U and V in separate half-width planes: two 8-B loads and four v_perm_b32 re-create the same form.
+template <int SRC, bool NT>
+VPF_DEV u32x4 load_uv16(const FrameDesc& f, uint32_t rp, uint32_t x) {
+  if constexpr (SRC == FC_NV12) {
+    return ldg<NT, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+  } else {
+    const u32x2 u = ldg<NT, u32x2>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1)), v = ldg<NT, u32x2>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
+    return u32x4{__builtin_amdgcn_perm(v[0], u[0], 0x05010400u), __builtin_amdgcn_perm(v[0], u[0], 0x07030602u),
+                 __builtin_amdgcn_perm(v[1], u[1], 0x05010400u), __builtin_amdgcn_perm(v[1], u[1], 0x07030602u)};
+  }
+}
+
 // 4 px -> 12 packed bytes (3 dwords) in R,G,B or B,G,R order
 template <int DST, int PACK>
 VPF_DEV void pack_rgb12(const Quad& q, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
 // XCD_SWZ: workgroups are dealt round-robin to the 8 XCDs (workgroup b -> XCD b % 8 when gridDim.x % 8 == 0); the
 // swizzle hands each XCD ONE contiguous eighth of every frame instead of every eighth row pair, so each XCD's L2
 // write-back stream is sequential (tools/write_probe.hip X0/X1: +6 % on pure writes).
-template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0, bool XCD_SWZ = false>
+template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0, bool XCD_SWZ = false, int SRC = FC_NV12>
 __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
                                                            uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   // BALLAST_KB > 0 pads the LDS footprint to cap the number of resident workgroups per CU (occupancy experiment)
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args,
   if (act) {
     y[0] = ldg<NTL, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
     y[1] = ldg<NTL, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
-    uv = ldg<NTL, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+    uv = load_uv16<SRC, NTL>(f, rp, x);
   }
   uint32_t o[2][12];
   if constexpr (NOMATH) {  // bandwidth-ceiling probe: same loads / LDS transpose / stores, no arithmetic (NOT a conversion)
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_r4(const BatchArgs args, const
 // UV line from L2, not HBM), three dense 1-KiB dwordx4 stores (R, G, B planes) — 3 stores per wave instead of the 6 a
 // row-pair wave needs for three planes (write-rate law, tools/write_probe.hip).  Requires w % 16 == 0, 16-B aligned planes.
 // ---------------------------------------------------------------------------------------------
-template <bool NTS>
+template <bool NTS, int SRC = FC_NV12>
 __global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
                                                          uint32_t chunks_x, uint32_t n_tasks) {
   const uint32_t wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, c
   const uint32_t y = 2 * rp + half;
   if (x >= w || y >= h) return;
   const u32x4 yq = ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x);
-  const u32x4 uv = ldg<false, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+  const u32x4 uv = load_uv16<SRC, false>(f, rp, x);
   u32x4 r, g, b;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -631,6 +644,33 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   //   37      r16 (planar outputs): one row x 1024 px per wave, 3 stores      38  r16 packed (LDS transpose; ties with 30)
   //   27      r4: one 768-B store per wave (lane = 4 px of one row)    28/29  b4: r4 + block LDS gather -> 1-KiB stores (NT / plain)
   //   14/16   p4 RP1 / RP2 with NT stores only          17/18/19 p16r (one LDS row tile per wave), 1/2/4 row pairs per task, NT stores
+  if constexpr (SRC == FC_YUV420) {
+    // I420 (what software decoders hand over): the same 16-px kernels with the chroma re-interleaved in registers
+    // (load_uv16).  Default policy as for NV12; tuning values other than these take the p4 / generic kernels below.
+    const bool ok420 = even && (w % 16 == 0) && aligned_all(a, n, 3, ndst, 16, 16, 8);
+    const bool mine = variant == 0 || variant == 8 || variant == 12 || variant == 30 || variant == 37 || variant == 44;
+    if (ok420 && mine) {
+      const int v = variant ? variant : (DST == FC_PLANAR ? 37 : (n >= 4 ? 30 : 8));
+      if constexpr (DST == FC_PLANAR) {
+        if (v == 37 || v == 44) {
+          const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;
+          dim3 grid((tasks + 3) / 4, n);
+          if (v == 37) VPF_LAUNCH((k_nv12_planar_r16<true, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          else VPF_LAUNCH((k_nv12_planar_r16<false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          return hipGetLastError();
+        }
+      } else {
+        if (v == 8 || v == 12 || v == 30) {
+          const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
+          dim3 grid((tasks + 3) / 4, n);
+          if (v == 8) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          else if (v == 12) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, false, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          else VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 16, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          return hipGetLastError();
+        }
+      }
+    }
+  }
   const bool p16_ok = (SRC == FC_NV12) && even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, 16);
   const bool p4_ok = aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
   // default policy (profiles/r01_bench_sweep.log): packed outputs -> p16 + LDS transpose with non-temporal loads and
@@ -780,7 +820,7 @@ hipError_t launch_yuv_to_rgb(hipStream_t st, int src_fc, int dst_fc, const Yuv2R
                              uint32_t n, const BatchArgs& a, int variant, bool dst_reused) {
   // VPF_EXEC_DST_REUSED: single-frame launches keep their output in the Infinity Cache (allocating stores) for the next
   // kernel of the chain: variant 12 = p16 with non-temporal loads only, 44 = planar r16 with plain stores
-  if (variant == 0 && dst_reused && n < 4 && src_fc == FC_NV12) variant = (dst_fc == FC_PLANAR) ? 44 : 12;
+  if (variant == 0 && dst_reused && n < 4 && (src_fc == FC_NV12 || src_fc == FC_YUV420)) variant = (dst_fc == FC_PLANAR) ? 44 : 12;
 #define VPF_DST_SWITCH(FN, ...)                                                   \
   switch (dst_fc) {                                                               \
     case FC_RGB: return FN<__VA_ARGS__ FC_RGB>(st, c, w, h, n, a, variant);       \
