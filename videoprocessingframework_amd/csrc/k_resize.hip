@@ -1084,10 +1084,10 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
 // structure needs no tap arithmetic, no LDS gathers and one chroma evaluation per destination pixel: a lane converts
 // 16 x 2 source pixels exactly like the NV12 -> RGB kernels (dwordx4 loads, convert4) and averages them; ~70 VALU per
 // destination pixel instead of ~120 in the general kernel.  Bit-identical to it (same fma order on the same values).
-// Requires NV12, sw == 2 dw, sh == 2 dh, sw % 16 == 0 (% 32 for packed outputs), 16-B aligned source rows, 8-B (planar) / 16-B
+// Requires NV12 or YUV420 (chroma planes 8-B aligned), sw == 2 dw, sh == 2 dh, sw % 16 == 0 (% 32 for packed outputs), 16-B aligned source rows, 8-B (planar) / 16-B
 // (packed) aligned destination rows.
 // ------------------------------------------------------------------------------------------
-template <int DST>
+template <int DST, int SRC>
 __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t dh,
                                                       uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[DST == FC_PLANAR ? 1 : 4 * 96];  // 1.5 KiB per wave: 64 lanes x 24 packed bytes
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, cons
   if (act) {
     const u32x4 ya = ldg<true, u32x4>(f.s[0] + (size_t)(2 * y) * f.sp[0] + xs);
     const u32x4 yb = ldg<true, u32x4>(f.s[0] + (size_t)(2 * y + 1) * f.sp[0] + xs);
-    const u32x4 uv = ldg<true, u32x4>(f.s[1] + (size_t)y * f.sp[1] + xs);
+    const u32x4 uv = load_uv16<SRC, true>(f, y, xs);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j])), k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
@@ -1160,16 +1160,18 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
   }
   // exact 2x from NV12: the quad-structured kernel (no taps, no gathers); tuning 40 / 9 keep the general kernels
   // (packed rows leave as 16-B stores: 3 * dw must be a multiple of 16)
-  if (src_fc == FC_NV12 && sw == 2 * dw && sh == 2 * dh && sw % (dst_fc == FC_PLANAR ? 16 : 32) == 0 && lds_ok && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40) {
+  if ((src_fc == FC_NV12 || src_fc == FC_YUV420) && sw == 2 * dw && sh == 2 * dh && sw % (dst_fc == FC_PLANAR ? 16 : 32) == 0 && lds_ok && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40) {
     bool ok16 = true;
     for (uint32_t i = 0; i < n; i++)
       for (int k = 0; k < (dst_fc == FC_PLANAR ? 3 : 1); k++) ok16 = ok16 && !(((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & (dst_fc == FC_PLANAR ? 7 : 15));
     if (ok16) {
       const uint32_t chunks = (sw + 1023) / 1024, tasks = chunks * dh;
       dim3 hgrid((tasks + 3) / 4, n);
-      if (dst_fc == FC_RGB) VPF_LAUNCH((k_convert_half<FC_RGB>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks);
-      else if (dst_fc == FC_BGR) VPF_LAUNCH((k_convert_half<FC_BGR>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks);
-      else VPF_LAUNCH((k_convert_half<FC_PLANAR>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks);
+#define VPF_HALF(S) do { if (dst_fc == FC_RGB) VPF_LAUNCH((k_convert_half<FC_RGB, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); \
+                         else if (dst_fc == FC_BGR) VPF_LAUNCH((k_convert_half<FC_BGR, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); \
+                         else VPF_LAUNCH((k_convert_half<FC_PLANAR, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); } while (0)
+      if (src_fc == FC_NV12) VPF_HALF(FC_NV12); else VPF_HALF(FC_YUV420);
+#undef VPF_HALF
       return hipGetLastError();
     }
   }

@@ -24,19 +24,6 @@ namespace vpf {
 // ---------------------------------------------------------------------------------------------
 // pixel math
 // ---------------------------------------------------------------------------------------------
-// The chroma of 16 luma pixels as four dwords of interleaved U V U V (NV12's native form).  YUV420 (I420, what software
-// decoders hand over) has U and V in separate half-width planes: two 8-B loads and four v_perm_b32 re-create the same form.
-template <int SRC, bool NT>
-VPF_DEV u32x4 load_uv16(const FrameDesc& f, uint32_t rp, uint32_t x) {
-  if constexpr (SRC == FC_NV12) {
-    return ldg<NT, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
-  } else {
-    const u32x2 u = ldg<NT, u32x2>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1)), v = ldg<NT, u32x2>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
-    return u32x4{__builtin_amdgcn_perm(v[0], u[0], 0x05010400u), __builtin_amdgcn_perm(v[0], u[0], 0x07030602u),
-                 __builtin_amdgcn_perm(v[1], u[1], 0x05010400u), __builtin_amdgcn_perm(v[1], u[1], 0x07030602u)};
-  }
-}
-
 // 4 px -> 12 packed bytes (3 dwords) in R,G,B or B,G,R order
 template <int DST, int PACK>
 VPF_DEV void pack_rgb12(const Quad& q, uint32_t& d0, uint32_t& d1, uint32_t& d2) {

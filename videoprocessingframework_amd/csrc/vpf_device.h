@@ -91,6 +91,19 @@ VPF_DEV void stg3(void* p, uint32_t a, uint32_t b, uint32_t c) {
   stg<NT, uint32_t>(q + 2, c);
 }
 
+// The chroma of 16 luma pixels as four dwords of interleaved U V U V (NV12's native form).  YUV420 (I420, what software
+// decoders hand over) has U and V in separate half-width planes: two 8-B loads and four v_perm_b32 re-create the same form.
+template <int SRC, bool NT>
+VPF_DEV u32x4 load_uv16(const FrameDesc& f, uint32_t rp, uint32_t x) {
+  if constexpr (SRC == FC_NV12) {
+    return ldg<NT, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+  } else {
+    const u32x2 u = ldg<NT, u32x2>(f.s[1] + (size_t)rp * f.sp[1] + (x >> 1)), v = ldg<NT, u32x2>(f.s[2] + (size_t)rp * f.sp[2] + (x >> 1));
+    return u32x4{__builtin_amdgcn_perm(v[0], u[0], 0x05010400u), __builtin_amdgcn_perm(v[0], u[0], 0x07030602u),
+                 __builtin_amdgcn_perm(v[1], u[1], 0x05010400u), __builtin_amdgcn_perm(v[1], u[1], 0x07030602u)};
+  }
+}
+
 // make one wave's LDS writes visible to its own other lanes (wave-private tiles: no workgroup barrier needed)
 VPF_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
