@@ -3,6 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoprocessingframework_amd import capi
 dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
+if len(sys.argv) > 1:
+    capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, int(sys.argv[1]))
 for (sw, sh, dw, dh) in ((3840,2160,1920,1080),(3840,2160,960,540),(3840,2160,2560,1440),(1920,1080,960,540),(1920,1080,416,416),(3840,2160,640,360)):
     sp, dp = (3*sw+255)//256*256, (3*dw+255)//256*256
     N=8

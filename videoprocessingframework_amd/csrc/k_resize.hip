@@ -527,9 +527,11 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
     return hipGetLastError();
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4);
-  // vertical scale < 2: consecutive destination rows share source rows -> tiled kernel (horizontal lerp once per source
-  // row; measured 1080p->720p 5.6 vs 7.4 us, 1080p->4K 16.6 vs 37.6 us; at 3x the row-pair kernel wins 8.4 vs 10.2 us)
-  if (interp == VPF_INTERP_LINEAR && (scy < 2.0f || tuning(VPF_TUNE_NV12_RGB_VARIANT) == 43) && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 &&
+  // up-scaling: several destination rows sit between the same two source rows -> tiled kernel (horizontal lerp once per
+  // source row).  Kernel durations (rocprofv3), tiled vs row-pair: 1080p->4K 16.6 vs 20.6 us, 720p->1080p 8.2 vs 9.0;
+  // for mild down-scales the row-pair kernel is as fast or faster (1080p->720p 5.9 vs 5.8, 4K->1440p 16.2 vs 12.4,
+  // 4K->3000x1688 21.2 vs 14.9), so the tiled kernel is used below 1.0 only
+  if (interp == VPF_INTERP_LINEAR && (scy < 1.0f || tuning(VPF_TUNE_NV12_RGB_VARIANT) == 43) && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 &&
       launch_resize_tile(st, false, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy))
     return hipGetLastError();
   const uint32_t rowb = (interp == VPF_INTERP_LINEAR) ? lds_strip_bytes(ch, sw, dw, src, sp, kResizeRowBytes) : 0;
