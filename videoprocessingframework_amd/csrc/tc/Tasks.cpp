@@ -418,8 +418,14 @@ RemapSurface::RemapSurface(const float* x_map, const float* y_map, uint32_t w, u
   pImpl->ymap.reset(CudaBuffer::Make(y_map, sizeof(float), (size_t)w * h, ctx, str));
   pImpl->out.reset(Surface::Make(f, w, h, ctx));
   // destination pixels whose source falls outside the image are left untouched: start from black, not garbage
+  // (on the task's own stream and waited for: a null-stream hipMemset may still be in flight when the first Run()
+  //  launches on a non-blocking user stream, and would then black out pixels the kernel has just written)
   DeviceScope scope(ctx);
-  (void)hipMemset((void*)pImpl->out->PlanePtr(0), 0, (size_t)pImpl->out->Pitch(0) * h);
+  if (!hip_ok(hipMemsetAsync((void*)pImpl->out->PlanePtr(0), 0, (size_t)pImpl->out->Pitch(0) * h, (hipStream_t)str), "RemapSurface: hipMemsetAsync") ||
+      !hip_ok(hipStreamSynchronize((hipStream_t)str), "RemapSurface: hipStreamSynchronize")) {
+    delete pImpl;
+    throw std::runtime_error("RemapSurface: can't clear the output surface");
+  }
 }
 RemapSurface::~RemapSurface() { delete pImpl; }
 RemapSurface* RemapSurface::Make(const float* x, const float* y, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
