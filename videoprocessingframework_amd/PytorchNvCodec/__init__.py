@@ -57,6 +57,12 @@ def _on_stream(stream: int):
 def DptrToTensor(ptr: int, width: int, height: int, pitch: int, elem_size: int, stream: int = 0) -> torch.Tensor:
     """New contiguous torch.uint8 tensor [height, width] holding a copy of the pitched plane."""
     _check(ptr, elem_size, "makefromDevicePtrUint8")
+    if not stream:
+        # The plane was usually written a moment ago by a converter on ITS stream (the per-GPU stream of the gpu_id
+        # constructors is non-blocking, like the reference's: PyNvCodec.cpp:107).  The reference's stream-less overload is a
+        # blocking cudaMemcpy2D that nothing orders after that stream; here the device is drained first, so the copy can
+        # never read a half-written surface.  Pass `stream` (the converter's) to stay asynchronous.
+        torch.cuda.synchronize()
     with _on_stream(stream):
         out = view_plane(ptr, width, height, pitch).contiguous().clone() if pitch == width else view_plane(ptr, width, height, pitch).contiguous()
     if not stream:
@@ -74,6 +80,8 @@ def TensorToDptr(tensor: torch.Tensor, ptr: int, width: int, height: int, pitch:
         raise RuntimeError("copytoDevicePtrUint8: need a CUDA/HIP torch.uint8 tensor")
     if tensor.numel() != width * height:
         raise RuntimeError("copytoDevicePtrUint8: tensor has the wrong number of elements")
+    if not stream:
+        torch.cuda.synchronize()  # earlier readers / writers of the destination surface on other streams (see DptrToTensor)
     with _on_stream(stream):
         view_plane(ptr, width, height, pitch, device=tensor.device).copy_(tensor.reshape(height, width))
     if not stream:
