@@ -462,6 +462,7 @@ struct CudaUploadFrame::Impl {
   Pixel_Format fmt;
   hipStream_t copy_stream = nullptr;
   hipEvent_t done[kSlots] = {nullptr, nullptr};
+  hipEvent_t consumed[kSlots] = {nullptr, nullptr};  // task-stream work submitted before the slot's surface is rewritten
   std::unique_ptr<Buffer> staging[kSlots];
   std::unique_ptr<Surface> surf[kSlots];
   uint64_t n = 0;
@@ -476,6 +477,7 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
     if (!pImpl->surf[i]) throw std::invalid_argument("CudaUploadFrame: unsupported pixel format");
     pImpl->staging[i].reset(Buffer::MakeOwnMem(pImpl->surf[i]->HostMemSize(), ctx ? ctx : (HipContext)-1));
     if (hipEventCreateWithFlags(&pImpl->done[i], hipEventDisableTiming) != hipSuccess) pImpl->done[i] = nullptr;
+    if (hipEventCreateWithFlags(&pImpl->consumed[i], hipEventDisableTiming) != hipSuccess) pImpl->consumed[i] = nullptr;
   }
   if (hipStreamCreateWithFlags(&pImpl->copy_stream, hipStreamNonBlocking) != hipSuccess) pImpl->copy_stream = nullptr;
 }
@@ -484,6 +486,8 @@ CudaUploadFrame::~CudaUploadFrame() {
     DeviceScope scope(pImpl->sref.ctx);
     if (pImpl->copy_stream) { (void)hipStreamSynchronize(pImpl->copy_stream); (void)hipStreamDestroy(pImpl->copy_stream); }
     for (auto& e : pImpl->done)
+      if (e) (void)hipEventDestroy(e);
+    for (auto& e : pImpl->consumed)
       if (e) (void)hipEventDestroy(e);
   }
   delete pImpl;
@@ -512,6 +516,13 @@ TaskExecStatus CudaUploadFrame::Run() {
     (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error for us
     std::memcpy(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
     src = stage->GetDataAs<uint8_t>();
+  }
+  // The surface of this slot was handed out two uploads ago; kernels that read it (converters on the task's stream)
+  // may still be queued.  Whatever has been submitted to the task stream so far must finish before the DMA rewrites it.
+  if (pImpl->consumed[slot] && cs != (hipStream_t)pImpl->sref.str) {
+    if (!hip_ok(hipEventRecord(pImpl->consumed[slot], (hipStream_t)pImpl->sref.str), "CudaUploadFrame: hipEventRecord") ||
+        !hip_ok(hipStreamWaitEvent(cs, pImpl->consumed[slot], 0), "CudaUploadFrame: hipStreamWaitEvent"))
+      return TASK_EXEC_FAIL;
   }
   for (uint32_t p = 0; p < s->NumPlanes(); p++) {  // planes concatenated at tight width (Tasks.cpp:643-658)
     const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
