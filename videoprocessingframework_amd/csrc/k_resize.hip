@@ -17,7 +17,7 @@
 //   k_resize_tile<CH, LZ>                 tiled + separable: horizontal pass once per (source row, column) into LDS, then
 //                                         the vertical pass (Lanczos-3 always; bilinear when the vertical scale is < 2)
 //   k_resize_half, k_convert_half         exact 2x: quad-structured streaming kernels (no taps, no gathers)
-//   k_remap3_tile, k_remap3_p4            remap with / without an LDS-staged source footprint
+//   k_remap3_p4, k_remap3                 remap: 4 px per lane with 12-B tap windows (all requested up front) / generic
 //   odd integer factors on both axes      every filter returns the centre sample -> nearest kernel
 #include "vpf_device.h"
 
@@ -164,11 +164,17 @@ __global__ __launch_bounds__(256) void k_resize_lanczos(const uint8_t* __restric
   for (int ky = 0; ky < 6; ky++) {
     const int32_t j = ty.i0 + ky - 2;
     const uint8_t* r = src + (size_t)(j < 0 ? 0 : (j > (int32_t)sh - 1 ? (int32_t)sh - 1 : j)) * sp;
+    uint8_t v[6][CH];  // all taps of the row requested before the first is used (see k_resize_f32)
+#pragma unroll
+    for (int kx = 0; kx < 6; kx++)
+#pragma unroll
+      for (int c = 0; c < CH; c++) v[kx][c] = r[xi[kx] + c];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       float ra = 0.f;
 #pragma unroll
-      for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], (float)r[xi[kx] + c], ra);
+      for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], (float)v[kx][c], ra);
       acc[c] = __builtin_fmaf(ty.w[ky], ra, acc[c]);
     }
   }
@@ -562,6 +568,8 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
 // order as the 8-bit kernels on float samples; the result is neither rounded nor clamped.  Lane = one destination pixel
 // (CH x 4 B per lane: a wave stores 256-768 contiguous bytes).
 // ------------------------------------------------------------------------------------------
+template <int CH>
+struct FloatPx { float c[CH]; };  // one pixel of an RGB_32F (CH = 3) / planar float (CH = 1) surface: 4-B aligned, loaded as one 4 * CH-byte access
 template <int CH, int INTERP>
 __global__ __launch_bounds__(256) void k_resize_f32(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
@@ -584,11 +592,22 @@ __global__ __launch_bounds__(256) void k_resize_f32(const uint8_t* __restrict__ 
     for (int ky = 0; ky < 6; ky++) {
       const int32_t j = ty.i0 + ky - 2;
       const float* r = reinterpret_cast<const float*>(src + (size_t)(j < 0 ? 0 : (j > (int32_t)sh - 1 ? (int32_t)sh - 1 : j)) * sp);
+      // a row's taps are requested together and only then accumulated: left alone, the compiler sinks each load to its
+      // fma and the lane waits out one memory round trip per tap (36 * CH of them)
+      // and a pixel's CH floats travel as one 4 * CH-byte load (the kernel is bound by the number of load instructions)
+      float v[6][CH];
+#pragma unroll
+      for (int kx = 0; kx < 6; kx++) {
+        const FloatPx<CH> px = *reinterpret_cast<const FloatPx<CH>*>(r + xi[kx]);
+#pragma unroll
+        for (int c = 0; c < CH; c++) v[kx][c] = px.c[c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < CH; c++) {
         float ra = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], r[xi[kx] + c], ra);
+        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], v[kx][c], ra);
         acc[c] = __builtin_fmaf(ty.w[ky], ra, acc[c]);
       }
     }
@@ -598,12 +617,17 @@ __global__ __launch_bounds__(256) void k_resize_f32(const uint8_t* __restrict__ 
     const Tap tx = make_tap<INTERP>(x, scx, sw), ty = make_tap<INTERP>(y, scy, sh);
     const float* r0 = reinterpret_cast<const float*>(src + (size_t)ty.i0 * sp);
     const float* r1 = reinterpret_cast<const float*>(src + (size_t)ty.i1 * sp);
+    FloatPx<CH> q00 = *reinterpret_cast<const FloatPx<CH>*>(r0 + CH * tx.i0), q01 = {}, q10 = {}, q11 = {};
+    if constexpr (INTERP != VPF_INTERP_NEAREST) {
+      q01 = *reinterpret_cast<const FloatPx<CH>*>(r0 + CH * tx.i1);
+      q10 = *reinterpret_cast<const FloatPx<CH>*>(r1 + CH * tx.i0); q11 = *reinterpret_cast<const FloatPx<CH>*>(r1 + CH * tx.i1);
+    }
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       if constexpr (INTERP == VPF_INTERP_NEAREST) {
-        o[c] = r0[CH * tx.i0 + c];
+        o[c] = q00.c[c];
       } else {
-        const float p00 = r0[CH * tx.i0 + c], p01 = r0[CH * tx.i1 + c], p10 = r1[CH * tx.i0 + c], p11 = r1[CH * tx.i1 + c];
+        const float p00 = q00.c[c], p01 = q01.c[c], p10 = q10.c[c], p11 = q11.c[c];
         const float top = __builtin_fmaf(tx.f, p01 - p00, p00), bot = __builtin_fmaf(tx.f, p11 - p10, p10);
         o[c] = __builtin_fmaf(ty.f, bot - top, top);
       }
@@ -651,205 +675,141 @@ __global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src,
     o[c] = (uint8_t)sat_trunc(bilerp(r0[3 * x0 + c], r0[3 * x1 + c], r1[3 * x0 + c], r1[3 * x1 + c], fx, fy));
 }
 
-// fast remap: lane = 4 consecutive destination pixels.  Maps come in as two 16-B loads, the two source texels of a
-// row (6 contiguous bytes at an arbitrary byte offset) as ONE 12-B load from the enclosing 4-B aligned address
-// (v_alignbyte_b32 extracts them), and four valid pixels leave as one 12-B store.  Same arithmetic as k_remap3.
-// Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0.
-VPF_DEV void remap_row_taps(const uint8_t* row, uint32_t x0, bool two, uint32_t pitch, float* t0, float* t1) {
-  const uint32_t o = 3 * x0, base = o & ~3u, sh = o & 3u;
-  if (base + 12 <= pitch) {
-    const uint32_t d0 = ldg<false, uint32_t>(row + base), d1 = ldg<false, uint32_t>(row + base + 4), d2 = ldg<false, uint32_t>(row + base + 8);
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
-    t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);  // two == false => fx == 0: the value is irrelevant
-  } else {  // right edge of the row allocation: byte loads
-    const uint32_t o1 = two ? o + 3 : o;
-    for (int c = 0; c < 3; c++) { t0[c] = row[o + c]; t1[c] = row[o1 + c]; }
+// fast remap: lane = 4 consecutive destination pixels, wave = 256 pixels of one row.  Maps come in as two 16-B loads, the
+// two source texels of a row (6 contiguous bytes at an arbitrary byte offset) as ONE 12-B load from the enclosing 4-B
+// aligned address (v_alignbyte_b32 extracts them), and four valid pixels leave as one 12-B store.  Same arithmetic as
+// k_remap3, spelled for the VALU (the kernel sits between the VALU and the HBM roofline, tools/gpu_pmc_remap.sh):
+//   * out-of-range coordinates are pulled to the border with one v_med3_f32 and the pixel is computed like any other
+//     (just not stored) instead of being steered around the arithmetic;
+//   * sx - (float)(int)sx for sx >= 0 is v_fract_f32 (the subtraction is exact, so the bits are the same);
+//   * source offsets are 32-bit (v_mad_u32_u24; the launcher checks the surface is < 4 GiB) on a scalar base pointer;
+//   * blends of 8-bit samples stay inside [0, 255.5], so the pack needs no clamp (pack4_trunc_inrange).
+// Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0, sp >= 12, sh * sp < 2^32.
+
+// truncating pack of four values known to lie in [0, 256): bilinear blends of 8-bit samples (plus the 0.5 of the rounding)
+// never leave that range — every fma result is the rounding of a point between two representable end points
+VPF_DEV uint32_t pack4_trunc_inrange(float a, float b, float c, float d) {
+  return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+// a * b + c for a, b < 2^24 (low 32 bits): v_mad_u32_u24, full rate (v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate)
+VPF_DEV uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+
+// The taps of one pixel column in one source row are 6 bytes starting `o` bytes into the surface; they are fetched as the
+// 12-B window that starts at the aligned address below them (tap_window) and cut out with v_alignbyte_b32 (window_taps).
+// A window that runs over the end of a row into the next one is harmless (the second tap of the last column has weight
+// fx == 0 and fma(0, finite, p0) == p0); only at the very end of the surface (`last` = surface bytes - 12) must it
+// slide left so that it never leaves the allocation — SLIDE, chosen per wave: the first tap then starts up to 9 bytes
+// into the window and bytes past it read as zero.
+struct TapWindow { uint32_t e0, e1, e2; };
+template <bool SLIDE>
+VPF_DEV TapWindow tap_window(const uint8_t* __restrict__ src, uint32_t o, uint32_t last) {
+  const uint8_t* p = src + (SLIDE ? min(o & ~3u, last) : (o & ~3u));
+  return TapWindow{ldg<false, uint32_t>(p), ldg<false, uint32_t>(p + 4), ldg<false, uint32_t>(p + 8)};
+}
+template <bool SLIDE>
+VPF_DEV void window_taps(TapWindow w, uint32_t o, uint32_t last, float* t0, float* t1) {
+  uint32_t lead = o & 3u;
+  if constexpr (SLIDE) {
+    lead = o - min(o & ~3u, last);
+    const uint32_t q = lead >> 2;
+    w = TapWindow{q == 0 ? w.e0 : (q == 1 ? w.e1 : w.e2), q == 0 ? w.e1 : (q == 1 ? w.e2 : 0u), q == 0 ? w.e2 : 0u};
+    lead &= 3u;
+  }
+  const uint32_t lo = __builtin_amdgcn_alignbyte(w.e1, w.e0, lead), hi = __builtin_amdgcn_alignbyte(w.e2, w.e1, lead);
+  t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
+  t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);
+}
+// four pixels of one lane -> 12 packed bytes.  All eight windows are requested before the first one is used
+// (sched_barrier keeps the compiler from sinking the loads to their uses, which would serialise eight memory round
+// trips per wave: 22 -> 28 us per 4K frame); pixels are packed as they are produced to keep the register count at 8
+// waves per SIMD.
+template <bool SLIDE>
+VPF_DEV void remap_blend4(const uint8_t* __restrict__ src, const uint32_t* o0, const uint32_t* o1, uint32_t last, const float* fx,
+                          const float* fy, uint32_t* d) {
+  float o[12];
+  if constexpr (SLIDE) {  // one wave per frame at most: pixel by pixel, so that this path does not set the kernel's register count
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float a0[3], a1[3], b0[3], b1[3];
+      window_taps<true>(tap_window<true>(src, o0[k], last), o0[k], last, a0, a1);
+      window_taps<true>(tap_window<true>(src, o1[k], last), o1[k], last, b0, b1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) o[3 * k + c] = bilerp(a0[c], a1[c], b0[c], b1[c], fx[k], fy[k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    d[0] = pack4_trunc_inrange(o[0], o[1], o[2], o[3]); d[1] = pack4_trunc_inrange(o[4], o[5], o[6], o[7]); d[2] = pack4_trunc_inrange(o[8], o[9], o[10], o[11]);
+  } else {
+    TapWindow w0[4], w1[4];
+    uint32_t lead[4];  // the pitch is a multiple of 4: both rows of a pixel share the lead
+#pragma unroll
+    for (int k = 0; k < 4; k++) { w0[k] = tap_window<false>(src, o0[k], last); w1[k] = tap_window<false>(src, o1[k], last); lead[k] = o0[k] & 3u; }
+    __builtin_amdgcn_sched_barrier(0);
+    d[0] = d[1] = d[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float a0[3], a1[3], b0[3], b1[3];
+      window_taps<false>(w0[k], lead[k], last, a0, a1);
+      window_taps<false>(w1[k], lead[k], last, b0, b1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int j = 3 * k + c;  // byte j of the 12
+        d[j >> 2] |= (uint32_t)bilerp(a0[c], a1[c], b0[c], b1[c], fx[k], fy[k]) << (8 * (j & 3));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void k_remap3_p4(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+// Cache policy (4K, us per frame): plain map loads + non-temporal destination stores 22.2; all plain 23.7; non-temporal
+// map loads 25.2 (+ NT stores 23.6).  Assigning each XCD a horizontal band of the picture (so that vertically adjacent
+// tiles share an L2) was slower as well: 23.4 vs 21.9.
+__global__ __launch_bounds__(256, 8) void k_remap3_p4(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                    const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
                                                    uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const uint32_t x = gx * 4;
+  const uint32_t x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
   const f32x4 sx4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(xmap) + (size_t)y * xp + 4 * (size_t)x);
   const f32x4 sy4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(ymap) + (size_t)y * yp + 4 * (size_t)x);
-  float o[12];
+  const float wmax = (float)(sw - 1), hmax = (float)(sh - 1);
+  const uint32_t last = sh * sp - 12;
+  float fx[4], fy[4];
+  uint32_t o0[4], o1[4];  // first tap of the two source rows, bytes into the surface
   bool ok[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const float sx = sx4[k], sy = sy4[k];
-    ok[k] = (sx >= 0.f && sx <= (float)(sw - 1) && sy >= 0.f && sy <= (float)(sh - 1));
-    const float cx = ok[k] ? sx : 0.f, cy = ok[k] ? sy : 0.f;
-    const uint32_t x0 = (uint32_t)(int)cx, y0 = (uint32_t)(int)cy;
-    const bool twox = x0 + 1 < sw;
-    const uint32_t y1 = (y0 + 1 < sh) ? y0 + 1 : sh - 1;
-    const float fx = cx - (float)x0, fy = cy - (float)y0;
-    float a0[3], a1[3], b0[3], b1[3];
-    remap_row_taps(src + (size_t)y0 * sp, x0, twox, sp, a0, a1);
-    remap_row_taps(src + (size_t)y1 * sp, x0, twox, sp, b0, b1);
-#pragma unroll
-    for (int c = 0; c < 3; c++) o[3 * k + c] = bilerp(a0[c], a1[c], b0[c], b1[c], fx, fy);
+    // in range <=> pulling the coordinate to the border leaves it unchanged (NaN compares unequal; -0.0 == 0.0)
+    const float cx = __builtin_amdgcn_fmed3f(sx, 0.f, wmax), cy = __builtin_amdgcn_fmed3f(sy, 0.f, hmax);
+    ok[k] = (bool)((int)(cx == sx) & (int)(cy == sy));
+    const uint32_t x0 = (uint32_t)(int)cx, y0 = (uint32_t)(int)cy;  // a NaN coordinate becomes 0 here (v_cvt_i32_f32)
+    fx[k] = __builtin_amdgcn_fractf(cx); fy[k] = __builtin_amdgcn_fractf(cy);
+    o0[k] = mad24(y0, sp, 3 * x0); o1[k] = o0[k] + (y0 + 1 < sh ? sp : 0u);
   }
+  // o0 <= o1: the lower row decides whether a window could leave the surface; wave-uniform, true for one wave at most
+  const uint32_t omax = max(max(o1[0], o1[1]), max(o1[2], o1[3]));
+  uint32_t d[3];
+  if (__builtin_amdgcn_ballot_w64((omax & ~3u) > last) != 0) remap_blend4<true>(src, o0, o1, last, fx, fy, d);
+  else remap_blend4<false>(src, o0, o1, last, fx, fy, d);
   uint8_t* out = dst + (size_t)y * dp + 3 * (size_t)x;
   if (vec_ok && ok[0] && ok[1] && ok[2] && ok[3]) {
-    stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+    stg3<true>(out, d[0], d[1], d[2]);
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (ok[k]) { out[3 * k] = (uint8_t)sat_trunc(o[3 * k]); out[3 * k + 1] = (uint8_t)sat_trunc(o[3 * k + 1]); out[3 * k + 2] = (uint8_t)sat_trunc(o[3 * k + 2]); }
-  }
-}
-
-// LDS-staged remap (default when it applies): a workgroup owns a 64 x 16 destination tile (lane = 4 consecutive pixels of
-// one row).  Smooth maps (lens undistortion, rotation, mild scaling: what PySurfaceRemaper exists for) send a tile to a
-// compact source footprint, so the workgroup reduces the footprint's bounding box (LDS atomics), stages those source rows
-// in LDS with dense 16-B loads and gathers the 2 x 2 taps from LDS with aligned dword reads + v_alignbyte_b32.  The
-// gather kernel above issues 8 scattered global loads per lane and is bound by the texture-address rate (34 us per 4K
-// frame); from LDS the same taps cost ~1/8.  Footprints that do not fit (wild maps) fall back, per workgroup, to the
-// global gathers.  Same arithmetic as k_remap3.  Requires what k_remap3_p4 requires plus 16-B aligned source rows.
-constexpr uint32_t kRemapLdsBytes = 20 * 1024;  // 8 workgroups per CU
-
-// min / max over the 64 lanes of a wave: four DPP steps inside each row of 16 lanes, then the four rows through SGPRs
-template <bool MAX>
-VPF_DEV int32_t wave_minmax(int32_t v) {
-  auto op = [](int32_t a, int32_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
-  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
-  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
-  return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-            op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
-// the same reduction on two unsigned 16-bit fields at once (v_pk_min_u16 / v_pk_max_u16): (x | y << 16)
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-template <bool MAX>
-VPF_DEV uint32_t wave_minmax_u16x2(uint32_t v) {
-  auto op = [](uint32_t a, uint32_t b) {
-    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
-    return __builtin_bit_cast(uint32_t, MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
-  };
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
-  return op(op((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
-            op((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
-}
-
-VPF_DEV void lds_row_taps(const uint8_t* lrow, uint32_t o, bool two, float* t0, float* t1) {
-  const uint32_t sh = o & 3u;
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(lrow + (o & ~3u));
-  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-  // at the last column (two == false) the coordinate is exactly sw - 1, so fx == 0 and the second tap is multiplied by
-  // zero: whatever finite bytes follow serve as well as a replicated tap (fma(0, p1 - p0, p0) == p0)
-  (void)two;
-  t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
-  t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);
-}
-
-__global__ __launch_bounds__(256) void k_remap3_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
-                                                     const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
-                                                     uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  __shared__ u32x4 L[kRemapLdsBytes / 16 + 2];
-  __shared__ uint32_t bb[4][2];  // per wave: (xmin | ymin << 16), (xmax | ymax << 16) of its source taps
-  const uint32_t t = threadIdx.x, lane = t & 63;
-  const uint32_t x = blockIdx.x * 64 + 4 * (lane & 15), y = blockIdx.y * 16 + (t >> 6) * 4 + (lane >> 4);
-  const bool in = x < dw && y < dh;  // dw % 4 == 0: a lane's four pixels are inside or outside together
-  f32x4 sx4 = {-1.f, -1.f, -1.f, -1.f}, sy4 = sx4;
-  if (in) {
-    sx4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(xmap) + (size_t)y * xp + 4 * (size_t)x);
-    sy4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(ymap) + (size_t)y * yp + 4 * (size_t)x);
-  }
-  bool ok[4], twox[4];
-  uint32_t x0[4], y0[4], y1[4];
-  float fx[4], fy[4];
-  uint32_t kmin = 0xffffffffu, kmax = 0u;  // packed (x | y << 16); source dimensions are <= 65536 (vpf_abi dims_ok), coordinates < 65536
-  auto pk = [](uint32_t a, uint32_t b, bool mx) {
-    const u16x2 p = __builtin_bit_cast(u16x2, a), q = __builtin_bit_cast(u16x2, b);
-    return __builtin_bit_cast(uint32_t, mx ? __builtin_elementwise_max(p, q) : __builtin_elementwise_min(p, q));
-  };
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const float sx = sx4[k], sy = sy4[k];
-    ok[k] = (sx >= 0.f && sx <= (float)(sw - 1) && sy >= 0.f && sy <= (float)(sh - 1));
-    const float cx = ok[k] ? sx : 0.f, cy = ok[k] ? sy : 0.f;
-    x0[k] = (uint32_t)(int)cx; y0[k] = (uint32_t)(int)cy;
-    twox[k] = x0[k] + 1 < sw;
-    y1[k] = (y0[k] + 1 < sh) ? y0[k] + 1 : sh - 1;
-    fx[k] = cx - (float)x0[k]; fy[k] = cy - (float)y0[k];
-    const uint32_t lo = x0[k] | (y0[k] << 16), hi = (twox[k] ? x0[k] + 1 : x0[k]) | (y1[k] << 16);
-    kmin = pk(kmin, ok[k] ? lo : 0xffffffffu, false);
-    kmax = pk(kmax, ok[k] ? hi : 0u, true);
-  }
-  {
-    const uint32_t a = wave_minmax_u16x2<false>(kmin), b = wave_minmax_u16x2<true>(kmax);
-    if (lane == 0) { bb[t >> 6][0] = a; bb[t >> 6][1] = b; }
-  }
-  __syncthreads();
-  const uint32_t bmin = pk(pk(bb[0][0], bb[1][0], false), pk(bb[2][0], bb[3][0], false), false);
-  const uint32_t bmax = pk(pk(bb[0][1], bb[1][1], true), pk(bb[2][1], bb[3][1], true), true);
-  if (bmin == 0xffffffffu) return;  // every pixel of the tile maps outside the source: destination untouched
-  const uint32_t xmin = bmin & 0xffffu, ymin = bmin >> 16, xmax = bmax & 0xffffu, ymax = bmax >> 16;
-  const uint32_t bx0 = (3 * xmin) & ~15u, pitch_l = (3 * (xmax + 1) - bx0 + 15) & ~15u, rows = ymax - ymin + 1;
-  const bool use_lds = (size_t)pitch_l * rows + 16 <= kRemapLdsBytes;
-  if (use_lds) {
-    const uint32_t upr = pitch_l >> 4, total = rows * upr;
-    for (uint32_t u = t; u < total; u += 256) {
-      const uint32_t r = u / upr, cidx = u - r * upr;
-      L[u] = ldg<false, u32x4>(src + (size_t)(ymin + r) * sp + bx0 + 16 * cidx);
-    }
-    __syncthreads();
-  }
-  if (!in) return;
-  float o[12];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    float a0[3], a1[3], b0[3], b1[3];
-    if (use_lds) {
-      const uint8_t* lb = reinterpret_cast<const uint8_t*>(L);
-      // pixels that map outside carry the placeholder coordinate (0, 0): clamping to the box minimum keeps their (unused)
-      // reads inside the staged box and leaves every valid coordinate unchanged
-      const uint32_t xc = x0[k] > xmin ? x0[k] : xmin, r0 = (y0[k] > ymin ? y0[k] : ymin) - ymin, r1 = (y1[k] > ymin ? y1[k] : ymin) - ymin;
-      const uint32_t oc = 3 * xc - bx0;
-      lds_row_taps(lb + r0 * pitch_l, oc, twox[k], a0, a1);
-      lds_row_taps(lb + r1 * pitch_l, oc, twox[k], b0, b1);
-    } else {
-      remap_row_taps(src + (size_t)y0[k] * sp, x0[k], twox[k], sp, a0, a1);
-      remap_row_taps(src + (size_t)y1[k] * sp, x0[k], twox[k], sp, b0, b1);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) o[3 * k + c] = bilerp(a0[c], a1[c], b0[c], b1[c], fx[k], fy[k]);
-  }
-  uint8_t* out = dst + (size_t)y * dp + 3 * (size_t)x;
-  if (vec_ok && ok[0] && ok[1] && ok[2] && ok[3]) {
-    stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (ok[k]) { out[3 * k] = (uint8_t)sat_trunc(o[3 * k]); out[3 * k + 1] = (uint8_t)sat_trunc(o[3 * k + 1]); out[3 * k + 2] = (uint8_t)sat_trunc(o[3 * k + 2]); }
+    for (int j = 0; j < 12; j++)
+      if (ok[j / 3]) out[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
   }
 }
 
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp, const float* xmap,
                         uint32_t xp, const float* ymap, uint32_t yp, uint32_t dw, uint32_t dh, uint8_t* dst,
                         uint32_t dp) {
-  const bool fast = tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && (dw % 4 == 0) && !(((uintptr_t)src | sp) & 3) &&
-                    !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sp >= 12;
-  if (fast && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15) && sw < 65536 && sh < 65536) {  // tap coordinates travel as u16 pairs
-    const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
-    dim3 tgrid((dw + 63) / 64, (dh + 15) / 16);
-    VPF_LAUNCH(k_remap3_tile, tgrid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh, vec_ok);
-    return hipGetLastError();
-  }
+  const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
+  const bool fast = tune != 9 && (dw % 4 == 0) && !(((uintptr_t)src | sp) & 3) &&
+                    !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sp >= 12 && sp < (1u << 24) &&
+                    (uint64_t)sh * sp < (1ull << 32);  // 32-bit source offsets (v_mad_u32_u24)
+  const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
   if (fast) {
-    const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
     dim3 fgrid((dw / 4 + 63) / 64, (dh + 3) / 4);
     VPF_LAUNCH(k_remap3_p4, fgrid, dim3(256), 0, st, src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh, vec_ok);
     return hipGetLastError();
