@@ -686,14 +686,6 @@ __global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src,
 //   * blends of 8-bit samples stay inside [0, 255.5], so the pack needs no clamp (pack4_trunc_inrange).
 // Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0, sp >= 12, sh * sp < 2^32.
 
-// truncating pack of four values known to lie in [0, 256): bilinear blends of 8-bit samples (plus the 0.5 of the rounding)
-// never leave that range — every fma result is the rounding of a point between two representable end points
-VPF_DEV uint32_t pack4_trunc_inrange(float a, float b, float c, float d) {
-  return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
-}
-// a * b + c for a, b < 2^24 (low 32 bits): v_mad_u32_u24, full rate (v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate)
-VPF_DEV uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
-
 // The taps of one pixel column in one source row are 6 bytes starting `o` bytes into the surface; they are fetched as the
 // 12-B window that starts at the aligned address below them (tap_window) and cut out with v_alignbyte_b32 (window_taps).
 // A window that runs over the end of a row into the next one is harmless (the second tap of the last column has weight
@@ -868,18 +860,18 @@ __global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, co
   if constexpr (DST == FC_PLANAR) {
     for (int ch = 0; ch < 3; ch++) {
       uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
-      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
-      else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[ch][i]);
+      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc_inrange(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+      else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(uint32_t)(o[ch][i]);
     }
   } else {
     const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
     if (vec_ok && nv == 4) {
-      stg3<false>(out, pack4_trunc(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc(o[1][1], o[b][1], o[a][2], o[1][2]),
-                  pack4_trunc(o[b][2], o[a][3], o[1][3], o[b][3]));
+      stg3<false>(out, pack4_trunc_inrange(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc_inrange(o[1][1], o[b][1], o[a][2], o[1][2]),
+                  pack4_trunc_inrange(o[b][2], o[a][3], o[1][3], o[b][3]));
     } else {
       for (uint32_t i = 0; i < nv; i++) {
-        out[3 * i] = (uint8_t)sat_trunc(o[a][i]); out[3 * i + 1] = (uint8_t)sat_trunc(o[1][i]); out[3 * i + 2] = (uint8_t)sat_trunc(o[b][i]);
+        out[3 * i] = (uint8_t)(uint32_t)(o[a][i]); out[3 * i + 1] = (uint8_t)(uint32_t)(o[1][i]); out[3 * i + 2] = (uint8_t)(uint32_t)(o[b][i]);
       }
     }
   }
@@ -944,7 +936,8 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
   const uint32_t x0 = xs + lane * 4;
   if (x0 >= dw) return;
   // Two horizontally adjacent taps are converted together on the packed-fp32 pipe (v_pk_fma_f32: two independent
-  // IEEE fmas per instruction, so every component is bit-identical to vpf_convert's scalar fma chain).
+  // IEEE fmas per instruction, so every component is bit-identical to vpf_convert's scalar fma chain).  Measured
+  // against the scalar spelling it is a wash (a packed op costs two issue slots): kept for the shorter instruction stream.
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2 cy2 = {c.cy, c.cy}, rv2 = {c.rv, c.rv}, gu2 = {c.gu, c.gu}, gv2 = {c.gv, c.gv}, bu2 = {c.bu, c.bu};
   const f32x2 br2 = {c.br, c.br}, bg2 = {c.bg, c.bg}, bb2 = {c.bb, c.bb};
@@ -988,6 +981,42 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     const float yv = (float)reinterpret_cast<const uint8_t*>(strip_at(r))[l0];
     t3[0] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.rc)); t3[1] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.gc)); t3[2] = (float)sat_rne(__builtin_fmaf(yv, c.cy, kk.bc));
   };
+  const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
+  const uint32_t kx = (uint32_t)scx;
+  if (!row1 && (float)kx == scx && (kx & 1u) && sw == kx * dw) {
+    // Odd integer scale factors (kernel-uniform on x, row-uniform on y): every destination pixel IS one converted source
+    // pixel — (x + 0.5) * k - 0.5 = k x + (k - 1) / 2 exactly, in float as well (all values < 2^24).  The general path
+    // would round it to 8 bits (sat_rne), go back to float, add 0.5, clamp and truncate — which returns the same integer —
+    // so the conversion's own v_cvt_pk_u8_f32 writes the destination bytes directly: ~25 instead of ~60 VALU per pixel.
+    float v[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i0 = kx * ((x0 + k < dw) ? x0 + k : dw - 1) + (kx >> 1);
+      const uint32_t l0 = i0 - ybase, a0 = (SRC == FC_NV12 ? (i0 & ~1u) : (i0 >> 1)) - cbase;
+      const Chroma ka = chroma1(a0, 0);
+      const float yv = (float)reinterpret_cast<const uint8_t*>(strip_at(0))[l0];
+      v[0][k] = __builtin_fmaf(yv, c.cy, ka.rc); v[1][k] = __builtin_fmaf(yv, c.cy, ka.gc); v[2][k] = __builtin_fmaf(yv, c.cy, ka.bc);
+    }
+    if constexpr (DST == FC_PLANAR) {
+      for (int ch = 0; ch < 3; ch++) {
+        uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
+        if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4<1>(v[ch][0], v[ch][1], v[ch][2], v[ch][3]));
+        else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_rne(v[ch][i]);
+      }
+    } else {
+      const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
+      uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
+      if (vec_ok && nv == 4) {
+        stg3<false>(out, pack4<1>(v[a][0], v[1][0], v[b][0], v[a][1]), pack4<1>(v[1][1], v[b][1], v[a][2], v[1][2]),
+                    pack4<1>(v[b][2], v[a][3], v[1][3], v[b][3]));
+      } else {
+        for (uint32_t i = 0; i < nv; i++) {
+          out[3 * i] = (uint8_t)sat_rne(v[a][i]); out[3 * i + 1] = (uint8_t)sat_rne(v[1][i]); out[3 * i + 2] = (uint8_t)sat_rne(v[b][i]);
+        }
+      }
+    }
+    return;
+  }
   float o[3][4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -1020,22 +1049,21 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
       for (int ch = 0; ch < 3; ch++) o[ch][k] = top[ch] + 0.5f;
     }
   }
-  const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
   if constexpr (DST == FC_PLANAR) {
     for (int ch = 0; ch < 3; ch++) {
       uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
-      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
-      else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[ch][i]);
+      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc_inrange(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+      else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(uint32_t)(o[ch][i]);
     }
   } else {
     const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
     if (vec_ok && nv == 4) {
-      stg3<false>(out, pack4_trunc(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc(o[1][1], o[b][1], o[a][2], o[1][2]),
-                  pack4_trunc(o[b][2], o[a][3], o[1][3], o[b][3]));
+      stg3<false>(out, pack4_trunc_inrange(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc_inrange(o[1][1], o[b][1], o[a][2], o[1][2]),
+                  pack4_trunc_inrange(o[b][2], o[a][3], o[1][3], o[b][3]));
     } else {
       for (uint32_t i = 0; i < nv; i++) {
-        out[3 * i] = (uint8_t)sat_trunc(o[a][i]); out[3 * i + 1] = (uint8_t)sat_trunc(o[1][i]); out[3 * i + 2] = (uint8_t)sat_trunc(o[b][i]);
+        out[3 * i] = (uint8_t)(uint32_t)(o[a][i]); out[3 * i + 1] = (uint8_t)(uint32_t)(o[1][i]); out[3 * i + 2] = (uint8_t)(uint32_t)(o[b][i]);
       }
     }
   }
@@ -1086,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, cons
     if (!act) return;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++)
-      stg<true, u32x2>(f.d[ch] + (size_t)y * f.dp[ch] + xd, u32x2{pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]), pack4_trunc(o[ch][4], o[ch][5], o[ch][6], o[ch][7])});
+      stg<true, u32x2>(f.d[ch] + (size_t)y * f.dp[ch] + xd, u32x2{pack4_trunc_inrange(o[ch][0], o[ch][1], o[ch][2], o[ch][3]), pack4_trunc_inrange(o[ch][4], o[ch][5], o[ch][6], o[ch][7])});
   } else {
     constexpr int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint32_t* t = reinterpret_cast<uint32_t*>(tile + wv * 96);
@@ -1094,9 +1122,9 @@ __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, cons
 #pragma unroll
       for (int g = 0; g < 2; g++) {  // 4 px -> 3 dwords, twice
         const int q = 4 * g;
-        t[lane * 6 + 3 * g] = pack4_trunc(o[a][q], o[1][q], o[b][q], o[a][q + 1]);
-        t[lane * 6 + 3 * g + 1] = pack4_trunc(o[1][q + 1], o[b][q + 1], o[a][q + 2], o[1][q + 2]);
-        t[lane * 6 + 3 * g + 2] = pack4_trunc(o[b][q + 2], o[a][q + 3], o[1][q + 3], o[b][q + 3]);
+        t[lane * 6 + 3 * g] = pack4_trunc_inrange(o[a][q], o[1][q], o[b][q], o[a][q + 1]);
+        t[lane * 6 + 3 * g + 1] = pack4_trunc_inrange(o[1][q + 1], o[b][q + 1], o[a][q + 2], o[1][q + 2]);
+        t[lane * 6 + 3 * g + 2] = pack4_trunc_inrange(o[b][q + 2], o[a][q + 3], o[1][q + 3], o[b][q + 3]);
       }
     }
     wave_lds_sync();

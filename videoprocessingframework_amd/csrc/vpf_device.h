@@ -47,6 +47,15 @@ VPF_DEV uint32_t pack4_trunc(float a, float b, float c, float d) {
   return sat_trunc(a) | (sat_trunc(b) << 8) | (sat_trunc(c) << 16) | (sat_trunc(d) << 24);
 }
 
+// the same for values known to lie in [0, 256): bilinear blends of 8-bit samples (plus the 0.5 of the rounding) never
+// leave that range — every fma result is the rounding of a point between two representable end points — so the
+// v_med3_f32 would be dead weight in the VALU-bound resize / remap kernels
+VPF_DEV uint32_t pack4_trunc_inrange(float a, float b, float c, float d) {
+  return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+// a * b + c for a, b < 2^24 (low 32 bits): v_mad_u32_u24, full rate (v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate)
+VPF_DEV uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+
 struct Chroma {
   float rc, gc, bc;
 };
