@@ -1089,32 +1089,37 @@ __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, cons
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint32_t xs = chunk * 1024 + lane * 16;  // first source pixel of the lane; destination pixel xs / 2
   const bool act = xs < sw;
-  float o[3][8];
+  // With fx = fy = 0.5 the blend of four 8-bit taps is (p00 + p01 + p10 + p11 + 2) >> 2: bilerp()'s float chain is exact
+  // on these operands (halves and quarters of small integers) and truncates the same quotient.  So the four converted
+  // taps are rounded straight into the bytes of one dword (v_cvt_pk_u8_f32, vpf_convert's rounding) and ONE
+  // v_dot4_u32_u8 with weights 64 and addend 128 leaves the pixel in byte 1: 64 * (sum + 2) >> 8.  ~40 instead of ~77
+  // VALU per destination pixel — the kernel was VALU-bound (tools/gpu_pmc_fused.sh 3840 2160 1920 1080).
+  uint32_t o[3][8];  // channel value of destination pixel i in byte 1
   if (act) {
     const u32x4 ya = ldg<true, u32x4>(f.s[0] + (size_t)(2 * y) * f.sp[0] + xs);
     const u32x4 yb = ldg<true, u32x4>(f.s[0] + (size_t)(2 * y + 1) * f.sp[0] + xs);
     const u32x4 uv = load_uv16<SRC, true>(f, y, xs);
+    auto avg = [](const float* t, const float* b, int i) { return __builtin_amdgcn_udot4(pack4<1>(t[i], t[i + 1], b[i], b[i + 1]), 0x40404040u, 128u, false); };
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j])), k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
       const Quad qa = convert4(c, ya[j], k0, k1), qb = convert4(c, yb[j], k0, k1);
-      auto half2 = [](const float* t, const float* b, int i) {  // bilerp(p00, p01, p10, p11, 0.5, 0.5) on rounded taps
-        const float p00 = (float)sat_rne(t[i]), p01 = (float)sat_rne(t[i + 1]), p10 = (float)sat_rne(b[i]), p11 = (float)sat_rne(b[i + 1]);
-        const float top = __builtin_fmaf(0.5f, p01 - p00, p00), bot = __builtin_fmaf(0.5f, p11 - p10, p10);
-        return __builtin_fmaf(0.5f, bot - top, top) + 0.5f;
-      };
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        o[0][2 * j + e] = half2(qa.r, qb.r, 2 * e); o[1][2 * j + e] = half2(qa.g, qb.g, 2 * e); o[2][2 * j + e] = half2(qa.b, qb.b, 2 * e);
+        o[0][2 * j + e] = avg(qa.r, qb.r, 2 * e); o[1][2 * j + e] = avg(qa.g, qb.g, 2 * e); o[2][2 * j + e] = avg(qa.b, qb.b, 2 * e);
       }
     }
   }
+  // byte 1 of four registers -> one dword (three v_perm_b32)
+  auto gather4 = [](uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    return __builtin_amdgcn_perm(__builtin_amdgcn_perm(v3, v2, 0x0c0c0501u), __builtin_amdgcn_perm(v1, v0, 0x0c0c0501u), 0x05040100u);
+  };
   const uint32_t xd = xs >> 1;
   if constexpr (DST == FC_PLANAR) {
     if (!act) return;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++)
-      stg<true, u32x2>(f.d[ch] + (size_t)y * f.dp[ch] + xd, u32x2{pack4_trunc_inrange(o[ch][0], o[ch][1], o[ch][2], o[ch][3]), pack4_trunc_inrange(o[ch][4], o[ch][5], o[ch][6], o[ch][7])});
+      stg<true, u32x2>(f.d[ch] + (size_t)y * f.dp[ch] + xd, u32x2{gather4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]), gather4(o[ch][4], o[ch][5], o[ch][6], o[ch][7])});
   } else {
     constexpr int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint32_t* t = reinterpret_cast<uint32_t*>(tile + wv * 96);
@@ -1122,9 +1127,9 @@ __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, cons
 #pragma unroll
       for (int g = 0; g < 2; g++) {  // 4 px -> 3 dwords, twice
         const int q = 4 * g;
-        t[lane * 6 + 3 * g] = pack4_trunc_inrange(o[a][q], o[1][q], o[b][q], o[a][q + 1]);
-        t[lane * 6 + 3 * g + 1] = pack4_trunc_inrange(o[1][q + 1], o[b][q + 1], o[a][q + 2], o[1][q + 2]);
-        t[lane * 6 + 3 * g + 2] = pack4_trunc_inrange(o[b][q + 2], o[a][q + 3], o[1][q + 3], o[b][q + 3]);
+        t[lane * 6 + 3 * g] = gather4(o[a][q], o[1][q], o[b][q], o[a][q + 1]);
+        t[lane * 6 + 3 * g + 1] = gather4(o[1][q + 1], o[b][q + 1], o[a][q + 2], o[1][q + 2]);
+        t[lane * 6 + 3 * g + 2] = gather4(o[b][q + 2], o[a][q + 3], o[1][q + 3], o[b][q + 3]);
       }
     }
     wave_lds_sync();
