@@ -684,12 +684,13 @@ __global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src,
 //   * sx - (float)(int)sx for sx >= 0 is v_fract_f32 (the subtraction is exact, so the bits are the same);
 //   * source offsets are 32-bit (v_mad_u32_u24; the launcher checks the surface is < 4 GiB) on a scalar base pointer;
 //   * blends of 8-bit samples stay inside [0, 255.5], so the pack needs no clamp (pack4_trunc_inrange).
-// Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0, sp >= 12, sh * sp < 2^32.
+// Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0, sw >= 4, sh * sp < 2^32.  Never reads past the
+// dword-rounded end of the last source row.
 
 // The taps of one pixel column in one source row are 6 bytes starting `o` bytes into the surface; they are fetched as the
 // 12-B window that starts at the aligned address below them (tap_window) and cut out with v_alignbyte_b32 (window_taps).
 // A window that runs over the end of a row into the next one is harmless (the second tap of the last column has weight
-// fx == 0 and fma(0, finite, p0) == p0); only at the very end of the surface (`last` = surface bytes - 12) must it
+// fx == 0 and fma(0, finite, p0) == p0); only at the very end of the pixel data (`last` = its dword-rounded end - 12) must it
 // slide left so that it never leaves the allocation — SLIDE, chosen per wave: the first tap then starts up to 9 bytes
 // into the window and bytes past it read as zero.
 struct TapWindow { uint32_t e0, e1, e2; };
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(256, 8) void k_remap3_p4(const uint8_t* __restrict_
   const f32x4 sx4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(xmap) + (size_t)y * xp + 4 * (size_t)x);
   const f32x4 sy4 = ldg<false, f32x4>(reinterpret_cast<const uint8_t*>(ymap) + (size_t)y * yp + 4 * (size_t)x);
   const float wmax = (float)(sw - 1), hmax = (float)(sh - 1);
-  const uint32_t last = sh * sp - 12;
+  const uint32_t last = (((sh - 1) * sp + 3 * sw + 3) & ~3u) - 12;  // the last window that stays inside the pixel data (rounded up to a dword)
   float fx[4], fy[4];
   uint32_t o0[4], o1[4];  // first tap of the two source rows, bytes into the surface
   bool ok[4];
@@ -798,7 +799,7 @@ hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t*
                         uint32_t dp) {
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
   const bool fast = tune != 9 && (dw % 4 == 0) && !(((uintptr_t)src | sp) & 3) &&
-                    !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sp >= 12 && sp < (1u << 24) &&
+                    !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sw >= 4 && sp < (1u << 24) &&
                     (uint64_t)sh * sp < (1ull << 32);  // 32-bit source offsets (v_mad_u32_u24)
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0);
   if (fast) {
