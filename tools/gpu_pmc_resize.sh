@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters + kernel-trace durations for the fused NV12 -> resize -> RGB kernel (tools/pmc_resize_run.py [dw dh])
+# SQ counters + kernel-trace durations for the resize kernels (tools/pmc_resize_run.py [sw sh dw dh [interp]])
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/pmc_resize; export TMPDIR=/tmp
 OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc_resize"
 cd /tmp
