@@ -220,6 +220,15 @@ VPF_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// the two 3-byte taps that start `a` bytes into an LDS strip (any alignment): 12-B window from the dword below + v_alignbyte_b32
+VPF_DEV void strip_window_taps(const uint8_t* strip, uint32_t a, float* t0, float* t1) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(strip + (a & ~3u));
+  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+  t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
+  t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);
+}
+
 template <int CH, int IT /* 1-KiB loads per strip */>
 __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
@@ -253,31 +262,50 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
     const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
     const uint32_t a = CH * tx.i0 - base, b = CH * tx.i1 - base;
     const bool tap1 = __builtin_amdgcn_ballot_w64(tx.f != 0.f) != 0;  // wave-uniform
+    if constexpr (CH == 3) {
+      // packed RGB: both taps of a row are 6 contiguous bytes -> three aligned dword reads + v_alignbyte_b32 instead of six
+      // ds_read_u8 (the kernel spends as long issuing LDS reads as VALU work).  At the right image edge i1 == i0 and the
+      // window's second tap is whatever follows the row — its weight is exactly 0 there (fma(0, finite, p) == p).
+      float t0[3], t1[3], u0[3], u1[3];
+      strip_window_taps(r0, a, t0, t1);
+      if (row1) strip_window_taps(r1, a, u0, u1);
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-      const float p00 = (float)r0[a + c];
-      const float top = tap1 ? __builtin_fmaf(tx.f, (float)r0[b + c] - p00, p00) : p00;
-      if (row1) {
-        const float p10 = (float)r1[a + c];
-        const float bot = tap1 ? __builtin_fmaf(tx.f, (float)r1[b + c] - p10, p10) : p10;
-        o[k * CH + c] = __builtin_fmaf(ty.f, bot - top, top) + 0.5f;
-      } else {
-        o[k * CH + c] = top + 0.5f;
+      for (int c = 0; c < 3; c++) {
+        const float top = tap1 ? __builtin_fmaf(tx.f, t1[c] - t0[c], t0[c]) : t0[c];
+        if (row1) {
+          const float bot = tap1 ? __builtin_fmaf(tx.f, u1[c] - u0[c], u0[c]) : u0[c];
+          o[k * 3 + c] = __builtin_fmaf(ty.f, bot - top, top) + 0.5f;
+        } else {
+          o[k * 3 + c] = top + 0.5f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const float p00 = (float)r0[a + c];
+        const float top = tap1 ? __builtin_fmaf(tx.f, (float)r0[b + c] - p00, p00) : p00;
+        if (row1) {
+          const float p10 = (float)r1[a + c];
+          const float bot = tap1 ? __builtin_fmaf(tx.f, (float)r1[b + c] - p10, p10) : p10;
+          o[k * CH + c] = __builtin_fmaf(ty.f, bot - top, top) + 0.5f;
+        } else {
+          o[k * CH + c] = top + 0.5f;
+        }
       }
     }
   }
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
     if constexpr (CH == 3) {
-      stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+      stg3<false>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7]), pack4_trunc_inrange(o[8], o[9], o[10], o[11]));
     } else if constexpr (CH == 2) {
-      stg<false, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+      stg<false, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
     } else {
-      stg<false, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+      stg<false, uint32_t>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]));
     }
   } else {
     const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
-    for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[i]);
+    for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(uint32_t)o[i];
   }
 }
 
@@ -544,7 +572,7 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
   const uint32_t rowb = (interp == VPF_INTERP_LINEAR) ? lds_strip_bytes(ch, sw, dw, src, sp, kResizeRowBytes) : 0;
   if (rowb) {
     // (capping residency at 4 / 2 / 1 workgroups per CU to stagger the waves was measured: 8.5 / 8.7 / 11.3 us vs 8.4)
-    const uint32_t it = (rowb + 1023) / 1024, lds = 4 * 2 * rowb;
+    const uint32_t it = (rowb + 1023) / 1024, lds = 4 * 2 * rowb + 16;  // + 16: a tap window may start in a strip's last dword
 #define VPF_RL(C, I) VPF_LAUNCH((k_resize_lds<C, I>), grid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, vec_ok, rowb / 16)
 #define VPF_RLI(C) do { if (it == 1) VPF_RL(C, 1); else if (it == 2) VPF_RL(C, 2); else if (it == 3) VPF_RL(C, 3); else VPF_RL(C, 4); } while (0)
     if (ch == 1) VPF_RLI(1); else if (ch == 2) VPF_RLI(2); else VPF_RLI(3);
