@@ -333,7 +333,7 @@ template <int CH, bool LZ>
 __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                      uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
                                                      float scx, float scy, uint32_t tile_rows, uint32_t nr_cap, int vec_ok) {
-  // dynamic LDS: [4 waves][kLzStripQ x 16 B] byte strips | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats
+  // dynamic LDS: [4 waves][kLzStripQ x 16 B] byte strips | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats | WX[7][64] (Lanczos)
   // (Lanczos: 6 weights + first H row; bilinear: fy, -, ..., top H row, bottom H row)
   constexpr int NT = LZ ? 6 : 2;
   u32x4* const strip = dyn_strip + (threadIdx.x >> 6) * kLzStripQ;
@@ -356,47 +356,88 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
   }
   const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
-  if (threadIdx.x < tile_rows) {  // vertical weights: one lane per destination row
-    const uint32_t y = y0 + threadIdx.x, yc = y < dh ? y : dh - 1;
+  Span<2> cur, nxt;  // the first source row is on its way while the weights are worked out
+  if (wv < nrows) cur.load(src + (size_t)clampi(R0 + (int32_t)wv, (int32_t)sh - 1) * sp, base, nq, lane);
+  // Lanczos weights cost ~150 VALU instructions per call (two polynomials, seven IEEE divisions): the horizontal set of the
+  // tile's 64 columns is computed ONCE, by wave 0, and handed to the other three waves through LDS (it used to be a
+  // quarter of the kernel's instructions); wave 1 computes the vertical sets meanwhile.
+  const uint32_t vt = LZ ? threadIdx.x - 64 : threadIdx.x;  // lane that owns destination row y0 + vt
+  if (vt < tile_rows) {  // vertical weights: one lane per destination row
+    const uint32_t y = y0 + vt, yc = y < dh ? y : dh - 1;
     if constexpr (LZ) {
       const LTap t = make_ltap(yc, scy);
 #pragma unroll
-      for (int k = 0; k < 6; k++) WY[threadIdx.x * 8 + k] = t.w[k];
-      WY[threadIdx.x * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
+      for (int k = 0; k < 6; k++) WY[vt * 8 + k] = t.w[k];
+      WY[vt * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
     } else {
       const Tap t = make_tap<VPF_INTERP_LINEAR>(yc, scy, sh);
-      WY[threadIdx.x * 8] = t.f;
-      WY[threadIdx.x * 8 + 6] = __int_as_float((int32_t)t.i0 - R0);
-      WY[threadIdx.x * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
+      WY[vt * 8] = t.f;
+      WY[vt * 8 + 6] = __int_as_float((int32_t)t.i0 - R0);
+      WY[vt * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
     }
   }
   if constexpr (LZ) {
-    const LTap tx = make_ltap(xc, scx);
+    float* const WX = WY + (size_t)tile_rows * 8;  // [7][64]: six weights and the first tap index of every column
+    if (wv == 0) {
+      const LTap tx = make_ltap(xc, scx);
 #pragma unroll
-    for (int k = 0; k < 6; k++) { xo[k] = clampi(tx.i0 + k - 2, (int32_t)sw - 1) * CH - base; wx[k] = tx.w[k]; }
+      for (int k = 0; k < 6; k++) WX[k * 64 + lane] = tx.w[k];
+      WX[6 * 64 + lane] = __int_as_float(tx.i0);
+    }
+    __syncthreads();
+    const int32_t i0 = __float_as_int(WX[6 * 64 + lane]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { xo[k] = clampi(i0 + k - 2, (int32_t)sw - 1) * CH - base; wx[k] = WX[k * 64 + lane]; }
   } else {
     const Tap tx = make_tap<VPF_INTERP_LINEAR>(xc, scx, sw);
     xo[0] = tx.i0 * CH - base; xo[1] = tx.i1 * CH - base; wx[0] = tx.f; wx[1] = 0.f;
   }
-  Span<2> cur, nxt;
-  if (wv < nrows) cur.load(src + (size_t)clampi(R0 + (int32_t)wv, (int32_t)sh - 1) * sp, base, nq, lane);
+  // wave-uniform: no lane's taps were clamped at an image edge (clamped taps repeat a pixel and break the run)
+  const bool contiguous = LZ && __builtin_amdgcn_ballot_w64(xo[NT - 1] - xo[0] != (uint32_t)(CH * (NT - 1))) == 0;
   for (uint32_t r = wv; r < nrows; r += 4) {
     if (r + 4 < nrows) nxt.load(src + (size_t)clampi(R0 + (int32_t)(r + 4), (int32_t)sh - 1) * sp, base, nq, lane);
     cur.store(strip, nq, lane);
     wave_lds_sync();
     const uint8_t* b = reinterpret_cast<const uint8_t*>(strip);
+    if (CH == 3 && LZ && contiguous) {
+      // packed RGB, no tap clamped anywhere in the wave: a lane's 6 taps are 18 contiguous bytes -> six aligned dword reads
+      // (three ds_read2_b32) + five v_alignbyte_b32 instead of eighteen ds_read_u8; same values, same fma order
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(b + (xo[0] & ~3u));
+      const uint32_t lead = xo[0] & 3u, d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
+      const uint32_t e[5] = {__builtin_amdgcn_alignbyte(d1, d0, lead), __builtin_amdgcn_alignbyte(d2, d1, lead), __builtin_amdgcn_alignbyte(d3, d2, lead),
+                             __builtin_amdgcn_alignbyte(d4, d3, lead), __builtin_amdgcn_alignbyte(d5, d4, lead)};
+      float t[18];  // byte j of the run = tap j / 3, channel j % 3
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-      float ra;
-      if constexpr (LZ) {
-        ra = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(wx[kx], (float)b[xo[kx] + c], ra);
-      } else {
-        const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
-        ra = __builtin_fmaf(wx[0], p1 - p0, p0);
+      for (int j = 0; j < 18; j++) {
+        const uint32_t w = e[j >> 2];
+        t[j] = (j & 3) == 0 ? ubyte<0>(w) : (j & 3) == 1 ? ubyte<1>(w) : (j & 3) == 2 ? ubyte<2>(w) : ubyte<3>(w);
       }
-      H[(r * CH + c) * 64 + lane] = ra;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float ra = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(wx[kx], t[3 * kx + c], ra);
+        H[(r * 3 + c) * 64 + lane] = ra;
+      }
+    } else if (CH == 3 && !LZ) {
+      float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
+      strip_window_taps(b, xo[0], t0, t1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx[0], t1[c] - t0[c], t0[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        float ra;
+        if constexpr (LZ) {
+          ra = 0.f;
+#pragma unroll
+          for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(wx[kx], (float)b[xo[kx] + c], ra);
+        } else {
+          const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
+          ra = __builtin_fmaf(wx[0], p1 - p0, p0);
+        }
+        H[(r * CH + c) * 64 + lane] = ra;
+      }
     }
     wave_lds_sync();  // the strip is rewritten next iteration
     cur = nxt;
@@ -521,7 +562,7 @@ static bool launch_resize_tile(hipStream_t st, bool lz, int ch, uint32_t sw, uin
   while (ty >= 16 && (size_t)((dw + 63) / 64) * ((dh + ty - 1) / ty) < 2048) ty = (ty + 1) / 2;
   if (ty > 4) ty &= ~3u;  // phase 2 hands out rows four per wave
   const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
-  const uint32_t lds = 4 * kLzStripQ * 16 + nr * ch * 64 * 4 + ty * 8 * 4;
+  const uint32_t lds = 4 * kLzStripQ * 16 + nr * ch * 64 * 4 + ty * 8 * 4 + (lz ? 7 * 64 * 4 : 0);  // strips | H | WY | WX (Lanczos)
   dim3 tgrid((dw + 63) / 64, (dh + ty - 1) / ty);
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
 #define VPF_TILE(C, L) VPF_LAUNCH((k_resize_tile<C, L>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr, vec_ok)
