@@ -283,7 +283,8 @@ def test_resize_bilinear(capi, oracle, fmt):
     for (sw, sh, dw, dh) in [(3840, 64, 1280, 22), (640, 360, 224, 224), (100, 60, 333, 201), (64, 64, 64, 64), (9, 7, 2, 2),
                              (1000, 40, 300, 13), (2000, 16, 260, 5), (4096, 8, 258, 2), (300, 20, 1000, 70),
                              (320, 180, 1280, 720), (640, 40, 700, 333), (50, 30, 1921, 47),
-                             (1920, 64, 960, 32), (72, 20, 36, 10), (1000, 8, 500, 4), (2056, 6, 1028, 3)]:  # last four: exact 2x
+                             (1920, 64, 960, 32), (72, 20, 36, 10), (1000, 8, 500, 4), (2056, 6, 1028, 3),  # exact 2x
+                             (3840, 16, 1920, 8), (1056, 4, 528, 2), (32, 2, 16, 1), (2080, 6, 1040, 3)]:  # exact 2x, r16 form (w % 32 == 0): whole / ragged last chunk
         _resize(capi, oracle, f, capi.INTERP_LINEAR, sw, sh, dw, dh)
     _resize(capi, oracle, f, capi.INTERP_LINEAR, 128, 72, 50, 30, align=1)
     _resize(capi, oracle, f, capi.INTERP_NEAREST, 128, 72, 50, 30)

@@ -16,7 +16,7 @@
 //                                         sized per scale factor) and picks taps from LDS; taps with weight exactly 0 are skipped
 //   k_resize_tile<CH, LZ>                 tiled + separable: horizontal pass once per (source row, column) into LDS, then
 //                                         the vertical pass (Lanczos-3 always; bilinear when the vertical scale is < 2)
-//   k_resize_half, k_convert_half         exact 2x: quad-structured streaming kernels (no taps, no gathers)
+//   k_resize_half(3_r16), k_convert_half  exact 2x: quad-structured streaming kernels (no taps, no gathers; integer blend)
 //   k_remap3_p4, k_remap3                 remap: 4 px per lane with 12-B tap windows (all requested up front) / generic
 //   odd integer factors on both axes      every filter returns the centre sample -> nearest kernel
 #include "vpf_device.h"
@@ -550,6 +550,61 @@ static uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* sr
 // tiled separable launch (Lanczos always; bilinear when up-scaling, where the horizontal lerp is shared by several
 // destination rows): needs 16-B aligned source rows and a 64-column span that fits the 2-KiB strip.  Returns false when
 // it does not apply.
+// Exact 2x down-scale of packed RGB / BGR in the r16 form: a wave turns two source rows x 1024 px into 512 destination
+// pixels.  Every global access is a dense 1-KiB wave access (load_run48 on the way in, an LDS-transposed 1 KiB + 512 B on
+// the way out; k_resize_half's 8-B lane loads reach ~0.6 of that rate), and the blend is integer: with fx = fy = 0.5 the
+// bilinear blend of four 8-bit taps is exactly (p00 + p01 + p10 + p11 + 2) >> 2 (see k_convert_half), taken per channel
+// from the de-interleaved dwords with two v_dot4_u32_u8 whose weights (64 on two bytes) pick a horizontal pair of each row.
+// Requires sw % 32 == 0 and 16-B aligned source / destination rows.
+__global__ __launch_bounds__(256) void k_resize_half3_r16(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
+                                                          uint32_t sw, uint32_t chunks_x, uint32_t n_tasks) {
+  __shared__ u32x4 tile[4 * 192];  // 3 KiB per wave
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t wt = blockIdx.x * 4 + wv;
+  if (wt >= n_tasks) return;
+  const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
+  u32x4* t = tile + wv * 192;
+  uint32_t top[12], bot[12];
+  u32x4 qt[3], qb[3];  // both rows' loads are in flight before the first transpose
+  run48_fetch(src + (size_t)(2 * y) * sp, chunk * 3072, 3 * sw, lane, qt);
+  run48_fetch(src + (size_t)(2 * y + 1) * sp, chunk * 3072, 3 * sw, lane, qb);
+  run48_transpose(t, lane, qt, top);
+  wave_sync();  // every lane has read its top bytes before the tile is rewritten
+  run48_transpose(t, lane, qb, bot);
+  uint32_t v[3][8];  // channel value of destination pixel i in byte 1
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    uint32_t tc[3], bc[3];
+    deint4(top[3 * g], top[3 * g + 1], top[3 * g + 2], tc[0], tc[1], tc[2]);
+    deint4(bot[3 * g], bot[3 * g + 1], bot[3 * g + 2], bc[0], bc[1], bc[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      v[c][2 * g] = __builtin_amdgcn_udot4(tc[c], 0x00004040u, __builtin_amdgcn_udot4(bc[c], 0x00004040u, 128u, false), false);
+      v[c][2 * g + 1] = __builtin_amdgcn_udot4(tc[c], 0x40400000u, __builtin_amdgcn_udot4(bc[c], 0x40400000u, 128u, false), false);
+    }
+  }
+  auto gather4 = [](uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {  // byte 1 of four registers -> one dword
+    return __builtin_amdgcn_perm(__builtin_amdgcn_perm(v3, v2, 0x0c0c0501u), __builtin_amdgcn_perm(v1, v0, 0x0c0c0501u), 0x05040100u);
+  };
+  uint32_t* tw = reinterpret_cast<uint32_t*>(t);
+  wave_sync();
+#pragma unroll
+  for (int g = 0; g < 2; g++) {  // 4 px -> 3 dwords, twice
+    const int q = 4 * g;
+    tw[lane * 6 + 3 * g] = gather4(v[0][q], v[1][q], v[2][q], v[0][q + 1]);
+    tw[lane * 6 + 3 * g + 1] = gather4(v[1][q + 1], v[2][q + 1], v[0][q + 2], v[1][q + 2]);
+    tw[lane * 6 + 3 * g + 2] = gather4(v[2][q + 2], v[0][q + 3], v[1][q + 3], v[2][q + 3]);
+  }
+  wave_sync();
+  uint8_t* row = dst + (size_t)y * dp;
+  const uint32_t row_bytes = 3 * (sw >> 1);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {  // the wave's 1536 B leave as one dense 1-KiB store and one 512-B store
+    const uint32_t idx = k * 64 + lane, off = chunk * 1536 + idx * 16;
+    if (idx < 96 && off < row_bytes) stg<true, u32x4>(row + off, t[idx]);
+  }
+}
+
 static bool launch_resize_tile(hipStream_t st, bool lz, int ch, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp,
                                uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp, float scx, float scy) {
   const double taps = lz ? 6.0 : 2.0;
@@ -588,6 +643,11 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
   // exact 2x bilinear: the quad-structured streaming kernel
   if (interp == VPF_INTERP_LINEAR && sw == 2 * dw && sh == 2 * dh && dw % 4 == 0 && !(((uintptr_t)src | sp) & 7) &&
       !(((uintptr_t)dst | dp) & (ch == 2 ? 7 : 3)) && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9) {
+    if (ch == 3 && sw % 32 == 0 && !(((uintptr_t)src | sp | (uintptr_t)dst | dp) & 15)) {
+      const uint32_t chunks = (sw + 1023) / 1024, tasks = chunks * dh;
+      VPF_LAUNCH(k_resize_half3_r16, dim3((tasks + 3) / 4), dim3(256), 0, st, src, sp, dst, dp, sw, chunks, tasks);
+      return hipGetLastError();
+    }
     dim3 hgrid((dw / 4 + 63) / 64, (dh + 3) / 4);
     if (ch == 1) VPF_LAUNCH((k_resize_half<1>), hgrid, dim3(256), 0, st, src, sp, dst, dp, dw, dh);
     else if (ch == 2) VPF_LAUNCH((k_resize_half<2>), hgrid, dim3(256), 0, st, src, sp, dst, dp, dw, dh);

@@ -145,14 +145,17 @@ VPF_DEV void swap4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t& o0, uint32_t
 // global side = three dense 1-KiB accesses (lane-contiguous 16 B), register side = 48 contiguous bytes (16 px) per lane.
 // ds_write/read_b128 at 48*lane + 16*j and 16*(64k + lane) are both bank-conflict-free (profiles/r01_pmc_sq.json).
 // `row` points at byte 0 of the run's row, `base` = byte offset of the run, `row_bytes` = 3 * width (multiple of 16).
-VPF_DEV void load_run48(u32x4* t, const uint8_t* row, uint32_t base, uint32_t row_bytes, uint32_t lane, uint32_t d[12]) {
-  u32x4 q[3];
+// the global half: three dense 16-B loads per lane (kernels that read several rows issue all of them before transposing any)
+VPF_DEV void run48_fetch(const uint8_t* row, uint32_t base, uint32_t row_bytes, uint32_t lane, u32x4 q[3]) {
 #pragma unroll
   for (int k = 0; k < 3; k++) {  // clamp instead of predicate: all three loads issue back to back; the clamped
     uint32_t off = base + (k * 64 + lane) * 16;  // duplicates land in slots only out-of-range lanes would read
     off = off < row_bytes ? off : row_bytes - 16;
     q[k] = ldg<true, u32x4>(row + off);
   }
+}
+// the LDS half: lane-contiguous 16-B units -> 48 contiguous bytes per lane
+VPF_DEV void run48_transpose(u32x4* t, uint32_t lane, const u32x4 q[3], uint32_t d[12]) {
 #pragma unroll
   for (int k = 0; k < 3; k++) t[k * 64 + lane] = q[k];
   wave_sync();
@@ -161,6 +164,11 @@ VPF_DEV void load_run48(u32x4* t, const uint8_t* row, uint32_t base, uint32_t ro
     const u32x4 v = t[lane * 3 + j];
     d[4 * j] = v[0]; d[4 * j + 1] = v[1]; d[4 * j + 2] = v[2]; d[4 * j + 3] = v[3];
   }
+}
+VPF_DEV void load_run48(u32x4* t, const uint8_t* row, uint32_t base, uint32_t row_bytes, uint32_t lane, uint32_t d[12]) {
+  u32x4 q[3];
+  run48_fetch(row, base, row_bytes, lane, q);
+  run48_transpose(t, lane, q, d);
 }
 VPF_DEV void store_run48(u32x4* t, uint8_t* row, uint32_t base, uint32_t row_bytes, uint32_t lane, const uint32_t d[12]) {
 #pragma unroll
