@@ -255,6 +255,25 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
   if (x0 >= dw) return;
   const uint8_t* r0 = reinterpret_cast<const uint8_t*>(st0);
   const uint8_t* r1 = reinterpret_cast<const uint8_t*>(st1);
+  if constexpr (CH == 3) {
+    // Odd integer scale factors (kernel-uniform on x, row-uniform on y; 4K -> 720p is 3x): every destination pixel IS the
+    // source pixel k x + (k - 1) / 2 — exactly, in float as well (all values < 2^24) — and the general path's float round
+    // trip (+ 0.5, truncate) returns its bytes unchanged.  So the bytes are moved as bytes: one 8-B LDS window +
+    // v_alignbyte_b32 per pixel, three v_perm_b32 per four pixels.
+    const uint32_t kx = (uint32_t)scx;
+    if (!row1 && (float)kx == scx && (kx & 1u) && sw == kx * dw && vec_ok && x0 + 4 <= dw) {
+      uint32_t e[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t a = 3 * (kx * (x0 + k) + (kx >> 1)) - base;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(r0 + (a & ~3u));
+        e[k] = __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);  // R G B of the pixel in bytes 0..2
+      }
+      stg3<false>(dst + (size_t)y * dp + 3 * (size_t)x0, __builtin_amdgcn_perm(e[1], e[0], 0x04020100u),
+                  __builtin_amdgcn_perm(e[2], e[1], 0x05040201u), __builtin_amdgcn_perm(e[3], e[2], 0x06050402u));
+      return;
+    }
+  }
   float o[4 * CH];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
