@@ -126,8 +126,7 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
 // swizzle hands each XCD ONE contiguous eighth of every frame instead of every eighth row pair, so each XCD's L2
 // write-back stream is sequential (tools/write_probe.hip X0/X1: +6 % on pure writes).
 template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0, bool XCD_SWZ = false, int SRC = FC_NV12>
-__global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
-                                                           uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void p16_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   // BALLAST_KB > 0 pads the LDS footprint to cap the number of resident workgroups per CU (occupancy experiment)
   __shared__ u32x4 tile[((LDS_T && DST != FC_PLANAR) ? WPB * 2 * 192 : 1) + BALLAST_KB * 64];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -135,7 +134,6 @@ __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args,
   if constexpr (XCD_SWZ) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);  // host guarantees gridDim.x % 8 == 0
   const uint32_t wt = bx * WPB + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t rp = wt / chunks_x, chunk = wt - rp * chunks_x;
   const uint32_t x = chunk * 1024 + lane * 16;
   const bool act = x < w;
@@ -206,6 +204,23 @@ __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args,
       }
     }
   }
+}
+
+// batched entry: up to 32 frame descriptors by value in the kernarg segment, blockIdx.y = frame
+template <int DST, int PACK, bool NTL, bool NTS, bool LDS_T, bool NOMATH, int WPB = 4, int BALLAST_KB = 0, bool XCD_SWZ = false, int SRC = FC_NV12>
+__global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                           uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  p16_task<DST, PACK, NTL, NTS, LDS_T, NOMATH, WPB, BALLAST_KB, XCD_SWZ, SRC>(args.f[blockIdx.y], c, w, h, chunks_x, n_tasks);
+}
+// single-frame entry (one Execute() = one launch): the frame arrives as scalar kernel arguments, source side first, which
+// the dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count): the wave's first loads no longer wait for a
+// scalar-cache round trip to the kernarg segment — worth 0.5-0.8 us on a kernel that lasts 6-7 us
+template <int DST, bool NTS, int SRC>
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16_one(const uint8_t* s0, const uint8_t* s1, const uint8_t* s2, uint32_t sp0, uint32_t sp1,
+                                                          uint32_t sp2, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks,
+                                                          uint8_t* d0, uint32_t dp0, const Yuv2RgbCoef c) {
+  const FrameDesc f = {{s0, s1, s2}, {d0, nullptr, nullptr}, {sp0, sp1, sp2}, {dp0, 0, 0}};
+  p16_task<DST, 1, true, NTS, true, false, 4, 0, false, SRC>(f, c, w, h, chunks_x, n_tasks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,7 +665,10 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
         if (v == 8 || v == 12 || v == 30) {
           const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
           dim3 grid((tasks + 3) / 4, n);
-          if (v == 8) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          const FrameDesc& f0 = a.f[0];
+          if (n == 1 && v == 8) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, true, FC_YUV420>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
+          else if (n == 1 && v == 12) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, false, FC_YUV420>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
+          else if (v == 8) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           else if (v == 12) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, false, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           else VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 16, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           return hipGetLastError();
@@ -730,6 +748,12 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       if ((variant == 41 || variant == 42) && (grid.x & 7)) variant = (variant == 41) ? 30 : 8;  // swizzle needs gridDim.x % 8 == 0
 #define VPF_P16(NTL, NTS, LDS, NOMATH) \
   VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, NTL, NTS, LDS, NOMATH>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks)
+      if (DST != FC_PLANAR && n == 1 && (variant == 8 || variant == 12)) {  // one packed frame per launch: scalar-argument entry
+        const FrameDesc& f0 = a.f[0];
+        if (variant == 8) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, true, FC_NV12>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
+        else VPF_LAUNCH((k_nv12_rgb_p16_one<DST, false, FC_NV12>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
+        return hipGetLastError();
+      }
       switch (variant) {
         case 7: VPF_P16(false, false, true, false); break;
         case 11: VPF_P16(false, true, true, false); break;
