@@ -249,13 +249,11 @@ __global__ __launch_bounds__(256) void k_rgb32f_planar_r4(const BatchArgs args, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rgb_relayout_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x,
-                                                          uint32_t n_tasks) {
+VPF_DEV void rgb_relayout_r16_task(const FrameDesc& f, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[4 * 192];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint32_t x = chunk * 1024 + lane * 16;
   u32x4* t = tile + wv * 192;
@@ -284,6 +282,15 @@ __global__ __launch_bounds__(256) void k_rgb_relayout_r16(const BatchArgs args, 
     for (int g = 0; g < 4; g++) swap4(d[3 * g], d[3 * g + 1], d[3 * g + 2], o[3 * g], o[3 * g + 1], o[3 * g + 2]);
     store_run48(t, f.d[0] + (size_t)y * f.dp[0], chunk * 3072, 3 * w, lane, o);  // each lane rewrites only its own 3 slots
   }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rgb_relayout_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  rgb_relayout_r16_task<MODE>(args.f[blockIdx.y], w, h, chunks_x, n_tasks);
+}
+template <int MODE>  // single-frame entry: scalar arguments (see VPF_ONE_SRC_PARAMS in vpf_internal.h)
+__global__ __launch_bounds__(256) void k_rgb_relayout_r16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks,
+                                                              VPF_ONE_DST_PARAMS) {
+  rgb_relayout_r16_task<MODE>(VPF_ONE_FRAME, w, h, chunks_x, n_tasks);
 }
 
 // RGB / BGR / RGB_PLANAR -> Y, 16 px per lane -> one dense 1-KiB store per wave.  SRC: 0 RGB, 1 BGR, 2 planar
@@ -479,7 +486,8 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     if (sf == VPF_FMT_BGR)
       for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].d[0], b.f[i].d[2]); std::swap(b.f[i].dp[0], b.f[i].dp[2]); }
     if (r16 && al(b, n, 1, 3, 16, 16, 16, 16)) {
-      VPF_LAUNCH((k_rgb_relayout_r16<0>), row_tasks(cx, h), dim3(256), 0, st, b, w, h, cx, cx * h);
+      if (n == 1) VPF_LAUNCH((k_rgb_relayout_r16_one<0>), row_tasks(cx, h), dim3(256), 0, st, VPF_ONE_SRC_ARGS(b.f[0]), w, h, cx, cx * h, VPF_ONE_DST_ARGS(b.f[0]));
+      else VPF_LAUNCH((k_rgb_relayout_r16<0>), row_tasks(cx, h), dim3(256), 0, st, b, w, h, cx, cx * h);
       return hipGetLastError();
     }
     if (!force_generic && w % 4 == 0 && al(b, n, 1, 3, 4, 4, 4, 4)) {
@@ -494,7 +502,8 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
     if (df == VPF_FMT_BGR)
       for (uint32_t i = 0; i < n; i++) { std::swap(b.f[i].s[0], b.f[i].s[2]); std::swap(b.f[i].sp[0], b.f[i].sp[2]); }
     if (r16 && al(b, n, 3, 1, 16, 16, 16, 16)) {
-      VPF_LAUNCH((k_rgb_relayout_r16<1>), row_tasks(cx, h), dim3(256), 0, st, b, w, h, cx, cx * h);
+      if (n == 1) VPF_LAUNCH((k_rgb_relayout_r16_one<1>), row_tasks(cx, h), dim3(256), 0, st, VPF_ONE_SRC_ARGS(b.f[0]), w, h, cx, cx * h, VPF_ONE_DST_ARGS(b.f[0]));
+      else VPF_LAUNCH((k_rgb_relayout_r16<1>), row_tasks(cx, h), dim3(256), 0, st, b, w, h, cx, cx * h);
       return hipGetLastError();
     }
     if (!force_generic && w % 4 == 0 && al(b, n, 3, 1, 4, 4, 4, 4)) {
@@ -506,7 +515,8 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   }
   if (packed_s && packed_d && sf != df) {
     if (r16 && al(a, n, 1, 1, 16, 16, 16, 16)) {
-      VPF_LAUNCH((k_rgb_relayout_r16<2>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
+      if (n == 1) VPF_LAUNCH((k_rgb_relayout_r16_one<2>), row_tasks(cx, h), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, cx, cx * h, VPF_ONE_DST_ARGS(a.f[0]));
+      else VPF_LAUNCH((k_rgb_relayout_r16<2>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
       return hipGetLastError();
     }
     if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 4, 4)) {

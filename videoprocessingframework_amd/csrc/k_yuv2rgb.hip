@@ -336,12 +336,10 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_r4(const BatchArgs args, const
 // UV line from L2, not HBM), three dense 1-KiB dwordx4 stores (R, G, B planes) — 3 stores per wave instead of the 6 a
 // row-pair wave needs for three planes (write-rate law, tools/write_probe.hip).  Requires w % 16 == 0, 16-B aligned planes.
 // ---------------------------------------------------------------------------------------------
-template <bool NTS, int SRC = FC_NV12>
-__global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
-                                                         uint32_t chunks_x, uint32_t n_tasks) {
+template <bool NTS, int SRC>
+VPF_DEV void planar_r16_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   const uint32_t wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   // consecutive waves of a block take rows 2rp, 2rp+1 of the same chunk, so the shared UV line is hot in L1/L2
   const uint32_t pair = wt >> 1, half = wt & 1;
   const uint32_t rp = pair / chunks_x, chunk = pair - rp * chunks_x;
@@ -362,6 +360,16 @@ __global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, c
   stg<NTS, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, r);
   stg<NTS, u32x4>(f.d[1] + (size_t)y * f.dp[1] + x, g);
   stg<NTS, u32x4>(f.d[2] + (size_t)y * f.dp[2] + x, b);
+}
+template <bool NTS, int SRC = FC_NV12>
+__global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
+                                                         uint32_t chunks_x, uint32_t n_tasks) {
+  planar_r16_task<NTS, SRC>(args.f[blockIdx.y], c, w, h, chunks_x, n_tasks);
+}
+template <bool NTS, int SRC>  // single-frame entry: scalar arguments (see VPF_ONE_SRC_PARAMS)
+__global__ __launch_bounds__(256) void k_nv12_planar_r16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks,
+                                                             VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  planar_r16_task<NTS, SRC>(VPF_ONE_FRAME, c, w, h, chunks_x, n_tasks);
 }
 
 // r16 for packed outputs: one row x 1024 px per wave (Y + the UV line it shares with its neighbour row), the 48 B/lane
@@ -657,7 +665,9 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
         if (v == 37 || v == 44) {
           const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;
           dim3 grid((tasks + 3) / 4, n);
-          if (v == 37) VPF_LAUNCH((k_nv12_planar_r16<true, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+          if (n == 1 && v == 37) VPF_LAUNCH((k_nv12_planar_r16_one<true, FC_YUV420>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c);
+          else if (n == 1) VPF_LAUNCH((k_nv12_planar_r16_one<false, FC_YUV420>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c);
+          else if (v == 37) VPF_LAUNCH((k_nv12_planar_r16<true, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           else VPF_LAUNCH((k_nv12_planar_r16<false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           return hipGetLastError();
         }
@@ -718,7 +728,9 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
     if (variant == 37 || variant == 44) {
       const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;  // one task per row per chunk (h even)
       dim3 grid((tasks + 3) / 4, n);
-      if (variant == 37) VPF_LAUNCH((k_nv12_planar_r16<true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
+      if (n == 1 && variant == 37) VPF_LAUNCH((k_nv12_planar_r16_one<true, FC_NV12>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c);
+      else if (n == 1) VPF_LAUNCH((k_nv12_planar_r16_one<false, FC_NV12>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c);
+      else if (variant == 37) VPF_LAUNCH((k_nv12_planar_r16<true>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
       else VPF_LAUNCH((k_nv12_planar_r16<false>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);  // allocating stores
       return hipGetLastError();
     }
