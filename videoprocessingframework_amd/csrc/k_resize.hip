@@ -1035,9 +1035,8 @@ __global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, co
 constexpr uint32_t kFusedRowBytes = 2048;  // cap; the launch sizes the strips for its own scale factor (dyn_strip)
 
 template <int SRC, int DST, int IT>
-__global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
-                                                            uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok, uint32_t rowq) {
-  const FrameDesc f = args.f[blockIdx.z];
+VPF_DEV void convert_resize_lds_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx,
+                                     float scy, int vec_ok, uint32_t rowq) {
   // per wave, NS strips of rowq x 16 B in dynamic LDS: 0,1 luma rows; 2,3 chroma rows (NV12: UV interleaved | YUV420: U);
   // 4,5 V rows (YUV420 only)
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1217,6 +1216,19 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
     }
   }
 }
+template <int SRC, int DST, int IT>
+__global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
+                                                            uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok, uint32_t rowq) {
+  convert_resize_lds_task<SRC, DST, IT>(args.f[blockIdx.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq);
+}
+// single-frame entry: scalar arguments, what the first loads need in front (see VPF_ONE_SRC_PARAMS in vpf_internal.h)
+template <int SRC, int DST, int IT>
+__global__ __launch_bounds__(256) void k_convert_resize_lds_one(const uint8_t* s0, const uint8_t* s1, uint32_t sp0, uint32_t sp1, uint32_t sw,
+                                                                uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy, uint32_t rowq,
+                                                                int vec_ok, const uint8_t* s2, uint32_t sp2, VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  convert_resize_lds_task<SRC, DST, IT>(VPF_ONE_FRAME, c, sw, sh, dw, dh, scx, scy, vec_ok, rowq);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Exact 2x down-scale (4K -> 1080p, 1080p -> 540p ...): s = (d + 0.5) * 2 - 0.5 = 2d + 0.5 exactly, so every destination
@@ -1228,13 +1240,11 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args
 // (packed) aligned destination rows.
 // ------------------------------------------------------------------------------------------
 template <int DST, int SRC>
-__global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t dh,
-                                                      uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void convert_half_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t dh, uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[DST == FC_PLANAR ? 1 : 4 * 96];  // 1.5 KiB per wave: 64 lanes x 24 packed bytes
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint32_t xs = chunk * 1024 + lane * 16;  // first source pixel of the lane; destination pixel xs / 2
   const bool act = xs < sw;
@@ -1291,6 +1301,16 @@ __global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, cons
     }
   }
 }
+template <int DST, int SRC>
+__global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t dh,
+                                                      uint32_t chunks_x, uint32_t n_tasks) {
+  convert_half_task<DST, SRC>(args.f[blockIdx.y], c, sw, dh, chunks_x, n_tasks);
+}
+template <int DST, int SRC>  // single-frame entry: scalar arguments
+__global__ __launch_bounds__(256) void k_convert_half_one(VPF_ONE_SRC_PARAMS, uint32_t sw, uint32_t dh, uint32_t chunks_x, uint32_t n_tasks,
+                                                          VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  convert_half_task<DST, SRC>(VPF_ONE_FRAME, c, sw, dh, chunks_x, n_tasks);
+}
 
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh,
                                  uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh) {
@@ -1312,18 +1332,21 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
     if (ok16) {
       const uint32_t chunks = (sw + 1023) / 1024, tasks = chunks * dh;
       dim3 hgrid((tasks + 3) / 4, n);
-#define VPF_HALF(S) do { if (dst_fc == FC_RGB) VPF_LAUNCH((k_convert_half<FC_RGB, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); \
-                         else if (dst_fc == FC_BGR) VPF_LAUNCH((k_convert_half<FC_BGR, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); \
-                         else VPF_LAUNCH((k_convert_half<FC_PLANAR, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); } while (0)
+#define VPF_HALF1(D, S) do { if (n == 1) VPF_LAUNCH((k_convert_half_one<D, S>), hgrid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), sw, dh, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c); \
+                            else VPF_LAUNCH((k_convert_half<D, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); } while (0)
+#define VPF_HALF(S) do { if (dst_fc == FC_RGB) VPF_HALF1(FC_RGB, S); else if (dst_fc == FC_BGR) VPF_HALF1(FC_BGR, S); else VPF_HALF1(FC_PLANAR, S); } while (0)
       if (src_fc == FC_NV12) VPF_HALF(FC_NV12); else VPF_HALF(FC_YUV420);
 #undef VPF_HALF
+#undef VPF_HALF1
       return hipGetLastError();
     }
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);
   const uint32_t lds = 4 * (src_fc == FC_NV12 ? 4 : 6) * rowb;
-#define VPF_GOL(S, D) do { if (rowb <= 1024) VPF_LAUNCH((k_convert_resize_lds<S, D, 1>), grid, dim3(256), lds, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); \
-                           else VPF_LAUNCH((k_convert_resize_lds<S, D, 2>), grid, dim3(256), lds, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); } while (0)
+#define VPF_GOL1(S, D, I) do { if (n == 1) VPF_LAUNCH((k_convert_resize_lds_one<S, D, I>), grid, dim3(256), lds, st, a.f[0].s[0], a.f[0].s[1], a.f[0].sp[0], a.f[0].sp[1], \
+                                                      sw, sh, dw, dh, scx, scy, rowb / 16, vec_ok, a.f[0].s[2], a.f[0].sp[2], VPF_ONE_DST_ARGS(a.f[0]), c); \
+                               else VPF_LAUNCH((k_convert_resize_lds<S, D, I>), grid, dim3(256), lds, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); } while (0)
+#define VPF_GOL(S, D) do { if (rowb <= 1024) VPF_GOL1(S, D, 1); else VPF_GOL1(S, D, 2); } while (0)
 #define VPF_GO(S, D) VPF_LAUNCH((k_convert_resize<S, D>), grid, dim3(256), 0, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok)
 #define VPF_PICK(S, D) do { if (lds_ok) VPF_GOL(S, D); else VPF_GO(S, D); } while (0)
   if (src_fc == FC_NV12) {
@@ -1336,6 +1359,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 #undef VPF_PICK
 #undef VPF_GO
 #undef VPF_GOL
+#undef VPF_GOL1
   return hipGetLastError();
 }
 
