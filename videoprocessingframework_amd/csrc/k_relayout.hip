@@ -334,13 +334,11 @@ __global__ __launch_bounds__(256) void k_gray_r16(const BatchArgs args, uint32_t
 // NV12 <-> YUV420, rows split by role: a luma wave copies 1 KiB (one load, one store); a chroma wave moves 2 KiB of
 // interleaved UV <-> 1 KiB of U + 1 KiB of V.  Requires w % 32 == 0, h even, every plane and pitch 16-B aligned.
 template <bool TO_PLANAR>
-__global__ __launch_bounds__(256) void k_nv12_yuv420_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_y,
-                                                         uint32_t luma_tasks, uint32_t chunks_c, uint32_t n_tasks) {
+VPF_DEV void nv12_yuv420_r16_task(const FrameDesc& f, uint32_t w, uint32_t h, uint32_t chunks_y, uint32_t luma_tasks, uint32_t chunks_c, uint32_t n_tasks) {
   __shared__ u32x4 tile[TO_PLANAR ? 1 : 4 * 128];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   if (wt < luma_tasks) {
     const uint32_t y = wt / chunks_y, x = (wt - y * chunks_y) * 1024 + lane * 16;
     if (x < w) stg<true, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, ldg<true, u32x4>(f.s[0] + (size_t)y * f.sp[0] + x));
@@ -382,6 +380,14 @@ __global__ __launch_bounds__(256) void k_nv12_yuv420_r16(const BatchArgs args, u
       if (off < w) stg<true, u32x4>(row + off, t[k * 64 + lane]);
     }
   }
+}
+template <bool TO_PLANAR>
+__global__ __launch_bounds__(256) void k_nv12_yuv420_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_y, uint32_t luma_tasks, uint32_t chunks_c, uint32_t n_tasks) {
+  nv12_yuv420_r16_task<TO_PLANAR>(args.f[blockIdx.y], w, h, chunks_y, luma_tasks, chunks_c, n_tasks);
+}
+template <bool TO_PLANAR>  // single-frame entry: scalar arguments (see VPF_ONE_SRC_PARAMS in vpf_internal.h)
+__global__ __launch_bounds__(256) void k_nv12_yuv420_r16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_y, uint32_t luma_tasks, uint32_t chunks_c, uint32_t n_tasks, VPF_ONE_DST_PARAMS) {
+  nv12_yuv420_r16_task<TO_PLANAR>(VPF_ONE_FRAME, w, h, chunks_y, luma_tasks, chunks_c, n_tasks);
 }
 
 // RGB -> RGB_32F, elementwise over the 3W bytes of a row: a wave takes 1 KiB of bytes as four dense 256-B dword loads
@@ -459,7 +465,9 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
                                             (sf == VPF_FMT_YUV420 && df == VPF_FMT_NV12 && al(a, n, 3, 2, 16, 16, 16, 16)))) {
     const uint32_t cc = (w + 2047) / 2048, luma = cx * h, total = luma + cc * (h / 2);
     dim3 grid((total + 3) / 4, n);
-    if (sf == VPF_FMT_NV12) VPF_LAUNCH((k_nv12_yuv420_r16<true>), grid, dim3(256), 0, st, a, w, h, cx, luma, cc, total);
+    if (n == 1 && sf == VPF_FMT_NV12) VPF_LAUNCH((k_nv12_yuv420_r16_one<true>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, cx, luma, cc, total, VPF_ONE_DST_ARGS(a.f[0]));
+    else if (n == 1) VPF_LAUNCH((k_nv12_yuv420_r16_one<false>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, cx, luma, cc, total, VPF_ONE_DST_ARGS(a.f[0]));
+    else if (sf == VPF_FMT_NV12) VPF_LAUNCH((k_nv12_yuv420_r16<true>), grid, dim3(256), 0, st, a, w, h, cx, luma, cc, total);
     else VPF_LAUNCH((k_nv12_yuv420_r16<false>), grid, dim3(256), 0, st, a, w, h, cx, luma, cc, total);
     return hipGetLastError();
   }

@@ -126,14 +126,12 @@ __global__ __launch_bounds__(256) void k_rgb_yuv_p4(const BatchArgs args, const 
 // Requires w % 16 == 0, h even for 4:2:0, 16-B aligned planes / pitches (8-B for subsampled chroma).
 // ------------------------------------------------------------------------------------------
 template <int SRC, bool SUB>
-__global__ __launch_bounds__(256) void k_rgb_yuv_r16(const BatchArgs args, const Rgb2YuvCoef c, uint32_t w, uint32_t h,
-                                                     uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void rgb_yuv_r16_task(const FrameDesc& f, const Rgb2YuvCoef& c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   constexpr int ROWS = SUB ? 2 : 1;
   __shared__ u32x4 tile[SRC == FC_PLANAR ? 1 : 4 * 192 * ROWS];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t rg = wt / chunks_x, chunk = wt - rg * chunks_x;
   const uint32_t y0 = rg * ROWS, x = chunk * 1024 + lane * 16;
   uint32_t p0[ROWS][4], p1[ROWS][4], p2[ROWS][4];  // channel planes in memory order, 4 px per dword
@@ -210,6 +208,14 @@ __global__ __launch_bounds__(256) void k_rgb_yuv_r16(const BatchArgs args, const
     stg<true, u32x2>(f.d[2] + (size_t)rg * f.dp[2] + (x >> 1), u32x2{cv[0], cv[1]});
   }
 }
+template <int SRC, bool SUB>
+__global__ __launch_bounds__(256) void k_rgb_yuv_r16(const BatchArgs args, const Rgb2YuvCoef c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  rgb_yuv_r16_task<SRC, SUB>(args.f[blockIdx.y], c, w, h, chunks_x, n_tasks);
+}
+template <int SRC, bool SUB>  // single-frame entry: scalar arguments (see VPF_ONE_SRC_PARAMS in vpf_internal.h)
+__global__ __launch_bounds__(256) void k_rgb_yuv_r16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks, VPF_ONE_DST_PARAMS, const Rgb2YuvCoef c) {
+  rgb_yuv_r16_task<SRC, SUB>(VPF_ONE_FRAME, c, w, h, chunks_x, n_tasks);
+}
 
 static bool rgb2yuv_r16_ok(const BatchArgs& a, uint32_t n, int src_fc, bool sub, uint32_t w, uint32_t h) {
   const int tv = tuning(VPF_TUNE_NV12_RGB_VARIANT);
@@ -245,7 +251,9 @@ hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc, const Rgb2Y
     const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (sub ? h / 2 : h);
     dim3 rgrid((tasks + 3) / 4, n);
 #define VPF_R16(S)                                                                                    \
-  if (sub) VPF_LAUNCH((k_rgb_yuv_r16<S, true>), rgrid, dim3(256), 0, st, a, c, w, h, chunks, tasks);   \
+  if (n == 1 && sub) VPF_LAUNCH((k_rgb_yuv_r16_one<S, true>), rgrid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c); \
+  else if (n == 1) VPF_LAUNCH((k_rgb_yuv_r16_one<S, false>), rgrid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c); \
+  else if (sub) VPF_LAUNCH((k_rgb_yuv_r16<S, true>), rgrid, dim3(256), 0, st, a, c, w, h, chunks, tasks);   \
   else VPF_LAUNCH((k_rgb_yuv_r16<S, false>), rgrid, dim3(256), 0, st, a, c, w, h, chunks, tasks);      \
   return hipGetLastError();
     switch (src_fc) {

@@ -542,13 +542,11 @@ __global__ __launch_bounds__(256) void k_yuv444_rgb_p4(const BatchArgs args, con
 // YUV444 -> RGB/BGR/PLANAR, r16: one row x 1024 px per wave, three dense 1-KiB plane loads, three dense 1-KiB stores
 // (packed outputs through store_run48).  Requires w % 16 == 0 and 16-B aligned planes / pitches.
 template <int DST>
-__global__ __launch_bounds__(256) void k_yuv444_rgb_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
-                                                        uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void yuv444_rgb_r16_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[DST == FC_PLANAR ? 1 : 4 * 192];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint32_t x = chunk * 1024 + lane * 16;
   if (DST == FC_PLANAR && x >= w) return;
@@ -583,6 +581,14 @@ __global__ __launch_bounds__(256) void k_yuv444_rgb_r16(const BatchArgs args, co
   } else {
     store_run48(tile + wv * 192, f.d[0] + (size_t)y * f.dp[0], chunk * 3072, 3 * w, lane, o);
   }
+}
+template <int DST>
+__global__ __launch_bounds__(256) void k_yuv444_rgb_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  yuv444_rgb_r16_task<DST>(args.f[blockIdx.y], c, w, h, chunks_x, n_tasks);
+}
+template <int DST>  // single-frame entry: scalar arguments (see VPF_ONE_SRC_PARAMS in vpf_internal.h)
+__global__ __launch_bounds__(256) void k_yuv444_rgb_r16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks, VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  yuv444_rgb_r16_task<DST>(VPF_ONE_FRAME, c, w, h, chunks_x, n_tasks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -826,7 +832,8 @@ static hipError_t launch_444(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   const int ndst = (DST == FC_PLANAR) ? 3 : 1;
   if (variant != 9 && variant != 40 && w % 16 == 0 && aligned_all(a, n, 3, ndst, 16, 16, 16)) {
     const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * h;
-    VPF_LAUNCH((k_yuv444_rgb_r16<DST>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, chunks, tasks);
+    if (n == 1) VPF_LAUNCH((k_yuv444_rgb_r16_one<DST>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c);
+    else VPF_LAUNCH((k_yuv444_rgb_r16<DST>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, chunks, tasks);
     return hipGetLastError();
   }
   if (variant != 9 && w % 4 == 0 && aligned_all(a, n, 3, ndst, 4, 4, 4) && h <= 65535) {
