@@ -233,12 +233,11 @@ __global__ __launch_bounds__(256) void k_p16_to_8_p8(const BatchArgs args, uint3
 // ------------------------------------------------------------------------------------------
 // RGB_32F -> RGB_32F_PLANAR is the same shape one size up: a 3-KiB run is 256 px of 12 B, a lane owns 4 px and
 // de-interleaves whole dwords.  Requires w % 4 == 0, 16-B aligned planes / pitches.
-__global__ __launch_bounds__(256) void k_rgb32f_planar_r4(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void rgb32f_planar_r4_task(const FrameDesc& f, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[4 * 192];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint32_t x = chunk * 256 + lane * 4;
   uint32_t d[12];
@@ -246,6 +245,12 @@ __global__ __launch_bounds__(256) void k_rgb32f_planar_r4(const BatchArgs args, 
   if (x >= w) return;
 #pragma unroll
   for (int k = 0; k < 3; k++) stg<true, u32x4>(f.d[k] + (size_t)y * f.dp[k] + 4 * (size_t)x, u32x4{d[k], d[3 + k], d[6 + k], d[9 + k]});
+}
+__global__ __launch_bounds__(256) void k_rgb32f_planar_r4(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  rgb32f_planar_r4_task(args.f[blockIdx.y], w, h, chunks_x, n_tasks);
+}
+__global__ __launch_bounds__(256) void k_rgb32f_planar_r4_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks, VPF_ONE_DST_PARAMS) {  // single-frame entry: scalar arguments
+  rgb32f_planar_r4_task(VPF_ONE_FRAME, w, h, chunks_x, n_tasks);
 }
 
 template <int MODE>
@@ -295,12 +300,11 @@ __global__ __launch_bounds__(256) void k_rgb_relayout_r16_one(VPF_ONE_SRC_PARAMS
 
 // RGB / BGR / RGB_PLANAR -> Y, 16 px per lane -> one dense 1-KiB store per wave.  SRC: 0 RGB, 1 BGR, 2 planar
 template <int SRC>
-__global__ __launch_bounds__(256) void k_gray_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void gray_r16_task(const FrameDesc& f, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   __shared__ u32x4 tile[SRC == 2 ? 1 : 4 * 192];
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint32_t x = chunk * 1024 + lane * 16;
   uint32_t c0[4], c1[4], c2[4];
@@ -329,6 +333,14 @@ __global__ __launch_bounds__(256) void k_gray_r16(const BatchArgs args, uint32_t
                        gray(ubyte<2>(r), ubyte<2>(gg), ubyte<2>(b)), gray(ubyte<3>(r), ubyte<3>(gg), ubyte<3>(b)));
   }
   stg<true, u32x4>(f.d[0] + (size_t)y * f.dp[0] + x, u32x4{o[0], o[1], o[2], o[3]});
+}
+template <int SRC>
+__global__ __launch_bounds__(256) void k_gray_r16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  gray_r16_task<SRC>(args.f[blockIdx.y], w, h, chunks_x, n_tasks);
+}
+template <int SRC>
+__global__ __launch_bounds__(256) void k_gray_r16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks, VPF_ONE_DST_PARAMS) {  // single-frame entry: scalar arguments
+  gray_r16_task<SRC>(VPF_ONE_FRAME, w, h, chunks_x, n_tasks);
 }
 
 // NV12 <-> YUV420, rows split by role: a luma wave copies 1 KiB (one load, one store); a chroma wave moves 2 KiB of
@@ -393,11 +405,10 @@ __global__ __launch_bounds__(256) void k_nv12_yuv420_r16_one(VPF_ONE_SRC_PARAMS,
 // RGB -> RGB_32F, elementwise over the 3W bytes of a row: a wave takes 1 KiB of bytes as four dense 256-B dword loads
 // (all in flight before the first use) and writes four dense 1-KiB runs of floats.
 template <int N>
-__global__ __launch_bounds__(256) void k_u8_to_f32_x4(const BatchArgs args, uint32_t wdwords, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void u8_to_f32_x4_task(const FrameDesc& f, uint32_t wdwords, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   const uint8_t* src = f.s[0] + (size_t)y * f.sp[0];
   uint8_t* dst = f.d[0] + (size_t)y * f.dp[0];
@@ -415,13 +426,20 @@ __global__ __launch_bounds__(256) void k_u8_to_f32_x4(const BatchArgs args, uint
     if (i < wdwords) stg<true, f32x4>(dst + 16 * (size_t)i, v);
   }
 }
+template <int N>
+__global__ __launch_bounds__(256) void k_u8_to_f32_x4(const BatchArgs args, uint32_t wdwords, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  u8_to_f32_x4_task<N>(args.f[blockIdx.y], wdwords, h, chunks_x, n_tasks);
+}
+template <int N>
+__global__ __launch_bounds__(256) void k_u8_to_f32_x4_one(VPF_ONE_SRC_PARAMS, uint32_t wdwords, uint32_t h, uint32_t chunks_x, uint32_t n_tasks, VPF_ONE_DST_PARAMS) {  // single-frame entry: scalar arguments
+  u8_to_f32_x4_task<N>(VPF_ONE_FRAME, wdwords, h, chunks_x, n_tasks);
+}
 
 // P10 / P12 -> NV12, 16 samples (32 B) per lane -> one dense 1-KiB store per wave; rows as in k_p16_to_8_p8.
-__global__ __launch_bounds__(256) void k_p16_to_8_x16(const BatchArgs args, uint32_t wsamples, uint32_t h, uint32_t ch, uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void p16_to_8_x16_task(const FrameDesc& f, uint32_t wsamples, uint32_t h, uint32_t ch, uint32_t chunks_x, uint32_t n_tasks) {
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wt = blockIdx.x * 4 + wv;
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t row = wt / chunks_x, chunk = wt - row * chunks_x;
   const int pl = row >= h;
   const uint32_t y = pl ? row - h : row;
@@ -435,6 +453,12 @@ __global__ __launch_bounds__(256) void k_p16_to_8_x16(const BatchArgs args, uint
   };
   const u32x4 o = {two(a[0], a[1]), two(a[2], a[3]), two(b[0], b[1]), two(b[2], b[3])};
   stg<true, u32x4>(f.d[pl] + (size_t)y * f.dp[pl] + xs, o);
+}
+__global__ __launch_bounds__(256) void k_p16_to_8_x16(const BatchArgs args, uint32_t wsamples, uint32_t h, uint32_t ch, uint32_t chunks_x, uint32_t n_tasks) {
+  p16_to_8_x16_task(args.f[blockIdx.y], wsamples, h, ch, chunks_x, n_tasks);
+}
+__global__ __launch_bounds__(256) void k_p16_to_8_x16_one(VPF_ONE_SRC_PARAMS, uint32_t wsamples, uint32_t h, uint32_t ch, uint32_t chunks_x, uint32_t n_tasks, VPF_ONE_DST_PARAMS) {  // single-frame entry: scalar arguments
+  p16_to_8_x16_task(VPF_ONE_FRAME, wsamples, h, ch, chunks_x, n_tasks);
 }
 
 static bool al(const BatchArgs& a, uint32_t n, int ns, int nd, uint32_t s0, uint32_t s12, uint32_t d0, uint32_t d12) {
@@ -553,7 +577,8 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if (sf == VPF_FMT_RGB && df == VPF_FMT_RGB_32F) {
     if (r16 && al(a, n, 1, 1, 4, 4, 16, 16)) {
       const uint32_t wd = 3 * w / 4, cn = (wd + 255) / 256;  // 4 loads + 4 stores per wave: measured 0.74 (2: 0.69, 8: 0.72)
-      VPF_LAUNCH(k_u8_to_f32_x4<4>, row_tasks(cn, h), dim3(256), 0, st, a, wd, h, cn, cn * h);
+      if (n == 1) VPF_LAUNCH(k_u8_to_f32_x4_one<4>, row_tasks(cn, h), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), wd, h, cn, cn * h, VPF_ONE_DST_ARGS(a.f[0]));
+      else VPF_LAUNCH(k_u8_to_f32_x4<4>, row_tasks(cn, h), dim3(256), 0, st, a, wd, h, cn, cn * h);
       return hipGetLastError();
     }
     if (!force_generic && w % 4 == 0 && al(a, n, 1, 1, 4, 4, 16, 16)) {
@@ -566,7 +591,8 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if (sf == VPF_FMT_RGB_32F && df == VPF_FMT_RGB_32F_PLANAR) {
     if (!force_generic && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && w % 4 == 0 && al(a, n, 1, 3, 16, 16, 16, 16)) {
       const uint32_t c4 = (w + 255) / 256;
-      VPF_LAUNCH(k_rgb32f_planar_r4, row_tasks(c4, h), dim3(256), 0, st, a, w, h, c4, c4 * h);
+      if (n == 1) VPF_LAUNCH(k_rgb32f_planar_r4_one, row_tasks(c4, h), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, c4, c4 * h, VPF_ONE_DST_ARGS(a.f[0]));
+      else VPF_LAUNCH(k_rgb32f_planar_r4, row_tasks(c4, h), dim3(256), 0, st, a, w, h, c4, c4 * h);
       return hipGetLastError();
     }
     return go_generic<OP_RGB32F_PLANAR>(st, w, h, n, a);
@@ -574,7 +600,8 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if ((sf == VPF_FMT_P10 || sf == VPF_FMT_P12) && df == VPF_FMT_NV12) {
     if (r16 && al(a, n, 2, 2, 16, 16, 16, 16)) {
       const uint32_t ch = (h + 1) / 2;
-      VPF_LAUNCH(k_p16_to_8_x16, row_tasks(cx, h + ch), dim3(256), 0, st, a, w, h, ch, cx, cx * (h + ch));
+      if (n == 1) VPF_LAUNCH(k_p16_to_8_x16_one, row_tasks(cx, h + ch), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, ch, cx, cx * (h + ch), VPF_ONE_DST_ARGS(a.f[0]));
+      else VPF_LAUNCH(k_p16_to_8_x16, row_tasks(cx, h + ch), dim3(256), 0, st, a, w, h, ch, cx, cx * (h + ch));
       return hipGetLastError();
     }
     if (!force_generic && w % 8 == 0 && al(a, n, 2, 2, 16, 16, 8, 8)) {  // luma and chroma rows both hold w 16-bit samples
@@ -588,9 +615,11 @@ hipError_t launch_relayout(hipStream_t st, int sf, int df, uint32_t w, uint32_t 
   if (df == VPF_FMT_Y && (sf == VPF_FMT_RGB || sf == VPF_FMT_BGR || sf == VPF_FMT_RGB_PLANAR)) {
     const int ns = (sf == VPF_FMT_RGB_PLANAR) ? 3 : 1;
     if (r16 && al(a, n, ns, 1, 16, 16, 16, 16)) {
-      if (sf == VPF_FMT_RGB) VPF_LAUNCH((k_gray_r16<0>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
-      else if (sf == VPF_FMT_BGR) VPF_LAUNCH((k_gray_r16<1>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
-      else VPF_LAUNCH((k_gray_r16<2>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h);
+      const int gs = sf == VPF_FMT_RGB ? 0 : (sf == VPF_FMT_BGR ? 1 : 2);
+#define VPF_GRAY(S) do { if (n == 1) VPF_LAUNCH((k_gray_r16_one<S>), row_tasks(cx, h), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, cx, cx * h, VPF_ONE_DST_ARGS(a.f[0])); \
+                         else VPF_LAUNCH((k_gray_r16<S>), row_tasks(cx, h), dim3(256), 0, st, a, w, h, cx, cx * h); } while (0)
+      if (gs == 0) VPF_GRAY(0); else if (gs == 1) VPF_GRAY(1); else VPF_GRAY(2);
+#undef VPF_GRAY
       return hipGetLastError();
     }
     if (!force_generic && w % 4 == 0 && al(a, n, ns, 1, 4, 4, 4, 4)) {
