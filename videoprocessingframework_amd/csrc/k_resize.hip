@@ -74,11 +74,11 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
     if constexpr (CH == 3) {
-      stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+      stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
     } else if constexpr (CH == 2) {
-      stg<false, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+      stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
     } else {
-      stg<false, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+      stg<true, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
     }
   } else {
     const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
         const uint32_t* q = reinterpret_cast<const uint32_t*>(r0 + (a & ~3u));
         e[k] = __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);  // R G B of the pixel in bytes 0..2
       }
-      stg3<false>(dst + (size_t)y * dp + 3 * (size_t)x0, __builtin_amdgcn_perm(e[1], e[0], 0x04020100u),
+      stg3<true>(dst + (size_t)y * dp + 3 * (size_t)x0, __builtin_amdgcn_perm(e[1], e[0], 0x04020100u),
                   __builtin_amdgcn_perm(e[2], e[1], 0x05040201u), __builtin_amdgcn_perm(e[3], e[2], 0x06050402u));
       return;
     }
@@ -316,11 +316,11 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
     if constexpr (CH == 3) {
-      stg3<false>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7]), pack4_trunc_inrange(o[8], o[9], o[10], o[11]));
+      stg3<true>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7]), pack4_trunc_inrange(o[8], o[9], o[10], o[11]));
     } else if constexpr (CH == 2) {
-      stg<false, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
+      stg<true, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
     } else {
-      stg<false, uint32_t>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]));
+      stg<true, uint32_t>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]));
     }
   } else {
     const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
@@ -503,11 +503,11 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
     uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
     if (vec_ok && x0 + 4 <= dw) {
       if constexpr (CH == 3) {
-        stg3<false>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+        stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
       } else if constexpr (CH == 2) {
-        stg<false, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+        stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
       } else {
-        stg<false, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+        stg<true, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
       }
     } else {
       const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
