@@ -961,6 +961,8 @@ hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------
+// (Stores: plain here — non-temporal stores measured 1.44 -> 1.61 us per 4K -> 720p frame in the batched fused kernel,
+// while the unfused resize kernels gain from them on large outputs: 1080p -> 4K 16.0 -> 13.8 us.)
 // fused NV12 / YUV420 -> bilinear -> RGB / BGR / RGB_PLANAR.  Defined as convert-then-resize: each of
 // the four source texels is converted to 8-bit RGB with exactly vpf_convert's arithmetic (including
 // its rounding), then interpolated — bit-identical to running the two kernels back to back, but the
