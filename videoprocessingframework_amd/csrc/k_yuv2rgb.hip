@@ -216,11 +216,9 @@ __global__ __launch_bounds__(64 * WPB) void k_nv12_rgb_p16(const BatchArgs args,
 // the dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count): the wave's first loads no longer wait for a
 // scalar-cache round trip to the kernarg segment — worth 0.5-0.8 us on a kernel that lasts 6-7 us
 template <int DST, bool NTS, int SRC>
-__global__ __launch_bounds__(256) void k_nv12_rgb_p16_one(const uint8_t* s0, const uint8_t* s1, const uint8_t* s2, uint32_t sp0, uint32_t sp1,
-                                                          uint32_t sp2, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks,
-                                                          uint8_t* d0, uint32_t dp0, const Yuv2RgbCoef c) {
-  const FrameDesc f = {{s0, s1, s2}, {d0, nullptr, nullptr}, {sp0, sp1, sp2}, {dp0, 0, 0}};
-  p16_task<DST, 1, true, NTS, true, false, 4, 0, false, SRC>(f, c, w, h, chunks_x, n_tasks);
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks,
+                                                          VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  p16_task<DST, 1, true, NTS, true, false, 4, 0, false, SRC>(VPF_ONE_FRAME, c, w, h, chunks_x, n_tasks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -682,8 +680,8 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
           const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);
           dim3 grid((tasks + 3) / 4, n);
           const FrameDesc& f0 = a.f[0];
-          if (n == 1 && v == 8) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, true, FC_YUV420>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
-          else if (n == 1 && v == 12) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, false, FC_YUV420>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
+          if (n == 1 && v == 8) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, true, FC_YUV420>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(f0), w, h, chunks, tasks, VPF_ONE_DST_ARGS(f0), c);
+          else if (n == 1 && v == 12) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, false, FC_YUV420>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(f0), w, h, chunks, tasks, VPF_ONE_DST_ARGS(f0), c);
           else if (v == 8) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           else if (v == 12) VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, false, true, false, 4, 0, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
           else VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, true, true, true, false, 4, 16, false, FC_YUV420>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
@@ -700,7 +698,10 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   // batched launches run long enough that 4 resident workgroups per CU (variant 30: LDS-capped) beat 6 by 1-2 %
   // (a narrower chip-wide write frontier; tools/write_probe.hip); short single-frame launches want all the waves they can get
   // planar outputs: r16 (one row per wave, three 1-KiB plane stores) beats p4's 256-B stores by ~9 % when batched
-  if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? 37 : (n >= 4 ? 30 : 8)) : 4;
+  // a lone big planar frame: the row-pair kernel (half as many waves, each bringing in 2.5 KiB) beats r16 — kernel durations
+  // 7.3 vs 7.9 us at 4K, but 4.3 vs 3.6 at 1080p and 3.7 vs 2.8 at 720p (tools/gpu_planar_single.sh)
+  const bool big_single = n < 4 && (size_t)w * h >= (size_t)3 << 20;
+  if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? (big_single ? 8 : 37) : (n >= 4 ? 30 : 8)) : 4;
   const bool want_p16 = (variant == 7 || variant == 8 || (variant >= 11 && variant <= 15) || (variant >= 17 && variant <= 21) || (variant >= 30 && variant <= 32) || variant == 36 || variant == 41 || variant == 42);
   const bool packed_only = (variant >= 17 && variant <= 19) || (variant >= 22 && variant <= 29) || variant == 38 || variant == 43;
   if ((want_p16 || packed_only || variant == 37 || variant == 44) && !p16_ok) variant = 4;
@@ -766,10 +767,10 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       if ((variant == 41 || variant == 42) && (grid.x & 7)) variant = (variant == 41) ? 30 : 8;  // swizzle needs gridDim.x % 8 == 0
 #define VPF_P16(NTL, NTS, LDS, NOMATH) \
   VPF_LAUNCH((k_nv12_rgb_p16<DST, 1, NTL, NTS, LDS, NOMATH>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks)
-      if (DST != FC_PLANAR && n == 1 && (variant == 8 || variant == 12)) {  // one packed frame per launch: scalar-argument entry
+      if (n == 1 && (variant == 8 || variant == 12)) {  // one frame per launch: scalar-argument entry
         const FrameDesc& f0 = a.f[0];
-        if (variant == 8) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, true, FC_NV12>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
-        else VPF_LAUNCH((k_nv12_rgb_p16_one<DST, false, FC_NV12>), grid, dim3(256), 0, st, f0.s[0], f0.s[1], f0.s[2], f0.sp[0], f0.sp[1], f0.sp[2], w, h, chunks, tasks, f0.d[0], f0.dp[0], c);
+        if (variant == 8) VPF_LAUNCH((k_nv12_rgb_p16_one<DST, true, FC_NV12>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(f0), w, h, chunks, tasks, VPF_ONE_DST_ARGS(f0), c);
+        else VPF_LAUNCH((k_nv12_rgb_p16_one<DST, false, FC_NV12>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(f0), w, h, chunks, tasks, VPF_ONE_DST_ARGS(f0), c);
         return hipGetLastError();
       }
       switch (variant) {
