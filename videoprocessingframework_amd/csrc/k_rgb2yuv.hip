@@ -245,9 +245,9 @@ static bool rgb2yuv_fast_ok(const BatchArgs& a, uint32_t n, int src_fc, bool sub
 hipError_t launch_rgb_to_yuv(hipStream_t st, int src_fc, int dst_fc, const Rgb2YuvCoef& c, uint32_t w, uint32_t h,
                              uint32_t n, const BatchArgs& a) {
   const bool sub = (dst_fc == FC_YUV420);
-  // a row-pair wave halves the wave count: on a lone 4K frame that is only ~4300 waves for 8192 slots, and the narrower
-  // p4 kernel wins by 8 % (profiles/r01_secondary_kernels.txt); batched launches have waves to spare
-  if (rgb2yuv_r16_ok(a, n, src_fc, sub, w, h) && !(sub && n < 2 && (size_t)w * h < (size_t)3840 * 2160 * 2)) {
+  // (a lone 4K frame used to take the narrower p4 kernel here — a row-pair wave halves the wave count, and p4 won by 8 %;
+  // with the scalar-argument single-frame entry r16 is the faster one again: 0.51 vs 0.47 of 8 TB/s)
+  if (rgb2yuv_r16_ok(a, n, src_fc, sub, w, h)) {
     const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (sub ? h / 2 : h);
     dim3 rgrid((tasks + 3) / 4, n);
 #define VPF_R16(S)                                                                                    \
