@@ -46,8 +46,7 @@ VPF_DEV void store_bytes(uint8_t* p, uint32_t d0, uint32_t d1, uint32_t d2, uint
 }
 
 template <int SRC, int DST, int RP, int PACK, bool NTL, bool NTS, int BALLAST_KB = 0>
-__global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
-                                                       uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+VPF_DEV void yuv420_rgb_p4_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   if constexpr (BALLAST_KB > 0) {  // occupancy experiment: an LDS footprint that caps resident workgroups per CU
     __shared__ uint32_t ballast[BALLAST_KB * 256];
     if (n_tasks == 0xffffffffu) ballast[threadIdx.x] = w;  // never true; keeps the allocation
@@ -55,7 +54,6 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
   // wave-uniform by construction; readfirstlane tells the compiler so (scalar branches, SGPR addressing)
   const uint32_t wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wt >= n_tasks) return;
-  const FrameDesc f = args.f[blockIdx.y];
   const uint32_t rpt = wt / chunks_x, chunk = wt - rpt * chunks_x;
   const uint32_t x = (chunk * 64 + (threadIdx.x & 63)) * 4;
   if (x >= w) return;
@@ -110,6 +108,16 @@ __global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, con
       }
     }
   }
+}
+template <int SRC, int DST, int RP, int PACK, bool NTL, bool NTS, int BALLAST_KB = 0>
+__global__ __launch_bounds__(256) void k_yuv420_rgb_p4(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w,
+                                                       uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
+  yuv420_rgb_p4_task<SRC, DST, RP, PACK, NTL, NTS, BALLAST_KB>(args.f[blockIdx.y], c, w, h, chunks_x, n_tasks);
+}
+template <int SRC, int DST>  // single-frame entry of the default p4 form (irregular sizes / alignments): scalar arguments
+__global__ __launch_bounds__(256) void k_yuv420_rgb_p4_one(VPF_ONE_SRC_PARAMS, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks,
+                                                           VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  yuv420_rgb_p4_task<SRC, DST, 1, 1, true, true, 0>(VPF_ONE_FRAME, c, w, h, chunks_x, n_tasks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -819,7 +827,13 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
       case 35: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true, 40>, 1);  // 4 blocks/CU
       case 14: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, false, true>, 1);
       case 16: return go(k_yuv420_rgb_p4<SRC, DST, 2, 1, false, true>, 2);
-      default: return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true>, 1);
+      default:
+        if (n == 1) {
+          const uint32_t tasks = chunks * ((h + 1) / 2);
+          VPF_LAUNCH((k_yuv420_rgb_p4_one<SRC, DST>), dim3((tasks + 3) / 4, 1), dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), w, h, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c);
+          return hipGetLastError();
+        }
+        return go(k_yuv420_rgb_p4<SRC, DST, 1, 1, true, true>, 1);
     }
   }
   dim3 grid(((w + 1) / 2 + 63) / 64, ((h + 1) / 2 + 3) / 4, n);
