@@ -15,10 +15,13 @@
 //   k_resize_lds, k_convert_resize_lds    a wave stages the source rows it needs in wave-private LDS strips (dynamic LDS
 //                                         sized per scale factor) and picks taps from LDS; taps with weight exactly 0 are skipped
 //   k_resize_tile<CH, LZ>                 tiled + separable: horizontal pass once per (source row, column) into LDS, then
-//                                         the vertical pass (Lanczos-3 always; bilinear when the vertical scale is < 2)
+//                                         the vertical pass (Lanczos-3 always; bilinear when the vertical scale is < 1)
 //   k_resize_half(3_r16), k_convert_half  exact 2x: quad-structured streaming kernels (no taps, no gathers; integer blend)
 //   k_remap3_p4, k_remap3                 remap: 4 px per lane with 12-B tap windows (all requested up front) / generic
-//   odd integer factors on both axes      every filter returns the centre sample -> nearest kernel
+//   odd integer factors on both axes      every filter returns the centre sample -> nearest kernel (Lanczos) / the LDS
+//                                         kernels' byte-move and direct-pack paths (bilinear, fused)
+//   packed RGB taps                       both taps of a row = 6 contiguous bytes: fetched as ONE 12-B window from the
+//                                         aligned address below (global or LDS) and cut out with v_alignbyte_b32
 #include "vpf_device.h"
 
 namespace vpf {
