@@ -906,7 +906,8 @@ VPF_DEV void remap_blend4(const uint8_t* __restrict__ src, const uint32_t* o0, c
 
 // Cache policy (4K, us per frame): plain map loads + non-temporal destination stores 22.2; all plain 23.7; non-temporal
 // map loads 25.2 (+ NT stores 23.6).  Assigning each XCD a horizontal band of the picture (so that vertically adjacent
-// tiles share an L2) was slower as well: 23.4 vs 21.9.
+// tiles share an L2) was slower as well: 23.4 vs 21.9; so was padding the grid width to a multiple of 8 (a column of tiles per
+// XCD): 23.0 vs 22.2.
 __global__ __launch_bounds__(256, 8) void k_remap3_p4(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                    const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
                                                    uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
