@@ -171,6 +171,46 @@ def test_batch_matches_single(capi, oracle):
         assert_planes_equal(got, want, f"batch frame {i}")
 
 
+def test_single_frame_entry_equals_batch_entry(capi, oracle):
+    """One frame per launch goes through the scalar-argument kernel entries (k_*_one), two or more through the by-value
+    BatchArgs entries: the same bytes must come out of both, for every converter family that has the two entries and
+    for the fused kernels (exact 3x, exact 2x, general ratio)."""
+    ex = capi.make_exec(stream_handle())
+    pairs = [("NV12", "RGB", 640, 36), ("NV12", "BGR", 1056, 8), ("NV12", "RGB_PLANAR", 640, 36), ("NV12", "RGB_PLANAR", 2048, 1536),
+             ("NV12", "RGB", 1366, 10), ("YUV420", "RGB", 640, 36), ("YUV420", "RGB_PLANAR", 640, 36), ("YUV444", "BGR", 640, 12),
+             ("RGB", "RGB_PLANAR", 640, 12), ("RGB_PLANAR", "BGR", 640, 12), ("RGB", "BGR", 640, 12), ("RGB", "YUV420", 640, 12),
+             ("BGR", "YUV444", 640, 12), ("NV12", "YUV420", 640, 12), ("YUV420", "NV12", 640, 12), ("RGB", "Y", 640, 12),
+             ("RGB", "RGB_32F", 640, 12), ("P10", "NV12", 640, 12)]
+    for sfmt, dfmt, w, h in pairs:
+        sf, df = getattr(oracle, sfmt), getattr(oracle, dfmt)
+        cs, cr = next((a, b) for a, b in MATS if capi.convert_supported(getattr(capi, sfmt), getattr(capi, dfmt), a, b))
+        srcs = [oracle.synth(sf, w, h, 4100 + i) for i in range(2)]
+        S = [DevPlanes(x) for x in srcs]
+        D1 = [DevPlanes(oracle.alloc(df, w, h)) for _ in range(2)]
+        D2 = [DevPlanes(oracle.alloc(df, w, h)) for _ in range(2)]
+        for s, d in zip(S, D1):
+            capi.convert(ex, getattr(capi, sfmt), getattr(capi, dfmt), cs, cr, w, h, s.desc(), d.desc())
+        capi.convert_batch(ex, getattr(capi, sfmt), getattr(capi, dfmt), cs, cr, w, h, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D2)]))
+        torch.cuda.synchronize()
+        for i in range(2):
+            (a, ia), (b, ib) = D1[i].download(), D2[i].download()
+            assert ia and ib
+            assert_planes_equal(a, b, f"single vs batch {sfmt}->{dfmt} {w}x{h} frame {i}")
+    for (sw, sh, dw, dh) in [(1920, 48, 640, 16), (1920, 64, 960, 32), (640, 360, 213, 120)]:
+        srcs = [oracle.synth(oracle.NV12, sw, sh, 4200 + i) for i in range(2)]
+        S = [DevPlanes(x) for x in srcs]
+        D1 = [DevPlanes(oracle.alloc(oracle.RGB, dw, dh)) for _ in range(2)]
+        D2 = [DevPlanes(oracle.alloc(oracle.RGB, dw, dh)) for _ in range(2)]
+        for s, d in zip(S, D1):
+            capi.convert_resize(ex, capi.NV12, capi.RGB, 1, 0, sw, sh, s.desc(), dw, dh, d.desc())
+        capi.convert_resize_batch(ex, capi.NV12, capi.RGB, 1, 0, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D2)]))
+        torch.cuda.synchronize()
+        for i in range(2):
+            (a, ia), (b, ib) = D1[i].download(), D2[i].download()
+            assert ia and ib
+            assert_planes_equal(a, b, f"single vs batch fused {sw}x{sh}->{dw}x{dh} frame {i}")
+
+
 def test_linearity_property_full_size(capi, oracle):
     """size-independent property at 4K: full-range luma ramp with neutral chroma maps to R=G=B=Y (JPEG matrices)"""
     w, h = 3840, 2160
