@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 from videoprocessingframework_amd import capi, sharding  # noqa: E402  (capi raises if libvpfhip.so is missing: no fallback)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
 
 
 def _pitched(rows, row_bytes, dev, gen=None, align=256):
@@ -142,21 +143,44 @@ class Workload:
         return [np.ascontiguousarray(src[:h, :w]), np.ascontiguousarray(src[h:, :w])], self.keep[1].cpu().numpy()
 
 
-def timed(wl: Workload, steps: int, warmup: int, dist_on: bool):
+class RehearsalWorkload:
+    """--rehearse-host: NO conversion happens and nothing is measured.  A host no-op of fixed duration stands in for the
+    step so that the multi-rank control flow of this file (rendezvous, LOCAL_RANK handling, barrier placement, sum-units /
+    max-time reduction, rank-0-only JSON line) can be executed by the CPU test suite under torch.distributed.run + gloo
+    (tests/test_sharding_gloo.py).  The line it prints says "data": "rehearsal" and carries no roofline."""
+
+    name, dev, w, h, ring, launches_per_step, kernel = "rehearsal", None, 3840, 2160, 32, 1, "none (host rehearsal)"
+
+    def __init__(self, rank):
+        self.px_per_step = self.ring * self.w * self.h
+        self.bytes_per_step = self.px_per_step * 9 // 2
+        self.sleep = 0.002 * (1 + rank)  # ranks differ on purpose: the reduction must pick the slowest
+
+    def step(self):
+        time.sleep(self.sleep)
+
+
+def timed(wl, steps: int, warmup: int, dist_on: bool):
+    gpu = wl.dev is not None
     for _ in range(warmup):
         wl.step()
-    torch.cuda.synchronize()
+    if gpu:
+        torch.cuda.synchronize()
     sharding.barrier(wl.dev)  # barrier + torch.cuda.synchronize on both sides of the timed region
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # on the launch stream
+    if gpu:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # on the launch stream
     t0 = time.perf_counter()
-    e0.record()
+    if gpu:
+        e0.record()
     for _ in range(steps):
         wl.step()
-    e1.record()
-    torch.cuda.synchronize()
+    if gpu:
+        e1.record()
+        torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
     sharding.barrier(wl.dev)
     wall = time.perf_counter() - t0
-    return wall, e0.elapsed_time(e1) * 1e-3
+    return wall, (e0.elapsed_time(e1) * 1e-3 if gpu else t_own)
 
 
 def effective_cpus() -> int:
@@ -219,6 +243,8 @@ def cpu_baseline(wl: Workload, budget_s=10.0):
     o.set_threads(1)
     matches = bool(np.array_equal(gpu_out[:, :3 * w], dst[0]))
     return {"value": round(n * w * h / el / 1e9, 4), "unit": "Gpix/s", "cores": best, "kind": "port", "matches_gpu": matches,
+            "decode_leg": "not measurable here: the reference's only software component is libav decode, and this image has no libav; "
+                          "this is the conversion half only (the reference itself has no CPU converter)",
             "sample": f"{n} frames of 3840x2160 NV12->RGB BT.709 limited in {el:.1f} s; oracle FP32 mode (AVX2+FMA rows, OpenMP), "
                       f"{best} threads; {avail} usable CPUs (affinity {len(os.sched_getaffinity(0))}, cgroup quota applied) (calibration Gpix/s: " +
                       ", ".join(f"{t}t={v / 1e9:.2f}" for t, v in calib.items()) + ")"}
@@ -259,18 +285,38 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also measure the other BASELINE configs / dispatch modes (adds 'other_configs'); "
                     "off by default so the default run launches ONE kernel shape and its rocprofv3 average is the headline's")
+    ap.add_argument("--rehearse-host", action="store_true", help="control-flow rehearsal without a GPU (CPU test suite only): no conversion, "
+                    "nothing measured, prints a line marked \"data\": \"rehearsal\"")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for testing)")
     a = ap.parse_args()
 
     rank, world, local = sharding.env_rank()
     dist_on = world > 1
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the conversion path has no CPU fallback)")
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed by hand: become the launch line the driver uses (one rank per GPU)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}")
+    if a.rehearse_host:
+        if a.backend == "nccl":
+            a.backend = "gloo"
+        dev = red_dev = None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the conversion path has no CPU fallback)")
+        ndev = torch.cuda.device_count()
+        if a.backend == "nccl" and world > ndev:
+            raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {ndev} (use --backend gloo to let ranks share a GPU for testing)")
+        local = local % ndev
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        red_dev = dev if a.backend == "nccl" else None  # gloo reduces CPU tensors
     sharding.init(a.backend, dev)  # one process per GPU over RCCL; ranks only meet at the timing barriers
-    red_dev = dev if a.backend == "nccl" else None  # gloo reduces CPU tensors
 
     if a.sweep and rank == 0:
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
@@ -293,21 +339,25 @@ def main():
             del wl
             torch.cuda.empty_cache()
 
-    wl = Workload(a.workload, dev, a.ring, a.variant, a.mode)
+    wl = RehearsalWorkload(rank) if a.rehearse_host else Workload(a.workload, dev, a.ring, a.variant, a.mode)
     wall, ev = timed(wl, a.steps, a.warmup, dist_on)
     total_px, wall_max = sharding.aggregate(wl.px_per_step * a.steps, wall, red_dev)  # sum of pixels, MAX time over ranks
+    per_rank_ms = [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)]  # each rank's own device time per step
 
     if rank == 0:
         n_launch = wl.launches_per_step * a.steps
         avg_launch_s = ev / n_launch  # rank 0's HIP-event time over the timed region / launches in it
         bytes_per_launch = wl.bytes_per_step / wl.launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
         if a.workload == "nv12_rgb_4k" and a.variant == 0 and a.mode == "batch" and os.path.exists(pmc):
             # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated on
-            # known-byte copy kernels: tools/pmc_calib.hip, tools/gpu_pmc.sh) — collected offline, scaled to this launch
+            # known-byte copy kernels: tools/pmc_calib.hip, tools/gpu_pmc.sh) — collected OFFLINE (PMC passes cannot run
+            # inside this process), scaled to this launch; `traffic_source` says so
             traffic = int(json.load(open(pmc))["hbm_bytes_per_frame"] * wl.ring / wl.launches_per_step)
+            traffic_source = (f"offline: profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc passes of this kernel on an earlier box, tools/gpu_pmc.sh), "
+                              "not measured in this run")
         out = {
             "metric": "Gpix/s NV12->RGB 3840x2160 + achieved %HBM-BW",
             "value": round(total_px / wall_max / 1e9, 2),
@@ -321,16 +371,22 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",  # u8 pixels in/out, fp32 FMA arithmetic, round-to-nearest-even saturating pack
             "data": "synthetic",
+            "per_rank_ms_per_step": per_rank_ms,
             "config": {"workload": f"{a.workload}: {wl.w}x{wl.h} NV12 -> {'RGB' if a.workload != 'nv12_planar_1080p' else 'RGB_PLANAR'}, BT.709 limited range, "
                                    f"ring of {a.ring} device-resident frames per GPU, {wl.launches_per_step} dispatch(es) per step",
                        "mode": a.mode, "frames_per_step_per_gpu": a.ring, "variant": a.variant,
                        "sharding": "independent frame rings, one process per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": wl.kernel, "bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches": n_launch},
         }
-        if not a.no_cpu and world == 1 and a.workload == "nv12_rgb_4k":
+        if a.rehearse_host:
+            out["data"] = "rehearsal"
+            out["rehearsal_units_per_s"], out["value"] = out["value"] * 1e9, None  # not a measurement of anything
+            out["roofline"] = None
+            out["config"] = {"workload": "host rehearsal of the multi-rank control flow: no conversion, nothing measured"}
+        if not a.no_cpu and world == 1 and a.workload == "nv12_rgb_4k" and not a.rehearse_host:
             out["cpu_baseline"] = cpu_baseline(wl)
         if a.extra and world == 1 and a.workload == "nv12_rgb_4k" and a.variant == 0 and a.mode == "batch":
             out["other_configs"] = other_configs(dev, wl)

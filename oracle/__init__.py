@@ -68,9 +68,30 @@ def lib() -> C.CDLL:
         L.vpfo_yuv2rgb_exhaustive.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.vpfo_rgb2yuv_exhaustive.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
         L.vpfo_set_threads.argtypes = [C.c_int]
+        L.vpfo_set_assumption.argtypes = [C.c_int, C.c_int]
+        L.vpfo_get_assumption.argtypes = [C.c_int]
         L.vpfo_version.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+A2_CHROMA_UPSAMPLE, A6_CHROMA_DECIMATE, A8_RESIZE_COORDS = 2, 6, 8
+
+
+class assume:
+    """with oracle.assume(A8_RESIZE_COORDS, 1): ...  — EXACT mode under a non-default convention (vpf_oracle.h)."""
+
+    def __init__(self, key: int, value: int):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.prev = lib().vpfo_set_assumption(self.key, self.value)
+        if self.prev < 0:
+            raise ValueError(f"assumption {self.key} has no value {self.value}")
+        return self
+
+    def __exit__(self, *exc):
+        lib().vpfo_set_assumption(self.key, self.prev)
 
 
 def set_threads(n: int) -> int:

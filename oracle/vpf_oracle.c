@@ -37,6 +37,22 @@ void vpfo_release_threads(void) {
   omp_pause_resource_all(omp_pause_soft);
 #endif
 }
+/* Assumption switches: what NPP does where its documentation is silent and a wrong guess
+ * moves results by far more than 1 LSB.  Defaults are the conventions the HIP kernels implement.  Non-default values
+ * change VPFO_EXACT only (FP32 restates the kernels and returns VPFO_UNSUPPORTED under a non-default switch), so that a
+ * mismatch on first contact with real NPP output (tests/test_reference_fixtures.py) is settled by flipping a switch. */
+static int g_a2 = 0, g_a6 = 0, g_a8 = 0;
+int vpfo_set_assumption(int key, int value) {
+  int* g = key == VPFO_A2_CHROMA_UPSAMPLE ? &g_a2 : key == VPFO_A6_CHROMA_DECIMATE ? &g_a6 : key == VPFO_A8_RESIZE_COORDS ? &g_a8 : 0;
+  const int hi = key == VPFO_A6_CHROMA_DECIMATE ? 1 : 2;
+  if (!g || value < 0 || value > hi) return -1;
+  const int prev = *g;
+  *g = value;
+  return prev;
+}
+int vpfo_get_assumption(int key) {
+  return key == VPFO_A2_CHROMA_UPSAMPLE ? g_a2 : key == VPFO_A6_CHROMA_DECIMATE ? g_a6 : key == VPFO_A8_RESIZE_COORDS ? g_a8 : -1;
+}
 const char* vpfo_version(void) { return "vpf-oracle 1 (parity unpinned: NPP closed source)"; }
 
 /* Hot loops are instantiated twice from one body: baseline x86-64 (fmaf = libm call, correct everywhere) and
@@ -80,6 +96,14 @@ static inline void yuv2rgb_exact(const yuv2rgb_dec* m, int y, int u, int v, uint
   *r = round6(yy + m->rv * vv);
   *g = round6(yy + m->gu * uu + m->gv * vv);
   *b = round6(yy + m->bu * uu);
+}
+
+/* the same with chroma given in sixteenths (interpolated chroma, A2 != 0): exact, round half up */
+static inline void yuv2rgb_exact_q16(const yuv2rgb_dec* m, int y, int u16, int v16, uint8_t* r, uint8_t* g, uint8_t* b) {
+  const int64_t yy = 16 * m->cy * (y - m->off), uu = u16 - 128 * 16, vv = v16 - 128 * 16;
+  *r = clamp_u8(floordiv(yy + m->rv * vv + 8000000, 16000000));
+  *g = clamp_u8(floordiv(yy + m->gu * uu + m->gv * vv + 8000000, 16000000));
+  *b = clamp_u8(floordiv(yy + m->bu * uu + 8000000, 16000000));
 }
 
 /* fp32 restatement of the HIP kernels' operation order (csrc/vpf_device.h chroma_terms / sat_rne,
@@ -295,6 +319,28 @@ static inline void fetch_yuv(int f, const vpfo_plane* s, uint32_t x, uint32_t y,
       *V = prow(&s[2], y)[x];
   }
 }
+/* A2 alternatives: 4:2:0 chroma interpolated bilinearly to luma resolution, in sixteenths, edges clamped.
+ *   siting 1 (centred, JPEG / MPEG-1): the chroma sample sits in the middle of its 2x2 luma quad: weights 3/4, 1/4 per axis
+ *   siting 2 (left, MPEG-2 / H.264 default): co-sited with even luma columns horizontally (1 or 1/2, 1/2), centred vertically */
+static inline int chroma_at(int f, const vpfo_plane* s, int k /*0=U,1=V*/, int32_t cx, int32_t cy, uint32_t cw, uint32_t ch) {
+  cx = cx < 0 ? 0 : (cx > (int32_t)cw - 1 ? (int32_t)cw - 1 : cx);
+  cy = cy < 0 ? 0 : (cy > (int32_t)ch - 1 ? (int32_t)ch - 1 : cy);
+  if (f == F_NV12) return prow(&s[1], (uint32_t)cy)[2 * cx + k];
+  return prow(&s[1 + k], (uint32_t)cy)[cx];
+}
+static inline void fetch_chroma_q16(int f, int siting, const vpfo_plane* s, uint32_t x, uint32_t y, uint32_t w, uint32_t h, int* U16, int* V16) {
+  const uint32_t cw = cdiv2(w), ch = cdiv2(h);
+  int32_t x0, y0;
+  int wx0, wx1, wy0, wy1; /* quarters */
+  if (siting == 1) { if (x & 1) { x0 = (int32_t)(x >> 1); wx0 = 3; wx1 = 1; } else { x0 = (int32_t)(x >> 1) - 1; wx0 = 1; wx1 = 3; } }
+  else { x0 = (int32_t)(x >> 1); if (x & 1) { wx0 = 2; wx1 = 2; } else { wx0 = 4; wx1 = 0; } }
+  if (y & 1) { y0 = (int32_t)(y >> 1); wy0 = 3; wy1 = 1; } else { y0 = (int32_t)(y >> 1) - 1; wy0 = 1; wy1 = 3; }
+  int acc[2];
+  for (int k = 0; k < 2; k++)
+    acc[k] = wy0 * (wx0 * chroma_at(f, s, k, x0, y0, cw, ch) + wx1 * chroma_at(f, s, k, x0 + 1, y0, cw, ch)) +
+             wy1 * (wx0 * chroma_at(f, s, k, x0, y0 + 1, cw, ch) + wx1 * chroma_at(f, s, k, x0 + 1, y0 + 1, cw, ch));
+  *U16 = acc[0]; *V16 = acc[1];
+}
 static inline void store_rgb(int f, const vpfo_plane* d, uint32_t x, uint32_t y, uint8_t r, uint8_t g, uint8_t b) {
   switch (f) {
     case F_RGB: { uint8_t* p = prow(&d[0], y) + 3 * x; p[0] = r; p[1] = g; p[2] = b; } break;
@@ -326,7 +372,11 @@ static void yuv_to_rgb(int mode, int sf, int df, const yuv2rgb_dec* m, uint32_t 
       int Y, U, V;
       uint8_t r, g, b;
       fetch_yuv(sf, s, x, y, &Y, &U, &V);
-      if (mode == VPFO_EXACT) yuv2rgb_exact(m, Y, U, V, &r, &g, &b);
+      if (mode == VPFO_EXACT && g_a2 && (sf == F_NV12 || sf == F_YUV420 || sf == F_YCBCR)) {
+        int U16, V16;
+        fetch_chroma_q16(sf, g_a2, s, x, y, w, h, &U16, &V16);
+        yuv2rgb_exact_q16(m, Y, U16, V16, &r, &g, &b);
+      } else if (mode == VPFO_EXACT) yuv2rgb_exact(m, Y, U, V, &r, &g, &b);
       else yuv2rgb_fp32(&c, Y, U, V, &r, &g, &b);
       store_rgb(df, d, x, y, r, g, b);
     }
@@ -425,7 +475,11 @@ static void rgb_to_yuv(int mode, int sf, int df, const rgb2yuv_dec* m, uint32_t 
         uint32_t x0 = 2 * cx, y0 = 2 * cy, x1 = (x0 + 1 < w) ? x0 + 1 : x0, y1 = (y0 + 1 < h) ? y0 + 1 : y0;
         uint32_t xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
         for (int k = 1; k < 3; k++) {
-          if (mode == VPFO_EXACT) {
+          if (mode == VPFO_EXACT && g_a6 == 1) { /* A6 alternative: the quad's top-left pixel alone */
+            int r, g, b;
+            fetch_rgb(sf, s, x0, y0, &r, &g, &b);
+            prow(&d[k], cy)[cx] = round6(rgb2yuv_num(m, k, r, g, b));
+          } else if (mode == VPFO_EXACT) {
             int64_t acc = 0;
             for (int t = 0; t < 4; t++) {
               int r, g, b;
@@ -523,6 +577,7 @@ int vpfo_convert_supported(int sf, int df, int cs, int cr) {
 int vpfo_convert(int mode, int sf, int df, int cs, int cr, uint32_t w, uint32_t h, const vpfo_plane s[3],
                  const vpfo_plane d[3]) {
   if (!vpfo_convert_supported(sf, df, cs, cr)) return VPFO_UNSUPPORTED;
+  if (mode != VPFO_EXACT && (g_a2 || g_a6)) return VPFO_UNSUPPORTED; /* FP32 restates the kernels: default conventions only */
   if (!w || !h || !check_planes(sf, w, s) || !check_planes(df, w, d)) return VPFO_BAD_ARG;
   if (is_yuv_src(sf) && is_rgb3(df)) {
     if (mode == VPFO_FP32 && sf == F_NV12 && df != F_RGB_PLANAR) nv12_to_rgb_fast(df == F_BGR, &k_yuv2rgb[cs][cr], w, h, s, d);
@@ -590,18 +645,25 @@ static inline uint8_t bilerp_u8(int mode, int p00, int p01, int p10, int p11, do
 }
 
 typedef struct { uint32_t i0, i1; double f; float ff; } tap;
+/* A8: source coordinate of destination index d (EXACT mode).  0 (default): pixel centres, s = (d + 0.5) S/D - 0.5;
+ * 1: top-left origin, s = d S/D;  2: corners aligned, s = d (S-1)/(D-1) */
+static inline double src_coord(uint32_t d, uint32_t S, uint32_t D) {
+  if (g_a8 == 1) return d * ((double)S / (double)D);
+  if (g_a8 == 2) return D > 1 ? d * ((double)(S - 1) / (double)(D - 1)) : 0.0;
+  return (d + 0.5) * ((double)S / (double)D) - 0.5;
+}
 static void make_taps(int mode, int interp, uint32_t S, uint32_t D, tap* t) {
   double sc = (double)S / (double)D;
   float scf = (float)S / (float)D;
   for (uint32_t d = 0; d < D; d++) {
     if (interp == 0) { /* nearest: floor((d+0.5)*S/D) */
-      uint32_t i = (mode == VPFO_EXACT) ? (uint32_t)floor((d + 0.5) * sc) : (uint32_t)(((float)d + 0.5f) * scf);
+      uint32_t i = (mode == VPFO_EXACT) ? (uint32_t)floor(g_a8 ? src_coord(d, S, D) + 0.5 : (d + 0.5) * sc) : (uint32_t)(((float)d + 0.5f) * scf);
       if (i > S - 1) i = S - 1;
       t[d].i0 = t[d].i1 = i; t[d].f = 0; t[d].ff = 0;
       continue;
     }
     if (mode == VPFO_EXACT) {
-      double s = (d + 0.5) * sc - 0.5;
+      double s = src_coord(d, S, D);
       if (s < 0) s = 0;
       if (s > (double)(S - 1)) s = (double)(S - 1);
       uint32_t i0 = (uint32_t)floor(s);
@@ -699,7 +761,7 @@ static void make_ltaps(int mode, uint32_t S, uint32_t D, ltap* t) {
   for (uint32_t d = 0; d < D; d++) {
     int32_t i0;
     if (mode == VPFO_EXACT) {
-      const double s = (d + 0.5) * sc - 0.5;
+      const double s = src_coord(d, S, D);
       i0 = (int32_t)floor(s);
       lanczos_weights_exact(s - i0, t[d].w);
       for (int k = 0; k < 6; k++) t[d].wf[k] = (float)t[d].w[k];
@@ -822,6 +884,7 @@ static int resize_plane_f32(int mode, int interp, int ch, uint32_t sw, uint32_t 
 int vpfo_resize(int mode, int fmt, int interp, uint32_t sw, uint32_t sh, const vpfo_plane s[3], uint32_t dw,
                 uint32_t dh, const vpfo_plane d[3]) {
   if (interp != 0 && interp != 1 && interp != 2) return VPFO_UNSUPPORTED;
+  if (mode != VPFO_EXACT && g_a8) return VPFO_UNSUPPORTED; /* FP32 restates the kernels: default convention only */
   if (!sw || !sh || !dw || !dh) return VPFO_BAD_ARG;
   if (!check_planes(fmt, sw, s) || !check_planes(fmt, dw, d)) return (nplanes(fmt) ? VPFO_BAD_ARG : VPFO_UNSUPPORTED);
   switch (fmt) {

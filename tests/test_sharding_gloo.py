@@ -56,3 +56,45 @@ def test_single_process_passthrough():
     assert sharding.aggregate(10.0, 2.0) == (10.0, 2.0)
     with pytest.raises(ValueError):
         sharding.assign_clips(5, 2, 2)
+
+
+def _run_bench(args, timeout=300):
+    import json
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line, from rank 0 only: {lines}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", ["driver", "self"])
+def test_bench_multi_rank_control_flow_rehearsal(launcher):
+    """bench.py's own N>1 control flow (rendezvous on 127.0.0.1, LOCAL_RANK handling, the barriers around the timed
+    region, sum-units / max-time reduction, one JSON line from rank 0) executed for real with 2 gloo ranks; the step is
+    a host no-op (--rehearse-host), so no GPU is needed and nothing is measured.  'driver' = the launch line the driver
+    uses; 'self' = `python bench.py --gpus 2` re-executing itself under torch.distributed.run."""
+    tail = ["--gpus", "2", "--steps", "5", "--warmup", "2", "--rehearse-host"]
+    if launcher == "driver":
+        out = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), "bench.py", *tail])
+    else:
+        out = _run_bench(["bench.py", *tail])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["data"] == "rehearsal" and out["value"] is None and out["roofline"] is None
+    per_rank = out["per_rank_ms_per_step"]
+    assert len(per_rank) == 2 and per_rank[1] > 1.5 * per_rank[0]           # rank 1's step sleeps twice as long
+    assert out["ms_per_step"] >= per_rank[1] * 0.99                          # MAX over ranks (+ the closing barrier), not the mean
+    px = 2 * 32 * 3840 * 2160 * 5                                            # both ranks' units are summed
+    assert abs(out["rehearsal_units_per_s"] - px / (out["ms_per_step"] * 5e-3)) / out["rehearsal_units_per_s"] < 0.01
+
+
+def test_bench_refuses_mismatched_world_size():
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rehearse-host"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

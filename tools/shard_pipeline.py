@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""shard_pipeline.py — BASELINE.json config 4's runner: S independent 4K clips sharded one-clip-per-GPU, each rank running
+host NV12 frames -> PyFrameUploader (pinned staging + side copy stream) -> PySurfaceConverter NV12->RGB through the drop-in
+Python API.  Clip s goes to rank s mod N (sharding.assign_clips); ranks never exchange data (no collective on the data
+path) and meet only at the timing barriers.
+
+Reference pattern: samples/SampleDecodeMultiThread.py:50-115 (one decoder + converter chain per GPU) over CudaResMgr's
+per-GPU context/stream (src/PyNvCodec/src/PyNvCodec.cpp:57-111).
+
+The decode stage is a STAND-IN: this image has no libav, so each clip's "decoder" is a generator that hands out frames
+already sitting in AllocPinned() buffers (what a software decoder writing into page-locked memory would produce), cycling
+over a few distinct frames per clip.  Two rates are reported (SURVEY §8e asks for both):
+  end_to_end       host frame -> upload -> convert, PCIe-inclusive (never the headline `value` of bench.py)
+  device_resident  convert only, on the surfaces already uploaded
+
+  python tools/shard_pipeline.py [--clips 8] [--frames 64]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         tools/shard_pipeline.py --gpus N [--backend gloo]   (gloo: several ranks may share one GPU, for testing)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "videoprocessingframework_amd"))
+from videoprocessingframework_amd import sharding  # noqa: E402
+import PyNvCodec as nvc  # noqa: E402
+
+
+class SyntheticClip:
+    """Stand-in for demux + software decode of one clip: `distinct` NV12 frames in page-locked host memory, seeded per clip."""
+
+    def __init__(self, clip_id, w, h, distinct=4):
+        rng = np.random.default_rng(7000 + clip_id)
+        self.frames = []
+        for _ in range(distinct):
+            buf = nvc.AllocPinned(w * h * 3 // 2)
+            buf[:] = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+            self.frames.append(buf)
+
+    def decode(self, i):
+        return self.frames[i % len(self.frames)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=64, help="frames per clip")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--backend", default="nccl")
+    a = ap.parse_args()
+    rank, world, local = sharding.env_rank()
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU (no CPU fallback)")
+    gpu = local % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    sharding.init(a.backend, dev)
+    red_dev = dev if a.backend == "nccl" else None
+    w, h, pf = a.width, a.height, nvc.PixelFormat
+    cc = nvc.ColorspaceConversionContext(nvc.ColorSpace.BT_709, nvc.ColorRange.MPEG)
+    mine = sharding.assign_clips(a.clips, world, rank)
+    chains = []
+    for c in mine:  # one stream + task chain per clip, like one worker thread per stream in the reference sample
+        stream = torch.cuda.Stream(device=dev)
+        ctx = nvc.GetContext(gpu)
+        chains.append({"clip": c, "src": SyntheticClip(c, w, h), "stream": stream,
+                       "up": nvc.PyFrameUploader(w, h, pf.NV12, ctx, stream.cuda_stream),
+                       "conv": nvc.PySurfaceConverter(w, h, pf.NV12, pf.RGB, ctx, stream.cuda_stream),
+                       "down": nvc.PySurfaceDownloader(w, h, pf.RGB, ctx, stream.cuda_stream)})
+
+    def run(end_to_end, frames):
+        last = {}
+        for i in range(frames):
+            for ch in chains:  # round-robin over this rank's clips: their uploads and kernels overlap across streams
+                if end_to_end or "nv12" not in ch:
+                    ch["nv12"] = ch["up"].UploadSingleFrame(ch["src"].decode(i))
+                rgb = ch["conv"].Execute(ch["nv12"], cc)
+                if rgb.Empty():
+                    raise SystemExit(f"rank {rank}: conversion failed on clip {ch['clip']}")
+                last[ch["clip"]] = (i, rgb)
+        torch.cuda.synchronize(dev)
+        return last
+
+    run(True, 2)  # warm-up
+    rates = {}
+    for key, e2e in (("end_to_end", True), ("device_resident", False)):
+        sharding.barrier(dev)
+        t0 = time.perf_counter()
+        last = run(e2e, a.frames)
+        own = time.perf_counter() - t0
+        sharding.barrier(dev)
+        px, t = sharding.aggregate(len(mine) * a.frames * w * h, time.perf_counter() - t0, red_dev)
+        rates[key] = {"value": round(px / t / 1e9, 3), "unit": "Gpix/s", "frames_per_s": round(px / t / (w * h), 1),
+                      "per_rank_s": [round(x, 4) for x in sharding.gather(own, red_dev)]}
+    # every clip's last frame: download and compare against the same conversion of the host frame this rank fed, done
+    # by a second, independent converter instance on the same GPU (catches cross-clip / cross-stream mix-ups)
+    verified = 0
+    chk = nvc.PySurfaceConverter(w, h, pf.NV12, pf.RGB, gpu)
+    up2, dl2 = nvc.PyFrameUploader(w, h, pf.NV12, gpu), nvc.PySurfaceDownloader(w, h, pf.RGB, gpu)
+    for ch in chains:
+        i, rgb = last[ch["clip"]]
+        got, want = np.zeros(1, np.uint8), np.zeros(1, np.uint8)
+        assert ch["down"].DownloadSingleSurface(rgb, got)
+        assert dl2.DownloadSingleSurface(chk.Execute(up2.UploadSingleFrame(ch["src"].decode(i)), cc), want)
+        if zlib.crc32(got.tobytes()) != zlib.crc32(want.tobytes()):
+            raise SystemExit(f"rank {rank}: clip {ch['clip']} frame {i} differs from its own source's conversion")
+        verified += 1
+    verified_all, _ = sharding.aggregate(verified, 0.0, red_dev)
+    clips_per_rank = [sharding.assign_clips(a.clips, world, r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"runner": "shard_pipeline", "n_gpus": world, "clips": a.clips, "clips_per_rank": clips_per_rank,
+                          "frames_total": a.clips * a.frames, "size": f"{w}x{h}", "verified_clips": int(verified_all),
+                          "decode": "stand-in: frames pre-decoded into AllocPinned() host buffers (no libav in this image)",
+                          "end_to_end": rates["end_to_end"], "device_resident": rates["device_resident"],
+                          "sharding": "clip s -> rank s mod N; no data-path collective"}), flush=True)
+    if world > 1:
+        sharding.barrier(dev)
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,17 @@ def aggregate(units_local: float, seconds_local: float, device: torch.device | N
     return float(u.item()), float(t.item())
 
 
+def gather(value_local: float, device: torch.device | None = None) -> List[float]:
+    """One float per rank, in rank order (per-rank step times next to the max-over-ranks figure)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value_local)]
+    dev = device if device is not None else torch.device("cpu")
+    mine = torch.tensor([value_local], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def throughput(units_local: float, seconds_local: float, device: torch.device | None = None) -> float:
     u, t = aggregate(units_local, seconds_local, device)
     return u / t
