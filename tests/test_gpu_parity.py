@@ -437,6 +437,9 @@ def test_remap(capi, oracle, kind):
         assert intact
         _, want = oracle.remap(oracle.RGB, w, h, src, xm, ym, dst=oracle.alloc(oracle.RGB, w, h, fill=9))
         assert_planes_equal(got, want, f"remap {kind} {w}x{h} v{variant} a{align}")
+        # the independent link: within 1 LSB of the specification-level oracle (float64 blend of the same float32 coordinates)
+        _, exact = oracle.remap(oracle.RGB, w, h, src, xm, ym, mode=oracle.EXACT, dst=oracle.alloc(oracle.RGB, w, h, fill=9))
+        assert np.abs(got[0].astype(int) - exact[0].astype(int)).max() <= 1, f"remap {kind} {w}x{h} v{variant}: HIP vs EXACT > 1 LSB"
         if kind == "identity":
             assert np.array_equal(got[0], src[0])
 
@@ -535,7 +538,7 @@ FUZZ_PAIRS = [("NV12", "RGB"), ("NV12", "BGR"), ("NV12", "RGB_PLANAR"), ("YUV420
               ("NV12", "Y"), ("Y", "YUV444"), ("P10", "NV12"), ("RGB", "RGB_32F"), ("RGB_PLANAR", "YUV420"), ("YUV420", "RGB_PLANAR")]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))  # soak: VPF_FUZZ_SEEDS=500
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))  # soak: VPF_FUZZ_SEEDS=500
 def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     for _ in range(12):
@@ -568,7 +571,7 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), cs, cr, w, h, src, align, extra, offset, variant=variant)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
 def test_fuzz_resize_and_fused(capi, oracle, seed):
     """random (format, filter, source size, destination size, alignment, kernel family): the tiled / row-pair / gather
     resize kernels and the LDS / gather fused kernels against the oracle, bit for bit"""
@@ -617,7 +620,7 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
         assert_planes_equal(got, want, f"{what} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
 def test_fuzz_remap(capi, oracle, seed):
     """random source size, map size (!= source size), map family (affine / noisy / mostly out of range, with NaN and Inf
     entries), pixel format, alignment, kernel: out-of-range destinations keep their previous content"""
@@ -662,6 +665,8 @@ def test_fuzz_remap(capi, oracle, seed):
         assert intact
         _, want = oracle.remap(getattr(oracle, fmt), sw, sh, src, xm, ym, dst=oracle.alloc(getattr(oracle, fmt), dw, dh, fill=77))
         assert_planes_equal(got, want, f"remap fam{fam} {fmt} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
+        _, exact = oracle.remap(getattr(oracle, fmt), sw, sh, src, xm, ym, mode=oracle.EXACT, dst=oracle.alloc(getattr(oracle, fmt), dw, dh, fill=77))
+        assert np.abs(got[0].astype(int) - exact[0].astype(int)).max() <= 1, f"remap fam{fam} {fmt} {sw}x{sh}->{dw}x{dh}: HIP vs EXACT > 1 LSB"
 
 
 def test_large_frame_8k(capi, oracle):
