@@ -319,14 +319,40 @@ def main():
     sharding.init(a.backend, dev)  # one process per GPU over RCCL; ranks only meet at the timing barriers
 
     if a.sweep and rank == 0:
+        # product kernels through the tuning hook (4 p4, 8 p16, 30 p16 at 4 workgroups/CU, 37 planar r16), then the measurement lab
+        # (tools/lab/libvpfhip_lab.so: round 1's other forms + the bandwidth probes 15 / 22 / 23, which are NOT conversions)
+        import ctypes as C
+        sys.path.insert(0, os.path.join(ROOT, "tools", "lab"))
+        import build_lab
+        labso = C.CDLL(build_lab.build())
+        labso.vpf_lab_nv12_rgb.argtypes = [C.POINTER(capi.Exec), C.c_int, C.c_int, C.c_int, C.c_int, capi.Size, C.c_uint32, C.POINTER(capi.FrameIO)]
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
             for mode in ("batch", "single"):
-                for v in (4, 8, 30, 37, 38, 41, 43, 15, 22, 23):
-                    wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, v, mode)
+                for v in (4, 8, 30, 37, -38, -41, -43, -15, -22, -23):   # negative: lab variant |v|
+                    wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, max(v, 0), mode)
+                    if v < 0:
+                        frames_all = [capi.make_batch([(s_, d_) for s_, d_ in wl.frames[i:i + 32]]) for i in range(0, len(wl.frames), 32)]
+                        one = [capi.make_batch([(s_, d_)]) for s_, d_ in wl.frames]
+
+                        def lab_step(wl=wl, v=-v, frames_all=frames_all, one=one):
+                            if wl.mode == "batch":
+                                rc = 0
+                                for chunk in frames_all:
+                                    rc |= labso.vpf_lab_nv12_rgb(C.byref(wl.ex), v, wl.dst_fmt, capi.BT_709, capi.MPEG, capi.Size(wl.w, wl.h), len(chunk), chunk)
+                            else:
+                                rc = 0
+                                for io in one:
+                                    rc |= labso.vpf_lab_nv12_rgb(C.byref(wl.ex), v, wl.dst_fmt, capi.BT_709, capi.MPEG, capi.Size(wl.w, wl.h), 1, io)
+                            if rc:
+                                raise RuntimeError(f"lab variant {v}: rc {rc}")
+                        if labso.vpf_lab_nv12_rgb(C.byref(wl.ex), -v, wl.dst_fmt, capi.BT_709, capi.MPEG, capi.Size(wl.w, wl.h), 1, one[0]) == 1:
+                            continue  # this form does not exist for this output class
+                        wl.step = lab_step
                     _, ev = timed(wl, a.steps, a.warmup, False)
-                    nbytes = wl.bytes_per_step * (1 / 3 if v == 22 else 2 / 3 if v in (23, 24, 25, 26) else 1)  # probes move only the reads / writes
+                    nbytes = wl.bytes_per_step * (1 / 3 if v == -22 else 2 / 3 if v == -23 else 1)  # probes move only the reads / writes
                     gbs = nbytes * a.steps / ev / 1e9
-                    print(f"[sweep] {wlname:18s} {mode:6s} variant {v}: {wl.px_per_step * a.steps / ev / 1e9:8.1f} Gpix/s "
+                    tag = f"variant {v}" if v >= 0 else f"lab {-v}" + (" (probe, not a conversion)" if labso.vpf_lab_is_conversion(-v) == 0 else "")
+                    print(f"[sweep] {wlname:18s} {mode:6s} {tag}: {wl.px_per_step * a.steps / ev / 1e9:8.1f} Gpix/s "
                           f"{gbs:7.0f} GB/s ({gbs / HBM_PEAK_GBS:.3f} of 8 TB/s)", file=sys.stderr, flush=True)
                     del wl
                     torch.cuda.empty_cache()

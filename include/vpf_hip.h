@@ -182,14 +182,22 @@ VPF_API const char* vpf_version(void);
  * (src/PyNvCodec/src/PyNvCodec.cpp:427-429). */
 VPF_API int vpf_device_count(void);
 
-/* Tuning hook used by bench.py / tests to select a kernel family (process-wide; 0 = default policy).  A hint, never a
- * correctness switch: every value produces identical pixels and silently falls back where it does not apply.
+/* Tracing (additive): with VPF_HIP_ROCTX=1 in the environment every entry point above runs inside a roctx range of its own name
+ * and every kernel selection leaves a roctx marker, visible in `rocprofv3 --marker-trace`; VPF_HIP_LOG=2 prints the selected kernel
+ * of every launch on stderr (=1: errors only).  Both replace the reference's compile-time NvtxMark (src/TC/inc/Tasks.hpp:27-52).
+ * vpf_trace_push / vpf_trace_pop let a caller (the Task layer) open ranges of its own through the same switch. */
+VPF_API int vpf_trace_push(const char* name);
+VPF_API void vpf_trace_pop(int opened);
+
+/* Tuning hook used by tests / benchmarks to select a kernel family (process-wide; 0 = default policy).  A hint, never a
+ * correctness switch: every accepted value produces identical pixels and silently falls back where it does not apply.
  *   0        default policy (fastest applicable kernel per call)
  *   9        the any-size / any-alignment generic kernels everywhere (byte accesses, gather resize / remap)
  *   40       the narrower fast paths instead of the 16-px "r16" / tiled / quad kernels (A/B runs, test coverage)
- *   1..43    individual NV12 -> RGB kernels and bandwidth probes (k_yuv2rgb.hip launch_420; probes 15, 22-26 write
- *            wrong pixels on purpose and are for bench.py --sweep only)
- * Not part of the reference surface.  Returns the previous value. */
+ *   43       resize: the tiled separable kernel for bilinear down-scales as well (default: up-scales only)
+ *   4, 8, 12, 30, 37, 44   one named NV12 / YUV420 -> RGB kernel of the default policy's set (k_yuv2rgb.hip launch_420)
+ * Any other value is rejected: -1 is returned and nothing changes (the experimental kernels and bandwidth probes of round 1
+ * are not in this library; they live in tools/lab).  Not part of the reference surface.  Returns the previous value. */
 VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_NV12_RGB_VARIANT 1
 

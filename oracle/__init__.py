@@ -41,6 +41,14 @@ def build(force: bool = False) -> str:
             so = os.path.join(ref, so)
             if force or not os.path.exists(so) or os.path.getmtime(so) < shim_m:
                 subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
+        # the reference's converter Task layer for the GPU: CUDA driver calls over HIP, nppi*_Ctx forwarding to libvpfhip
+        vpflib = os.path.join(os.path.dirname(_HERE), "videoprocessingframework_amd", "libvpfhip.so")
+        if os.path.exists(vpflib):
+            so = os.path.join(ref, "libtc_ref_hip.so")
+            dep_m = max([os.path.getmtime(vpflib), os.path.getmtime(os.path.join(_HERE, "ref_tc_hip_shim.cpp")), os.path.getmtime(os.path.join(_HERE, "Makefile")),
+                         os.path.getmtime(os.path.join(_HERE, "ref_shim_hip", "npp_over_vpf.h"))])
+            if force or not os.path.exists(so) or os.path.getmtime(so) < dep_m:
+                subprocess.check_call(["make", "-C", _HERE, "ref_tc_hip"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

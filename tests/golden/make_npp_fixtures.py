@@ -117,7 +117,7 @@ def main():
                     if dst is None or dst.Empty():
                         outs["refused_" + key] = np.zeros(0, np.uint8)
                         continue
-                    outs["dst_" + key] = download(df, w, h, dst)
+                    outs["out_" + key] = download(df, w, h, dst)
                     accepted.append(key)
                 save(f"convert_{sf}_{df}_{w}x{h}_{dist}", kind="convert", src_fmt=sf, dst_fmt=df, w=w, h=h, src=src, **outs)
                 print(f"convert {sf}->{df} {w}x{h} {dist}: accepted contexts {accepted}")
@@ -131,7 +131,7 @@ def main():
         for dw, dh in ((224, 224), (424, 232), (1280, 720), (283, 155)):
             dst = nvc.PySurfaceResizer(dw, dh, getattr(PF, fmt), a.gpu).Execute(surf)
             if dst is not None and not dst.Empty():
-                outs[f"dst_{dw}x{dh}"] = download(fmt, dw, dh, dst)
+                outs[f"out_{dw}x{dh}"] = download(fmt, dw, dh, dst)
         save(f"resize_{fmt}_{w}x{h}", kind="resize", fmt=fmt, w=w, h=h, src=src, **outs)
         print(f"resize {fmt}: {sorted(outs)}")
     imp = np.zeros((16, 16, 3), np.uint8)
@@ -141,7 +141,7 @@ def main():
     for dw, dh in ((40, 40), (5, 5), (16, 16), (32, 32), (8, 8)):
         dst = nvc.PySurfaceResizer(dw, dh, PF.RGB, a.gpu).Execute(upload("RGB", 16, 16, imp.reshape(-1)))
         if dst is not None and not dst.Empty():
-            outs[f"dst_{dw}x{dh}"] = download("RGB", dw, dh, dst)
+            outs[f"out_{dw}x{dh}"] = download("RGB", dw, dh, dst)
     save("resize_RGB_impulse_16x16", kind="resize", fmt="RGB", w=16, h=16, src=imp.reshape(-1), **outs)
 
     # ---- remap ---------------------------------------------------------------------------------------------------------
@@ -158,7 +158,7 @@ def main():
         if dst is None or dst.Empty():
             print(f"remap {name}: refused")
             continue
-        save(f"remap_RGB_{name}_{w}x{h}", kind="remap", fmt="RGB", w=w, h=h, src=src, xmap=mx, ymap=my, dst=download("RGB", w, h, dst))
+        save(f"remap_RGB_{name}_{w}x{h}", kind="remap", fmt="RGB", w=w, h=h, src=src, xmap=mx, ymap=my, out=download("RGB", w, h, dst))
         print(f"remap {name}: ok")
 
     json.dump(manifest, open(os.path.join(a.out, "manifest.json"), "w"), indent=1)

@@ -83,6 +83,27 @@ def test_product_does_not_touch_oracle():
                 assert "vpf_oracle" not in txt and "libvpforacle" not in txt, f
 
 
+def test_product_does_not_touch_lab():
+    """the measurement lab (tools/lab: round 1's experimental kernel forms and bandwidth probes) is not part of libvpfhip: no product
+    source mentions it, no probe kernel is compiled into the product library, and the tuning hook documents no wrong-pixel value"""
+    pkg = os.path.join(ROOT, "videoprocessingframework_amd")
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "libvpfhip_lab" not in txt and "k_probe" not in txt and "NOMATH" not in txt, f
+    blob = open(os.path.join(pkg, "libvpfhip.so"), "rb").read()
+    for name in (b"k_probe_p16", b"k_probe_nomath", b"k_nv12_rgb_s16", b"k_nv12_rgb_r4", b"k_nv12_rgb_p16r", b"vpf_lab_"):
+        assert name not in blob, name
+    hdr = open(os.path.join(ROOT, "include", "vpf_hip.h")).read()
+    assert "wrong pixels" not in hdr
+
+
+def test_tuning_hook_rejects_unknown_values_without_a_gpu(capi):
+    assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 15) == -1 and capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 22) == -1
+    assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 40) == 0 and capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 40
+
+
 @pytest.mark.parametrize("first", ["capi", "PyNvCodec"])
 def test_single_hip_runtime_whatever_the_import_order(first):
     """torch-ROCm bundles its own libamdhip64.so under the same SONAME as /opt/rocm's; loading ours first must not end

@@ -270,8 +270,15 @@ def test_surface_copy_clone_crop(oracle):
         planes = oracle.synth(ofmt, w, h, 17)
         s = upload(fmt, w, h, planes)
         d = nvc.Surface.Make(fmt, w, h, GPU)
-        d.CopyFrom(s, GPU)  # other -> self (what the name says; the reference binding copies the other way round)
+        s.CopyFrom(d, GPU)  # SELF -> OTHER: the reference binding's direction (PySurface.cpp:54-81,361), kept for drop-in behaviour
         assert np.array_equal(download(d), host_frame(planes))
+        assert np.array_equal(download(s), host_frame(planes))   # the source is untouched
+        d2 = nvc.Surface.Make(fmt, w, h, GPU)
+        d2.UpdateFrom(s, GPU)  # additive, unambiguous: src -> self
+        assert np.array_equal(download(d2), host_frame(planes))
+        d3 = nvc.Surface.Make(fmt, w, h, GPU)
+        s.CopyFrom(d3, nvc.GetContext(GPU), nvc.GetStream(GPU))
+        assert np.array_equal(download(d3), host_frame(planes))
         st = torch.cuda.Stream()
         assert np.array_equal(download(s.Clone(nvc.GetContext(GPU), st.cuda_stream)), host_frame(planes))
         assert np.array_equal(download(s.Clone()), host_frame(planes))
@@ -485,3 +492,31 @@ def test_concurrent_threads_mixed_operations(oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors[:3]
+
+
+def test_tracing_hooks_kernel_selection_log_and_roctx_ranges():
+    """the reference's NvtxMark (src/TC/inc/Tasks.hpp:27-52) has a counterpart — VPF_HIP_LOG=2 names the kernel every
+    launch selected, VPF_HIP_ROCTX=1 wraps ABI entries / Task::Run in roctx ranges (the library is dlopen()ed; no link dependency)"""
+    import subprocess
+    import sys
+
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.join(ROOT, 'videoprocessingframework_amd')!r})
+import numpy as np
+import PyNvCodec as nvc
+w, h = 256, 64
+up = nvc.PyFrameUploader(w, h, nvc.PixelFormat.NV12, 0)
+conv = nvc.PySurfaceConverter(w, h, nvc.PixelFormat.NV12, nvc.PixelFormat.RGB, 0)
+rs = nvc.PySurfaceResizer(96, 32, nvc.PixelFormat.RGB, 0)
+s = conv.Execute(up.UploadSingleFrame(np.arange(w * h * 3 // 2, dtype=np.uint8)), nvc.ColorspaceConversionContext(nvc.ColorSpace.BT_709, nvc.ColorRange.MPEG))
+assert not s.Empty() and not rs.Execute(s).Empty()
+print("done")
+"""
+    env = dict(os.environ, VPF_HIP_LOG="2", VPF_HIP_ROCTX="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, r.stdout + r.stderr
+    assert "libvpfhip: launch (k_nv12_rgb_p16_one<" in r.stderr and "libvpfhip: launch (k_resize" in r.stderr, r.stderr
+    assert "no roctx library" not in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, VPF_HIP_LOG="0"), timeout=300)
+    assert r.returncode == 0 and "libvpfhip" not in r.stderr

@@ -107,7 +107,7 @@ def check_convert(path, o, produce):
     for key in z.files:
         if key.startswith("refused_"):
             assert produce(sf, df, w, h, z["src"], _ctx_of(key[8:])) is None, f"{os.path.basename(path)}: the reference refuses ctx {key[8:]}, we accept it"
-        elif key.startswith("dst_"):
+        elif key.startswith("out_"):
             want = z[key]
             got = produce(sf, df, w, h, z["src"], _ctx_of(key[4:]))
             assert got is not None, f"{os.path.basename(path)}: the reference accepts ctx {key[4:]}, we refuse it"
@@ -142,7 +142,7 @@ def test_oracle_exact_matches_reference_converters(oracle, path):
         assert check_convert(path, o, produce) >= 1
     except AssertionError as e:
         z = np.load(path)
-        hint = [which_assumptions(o, produce.last_run, z[k]) for k in z.files if k.startswith("dst_")][:1] if hasattr(produce, "last_run") else []
+        hint = [which_assumptions(o, produce.last_run, z[k]) for k in z.files if k.startswith("out_")][:1] if hasattr(produce, "last_run") else []
         raise AssertionError(f"{e}\nassumption switches that WOULD match the last checked context: {hint}") from None
 
 
@@ -153,7 +153,7 @@ def test_oracle_exact_matches_reference_resizer(oracle, path):
     z = np.load(path)
     fmt, w, h = str(z["fmt"]), int(z["w"]), int(z["h"])
     src = split_planes(o, fmt, w, h, z["src"])
-    for key in (k for k in z.files if k.startswith("dst_")):
+    for key in (k for k in z.files if k.startswith("out_")):
         dw, dh = (int(v) for v in key[4:].split("x"))
         run = lambda: o.resize(getattr(o, fmt), o.LANCZOS3, w, h, src, dw, dh, o.EXACT)  # noqa: E731  (Tasks.cpp:1190: NPPI_INTER_LANCZOS)
         st, out = run()
@@ -172,7 +172,7 @@ def test_oracle_exact_matches_reference_remaper(oracle, path):
     st, out = o.remap(o.RGB, w, h, split_planes(o, "RGB", w, h, z["src"]), z["xmap"], z["ymap"], o.EXACT)
     assert st == 0
     inside = (z["xmap"] >= 0) & (z["xmap"] <= w - 1) & (z["ymap"] >= 0) & (z["ymap"] <= h - 1)  # unmapped pixels are left untouched [A9]
-    got, want = out[0].reshape(h, w, 3)[inside], z["dst"].reshape(h, w, 3)[inside]
+    got, want = out[0].reshape(h, w, 3)[inside], z["out"].reshape(h, w, 3)[inside]
     mx, frac = lsb_report(got, want)
     assert mx <= 1, f"{os.path.basename(path)}: max |diff| {mx}, {frac:.2%} off by more than 1 LSB"
 
@@ -219,7 +219,7 @@ def test_hip_matches_reference_resizer(path):
     up, down = _hip_io(nvc)
     z = np.load(path)
     fmt, w, h = str(z["fmt"]), int(z["w"]), int(z["h"])
-    for key in (k for k in z.files if k.startswith("dst_")):
+    for key in (k for k in z.files if k.startswith("out_")):
         dw, dh = (int(v) for v in key[4:].split("x"))
         rs = nvc.PySurfaceResizer(dw, dh, getattr(nvc.PixelFormat, fmt), 0)
         rs.SetInterpolation(2)  # Lanczos: what the reference's resizer asks NPP for (Tasks.cpp:1190); bilinear is this repo's default
@@ -237,7 +237,7 @@ def test_hip_matches_reference_remaper(path):
     w, h = int(z["w"]), int(z["h"])
     dst = nvc.PySurfaceRemaper(z["xmap"], z["ymap"], nvc.PixelFormat.RGB, 0).Execute(up("RGB", w, h, z["src"]))
     inside = (z["xmap"] >= 0) & (z["xmap"] <= w - 1) & (z["ymap"] >= 0) & (z["ymap"] <= h - 1)
-    mx, frac = lsb_report(down("RGB", w, h, dst).reshape(h, w, 3)[inside], z["dst"].reshape(h, w, 3)[inside])
+    mx, frac = lsb_report(down("RGB", w, h, dst).reshape(h, w, 3)[inside], z["out"].reshape(h, w, 3)[inside])
     assert mx <= 1, f"{os.path.basename(path)}: max |diff| {mx}, {frac:.2%} off by more than 1 LSB"
 
 

@@ -1,6 +1,6 @@
 """Does the intermediate of a per-frame chain (NV12 -> RGB -> RGB_PLANAR, the reference's sample chain) benefit from being
 left in the 256 MiB Infinity Cache?  k1 = NV12->RGB with non-temporal stores (variant 8, the per-frame default) vs plain
-stores (variant 7); k2 = RGB->RGB_PLANAR reads the intermediate right after.  Ring of 32 distinct frame sets."""
+stores (variant 12: allocating stores); k2 = RGB->RGB_PLANAR reads the intermediate right after.  Ring of 32 distinct frame sets."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ for (w, h) in ((3840, 2160), (1920, 1080)):
     mid = [torch.zeros((h, p3), dtype=torch.uint8, device=dev) for _ in range(N)]
     out = [torch.zeros((3 * h, p1), dtype=torch.uint8, device=dev) for _ in range(N)]
     exr = capi.make_exec(torch.cuda.current_stream().cuda_stream, flags=capi.EXEC_DST_REUSED)
-    for variant in (8, 7, 12, 11, -1):  # -1: default kernel policy with the VPF_EXEC_DST_REUSED hint on k1
+    for variant in (8, 12, -1):  # -1: default kernel policy with the VPF_EXEC_DST_REUSED hint on k1
         def step():
             for s, m, o in zip(src, mid, out):
                 capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, max(variant, 0))

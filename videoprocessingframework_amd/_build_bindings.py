@@ -34,26 +34,52 @@ def have_libav() -> bool:
         return r.returncode == 0
 
 
-def build(force: bool = False):
+def _build_module(out_dir: str, obj_prefix: str, sources, extra_flags, link_tail, rpath: str, force: bool):
     os.makedirs(B.OBJ, exist_ok=True)
-    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
     hdrs = B._headers()
-    libav = os.environ.get("VPF_WITH_LIBAV", "auto")
-    libav = have_libav() if libav == "auto" else libav not in ("0", "no", "off")
-    sources = list(SOURCES) + ([os.path.join(B.CSRC, "feeder", "FfmpegFeeder.cpp")] if libav else [])
     flags = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-x", "hip", "--offload-arch=gfx950",
              f"-I{B.INC}", f"-I{TC}", f"-I{os.path.join(B.CSRC, 'feeder')}", f"-I{pybind11.get_include()}",
-             f"-I{sysconfig.get_paths()['include']}"] + (["-DVPF_WITH_LIBAV"] if libav else [])
+             f"-I{sysconfig.get_paths()['include']}"] + list(extra_flags)
     jobs, objs = [], []
     for src in sources:
-        obj = os.path.join(B.OBJ, "tc_" + os.path.basename(src).replace(".cpp", ".o"))
+        if src.endswith(".o"):  # a prebuilt object (the C stub of libav in the test variant)
+            objs.append(src)
+            continue
+        obj = os.path.join(B.OBJ, obj_prefix + os.path.basename(src).replace(".cpp", ".o"))
         objs.append(obj)
         if force or B._newer(obj, [src] + hdrs):
             jobs.append([B.HIPCC, *flags, "-c", src, "-o", obj])
     with cf.ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
         list(ex.map(B._run, jobs))
-    out = module_path()
+    out = os.path.join(out_dir, "_PyNvCodec" + sysconfig.get_config_var("EXT_SUFFIX"))
     if force or jobs or B._newer(out, objs + [B.LIB]):
-        B._run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, f"-L{B.PKG}", "-lvpfhip", "-Wl,-rpath,$ORIGIN/.."] +
-               (["-lavformat", "-lavcodec", "-lavutil"] if libav else []))
-    return [out]
+        B._run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, f"-L{B.PKG}", "-lvpfhip", f"-Wl,-rpath,{rpath}"] + list(link_tail))
+    return out
+
+
+def build(force: bool = False):
+    libav = os.environ.get("VPF_WITH_LIBAV", "auto")
+    libav = have_libav() if libav == "auto" else libav not in ("0", "no", "off")
+    sources = list(SOURCES) + ([os.path.join(B.CSRC, "feeder", "FfmpegFeeder.cpp")] if libav else [])
+    return [_build_module(OUT_DIR, "tc_", sources, ["-DVPF_WITH_LIBAV"] if libav else [], ["-lavformat", "-lavcodec", "-lavutil"] if libav else [],
+                          "$ORIGIN/..", force)]
+
+
+def build_stub_libav_variant(force: bool = False) -> str:
+    """TEST BUILD (tests/test_feeder_stub_libav.py): the same bindings with the optional PyFfmpegDecoder section compiled in
+    (-DVPF_WITH_LIBAV) and linked against tests/libav_stub/stub_libav.c instead of FFmpeg, into tests/_build/pynvcodec_stubav/PyNvCodec/.
+    Returns the directory to put on sys.path.  Never part of the product build."""
+    import shutil
+    import subprocess
+
+    stub = os.path.join(B.ROOT, "tests", "libav_stub")
+    base = os.path.join(B.ROOT, "tests", "_build", "pynvcodec_stubav")
+    pkg = os.path.join(base, "PyNvCodec")
+    os.makedirs(pkg, exist_ok=True)
+    shutil.copyfile(os.path.join(OUT_DIR, "__init__.py"), os.path.join(pkg, "__init__.py"))
+    stub_o = os.path.join(base, "stub_libav.o")
+    if force or B._newer(stub_o, [os.path.join(stub, "stub_libav.c")]):
+        subprocess.check_call(["gcc", "-std=c99", "-O1", "-fPIC", f"-I{stub}", "-c", os.path.join(stub, "stub_libav.c"), "-o", stub_o])
+    _build_module(pkg, "tcstub_", list(SOURCES) + [os.path.join(B.CSRC, "feeder", "FfmpegFeeder.cpp"), stub_o], ["-DVPF_WITH_LIBAV", f"-I{stub}"], [], B.PKG, force)
+    return base

@@ -25,7 +25,7 @@ TUNE_NV12_RGB_VARIANT = 1
 EXPORTS = [
     "vpf_convert", "vpf_convert_batch", "vpf_convert_supported", "vpf_resize", "vpf_remap", "vpf_convert_resize",
     "vpf_convert_resize_batch",
-    "vpf_status_string", "vpf_version", "vpf_device_count", "vpf_set_tuning",
+    "vpf_status_string", "vpf_version", "vpf_device_count", "vpf_set_tuning", "vpf_trace_push", "vpf_trace_pop",
 ]
 
 

@@ -290,15 +290,25 @@ public:
   ColorSpace GetColorSpace() const { return dec_->GetColorSpace(); }
   ColorRange GetColorRange() const { return dec_->GetColorRange(); }
   Pixel_Format GetPixelFormat() const { return dec_->GetPixelFormat(); }
+  uint32_t up_w_ = 0, up_h_ = 0;
+  std::vector<std::unique_ptr<PyFrameUploader>> retired_;  // uploaders of earlier resolutions: surfaces already handed out alias their memory
+
   bool DecodeSingleFrame(py::array_t<uint8_t>& frame) {
-    const size_t n = dec_->FrameBytes();
+    if (!dec_->NextFrame()) return false;
+    const size_t n = dec_->PendingFrameBytes();  // sized from the decoded picture: a stream may change resolution mid-way
     if ((size_t)frame.size() != n) frame.resize({(py::ssize_t)n}, false);
-    return dec_->DecodeNextFrame(frame.mutable_data(), n);
+    return dec_->CopyFrameNV12(frame.mutable_data(), n);
   }
   std::shared_ptr<Surface> DecodeSingleSurface() {
-    host_.resize(dec_->FrameBytes());
-    if (!dec_->DecodeNextFrame(host_.data(), host_.size())) return empty_surface(NV12);
-    if (!up_) up_.reset(new PyFrameUploader(dec_->Width(), dec_->Height(), NV12, ctx_of(gpu_), str_of(gpu_)));
+    if (!dec_->NextFrame()) return empty_surface(NV12);
+    const uint32_t w = dec_->FrameWidth(), h = dec_->FrameHeight();
+    host_.resize(dec_->PendingFrameBytes());
+    if (!dec_->CopyFrameNV12(host_.data(), host_.size())) return empty_surface(NV12);
+    if (!up_ || w != up_w_ || h != up_h_) {
+      if (up_) retired_.push_back(std::move(up_));
+      up_.reset(new PyFrameUploader(w, h, NV12, ctx_of(gpu_), str_of(gpu_)));
+      up_w_ = w; up_h_ = h;
+    }
     return up_->Upload(host_.data(), host_.size());
   }
 };
@@ -393,20 +403,33 @@ PYBIND11_MODULE(_PyNvCodec, m) {
              return std::make_shared<SurfacePlane>(*p);  // non-owning copy
            },
            py::arg("plane") = 0U)
-      // NB: the reference's binding copies self -> other (PySurface.cpp:361,382), the opposite of the method's
-      // name; this one does what the name says: other -> self.
+      // Drop-in semantics: the reference's binding copies SELF -> OTHER (PySurface.cpp:54-81 takes (self, other) as (source,
+      // destination) and :361,382 pass them in that order) — the opposite of what the name suggests, but code written against the
+      // reference relies on it, so it is kept.  UpdateFrom (additive) is the unambiguous other -> self copy.
       .def("CopyFrom",
            [](std::shared_ptr<Surface> self, std::shared_ptr<Surface> other, int gpu) {
              check_same(*self, *other);
-             copy_surface(*other, *self, ctx_of(gpu), str_of(gpu));
+             copy_surface(*self, *other, ctx_of(gpu), str_of(gpu));
            },
-           py::arg("other"), py::arg("gpu_id"))
+           py::arg("other"), py::arg("gpu_id"), "DtoD copy of THIS surface INTO `other` (the reference's direction, PySurface.cpp:361)")
       .def("CopyFrom",
            [](std::shared_ptr<Surface> self, std::shared_ptr<Surface> other, size_t ctx, size_t str) {
              check_same(*self, *other);
-             copy_surface(*other, *self, (HipContext)ctx, (HipStream)str);
+             copy_surface(*self, *other, (HipContext)ctx, (HipStream)str);
            },
-           py::arg("other"), py::arg("context"), py::arg("stream"))
+           py::arg("other"), py::arg("context"), py::arg("stream"), "DtoD copy of THIS surface INTO `other` (the reference's direction, PySurface.cpp:382)")
+      .def("UpdateFrom",
+           [](std::shared_ptr<Surface> self, std::shared_ptr<Surface> src, int gpu) {
+             check_same(*self, *src);
+             copy_surface(*src, *self, ctx_of(gpu), str_of(gpu));
+           },
+           py::arg("src"), py::arg("gpu_id"), "additive: DtoD copy of `src` into THIS surface")
+      .def("UpdateFrom",
+           [](std::shared_ptr<Surface> self, std::shared_ptr<Surface> src, size_t ctx, size_t str) {
+             check_same(*self, *src);
+             copy_surface(*src, *self, (HipContext)ctx, (HipStream)str);
+           },
+           py::arg("src"), py::arg("context"), py::arg("stream"), "additive: DtoD copy of `src` into THIS surface")
       .def("Clone",
            [](std::shared_ptr<Surface> self) {
              auto n = make_surface(self->PixelFormat(), self->Width(), self->Height(), self->Context());

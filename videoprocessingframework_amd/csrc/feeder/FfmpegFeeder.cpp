@@ -36,7 +36,7 @@ struct FfmpegFeeder::Impl {
   AVFrame* frame = nullptr;
   AVPacket* pkt = nullptr;
   int stream = -1;
-  bool draining = false, done = false;
+  bool draining = false, done = false, have_frame = false;
 
   ~Impl() {
     if (pkt) av_packet_free(&pkt);
@@ -46,6 +46,12 @@ struct FfmpegFeeder::Impl {
   }
 
   // one decoded picture -> tight NV12.  Planar 4:2:0 (YUV420P / YUVJ420P) gets its chroma interleaved; NV12 is copied.
+  // Sizes come from the FRAME (a stream may change resolution mid-way; the codec context's width / height are only what the
+  // container announced): the caller checks frame_bytes() against its buffer before calling this.
+  size_t frame_bytes() const {
+    const size_t w = (size_t)frame->width, h = (size_t)frame->height;
+    return w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2);
+  }
   bool to_nv12(uint8_t* out) const {
     const int w = frame->width, h = frame->height, cw = (w + 1) / 2, ch = (h + 1) / 2;
     for (int y = 0; y < h; y++) std::memcpy(out + (size_t)y * w, frame->data[0] + (size_t)y * frame->linesize[0], (size_t)w);
@@ -129,14 +135,17 @@ ColorRange FfmpegFeeder::GetColorRange() const {
   }
 }
 
-bool FfmpegFeeder::DecodeNextFrame(uint8_t* nv12, size_t capacity) {
-  if (p->done || !nv12 || capacity < FrameBytes()) return false;
+bool FfmpegFeeder::NextFrame() {
+  if (p->have_frame) { av_frame_unref(p->frame); p->have_frame = false; }
+  if (p->done) return false;
   for (;;) {
     const int got = avcodec_receive_frame(p->dec, p->frame);
     if (got == 0) {
-      const bool ok = p->to_nv12(nv12);
-      av_frame_unref(p->frame);
-      if (!ok) throw std::runtime_error("FfmpegFeeder: decoded pixel format is not 8-bit 4:2:0");
+      if (p->frame->width <= 0 || p->frame->height <= 0) {
+        av_frame_unref(p->frame);
+        throw std::runtime_error("FfmpegFeeder: decoder returned an empty picture");
+      }
+      p->have_frame = true;
       return true;
     }
     if (got == AVERROR_EOF) { p->done = true; return false; }
@@ -154,6 +163,31 @@ bool FfmpegFeeder::DecodeNextFrame(uint8_t* nv12, size_t capacity) {
     av_packet_unref(p->pkt);
     if (sent < 0 && sent != AVERROR(EAGAIN)) throw std::runtime_error("FfmpegFeeder: send_packet failed: " + av_err(sent));
   }
+}
+uint32_t FfmpegFeeder::FrameWidth() const { return p->have_frame ? (uint32_t)p->frame->width : 0; }
+uint32_t FfmpegFeeder::FrameHeight() const { return p->have_frame ? (uint32_t)p->frame->height : 0; }
+size_t FfmpegFeeder::PendingFrameBytes() const { return p->have_frame ? p->frame_bytes() : 0; }
+
+bool FfmpegFeeder::CopyFrameNV12(uint8_t* nv12, size_t capacity) {
+  if (!p->have_frame || !nv12) return false;
+  if (capacity < p->frame_bytes()) {  // never write past the caller's buffer (a mid-stream resolution change lands here)
+    std::stringstream ss;
+    ss << "FfmpegFeeder: decoded frame is " << p->frame->width << "x" << p->frame->height << " (" << p->frame_bytes() << " B of NV12) but the destination holds "
+       << capacity << " B (stream announced " << Width() << "x" << Height() << ")";
+    av_frame_unref(p->frame);
+    p->have_frame = false;
+    throw std::runtime_error(ss.str());
+  }
+  const bool ok = p->to_nv12(nv12);
+  av_frame_unref(p->frame);
+  p->have_frame = false;
+  if (!ok) throw std::runtime_error("FfmpegFeeder: decoded pixel format is not 8-bit 4:2:0");
+  return true;
+}
+
+bool FfmpegFeeder::DecodeNextFrame(uint8_t* nv12, size_t capacity) {
+  if (!nv12) return false;
+  return NextFrame() && CopyFrameNV12(nv12, capacity);
 }
 
 }  // namespace VPF

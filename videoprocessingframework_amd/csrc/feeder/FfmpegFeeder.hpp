@@ -2,8 +2,10 @@
 // surface path as real NV12.  SURVEY §8(f) N3; reference: src/TC/src/FfmpegSwDecoder.cpp:60-170,254-360 (open, find the
 // best video stream, send/receive loop, SaveYUV420 :141-168) and src/PyNvCodec/src/PyFFMpegDecoder.cpp:37-70.
 //
-// Built ONLY where the libav headers and libraries exist (videoprocessingframework_amd/_build_bindings.py probes for them);
-// this image has none, so here the component is compiled against tests/libav_stub (syntax only) and is otherwise UNTESTED.
+// Built into the product ONLY where the libav headers and libraries exist (videoprocessingframework_amd/_build_bindings.py probes
+// for them); this image has none, so here it is compiled and RUN against tests/libav_stub — a stand-in implementation of the dozen
+// libav entry points that decodes synthetic clips (tests/test_feeder_stub_libav.py): the send / receive loop, the YUV420P -> NV12
+// repack, end of stream and the error paths execute; real bitstreams do not.
 // Not on the conversion hot path: decode stays on the host, as north_star prescribes.
 //
 // Deliberate difference from the reference: its decoder stores planar YUV420P and labels it NV12
@@ -35,8 +37,18 @@ public:
   Pixel_Format GetPixelFormat() const { return NV12; }
   size_t FrameBytes() const { return (size_t)Width() * Height() * 3 / 2; }
 
-  // Decode the next frame into `nv12` (tight W x 1.5H bytes: Y plane then interleaved UV).  false at end of stream.
+  // Decode the next frame into `nv12` (tight W x 1.5H bytes: Y plane then interleaved UV).  false at end of stream.  Throws when
+  // the decoded frame does not fit `capacity` (sizes are taken from the frame itself, not from the container's announcement).
   bool DecodeNextFrame(uint8_t* nv12, size_t capacity);
+
+  // The same in two steps, for callers that size their buffer per frame (streams may change resolution): NextFrame() decodes
+  // and holds one picture (false at end of stream), FrameWidth / FrameHeight / PendingFrameBytes describe it, CopyFrameNV12
+  // writes it out as tight NV12 and releases it.
+  bool NextFrame();
+  uint32_t FrameWidth() const;
+  uint32_t FrameHeight() const;
+  size_t PendingFrameBytes() const;
+  bool CopyFrameNV12(uint8_t* nv12, size_t capacity);
 
 private:
   struct Impl;

@@ -3,6 +3,8 @@
 // SurfaceRGB/BGR :1361-1519, SurfaceRGBPlanar/YUV444 :1521-1637, RGB32F :1639-1860) through one table.
 #include "MemoryInterfaces.hpp"
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -129,6 +131,15 @@ void SetDeviceAllocator(const DeviceAllocator* a) {
 }
 
 // ---------------------------------------------------------------------------------------------- Buffer
+// A staging buffer that was asked to be page-locked but is not (hipHostMalloc failed: no device / pinned-memory limit) still
+// works, but every upload / download through it loses its asynchronous, overlapped DMA.  Said once per process on stderr.
+static void note_unpinned(size_t size) {
+  static std::atomic<bool> said{false};
+  (void)hipGetLastError();
+  if (!said.exchange(true))
+    std::cerr << "libvpf (MemoryInterfaces): hipHostMalloc(" << size << " B) failed; staging falls back to pageable host memory — uploads / "
+                 "downloads through it are no longer asynchronous or overlapped (reported once)" << std::endl;
+}
 Buffer::Buffer(size_t size, void* wrap, bool own, bool pinned) : own_(own), pinned_(false), size_(size) {
   if (!own) {
     data_ = wrap;
@@ -137,6 +148,7 @@ Buffer::Buffer(size_t size, void* wrap, bool own, bool pinned) : own_(own), pinn
   if (pinned && hipHostMalloc(&data_, size ? size : 1, hipHostMallocDefault) == hipSuccess) {
     pinned_ = true;
   } else {
+    if (pinned) note_unpinned(size);
     data_ = std::calloc(size ? size : 1, 1);
     if (!data_) throw std::bad_alloc();
   }
@@ -164,7 +176,7 @@ void Buffer::Update(size_t newSize, void* newPtr) {
     release();
     size_ = newSize;
     if (pin && hipHostMalloc(&data_, newSize ? newSize : 1, hipHostMallocDefault) == hipSuccess) pinned_ = true;
-    else { pinned_ = false; data_ = std::calloc(newSize ? newSize : 1, 1); }
+    else { if (pin) note_unpinned(newSize); pinned_ = false; data_ = std::calloc(newSize ? newSize : 1, 1); }
     if (newPtr) std::memcpy(data_, newPtr, newSize);
   } else {
     size_ = newSize;
@@ -244,12 +256,14 @@ void SurfacePlane::Allocate() {
   { std::lock_guard<std::mutex> lock(g_alloc_mutex); a = g_alloc; }
   gpuMem = (DevicePtr)a.alloc(bytes ? bytes : 1, dev, a.user);
   if (!gpuMem) throw std::runtime_error("SurfacePlane: device allocation failed");
+  allocDevice = dev;
 }
 void SurfacePlane::Deallocate() {
   if (ownMem && gpuMem) {
     DeviceAllocator a;
     { std::lock_guard<std::mutex> lock(g_alloc_mutex); a = g_alloc; }
-    a.free((void*)gpuMem, DeviceOfContext(ctx), a.user);
+    DeviceScope scope(ctx);  // a per-device allocator sees the same (device, ordinal) pair on free as on alloc
+    a.free((void*)gpuMem, allocDevice, a.user);
   }
   gpuMem = 0;
   ownMem = false;
@@ -315,6 +329,7 @@ Surface* Surface::Make(Pixel_Format f, uint32_t w, uint32_t h, HipContext ctx) {
     // move ownership into the member (operator= makes aliases, so hand the pointer over explicitly)
     s->alloc_[a].gpuMem = owned.gpuMem; s->alloc_[a].ctx = ctx; s->alloc_[a].width = aw; s->alloc_[a].height = ah;
     s->alloc_[a].pitch = owned.pitch; s->alloc_[a].elemSize = t.elem; s->alloc_[a].ownMem = true;
+    s->alloc_[a].allocDevice = owned.allocDevice;
     owned.ownMem = false; owned.gpuMem = 0;
   }
   s->refresh_views();

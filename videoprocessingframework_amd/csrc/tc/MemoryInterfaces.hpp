@@ -114,6 +114,7 @@ struct SurfacePlane {
   HipContext ctx = 0;
   uint32_t width = 0, height = 0, pitch = 0, elemSize = 0;
   bool ownMem = false;
+  int allocDevice = -1;  // device ordinal the allocator was given in Allocate(): handed back unchanged to its free()
 
   SurfacePlane() = default;
   SurfacePlane(const SurfacePlane& other);             // non-owning alias

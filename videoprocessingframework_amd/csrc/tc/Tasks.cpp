@@ -20,6 +20,15 @@
 namespace VPF {
 
 namespace {
+// the reference brackets every Task::Run with an NvtxMark (src/TC/inc/Tasks.hpp:27-52, e.g. TasksColorCvt.cpp:124); here the same
+// ranges are roctx ranges, switched on at run time with VPF_HIP_ROCTX=1 (libvpfhip dlopen()s roctx; nothing is linked)
+struct HipMark {
+  int opened;
+  explicit HipMark(const char* name) : opened(vpf_trace_push(name)) {}
+  ~HipMark() { vpf_trace_pop(opened); }
+  HipMark(const HipMark&) = delete;
+  HipMark& operator=(const HipMark&) = delete;
+};
 constexpr auto TASK_EXEC_SUCCESS = TaskExecStatus::TASK_EXEC_SUCCESS;
 constexpr auto TASK_EXEC_FAIL = TaskExecStatus::TASK_EXEC_FAIL;
 
@@ -202,22 +211,23 @@ bool ConvertSurface::ResolveContext(Pixel_Format in, Pixel_Format out, const Col
 }
 
 ConvertSurface::ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str)
-    : Task("HipConvertSurface", numInputs, numOutputs, nullptr, nullptr), pImpl(nullptr) {
+    : Task("HipConvertSurface", numInputs, numOutputs, nullptr, nullptr), pImpl() {
   const PairInfo* p = find_pair(in, out);
   if (!p) {
     std::stringstream ss;
     ss << "Unsupported pixel format conversion: " << in << " to " << out;
     throw std::invalid_argument(ss.str());
   }
-  pImpl = new Impl{p, w, h, ctx, str, nullptr, false};
+  pImpl.reset(new Impl{p, w, h, ctx, str, nullptr, false});
   pImpl->out.reset(Surface::Make(out, w, h, ctx));
 }
-ConvertSurface::~ConvertSurface() { delete pImpl; }
+ConvertSurface::~ConvertSurface() {}
 ConvertSurface* ConvertSurface::Make(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str) {
   return new ConvertSurface(w, h, in, out, ctx, str);
 }
 
 TaskExecStatus ConvertSurface::Run() {
+  const HipMark tick("ConvertSurface::Run");
   ClearOutputs();
   auto* in = static_cast<Surface*>(GetInput(0));
   const ColorspaceConversionContext* cc = nullptr;
@@ -277,7 +287,7 @@ struct ConvertResizeSurface::Impl {
 };
 ConvertResizeSurface::ConvertResizeSurface(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out,
                                            HipContext ctx, HipStream str)
-    : Task("HipConvertResizeSurface", numInputs, numOutputs, nullptr, nullptr), pImpl(nullptr) {
+    : Task("HipConvertResizeSurface", numInputs, numOutputs, nullptr, nullptr), pImpl() {
   const PairInfo* p = find_pair(in, out);
   const bool fusable = p && (in == NV12 || in == YUV420) && (out == RGB || out == BGR || out == RGB_PLANAR);
   if (!fusable || !sw || !sh || !dw || !dh) {
@@ -285,15 +295,16 @@ ConvertResizeSurface::ConvertResizeSurface(uint32_t sw, uint32_t sh, Pixel_Forma
     ss << "Unsupported fused conversion + resize: " << in << " to " << out;
     throw std::invalid_argument(ss.str());
   }
-  pImpl = new Impl{p, sw, sh, dw, dh, ctx, str, nullptr};
+  pImpl.reset(new Impl{p, sw, sh, dw, dh, ctx, str, nullptr});
   pImpl->out.reset(Surface::Make(out, dw, dh, ctx));
 }
-ConvertResizeSurface::~ConvertResizeSurface() { delete pImpl; }
+ConvertResizeSurface::~ConvertResizeSurface() {}
 ConvertResizeSurface* ConvertResizeSurface::Make(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out,
                                                  HipContext ctx, HipStream str) {
   return new ConvertResizeSurface(sw, sh, in, dw, dh, out, ctx, str);
 }
 TaskExecStatus ConvertResizeSurface::Run() {
+  const HipMark tick("ConvertResizeSurface::Run");
   ClearOutputs();
   auto* in = static_cast<Surface*>(GetInput(0));
   const ColorspaceConversionContext* cc = nullptr;
@@ -363,24 +374,25 @@ static bool resize_format_ok(Pixel_Format f) {
   }
 }
 ResizeSurface::ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str)
-    : Task("HipResizeSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(nullptr) {
+    : Task("HipResizeSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl() {
   if (!resize_format_ok(f)) {
     std::stringstream ss;
     ss << "pixel format not supported";
     throw std::runtime_error(ss.str());
   }
-  pImpl = new Impl{f, w, h, StreamRef{ctx, str}, nullptr, VPF_INTERP_LINEAR};
+  pImpl.reset(new Impl{f, w, h, StreamRef{ctx, str}, nullptr, VPF_INTERP_LINEAR});
   if (const char* e = std::getenv("VPF_HIP_RESIZE_INTERP")) {  // "lanczos" restores the reference resizer's filter
     if (!std::strcmp(e, "lanczos") || !std::strcmp(e, "2")) pImpl->interp = VPF_INTERP_LANCZOS3;
     else if (!std::strcmp(e, "nearest") || !std::strcmp(e, "0")) pImpl->interp = VPF_INTERP_NEAREST;
   }
   pImpl->out.reset(Surface::Make(f, w, h, ctx));
 }
-ResizeSurface::~ResizeSurface() { delete pImpl; }
+ResizeSurface::~ResizeSurface() {}
 ResizeSurface* ResizeSurface::Make(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
   return new ResizeSurface(w, h, f, ctx, str);
 }
 TaskExecStatus ResizeSurface::Run() {
+  const HipMark tick("ResizeSurface::Run");
   ClearOutputs();
   auto* in = static_cast<Surface*>(GetInput(0));
   if (!in || in->Empty() || !pImpl->out || pImpl->out->Empty()) return TASK_EXEC_FAIL;
@@ -409,10 +421,10 @@ struct RemapSurface::Impl {
   std::unique_ptr<Surface> out;
 };
 RemapSurface::RemapSurface(const float* x_map, const float* y_map, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str)
-    : Task("HipRemapSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(nullptr) {
+    : Task("HipRemapSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl() {
   if (f != RGB && f != BGR) throw std::runtime_error("pixel format not supported");  // Tasks.cpp:1615-1620
   if (!x_map || !y_map || !w || !h) throw std::runtime_error("RemapSurface: empty map");
-  pImpl = new Impl{f, w, h, StreamRef{ctx, str}, nullptr, nullptr, nullptr};
+  pImpl.reset(new Impl{f, w, h, StreamRef{ctx, str}, nullptr, nullptr, nullptr});
   // maps go to the device once, synchronously, as two tight float[h*w] buffers (Tasks.cpp:1523-1526)
   pImpl->xmap.reset(CudaBuffer::Make(x_map, sizeof(float), (size_t)w * h, ctx, str));
   pImpl->ymap.reset(CudaBuffer::Make(y_map, sizeof(float), (size_t)w * h, ctx, str));
@@ -423,15 +435,15 @@ RemapSurface::RemapSurface(const float* x_map, const float* y_map, uint32_t w, u
   DeviceScope scope(ctx);
   if (!hip_ok(hipMemsetAsync((void*)pImpl->out->PlanePtr(0), 0, (size_t)pImpl->out->Pitch(0) * h, (hipStream_t)str), "RemapSurface: hipMemsetAsync") ||
       !hip_ok(hipStreamSynchronize((hipStream_t)str), "RemapSurface: hipStreamSynchronize")) {
-    delete pImpl;
     throw std::runtime_error("RemapSurface: can't clear the output surface");
   }
 }
-RemapSurface::~RemapSurface() { delete pImpl; }
+RemapSurface::~RemapSurface() {}
 RemapSurface* RemapSurface::Make(const float* x, const float* y, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
   return new RemapSurface(x, y, w, h, f, ctx, str);
 }
 TaskExecStatus RemapSurface::Run() {
+  const HipMark tick("RemapSurface::Run");
   ClearOutputs();
   auto* in = static_cast<Surface*>(GetInput(0));
   if (!in || in->Empty() || in->PixelFormat() != pImpl->fmt) return TASK_EXEC_FAIL;
@@ -466,6 +478,14 @@ struct CudaUploadFrame::Impl {
   std::unique_ptr<Buffer> staging[kSlots];
   std::unique_ptr<Surface> surf[kSlots];
   uint64_t n = 0;
+  ~Impl() {  // owns the HIP objects itself, so a constructor that throws half-way releases what it had created
+    DeviceScope scope(sref.ctx);
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    for (auto& e : done)
+      if (e) (void)hipEventDestroy(e);
+    for (auto& e : consumed)
+      if (e) (void)hipEventDestroy(e);
+  }
 };
 CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f)
     : Task("HipUploadFrame", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl) {
@@ -481,21 +501,12 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
   }
   if (hipStreamCreateWithFlags(&pImpl->copy_stream, hipStreamNonBlocking) != hipSuccess) pImpl->copy_stream = nullptr;
 }
-CudaUploadFrame::~CudaUploadFrame() {
-  if (pImpl) {
-    DeviceScope scope(pImpl->sref.ctx);
-    if (pImpl->copy_stream) { (void)hipStreamSynchronize(pImpl->copy_stream); (void)hipStreamDestroy(pImpl->copy_stream); }
-    for (auto& e : pImpl->done)
-      if (e) (void)hipEventDestroy(e);
-    for (auto& e : pImpl->consumed)
-      if (e) (void)hipEventDestroy(e);
-  }
-  delete pImpl;
-}
+CudaUploadFrame::~CudaUploadFrame() {}
 CudaUploadFrame* CudaUploadFrame::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
   return new CudaUploadFrame(str, ctx, w, h, f);
 }
 TaskExecStatus CudaUploadFrame::Run() {
+  const HipMark tick("CudaUploadFrame::Run");
   auto* host = static_cast<Buffer*>(GetInput(0));
   if (!host) return TASK_EXEC_FAIL;
   ClearOutputs();
@@ -551,16 +562,16 @@ struct CudaDownloadSurface::Impl {
   std::unique_ptr<Buffer> host;  // pinned
 };
 CudaDownloadSurface::CudaDownloadSurface(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f)
-    : Task("HipDownloadSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(nullptr) {
+    : Task("HipDownloadSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl() {
   if (!Surface::Supported(f)) {
     std::stringstream ss;
     ss << "CudaDownloadSurface: unsupported pixel format: " << f;
     throw std::invalid_argument(ss.str());  // Tasks.cpp:759-762
   }
-  pImpl = new Impl{StreamRef{ctx, str}, f, w, h, nullptr};
+  pImpl.reset(new Impl{StreamRef{ctx, str}, f, w, h, nullptr});
   pImpl->host.reset(Buffer::MakeOwnMem(Surface::HostMemSizeOf(f, w, h), ctx ? ctx : (HipContext)-1));
 }
-CudaDownloadSurface::~CudaDownloadSurface() { delete pImpl; }
+CudaDownloadSurface::~CudaDownloadSurface() {}
 CudaDownloadSurface* CudaDownloadSurface::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
   return new CudaDownloadSurface(str, ctx, w, h, f);
 }
@@ -578,6 +589,7 @@ static bool download_planes(Surface* s, uint8_t* dst, hipStream_t str) {
   return true;
 }
 TaskExecStatus CudaDownloadSurface::Run() {
+  const HipMark tick("CudaDownloadSurface::Run");
   auto* s = static_cast<Surface*>(GetInput(0));
   if (!s) return TASK_EXEC_FAIL;
   ClearOutputs();
@@ -620,9 +632,10 @@ UploadBuffer::UploadBuffer(HipStream str, HipContext ctx, uint32_t e, uint32_t n
     : Task("HipUploadBuffer", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl{StreamRef{ctx, str}, nullptr}) {
   pImpl->buf.reset(CudaBuffer::Make(e, n, ctx));
 }
-UploadBuffer::~UploadBuffer() { delete pImpl; }
+UploadBuffer::~UploadBuffer() {}
 UploadBuffer* UploadBuffer::Make(HipStream str, HipContext ctx, uint32_t e, uint32_t n) { return new UploadBuffer(str, ctx, e, n); }
 TaskExecStatus UploadBuffer::Run() {
+  const HipMark tick("UploadBuffer::Run");
   auto* host = static_cast<Buffer*>(GetInput(0));
   if (!host) return TASK_EXEC_FAIL;
   ClearOutputs();
@@ -644,9 +657,10 @@ DownloadCudaBuffer::DownloadCudaBuffer(HipStream str, HipContext ctx, uint32_t e
     : Task("HipDownloadBuffer", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl{StreamRef{ctx, str}, nullptr}) {
   pImpl->host.reset(Buffer::MakeOwnMem((size_t)e * n, ctx ? ctx : (HipContext)-1));
 }
-DownloadCudaBuffer::~DownloadCudaBuffer() { delete pImpl; }
+DownloadCudaBuffer::~DownloadCudaBuffer() {}
 DownloadCudaBuffer* DownloadCudaBuffer::Make(HipStream str, HipContext ctx, uint32_t e, uint32_t n) { return new DownloadCudaBuffer(str, ctx, e, n); }
 TaskExecStatus DownloadCudaBuffer::Run() {
+  const HipMark tick("DownloadCudaBuffer::Run");
   auto* b = static_cast<CudaBuffer*>(GetInput(0));
   if (!b) return TASK_EXEC_FAIL;
   ClearOutputs();

@@ -34,7 +34,7 @@ public:
 private:
   static const uint32_t numInputs = 2U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   ConvertSurface(uint32_t w, uint32_t h, Pixel_Format in, Pixel_Format out, HipContext ctx, HipStream str);
 };
 
@@ -52,7 +52,7 @@ public:
 private:
   static const uint32_t numInputs = 2U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   ConvertResizeSurface(uint32_t sw, uint32_t sh, Pixel_Format in, uint32_t dw, uint32_t dh, Pixel_Format out, HipContext ctx, HipStream str);
 };
 
@@ -68,7 +68,7 @@ public:
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str);
 };
 
@@ -82,7 +82,7 @@ public:
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   RemapSurface(const float* x_map, const float* y_map, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str);
 };
 
@@ -96,7 +96,7 @@ public:
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f);
 };
 
@@ -114,7 +114,7 @@ public:
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   CudaDownloadSurface(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f);
 };
 
@@ -127,7 +127,7 @@ public:
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   UploadBuffer(HipStream str, HipContext ctx, uint32_t elem_size, uint32_t num_elems);
 };
 
@@ -140,7 +140,7 @@ public:
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
   struct Impl;
-  Impl* pImpl;
+  std::unique_ptr<Impl> pImpl;  // unique_ptr: a constructor that throws after allocating it (device OOM) frees it
   DownloadCudaBuffer(HipStream str, HipContext ctx, uint32_t elem_size, uint32_t num_elems);
 };
 

@@ -4,38 +4,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
+#include <dlfcn.h>
+
+#include "vpf_coef.h"
 #include "vpf_internal.h"
 
 namespace vpf {
 
-// ------------------------------------------------------------------------------------------
-// colour matrices.  Decimal coefficients x 1e6 as published for NPP's colour models / BT.601 /
-// BT.709.  Everything the device sees is derived from these integers by one
-// correctly rounded division and one narrowing, so host and device agree bit for bit everywhere.
-// ------------------------------------------------------------------------------------------
-struct Yuv2RgbDec {
-  int64_t cy, rv, gu, gv, bu;
-  int off;
-};
-static const Yuv2RgbDec kYuv2Rgb[2][2] = {
-    {{1164000, 1596000, -392000, -813000, 2017000, 16},   // BT.601 MPEG : NPP "YCbCr"
-     {1000000, 1140000, -394000, -581000, 2032000, 0}},   // BT.601 JPEG : NPP "YUV"
-    {{1164384, 1792741, -213249, -532909, 2112402, 16},   // BT.709 MPEG : "709CSC"
-     {1000000, 1574800, -187324, -468124, 1855600, 0}}};  // BT.709 JPEG : "709HDTV"
-
-static inline float q6(int64_t v) { return (float)((double)v / 1e6); }
-
-bool make_yuv2rgb(int cs, int cr, Yuv2RgbCoef* o) {
-  if ((cs != VPF_BT_601 && cs != VPF_BT_709) || (cr != VPF_MPEG && cr != VPF_JPEG)) return false;
-  const Yuv2RgbDec& m = kYuv2Rgb[cs][cr];
-  o->cy = q6(m.cy); o->rv = q6(m.rv); o->gu = q6(m.gu); o->gv = q6(m.gv); o->bu = q6(m.bu);
-  const int64_t yoff = -(int64_t)m.off * m.cy;  // luma offset (rounding is done by v_cvt_pk_u8_f32: nearest even)
-  o->br = q6(yoff - 128 * m.rv);
-  o->bg = q6(yoff - 128 * (m.gu + m.gv));
-  o->bb = q6(yoff - 128 * m.bu);
-  return true;
-}
+bool make_yuv2rgb(int cs, int cr, Yuv2RgbCoef* o) { return coef_yuv2rgb(cs, cr, o); }
 
 struct Rgb2YuvDec {
   int64_t m[3][3];
@@ -53,6 +31,55 @@ bool make_rgb2yuv(int cr, Rgb2YuvCoef* o) {
     o->d[k] = q6((int64_t)m.d[k] * 1000000 + 500000);
   }
   return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// diagnostics: VPF_HIP_LOG / VPF_HIP_ROCTX (vpf_internal.h)
+// ------------------------------------------------------------------------------------------
+static std::atomic<int> g_log_level{-1}, g_trace{-1};
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static void (*g_roctx_mark)(const char*) = nullptr;
+int log_level() {
+  int v = g_log_level.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("VPF_HIP_LOG");
+    v = e ? (std::atoi(e) > 0 ? std::atoi(e) : 1) : 0;
+    g_log_level.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+bool trace_on() {
+  int v = g_trace.load(std::memory_order_acquire);
+  if (v < 0) {
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    v = g_trace.load(std::memory_order_acquire);
+    if (v < 0) {
+      v = 0;
+      const char* e = std::getenv("VPF_HIP_ROCTX");
+      if (e && std::atoi(e) > 0) {
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+          g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+          g_roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+          g_roctx_mark = reinterpret_cast<void (*)(const char*)>(dlsym(h, "roctxMarkA"));
+        }
+        if (g_roctx_push && g_roctx_pop) v = 1;
+        else std::fprintf(stderr, "libvpfhip: VPF_HIP_ROCTX is set but no roctx library could be loaded; tracing stays off\n");
+      }
+      g_trace.store(v, std::memory_order_release);
+    }
+  }
+  return v > 0;
+}
+void trace_push(const char* name) { if (g_roctx_push) g_roctx_push(name); }
+void trace_pop() { if (g_roctx_pop) g_roctx_pop(); }
+void note_kernel(const char* k) {
+  if (log_level() >= 2) std::fprintf(stderr, "libvpfhip: launch %s\n", k);
+  if (trace_on() && g_roctx_mark) g_roctx_mark(k);
 }
 
 static std::atomic<int> g_tune_variant{0};
@@ -156,7 +183,7 @@ static void fill_desc(FrameDesc& d, const vpf_plane* s, int ns, const vpf_plane*
 
 static vpf_status status_of(hipError_t e) {
   if (e == hipSuccess) return VPF_OK;
-  if (std::getenv("VPF_HIP_LOG")) std::fprintf(stderr, "libvpfhip: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
+  if (log_level() >= 1) std::fprintf(stderr, "libvpfhip: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return VPF_ERR_NO_DEVICE;
   return VPF_ERR_LAUNCH;
 }
@@ -171,6 +198,7 @@ int vpf_convert_supported(int sf, int df, int cs, int cr) { return classify(sf, 
 
 vpf_status vpf_convert_batch(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size size, uint32_t n,
                              const vpf_frame_io* frames) {
+  const Mark mark("vpf_convert_batch");
   const Family fam = classify(sf, df, cs, cr);
   if (fam == FAM_NONE) return VPF_ERR_UNSUPPORTED;
   if (!exec || !frames || !n || !dims_ok(size)) return VPF_ERR_BAD_ARG;
@@ -219,6 +247,7 @@ vpf_status vpf_convert(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf
 
 vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, const vpf_plane src[3], vpf_size ds,
                       const vpf_plane dst[3]) {
+  const Mark mark("vpf_resize");
   if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR && interp != VPF_INTERP_LANCZOS3) return VPF_ERR_UNSUPPORTED;
   switch (fmt) {
     case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_Y: case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
@@ -267,6 +296,7 @@ vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, co
 
 vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane* src, const float* xmap, uint32_t xp,
                      const float* ymap, uint32_t yp, vpf_size ds, const vpf_plane* dst) {
+  const Mark mark("vpf_remap");
   if (fmt != VPF_FMT_RGB && fmt != VPF_FMT_BGR) return VPF_ERR_UNSUPPORTED;
   if (!exec || !dims_ok(ss) || !dims_ok(ds) || !xmap || !ymap || !planes_ok(fmt, ss.width, src) ||
       !planes_ok(fmt, ds.width, dst) || xp < 4 * ds.width || yp < 4 * ds.width || (xp & 3) || (yp & 3) ||
@@ -281,6 +311,7 @@ vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane
 
 vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf_size ss, vpf_size ds,
                                     uint32_t n, const vpf_frame_io* frames) {
+  const Mark mark("vpf_convert_resize_batch");
   if (!(sf == VPF_FMT_NV12 || sf == VPF_FMT_YUV420) || rgb_class(df) < 0 || !cscr_ok(cs, cr)) return VPF_ERR_UNSUPPORTED;
   if (!exec || !frames || !n || !dims_ok(ss) || !dims_ok(ds)) return VPF_ERR_BAD_ARG;
   for (uint32_t i = 0; i < n; i++)
@@ -328,9 +359,21 @@ int vpf_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+/* Additive, for the Task layer's marks (the reference brackets every Task::Run with an NvtxMark): a roctx range when VPF_HIP_ROCTX=1,
+ * nothing otherwise.  vpf_trace_push returns 1 if a range was opened (pass that to vpf_trace_pop). */
+int vpf_trace_push(const char* name) {
+  if (!trace_on()) return 0;
+  trace_push(name);
+  return 1;
+}
+void vpf_trace_pop(int opened) { if (opened) trace_pop(); }
+
 int vpf_set_tuning(int key, int value) {
-  if (key == VPF_TUNE_NV12_RGB_VARIANT) return g_tune_variant.exchange(value);
-  return 0;
+  if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
+  switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
+    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: return g_tune_variant.exchange(value);
+    default: return -1;  // unknown value: nothing changes
+  }
 }
 
 }  // extern "C"

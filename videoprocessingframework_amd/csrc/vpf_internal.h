@@ -74,12 +74,31 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 
 int tuning(int key);
 
+// Diagnostics (both off by default, one relaxed atomic load per call when off):
+//   VPF_HIP_LOG=1    launch / runtime errors on stderr;  VPF_HIP_LOG=2  also which kernel every launch selected
+//   VPF_HIP_ROCTX=1  a roctx range around every C-ABI entry and a marker per kernel selection (rocprofv3 --marker-trace shows them
+//                    next to the kernels) — the counterpart of the reference's NvtxMark (src/TC/inc/Tasks.hpp:27-52, USE_NVTX);
+//                    librocprofiler-sdk-roctx is dlopen()ed on first use, so there is no link-time dependency
+int log_level();
+void note_kernel(const char* kernel_expr);  // called by VPF_LAUNCH when log_level() >= 2 or roctx is on
+bool trace_on();
+void trace_push(const char* name);
+void trace_pop();
+struct Mark {
+  bool on;
+  explicit Mark(const char* name) : on(trace_on()) { if (on) trace_push(name); }
+  ~Mark() { if (on) trace_pop(); }
+  Mark(const Mark&) = delete;
+  Mark& operator=(const Mark&) = delete;
+};
+
 // hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a caller's bad memcpy) would be
 // reported by the check that follows a launch.  Clear it first so the check sees this launch only.
-#define VPF_LAUNCH(...)          \
-  do {                           \
-    (void)hipGetLastError();     \
-    hipLaunchKernelGGL(__VA_ARGS__); \
+#define VPF_LAUNCH(K, ...)                                               \
+  do {                                                                   \
+    if (vpf::log_level() >= 2 || vpf::trace_on()) vpf::note_kernel(#K);  \
+    (void)hipGetLastError();                                             \
+    hipLaunchKernelGGL(K, __VA_ARGS__);                                  \
   } while (0)
 
 }  // namespace vpf
