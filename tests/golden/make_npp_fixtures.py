@@ -123,13 +123,19 @@ def main():
                 print(f"convert {sf}->{df} {w}x{h} {dist}: accepted contexts {accepted}")
 
     # ---- resize (the reference's resizer = NPP Lanczos) ---------------------------------------------------------------
+    def resizer(dw, dh, fmt):
+        rs = nvc.PySurfaceResizer(dw, dh, getattr(PF, fmt), a.gpu)
+        if hasattr(rs, "SetInterpolation"):  # this repo's module defaults to bilinear (north_star); the reference always asks NPP for Lanczos
+            rs.SetInterpolation(2)
+        return rs
+
     w, h = 848, 464
     for fmt in ("RGB", "RGB_PLANAR", "YUV420", "NV12"):
         src = synth(fmt, w, h, 2000 + len(manifest["cases"]), "A")
         surf = upload(fmt, w, h, src)
         outs = {}
         for dw, dh in ((224, 224), (424, 232), (1280, 720), (283, 155)):
-            dst = nvc.PySurfaceResizer(dw, dh, getattr(PF, fmt), a.gpu).Execute(surf)
+            dst = resizer(dw, dh, fmt).Execute(surf)
             if dst is not None and not dst.Empty():
                 outs[f"out_{dw}x{dh}"] = download(fmt, dw, dh, dst)
         save(f"resize_{fmt}_{w}x{h}", kind="resize", fmt=fmt, w=w, h=h, src=src, **outs)
@@ -139,7 +145,7 @@ def main():
     imp[12, 2] = (32, 255, 200)
     outs = {}
     for dw, dh in ((40, 40), (5, 5), (16, 16), (32, 32), (8, 8)):
-        dst = nvc.PySurfaceResizer(dw, dh, PF.RGB, a.gpu).Execute(upload("RGB", 16, 16, imp.reshape(-1)))
+        dst = resizer(dw, dh, "RGB").Execute(upload("RGB", 16, 16, imp.reshape(-1)))
         if dst is not None and not dst.Empty():
             outs[f"out_{dw}x{dh}"] = download("RGB", dw, dh, dst)
     save("resize_RGB_impulse_16x16", kind="resize", fmt="RGB", w=16, h=16, src=imp.reshape(-1), **outs)
