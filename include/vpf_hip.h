@@ -154,6 +154,13 @@ VPF_API int vpf_convert_supported(int src_fmt, int dst_fmt, int color_space, int
 VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size src_size,
                               const vpf_plane src[3], vpf_size dst_size, const vpf_plane dst[3]);
 
+/* The same resize over `n` independent same-shape frames, every plane of every frame in as few dispatches as possible (one per 32
+ * frames when all planes take the same kernel family — always the case for NV12 / YUV420 / planar surfaces allocated by this
+ * library).  A 720p plane is 2-3 us of GPU work, the same order as a kernel boundary: per-frame, per-plane dispatch leaves the chip
+ * idle most of the time.  `frames` is a HOST array consumed before return.  vpf_resize is this call with n = 1. */
+VPF_API vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size src_size, vpf_size dst_size, uint32_t n,
+                                    const vpf_frame_io* frames);
+
 /* Per-pixel remap with bilinear sampling, packed RGB/BGR only (Tasks.cpp:1555-1602,
  * nppiRemap_8u_C3R + NPPI_INTER_LINEAR).  xmap/ymap are device pointers to float32 rows of
  * dst_size.width entries, row pitch in bytes.  Destination pixels whose source coordinate lies
@@ -161,6 +168,11 @@ VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_siz
 VPF_API vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size src_size, const vpf_plane* src,
                              const float* xmap, uint32_t xmap_pitch, const float* ymap,
                              uint32_t ymap_pitch, vpf_size dst_size, const vpf_plane* dst);
+
+/* One pair of maps applied to `n` independent same-shape frames in one dispatch per 32 frames (a camera-undistortion map is the
+ * same for every frame of a stream; frames after the first find the maps in the Infinity Cache).  frames[i].src[0] / dst[0] only. */
+VPF_API vpf_status vpf_remap_batch(const vpf_exec* exec, int fmt, vpf_size src_size, const float* xmap, uint32_t xmap_pitch, const float* ymap,
+                                   uint32_t ymap_pitch, vpf_size dst_size, uint32_t n, const vpf_frame_io* frames);
 
 /* Fused NV12 -> bilinear resize -> packed RGB/BGR / RGB_PLANAR in one pass: reads only the source
  * texels it needs (BASELINE.md config 3 "fused").  Result is defined as: convert every NV12 texel
@@ -200,6 +212,8 @@ VPF_API void vpf_trace_pop(int opened);
  * are not in this library; they live in tools/lab).  Not part of the reference surface.  Returns the previous value. */
 VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_NV12_RGB_VARIANT 1
+#define VPF_TUNE_RESIZE_TILE 2 /* shape of the tiled resize kernels for measurement sweeps: 0 = policy, else rows-per-tile | waves-per-workgroup << 8
+                                  (rows 4..64 in steps of 4, waves 4 or 8); same pixels whatever the shape */
 
 #ifdef __cplusplus
 }

@@ -769,3 +769,88 @@ def test_tuning_hook_rejects_values_outside_the_product(capi):
     for v in (4, 8, 9, 12, 30, 37, 40, 43, 44):
         capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v)
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == v
+
+
+# ---------------------------------------------------------------------------------------------
+# vpf_resize_batch / vpf_remap_batch: every plane of every frame in as few dispatches as possible
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", ["RGB", "NV12", "YUV420", "RGB_PLANAR", "Y", "RGB_32F", "RGB_32F_PLANAR"])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_resize_batch_equals_the_oracle_frame_by_frame(capi, oracle, fmt, interp):
+    """n frames through ONE vpf_resize_batch call (multi-plane kernels where every plane lands in the same family, per-plane batched
+    launches otherwise) must equal n independent oracle resizes: tiled (Lanczos, up-scale), row-pair (bilinear down-scale), exact 2x,
+    odd-integer 3x, gather (unaligned), float surfaces; n = 1, 3 and 33 (two dispatches)"""
+    f = getattr(capi, fmt)
+    cases = [(640, 360, 224, 224, 256), (320, 180, 1280, 720, 256), (1920, 64, 960, 32, 256), (1152, 48, 384, 16, 256), (128, 72, 50, 30, 1), (100, 60, 333, 201, 256)]
+    if fmt.startswith("RGB_32F"):
+        cases = [(320, 180, 200, 101, 256), (96, 54, 32, 18, 256)]
+    for ci, (sw, sh, dw, dh, align) in enumerate(cases):
+        for n in ((1, 3, 33) if ci == 0 else (3,)):
+            srcs = [oracle.synth(f, sw, sh, 5000 + i) for i in range(min(n, 4))]
+            S = [DevPlanes(srcs[i % len(srcs)], align) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(f, dw, dh), align) for _ in range(n)]
+            capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+            torch.cuda.synchronize()
+            wants = [oracle.resize(f, interp, sw, sh, s, dw, dh, oracle.FP32)[1] for s in srcs]
+            for i in range(n):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, wants[i % len(srcs)], f"resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+
+
+def test_resize_batch_validation(capi, oracle):
+    ex = capi.make_exec(stream_handle())
+    s, d = DevPlanes(oracle.synth(capi.RGB, 64, 32, 1)), DevPlanes(oracle.alloc(capi.RGB, 32, 16))
+    b = capi.make_batch([(s.desc(), d.desc())])
+    assert capi.resize_batch(ex, capi.P10, 1, 64, 32, 32, 16, b, check=False) == capi.ERR_UNSUPPORTED
+    assert capi.resize_batch(ex, capi.RGB, 7, 64, 32, 32, 16, b, check=False) == capi.ERR_UNSUPPORTED
+    assert capi.resize_batch(ex, capi.RGB, 1, 64, 32, 32, 16, b, n=0, check=False) == capi.ERR_BAD_ARG
+    assert capi.resize_batch(ex, capi.RGB, 1, 6400, 32, 32, 16, b, check=False) == capi.ERR_BAD_ARG      # pitch < row bytes
+    assert capi.remap_batch(ex, capi.NV12, 64, 32, 16, 256, 16, 256, 32, 16, b, check=False) == capi.ERR_UNSUPPORTED
+    assert capi.remap_batch(ex, capi.RGB, 64, 32, 0, 256, 16, 256, 32, 16, b, check=False) == capi.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("n", [1, 5, 34])
+def test_remap_batch_equals_the_oracle_frame_by_frame(capi, oracle, n):
+    for (sw, sh, dw, dh, variant, align) in [(640, 360, 640, 360, 0, 256), (333, 77, 200, 61, 0, 256), (640, 48, 320, 24, 9, 256), (644, 40, 644, 40, 0, 4)]:
+        rng = np.random.default_rng(n + dw)
+        xm = (np.tile(np.arange(dw, dtype=np.float32), (dh, 1)) * (sw / dw) + rng.uniform(-0.7, 0.7, (dh, dw))).astype(np.float32)
+        ym = (np.tile(np.arange(dh, dtype=np.float32)[:, None], (1, dw)) * (sh / dh) + rng.uniform(-0.7, 0.7, (dh, dw))).astype(np.float32)
+        xm[1, 2:6] = np.nan
+        srcs = [oracle.synth(oracle.RGB, sw, sh, 6000 + i) for i in range(min(n, 3))]
+        S = [DevPlanes(srcs[i % len(srcs)], align) for i in range(n)]
+        D = [DevPlanes(oracle.alloc(oracle.RGB, dw, dh, fill=9), align) for _ in range(n)]
+        dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+        prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        try:
+            capi.remap_batch(capi.make_exec(stream_handle()), capi.RGB, sw, sh, dx.data_ptr(), 4 * dw, dy.data_ptr(), 4 * dw, dw, dh,
+                             capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+        finally:
+            capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+        torch.cuda.synchronize()
+        wants = [oracle.remap(oracle.RGB, sw, sh, s, xm, ym, dst=oracle.alloc(oracle.RGB, dw, dh, fill=9))[1] for s in srcs]
+        for i in range(n):
+            got, intact = D[i].download()
+            assert intact
+            assert_planes_equal(got, wants[i % len(srcs)], f"remap_batch {sw}x{sh}->{dw}x{dh} v{variant} frame {i} of {n}")
+
+
+@pytest.mark.parametrize("shape", [(16, 4), (16, 8), (32, 8), (64, 8), (8, 4), (24, 4)])
+def test_tiled_resize_shapes_write_identical_pixels(capi, oracle, shape):
+    """VPF_TUNE_RESIZE_TILE (rows per tile | waves per workgroup << 8) is a measurement knob: every shape the planner could pick writes
+    the oracle's pixels; a shape that does not fit falls back (gather form) with the same pixels"""
+    ty, wpb = shape
+    assert capi.set_tuning(capi.TUNE_RESIZE_TILE, ty | (wpb << 8)) >= 0
+    try:
+        for fmt, interp, (sw, sh, dw, dh) in [(capi.RGB, 2, (640, 360, 427, 240)), (capi.NV12, 2, (320, 180, 640, 360)), (capi.RGB, 1, (320, 180, 1280, 720)),
+                                              (capi.YUV420, 2, (1280, 96, 200, 15))]:
+            src = oracle.synth(fmt, sw, sh, 7000)
+            s, d = DevPlanes(src), DevPlanes(oracle.alloc(fmt, dw, dh))
+            capi.resize(capi.make_exec(stream_handle()), fmt, interp, sw, sh, s.desc(), dw, dh, d.desc())
+            torch.cuda.synchronize()
+            got, intact = d.download()
+            assert intact
+            assert_planes_equal(got, oracle.resize(fmt, interp, sw, sh, src, dw, dh, oracle.FP32)[1], f"tile shape {shape} fmt {fmt} interp {interp}")
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_TILE, 0)
+    assert capi.set_tuning(capi.TUNE_RESIZE_TILE, 7) == -1 and capi.set_tuning(capi.TUNE_RESIZE_TILE, 16 | (5 << 8)) == -1

@@ -520,3 +520,38 @@ print("done")
     assert "no roctx library" not in r.stderr
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, VPF_HIP_LOG="0"), timeout=300)
     assert r.returncode == 0 and "libvpfhip" not in r.stderr
+
+
+def test_resizer_and_remaper_execute_batch(oracle):
+    """additive PySurfaceResizer.ExecuteBatch / PySurfaceRemaper.ExecuteBatch: n surfaces -> n caller-owned surfaces, same pixels as n
+    Execute() calls (and as the oracle)"""
+    w, h, dw, dh, n = 320, 180, 200, 120, 5
+    for name in ("NV12", "RGB", "YUV420"):
+        fmt, ofmt = getattr(PF, name), getattr(oracle, name)
+        planes = [oracle.synth(ofmt, w, h, 50 + i) for i in range(n)]
+        srcs = [upload(fmt, w, h, p) for p in planes]
+        for interp in (1, 2):
+            rs = nvc.PySurfaceResizer(dw, dh, fmt, GPU)
+            rs.SetInterpolation(interp)
+            outs = [nvc.Surface.Make(fmt, dw, dh, GPU) for _ in range(n)]
+            assert rs.ExecuteBatch(srcs, outs)
+            torch.cuda.synchronize()
+            for i in range(n):
+                want = host_frame(oracle.resize(ofmt, interp, w, h, planes[i], dw, dh, oracle.FP32)[1])
+                assert np.array_equal(download(outs[i]), want), (name, interp, i)
+                assert np.array_equal(download(rs.Execute(srcs[i])), want)
+        assert not nvc.PySurfaceResizer(dw, dh, fmt, GPU).ExecuteBatch(srcs, outs[:2])                           # length mismatch
+        assert not nvc.PySurfaceResizer(dw, dh, fmt, GPU).ExecuteBatch(srcs, [nvc.Surface.Make(fmt, dw + 2, dh, GPU) for _ in range(n)])
+    yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
+    xm, ym = (xx * (w / dw) + 0.3).astype(np.float32), (yy * (h / dh) + 0.6).astype(np.float32)
+    planes = [oracle.synth(oracle.RGB, w, h, 80 + i) for i in range(n)]
+    srcs = [upload(PF.RGB, w, h, p) for p in planes]
+    rm = nvc.PySurfaceRemaper(xm, ym, PF.RGB, GPU)
+    outs = [nvc.Surface.Make(PF.RGB, dw, dh, GPU) for _ in range(n)]
+    assert rm.ExecuteBatch(srcs, outs)
+    torch.cuda.synchronize()
+    inside = ((xm <= w - 1) & (ym <= h - 1))[:, :, None].repeat(3, 2).reshape(-1)
+    for i in range(n):
+        want = oracle.remap(oracle.RGB, w, h, planes[i], xm, ym)[1][0].reshape(-1)
+        assert np.array_equal(download(outs[i])[inside], want[inside]), i
+        assert np.array_equal(download(rm.Execute(srcs[i]))[inside], want[inside])

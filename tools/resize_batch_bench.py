@@ -1,0 +1,76 @@
+"""vpf_resize_batch / vpf_remap_batch vs one dispatch per frame (and per plane): us per frame and fraction of the 8 TB/s HBM roofline on
+ALGORITHMIC bytes (whole source frame read once + destination written once; a down-scale that skips source rows reads less).
+Rings are sized past the 256 MiB Infinity Cache.  python tools/resize_batch_bench.py"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videoprocessingframework_amd import capi
+
+dev = torch.device("cuda", 0)
+ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
+NAMES = {0: "nearest", 1: "bilinear", 2: "lanczos3"}
+
+
+def surf(fmt, w, h, rand):
+    """-> (keepalive tensors, plane descriptors)"""
+    def alloc(rows, rb):
+        p = (rb + 255) // 256 * 256
+        t = torch.randint(0, 256, (rows, p), dtype=torch.uint8, device=dev) if rand else torch.zeros((rows, p), dtype=torch.uint8, device=dev)
+        return t, p
+    if fmt == capi.RGB:
+        t, p = alloc(h, 3 * w)
+        return [t], [(t.data_ptr(), p)], 3 * w * h
+    if fmt == capi.NV12:
+        t, p = alloc(h * 3 // 2, w)
+        return [t], [(t.data_ptr(), p), (t.data_ptr() + h * p, p)], w * h * 3 // 2
+    if fmt == capi.YUV420:
+        a, pa = alloc(h, w); b, pb = alloc(h // 2, w // 2); c, pc = alloc(h // 2, w // 2)
+        return [a, b, c], [(a.data_ptr(), pa), (b.data_ptr(), pb), (c.data_ptr(), pc)], w * h * 3 // 2
+    raise ValueError(fmt)
+
+
+def timed(fn, reps):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")):
+    for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (1920, 1080, 416, 416), (3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (1280, 720, 1920, 1080)):
+        ring = max(32, min(256, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // 32 * 32))
+        S = [surf(fmt, sw, sh, True) for _ in range(ring)]
+        D = [surf(fmt, dw, dh, False) for _ in range(ring)]
+        batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
+        planes = [(capi.planes(s[1]), capi.planes(d[1])) for s, d in zip(S, D)]
+        nbytes = S[0][2] + D[0][2]
+        for interp in (1, 2):
+            if fmt != capi.RGB and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
+                continue
+            tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
+            ts = timed(lambda: [capi.resize(ex, fmt, interp, sw, sh, s, dw, dh, d) for s, d in planes], 3) / ring
+            print(f"[resize_batch] {fname:6s} {sw}x{sh}->{dw}x{dh} {NAMES[interp]:8s}: batched {tb:6.2f} us/frame = {nbytes / tb / 1e6:5.2f} TB/s ({nbytes / tb / 8e6:.2f} of 8 TB/s)"
+                  f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f})  ring {ring}", flush=True)
+        del S, D, batch, planes
+        torch.cuda.empty_cache()
+
+# remap: one pair of maps, many frames
+for (w, h) in ((1920, 1080), (3840, 2160)):
+    ring = 32
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
+    nx, ny = (xx - (w - 1) / 2) / ((w - 1) / 2), (yy - (h - 1) / 2) / ((h - 1) / 2)
+    k = 1 + 0.1 * (nx * nx + ny * ny)
+    xm, ym = (nx * k * ((w - 1) / 2) + (w - 1) / 2).contiguous(), (ny * k * ((h - 1) / 2) + (h - 1) / 2).contiguous()
+    S = [surf(capi.RGB, w, h, True) for _ in range(ring)]
+    D = [surf(capi.RGB, w, h, False) for _ in range(ring)]
+    batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
+    tb = timed(lambda: capi.remap_batch(ex, capi.RGB, w, h, xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, batch), 5) / ring
+    ts = timed(lambda: [capi.remap(ex, capi.RGB, w, h, s[1][0], xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, d[1][0]) for s, d in zip(S, D)], 3) / ring
+    nb = 14 * w * h  # 8 B of maps + 3 B of source + 3 B written per pixel
+    print(f"[remap_batch] RGB {w}x{h} barrel map: batched {tb:6.2f} us/frame = {nb / tb / 1e6:5.2f} TB/s ({nb / tb / 8e6:.2f} of 8 TB/s on 14 B/px)"
+          f" | one dispatch per frame {ts:6.2f} us/frame ({nb / ts / 8e6:.2f})", flush=True)
+    del S, D, batch
+    torch.cuda.empty_cache()

@@ -21,10 +21,11 @@ MPEG, JPEG, CR_UDEF = 0, 1, 2
 INTERP_NEAREST, INTERP_LINEAR, INTERP_LANCZOS3 = 0, 1, 2
 OK, ERR_UNSUPPORTED, ERR_BAD_ARG, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
 TUNE_NV12_RGB_VARIANT = 1
+TUNE_RESIZE_TILE = 2
 
 EXPORTS = [
     "vpf_convert", "vpf_convert_batch", "vpf_convert_supported", "vpf_resize", "vpf_remap", "vpf_convert_resize",
-    "vpf_convert_resize_batch",
+    "vpf_convert_resize_batch", "vpf_resize_batch", "vpf_remap_batch",
     "vpf_status_string", "vpf_version", "vpf_device_count", "vpf_set_tuning", "vpf_trace_push", "vpf_trace_pop",
 ]
 
@@ -74,6 +75,8 @@ def lib() -> C.CDLL:
         L.vpf_remap.argtypes = [PE, C.c_int, Size, PP, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Size, PP]
         L.vpf_convert_resize.argtypes = [PE, C.c_int, C.c_int, C.c_int, C.c_int, Size, PP, Size, PP]
         L.vpf_convert_resize_batch.argtypes = [PE, C.c_int, C.c_int, C.c_int, C.c_int, Size, Size, C.c_uint32, PF]
+        L.vpf_resize_batch.argtypes = [PE, C.c_int, C.c_int, Size, Size, C.c_uint32, PF]
+        L.vpf_remap_batch.argtypes = [PE, C.c_int, Size, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Size, C.c_uint32, PF]
         L.vpf_status_string.argtypes = [C.c_int]
         L.vpf_status_string.restype = C.c_char_p
         L.vpf_version.restype = C.c_char_p
@@ -154,6 +157,21 @@ def resize(ex: Exec, fmt, interp, sw, sh, src, dw, dh, dst, check=True) -> int:
     st = lib().vpf_resize(C.byref(ex), fmt, interp, Size(sw, sh), planes(src), Size(dw, dh), planes(dst))
     if check:
         _check(st, "vpf_resize")
+    return st
+
+
+def resize_batch(ex: Exec, fmt, interp, sw, sh, dw, dh, batch, n=None, check=True) -> int:
+    """batch: FrameIO array from make_batch(); every plane of every frame in as few dispatches as possible"""
+    st = lib().vpf_resize_batch(C.byref(ex), fmt, interp, Size(sw, sh), Size(dw, dh), len(batch) if n is None else n, batch)
+    if check:
+        _check(st, "vpf_resize_batch")
+    return st
+
+
+def remap_batch(ex: Exec, fmt, sw, sh, xmap_ptr, xmap_pitch, ymap_ptr, ymap_pitch, dw, dh, batch, n=None, check=True) -> int:
+    st = lib().vpf_remap_batch(C.byref(ex), fmt, Size(sw, sh), xmap_ptr, xmap_pitch, ymap_ptr, ymap_pitch, Size(dw, dh), len(batch) if n is None else n, batch)
+    if check:
+        _check(st, "vpf_remap_batch")
     return st
 
 

@@ -171,6 +171,14 @@ public:
     auto* out = static_cast<Surface*>(rs_->GetOutput(0U));
     return std::shared_ptr<Surface>(out ? out->Clone() : Surface::Make(fmt_));
   }
+  // additive: n surfaces in, n caller-owned surfaces out, every plane of every frame in as few dispatches as possible
+  bool ExecuteBatch(const std::vector<std::shared_ptr<Surface>>& src, const std::vector<std::shared_ptr<Surface>>& dst) {
+    if (src.size() != dst.size() || src.empty()) return false;
+    std::vector<Surface*> a, b;
+    for (auto& s : src) a.push_back(s.get());
+    for (auto& d : dst) b.push_back(d.get());
+    return TASK_EXEC_SUCCESS == rs_->RunBatch(a.data(), b.data(), (uint32_t)a.size());
+  }
 };
 
 class PySurfaceRemaper {
@@ -192,6 +200,14 @@ public:
     if (TASK_EXEC_SUCCESS != rm_->Execute()) return empty_surface(fmt_);
     auto* out = static_cast<Surface*>(rm_->GetOutput(0U));
     return std::shared_ptr<Surface>(out ? out->Clone() : Surface::Make(fmt_));
+  }
+  // additive: the same maps applied to n surfaces into n caller-owned surfaces, one dispatch per 32 frames
+  bool ExecuteBatch(const std::vector<std::shared_ptr<Surface>>& src, const std::vector<std::shared_ptr<Surface>>& dst) {
+    if (src.size() != dst.size() || src.empty()) return false;
+    std::vector<Surface*> a, b;
+    for (auto& s : src) a.push_back(s.get());
+    for (auto& d : dst) b.push_back(d.get());
+    return TASK_EXEC_SUCCESS == rm_->RunBatch(a.data(), b.data(), (uint32_t)a.size());
   }
 };
 
@@ -515,7 +531,9 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def("SetInterpolation", &PySurfaceResizer::SetInterpolation, py::arg("interp"),
            "additive: 0 nearest, 1 bilinear (default), 2 Lanczos-3 (the filter the reference requests from NPP)")
       .def("GetInterpolation", &PySurfaceResizer::GetInterpolation)
-      .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>());
+      .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>())
+      .def("ExecuteBatch", &PySurfaceResizer::ExecuteBatch, py::arg("src"), py::arg("dst"), py::call_guard<py::gil_scoped_release>(),
+           "additive: n same-shape surfaces into n caller-owned surfaces, all planes of all frames in as few dispatches as possible; asynchronous on the resizer's stream");
 
   using FMap = py::array_t<float, py::array::c_style | py::array::forcecast>;
   py::class_<PySurfaceRemaper>(m, "PySurfaceRemaper")
@@ -524,7 +542,9 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](FMap& x, FMap& y, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceRemaper(x, y, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("x_map"), py::arg("y_map"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceRemaper::GetFormat)
-      .def("Execute", &PySurfaceRemaper::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>());
+      .def("Execute", &PySurfaceRemaper::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>())
+      .def("ExecuteBatch", &PySurfaceRemaper::ExecuteBatch, py::arg("src"), py::arg("dst"), py::call_guard<py::gil_scoped_release>(),
+           "additive: the remaper's maps applied to n surfaces into n caller-owned surfaces, one dispatch per 32 frames; asynchronous on the remaper's stream");
 
   py::class_<PyFrameUploader>(m, "PyFrameUploader")
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, uint32_t gpu) { return new PyFrameUploader(w, h, f, ctx_of((int)gpu), str_of((int)gpu)); }),

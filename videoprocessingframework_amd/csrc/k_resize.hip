@@ -53,13 +53,62 @@ VPF_DEV float bilerp(float p00, float p01, float p10, float p11, float fx, float
   return __builtin_fmaf(fy, bot - top, top) + 0.5f;
 }
 
+
+// Geometry of one plane of a resize launch, in the form every kernel family takes it.  a0..a3 are family-specific:
+//   tiled kernels     a0 = destination rows per tile, a1 = source rows the LDS layout is sized for, a2 = 16-B units per staged source row,
+//                     a3 = log2(lanes per row while staging)
+//   row-pair kernels  a0 = strip size in 16-B units
+//   half3_r16         a0 = 1024-px chunks per row, a1 = tasks
+struct PlaneGeom {
+  uint32_t sw, sh, dw, dh;
+  float scx, scy;
+  int vec_ok;
+  uint32_t a0, a1, a2, a3;
+};
+// A resize "Task" is a struct with `static constexpr int kThreads` and
+//   static VPF_DEV void run(const uint8_t* src, uint32_t sp, uint8_t* dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by)
+// The single-frame kernels below keep their scalar-argument entries (kernarg preload, see VPF_ONE_SRC_PARAMS in vpf_internal.h);
+// vpf_resize_batch reaches the same task bodies through these two generic entries:
+//   k_plane_batch   ONE plane (index k in FrameDesc) of up to 32 frames: blockIdx.z = frame
+//   k_planes_mp     EVERY plane of up to 32 frames in one dispatch: blockIdx.z = frame, blockIdx.y runs through the planes' block rows
+//                   one plane after the other (by0[p] = first blockIdx.y of plane p), blockIdx.x covers the widest plane (a task returns
+//                   at once when its block lies outside its plane)
+template <class Task>
+__global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BatchArgs args, const int k, const PlaneGeom G) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  Task::run(f.s[k], f.sp[k], f.d[k], f.dp[k], G, blockIdx.x, blockIdx.y);
+}
+struct PlaneTable {
+  PlaneGeom g[3];
+  uint32_t by0[3], k[3], ch[3], np;
+};
+template <template <int> class TaskCH>
+__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchArgs args, const PlaneTable T) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  const uint32_t by = blockIdx.y;
+  const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
+  const uint32_t k = T.k[pi], lby = by - T.by0[pi];
+  switch (T.ch[pi]) {  // workgroup-uniform
+    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+  }
+}
+
 // CH interleaved channels per pixel (1, 2 or 3); 4 destination pixels per lane
 template <int CH, int INTERP>
-__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
-                                                uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
-                                                float scx, float scy, int vec_ok) {
-  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+struct GatherTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
+template <int CH, int INTERP>
+VPF_DEV void GatherTask<CH, INTERP>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                         uint32_t bx, uint32_t by) {
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh;
+  const float scx = G.scx, scy = G.scy;
+  const int vec_ok = G.vec_ok;
+  const uint32_t gx = bx * 64 + (threadIdx.x & 63);
+  const uint32_t y = by * 4 + (threadIdx.x >> 6);
   const uint32_t x0 = gx * 4;
   if (x0 >= dw || y >= dh) return;
   const Tap ty = make_tap<INTERP>(y, scy, sh);
@@ -87,6 +136,13 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
     for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[i]);
   }
+}
+
+template <int CH, int INTERP>
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                float scx, float scy, int vec_ok) {
+  GatherTask<CH, INTERP>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, 0, 0, 0, 0}, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -132,13 +188,26 @@ VPF_DEV LTap make_ltap(uint32_t d, float scale) {
   constexpr float cm[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};
   constexpr float sm[6] = {-0.866025388f, -0.866025388f, 0.0f, 0.866025388f, 0.866025388f, 0.0f};
   constexpr float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
-  float sum = 0.f;
+  // w_k = L(t_k) / sum_j L(t_j) with L(t) = 3 sin(pi t) sin(pi t / 3) / (pi t)^2, t_k = f - (k - 2): multiplying numerator and
+  // denominator by prod_j t_j^2 leaves n_k D_k / sum_j n_j D_j with n_k = sin(pi t_k) sin(pi t_k / 3) and D_k = prod_{j != k} t_j^2
+  // — ONE division per weight set instead of seven (the weights are ~1/4 of the tiled kernel's instructions at small tiles)
+  float n[6], u[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const float tt = f - (float)(k - 2);
-    const float a = sg[k] * s1;
-    const float b = __builtin_fmaf(s3, cm[k], -(c3 * sm[k]));
-    t.w[k] = (0.303963542f * (a * b)) / (tt * tt);
+    u[k] = tt * tt;
+    n[k] = (sg[k] * s1) * __builtin_fmaf(s3, cm[k], -(c3 * sm[k]));
+  }
+  float pre[6], suf[6];  // pre[k] = u_0 .. u_{k-1}, suf[k] = u_{k+1} .. u_5
+  pre[0] = 1.0f; suf[5] = 1.0f;
+#pragma unroll
+  for (int k = 1; k < 6; k++) pre[k] = pre[k - 1] * u[k - 1];
+#pragma unroll
+  for (int k = 4; k >= 0; k--) suf[k] = suf[k + 1] * u[k + 1];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    t.w[k] = n[k] * (pre[k] * suf[k]);
     sum += t.w[k];
   }
   const float inv = 1.0f / sum;
@@ -147,13 +216,50 @@ VPF_DEV LTap make_ltap(uint32_t d, float scale) {
   return t;
 }
 
+// The horizontal pass on 8-bit surfaces runs in integers: the six normalised weights become Q14 fixed point (ties to even), tap 2
+// absorbs the rounding residue so that they sum to exactly 16384 (a flat picture stays flat), and H = sum q_k p_k is exact in 32
+// bits whatever the order — which is what lets the tiled kernel take two taps per v_dot2_i32_i16 and still match the gather form
+// and the oracle bit for bit.  Every |q_k| <= 16384 fits an int16.
+struct QTap {
+  int32_t i0;
+  int32_t q[6];
+};
+VPF_DEV QTap quantize_ltap(const LTap& t) {
+  QTap o;
+  o.i0 = t.i0;
+  int32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { o.q[k] = (int32_t)__builtin_rintf(t.w[k] * 16384.0f); sum += o.q[k]; }
+  o.q[2] += 16384 - sum;
+  return o;
+}
+VPF_DEV uint32_t pack_i16(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+VPF_DEV int32_t dot2(uint32_t a, uint32_t b, int32_t c) {  // a.lo * b.lo + a.hi * b.hi + c on int16 halves
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+constexpr float kQ14Inv = 6.103515625e-05f;  // 2^-14
+
+template <int CH>
+struct LanczosGatherTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
 template <int CH>
 __global__ __launch_bounds__(256) void k_resize_lanczos(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                         uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
                                                         float scx, float scy) {
-  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  LanczosGatherTask<CH>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, 0, 0, 0, 0, 0}, blockIdx.x, blockIdx.y);
+}
+template <int CH>
+VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                        uint32_t bx, uint32_t by) {
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh;
+  const float scx = G.scx, scy = G.scy;
+  const uint32_t x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
-  const LTap tx = make_ltap(x, scx), ty = make_ltap(y, scy);
+  const QTap tx = quantize_ltap(make_ltap(x, scx));
+  const LTap ty = make_ltap(y, scy);
   uint32_t xi[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -175,15 +281,15 @@ __global__ __launch_bounds__(256) void k_resize_lanczos(const uint8_t* __restric
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-      float ra = 0.f;
+      int32_t h = 0;  // exact: |h| <= 255 * sum |q| < 2^24
 #pragma unroll
-      for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(tx.w[kx], (float)v[kx][c], ra);
-      acc[c] = __builtin_fmaf(ty.w[ky], ra, acc[c]);
+      for (int kx = 0; kx < 6; kx++) h += tx.q[kx] * (int32_t)v[kx][c];
+      acc[c] = __builtin_fmaf(ty.w[ky], (float)h, acc[c]);
     }
   }
   uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
 #pragma unroll
-  for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_trunc(acc[c] + 0.5f);
+  for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_trunc(__builtin_fmaf(acc[c], kQ14Inv, 0.5f));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -233,13 +339,26 @@ VPF_DEV void strip_window_taps(const uint8_t* strip, uint32_t a, float* t0, floa
 }
 
 template <int CH, int IT /* 1-KiB loads per strip */>
+struct RowPairTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
+template <int CH, int IT>
 __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
                                                     float scx, float scy, int vec_ok, uint32_t rowq /* strip size in 16-B units */) {
+  RowPairTask<CH, IT>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, rowq, 0, 0, 0}, blockIdx.x, blockIdx.y);
+}
+template <int CH, int IT>
+VPF_DEV void RowPairTask<CH, IT>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                      uint32_t bx, uint32_t by) {
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0;
+  const float scx = G.scx, scy = G.scy;
+  const int vec_ok = G.vec_ok;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t y = blockIdx.y * 4 + wv;
-  if (y >= dh) return;
-  const uint32_t xs = blockIdx.x * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;  // this wave's dst columns [xs, xe]
+  const uint32_t y = by * 4 + wv;
+  if (y >= dh || bx * 256 >= dw) return;
+  const uint32_t xs = bx * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;  // this wave's dst columns [xs, xe]
   const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
@@ -332,43 +451,56 @@ __global__ __launch_bounds__(256) void k_resize_lds(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Lanczos-3, tiled and separable (the default when it applies; k_resize_lanczos above remains the any-input gather form).
-// The gather kernel evaluates, per destination pixel, six horizontal 6-tap dots (one per source row) and then the
-// vertical 6-tap dot.  The horizontal dot of (source row r, destination column x) does not depend on the destination
-// row, so a workgroup that owns a tile of 64 columns x TY rows computes each of them ONCE:
-//   phase 1  each wave takes source rows r, r+4, ...: stages the row's byte span in a wave-private LDS strip with dense
-//            16-B loads (the next row's load is already in flight), every lane (= one destination column) reads its
-//            6 x CH taps with ds_read_u8 and leaves the fp32 dot in LDS (H[row][channel][column]);
-//   phase 2  every lane combines six H rows per destination pixel with the vertical weights (computed once per
-//            destination row by one lane and broadcast from LDS).
-// Both dots use the gather kernel's fma order, so results are bit-identical to it (and to the oracle's FP32 mode).
-// 3x down-scale: 3.4-3.8 horizontal dots per destination pixel instead of 6; 2x up-scale: 0.6 instead of 6.
+// Tiled, separable resize: Lanczos-3 (always) and bilinear up-scaling (k_resize_lanczos / k_resize remain the any-input gather forms).
+// The gather kernel evaluates, per destination pixel, six horizontal 6-tap dots (one per source row) and then the vertical 6-tap
+// dot.  The horizontal dot of (source row r, destination column x) does not depend on the destination row, so a workgroup that
+// owns a tile of 64 columns x TY rows computes each of them ONCE:
+//   phase 1  wave w takes source rows w, w + WPB, ...: stages the row's byte span in a wave-private LDS strip with dense 16-B loads
+//            (the next row's load is already in flight); every lane (= one destination column) takes its 6 x CH taps out of the
+//            strip as aligned dwords, spreads tap PAIRS into int16 halves with v_perm_b32 and multiplies them with the column's Q14
+//            weight pairs, two taps per v_dot2_i32_i16 (exact integer sums: see quantize_ltap); the sum goes to LDS as a float,
+//            H[row][channel][column];
+//   phase 2  every lane combines six H rows per destination pixel with the vertical fp32 weights (computed once per destination
+//            row by one lane and broadcast from LDS) and scales the result back by 2^-14 in the rounding fma.
+// Bilinear (LZ = false): 2 taps; H = the horizontal lerp fma(fx, p1 - p0, p0) of k_resize's bilerp, which for an up-scale is shared
+// by every destination row between two source rows.  Same arithmetic as the gather forms -> bit-identical to them and to the oracle.
+// 1.5x down-scale: 1.9 horizontal dots per destination pixel instead of 6; 2x up-scale: 0.7 instead of 6.
+// WPB = waves per workgroup (4 or 8): 8 halves the number of source rows a wave walks through one after the other, which is what
+// the duration of a single-frame launch (one round of workgroups, each a chain of dependent steps) is made of.
 // ------------------------------------------------------------------------------------------
 VPF_DEV int32_t ltap_i0(uint32_t d, float scale) {  // make_ltap's first expression sequence
   return (int32_t)__builtin_floorf(__builtin_fmaf((float)d + 0.5f, scale, -0.5f));
 }
-constexpr uint32_t kLzStripQ = 128;  // 2 KiB of source bytes per wave
+constexpr uint32_t kLzStripQ = 128;  // at most 2 KiB of source bytes per row of a tile
 
-// LZ = true: Lanczos-3 (6 taps per axis); LZ = false: bilinear (2 taps; H = the horizontal lerp fma(fx, p1 - p0, p0) of
-// k_resize's bilerp, which for an up-scale is shared by every destination row between two source rows)
-template <int CH, bool LZ>
-__global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
-                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
-                                                     float scx, float scy, uint32_t tile_rows, uint32_t nr_cap, int vec_ok) {
-  // dynamic LDS: [4 waves][kLzStripQ x 16 B] byte strips | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats | WX[7][64] (Lanczos)
-  // (Lanczos: 6 weights + first H row; bilinear: fy, -, ..., top H row, bottom H row)
+constexpr int kTileStagePasses = 6;  // staging loads a thread may have in flight (the launcher sizes tiles accordingly)
+
+template <int CH, bool LZ, int WPB>
+struct TileTask {
+  static constexpr int kThreads = 64 * WPB;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P, uint32_t bx, uint32_t by);
+};
+template <int CH, bool LZ, int WPB>
+VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P,
+                                        uint32_t bx, uint32_t by) {
+  // dynamic LDS: RAW[nr_cap][rowq x 16 B] source bytes | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats | WX[4][64] dwords (Lanczos)
+  // (WY — Lanczos: 6 weights + first H row; bilinear: fy, -, ..., top H row, bottom H row)
   constexpr int NT = LZ ? 6 : 2;
-  u32x4* const strip = dyn_strip + (threadIdx.x >> 6) * kLzStripQ;
-  float* const H = reinterpret_cast<float*>(dyn_strip + 4 * kLzStripQ);
+  constexpr uint32_t T = 64 * WPB;
+  const uint32_t sw = P.sw, sh = P.sh, dw = P.dw, dh = P.dh, tile_rows = P.a0, nr_cap = P.a1, rowq = P.a2, lshift = P.a3;
+  const float scx = P.scx, scy = P.scy;
+  u32x4* const RAW = dyn_strip;
+  float* const H = reinterpret_cast<float*>(dyn_strip + (size_t)nr_cap * rowq);
   float* const WY = H + (size_t)nr_cap * CH * 64;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t xf = blockIdx.x * 64, xl = (xf + 63 < dw - 1) ? xf + 63 : dw - 1;
+  const uint32_t xf = bx * 64, xl = (xf + 63 < dw - 1) ? xf + 63 : dw - 1;
+  if (xf >= dw) return;  // a narrower plane of a multi-plane launch (workgroup-uniform)
   const uint32_t x = xf + lane, xc = x < dw ? x : dw - 1;  // lanes past the right edge compute a duplicate, never stored
-  const uint32_t y0 = blockIdx.y * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
+  const uint32_t y0 = by * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
   auto clampi = [](int32_t i, int32_t hi) { return (uint32_t)(i < 0 ? 0 : (i > hi ? hi : i)); };
   int32_t R0, R1;
   uint32_t first, last, xo[NT];
-  float wx[NT];
+  float wx = 0.f;  // bilinear: fx
   if constexpr (LZ) {
     R0 = ltap_i0(y0, scy) - 2; R1 = ltap_i0(yl, scy) + 3;
     first = clampi(ltap_i0(xf, scx) - 2, (int32_t)sw - 1); last = clampi(ltap_i0(xl, scx) + 3, (int32_t)sw - 1);
@@ -378,11 +510,19 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
   }
   const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
-  Span<2> cur, nxt;  // the first source row is on its way while the weights are worked out
-  if (wv < nrows) cur.load(src + (size_t)clampi(R0 + (int32_t)wv, (int32_t)sh - 1) * sp, base, nq, lane);
-  // Lanczos weights cost ~150 VALU instructions per call (two polynomials, seven IEEE divisions): the horizontal set of the
-  // tile's 64 columns is computed ONCE, by wave 0, and handed to the other three waves through LDS (it used to be a
-  // quarter of the kernel's instructions); wave 1 computes the vertical sets meanwhile.
+  // Phase 0: the tile's whole source window goes to LDS in ONE sweep — every 16-B unit of every source row is requested before the
+  // first one is waited for, so the workgroup pays one memory latency, not one per source row (a per-row prefetch chain spent
+  // 3 of the kernel's 9 us at 1080p -> 720p waiting: the compiler's conservative vmcnt(0) around the predicated loads serialised
+  // it).  The weights are computed while the loads are in flight.
+  const uint32_t scol = threadIdx.x & ((1u << lshift) - 1u), srow0 = threadIdx.x >> lshift, srows = T >> lshift;
+  u32x4 stage[kTileStagePasses];
+#pragma unroll
+  for (int k = 0; k < kTileStagePasses; k++) {
+    const uint32_t r = srow0 + k * srows;
+    if (r < nrows && scol < nq) stage[k] = ldg<false, u32x4>(src + (size_t)clampi(R0 + (int32_t)r, (int32_t)sh - 1) * sp + base + 16 * scol);
+  }
+  // A Lanczos weight set is ~100 VALU instructions (two polynomials, one division): the horizontal sets of the tile's 64 columns are
+  // computed ONCE, by wave 0, and handed to the other waves through LDS; wave 1 computes the vertical sets meanwhile.
   const uint32_t vt = LZ ? threadIdx.x - 64 : threadIdx.x;  // lane that owns destination row y0 + vt
   if (vt < tile_rows) {  // vertical weights: one lane per destination row
     const uint32_t y = y0 + vt, yc = y < dh ? y : dh - 1;
@@ -398,113 +538,142 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
       WY[vt * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
     }
   }
+  uint32_t* const WX = reinterpret_cast<uint32_t*>(WY + (size_t)tile_rows * 8);  // Lanczos, [4][64]: three weight pairs and the first tap index of every column
   if constexpr (LZ) {
-    float* const WX = WY + (size_t)tile_rows * 8;  // [7][64]: six weights and the first tap index of every column
     if (wv == 0) {
-      const LTap tx = make_ltap(xc, scx);
+      const QTap tx = quantize_ltap(make_ltap(xc, scx));
 #pragma unroll
-      for (int k = 0; k < 6; k++) WX[k * 64 + lane] = tx.w[k];
-      WX[6 * 64 + lane] = __int_as_float(tx.i0);
+      for (int k = 0; k < 3; k++) WX[k * 64 + lane] = pack_i16(tx.q[2 * k], tx.q[2 * k + 1]);
+      WX[3 * 64 + lane] = (uint32_t)tx.i0;
     }
-    __syncthreads();
-    const int32_t i0 = __float_as_int(WX[6 * 64 + lane]);
+  }
 #pragma unroll
-    for (int k = 0; k < 6; k++) { xo[k] = clampi(i0 + k - 2, (int32_t)sw - 1) * CH - base; wx[k] = WX[k * 64 + lane]; }
+  for (int k = 0; k < kTileStagePasses; k++) {
+    const uint32_t r = srow0 + k * srows;
+    if (r < nrows && scol < nq) RAW[r * rowq + scol] = stage[k];
+  }
+  __syncthreads();
+  uint32_t qx[3] = {0, 0, 0};  // Lanczos: the column's six Q14 weights as three int16 pairs (taps 0|1, 2|3, 4|5)
+  if constexpr (LZ) {
+    const int32_t i0 = (int32_t)WX[3 * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 6; k++) xo[k] = clampi(i0 + k - 2, (int32_t)sw - 1) * CH - base;
+#pragma unroll
+    for (int k = 0; k < 3; k++) qx[k] = WX[k * 64 + lane];
   } else {
     const Tap tx = make_tap<VPF_INTERP_LINEAR>(xc, scx, sw);
-    xo[0] = tx.i0 * CH - base; xo[1] = tx.i1 * CH - base; wx[0] = tx.f; wx[1] = 0.f;
+    xo[0] = tx.i0 * CH - base; xo[1] = tx.i1 * CH - base; wx = tx.f;
   }
+  // Phase 1, horizontal: wave w takes source rows w, w + WPB, ...; rows are independent of one another (no barrier inside the loop)
   // wave-uniform: no lane's taps were clamped at an image edge (clamped taps repeat a pixel and break the run)
   const bool contiguous = LZ && __builtin_amdgcn_ballot_w64(xo[NT - 1] - xo[0] != (uint32_t)(CH * (NT - 1))) == 0;
-  for (uint32_t r = wv; r < nrows; r += 4) {
-    if (r + 4 < nrows) nxt.load(src + (size_t)clampi(R0 + (int32_t)(r + 4), (int32_t)sh - 1) * sp, base, nq, lane);
-    cur.store(strip, nq, lane);
-    wave_lds_sync();
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(strip);
-    if (CH == 3 && LZ && contiguous) {
-      // packed RGB, no tap clamped anywhere in the wave: a lane's 6 taps are 18 contiguous bytes -> six aligned dword reads
-      // (three ds_read2_b32) + five v_alignbyte_b32 instead of eighteen ds_read_u8; same values, same fma order
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(b + (xo[0] & ~3u));
-      const uint32_t lead = xo[0] & 3u, d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
-      const uint32_t e[5] = {__builtin_amdgcn_alignbyte(d1, d0, lead), __builtin_amdgcn_alignbyte(d2, d1, lead), __builtin_amdgcn_alignbyte(d3, d2, lead),
-                             __builtin_amdgcn_alignbyte(d4, d3, lead), __builtin_amdgcn_alignbyte(d5, d4, lead)};
-      float t[18];  // byte j of the run = tap j / 3, channel j % 3
+  for (uint32_t r = wv; r < nrows; r += WPB) {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq);
+    if constexpr (LZ) {
+      // In integers, two taps per v_dot2_i32_i16.  No tap clamped anywhere in the wave (everything but the tiles on the left / right
+      // image edge): a lane's 6 x CH taps are contiguous bytes -> aligned dword reads, v_alignbyte_b32 to drop the lead, one
+      // v_perm_b32 per tap pair to spread two bytes into int16 halves, then the dots; same exact sums as the byte-by-byte form below
+      // and as the gather kernel.
+      int32_t h[CH];
+      if (contiguous) {
+        constexpr int NE = (6 * CH + 3) / 4;  // dwords of the lead-free run
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(b + (xo[0] & ~3u));
+        const uint32_t lead = xo[0] & 3u;
+        uint32_t d[NE + 1], e[NE];
 #pragma unroll
-      for (int j = 0; j < 18; j++) {
-        const uint32_t w = e[j >> 2];
-        t[j] = (j & 3) == 0 ? ubyte<0>(w) : (j & 3) == 1 ? ubyte<1>(w) : (j & 3) == 2 ? ubyte<2>(w) : ubyte<3>(w);
+        for (int i = 0; i <= NE; i++) d[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c
+          if constexpr (CH == 3) {  // bytes c, 3 + c | 6 + c, 9 + c | 12 + c, 15 + c of the run
+            p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+            p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
+            p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+          } else if constexpr (CH == 2) {  // bytes c, 2 + c of dwords 0, 1, 2
+            const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
+            p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
+          } else {  // bytes 0, 1 | 2, 3 | 4, 5
+            p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
+          }
+          h[c] = dot2(p2, qx[2], dot2(p1, qx[1], dot2(p0, qx[0], 0)));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          int32_t a = 0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) a = dot2((uint32_t)b[xo[2 * k] + c] | ((uint32_t)b[xo[2 * k + 1] + c] << 16), qx[k], a);
+          h[c] = a;
+        }
       }
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        float ra = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(wx[kx], t[3 * kx + c], ra);
-        H[(r * 3 + c) * 64 + lane] = ra;
-      }
-    } else if (CH == 3 && !LZ) {
+      for (int c = 0; c < CH; c++) H[(r * CH + c) * 64 + lane] = (float)h[c];  // exact: |h| < 2^24
+    } else if (CH == 3) {
       float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
       strip_window_taps(b, xo[0], t0, t1);
 #pragma unroll
-      for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx[0], t1[c] - t0[c], t0[c]);
+      for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx, t1[c] - t0[c], t0[c]);
     } else {
 #pragma unroll
       for (int c = 0; c < CH; c++) {
-        float ra;
-        if constexpr (LZ) {
-          ra = 0.f;
-#pragma unroll
-          for (int kx = 0; kx < 6; kx++) ra = __builtin_fmaf(wx[kx], (float)b[xo[kx] + c], ra);
-        } else {
-          const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
-          ra = __builtin_fmaf(wx[0], p1 - p0, p0);
-        }
-        H[(r * CH + c) * 64 + lane] = ra;
+        const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
+        H[(r * CH + c) * 64 + lane] = __builtin_fmaf(wx, p1 - p0, p0);
       }
     }
-    wave_lds_sync();  // the strip is rewritten next iteration
-    cur = nxt;
   }
   __syncthreads();
   // phase 2: a lane owns 4 consecutive columns of one destination row (a wave = 4 rows x 64 columns): H comes out of LDS
   // as one ds_read_b128 per (tap, channel) and the pixels leave as one 4-12 B vector store per lane
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const uint32_t cg = lane & 15, rsub = lane >> 4, x0 = xf + 4 * cg;
-  for (uint32_t yb = 0; yb < tile_rows; yb += 16) {
+  for (uint32_t yb = 0; yb < tile_rows; yb += 4 * WPB) {
     const uint32_t yy = yb + wv * 4 + rsub, y = y0 + yy;
     if (yy >= tile_rows || y >= dh || x0 >= dw) continue;
     const uint32_t r0 = (uint32_t)__float_as_int(WY[yy * 8 + 6]);
-    f32x4 acc[CH];
+    // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two independent IEEE operations per instruction at the issue cost of one —
+    // tools/probe_valu_rate.hip, profiles/r02_probe_valu_rate.txt: 4.4 cycles per wave-instruction, the same as a scalar v_fma_f32);
+    // every component goes through exactly the scalar form's operations, so results are bit-identical to it
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[CH][2];
     if constexpr (LZ) {
 #pragma unroll
-      for (int c = 0; c < CH; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < CH; c++) acc[c][0] = acc[c][1] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int ky = 0; ky < 6; ky++) {
         const float wy = WY[yy * 8 + ky];
+        const f32x2 wy2 = {wy, wy};
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           const f32x4 hv = *reinterpret_cast<const f32x4*>(&H[((r0 + ky) * CH + c) * 64 + 4 * cg]);
-#pragma unroll
-          for (int k = 0; k < 4; k++) acc[c][k] = __builtin_fmaf(wy, hv[k], acc[c][k]);
+          acc[c][0] = __builtin_elementwise_fma(wy2, f32x2{hv[0], hv[1]}, acc[c][0]);
+          acc[c][1] = __builtin_elementwise_fma(wy2, f32x2{hv[2], hv[3]}, acc[c][1]);
         }
       }
     } else {
       const uint32_t r1 = (uint32_t)__float_as_int(WY[yy * 8 + 7]);
       const float fy = WY[yy * 8];
+      const f32x2 fy2 = {fy, fy};
 #pragma unroll
       for (int c = 0; c < CH; c++) {
         const f32x4 top = *reinterpret_cast<const f32x4*>(&H[(r0 * CH + c) * 64 + 4 * cg]);
         const f32x4 bot = *reinterpret_cast<const f32x4*>(&H[(r1 * CH + c) * 64 + 4 * cg]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc[c][k] = __builtin_fmaf(fy, bot[k] - top[k], top[k]);
+        const f32x2 t0 = {top[0], top[1]}, t1 = {top[2], top[3]}, b0 = {bot[0], bot[1]}, b1 = {bot[2], bot[3]};
+        acc[c][0] = __builtin_elementwise_fma(fy2, b0 - t0, t0);
+        acc[c][1] = __builtin_elementwise_fma(fy2, b1 - t1, t1);
       }
     }
-    float o[4 * CH];  // pixel-major, + 0.5 for the truncating pack
+    float o[4 * CH];  // pixel-major, + 0.5 for the truncating pack (Lanczos: the sums are Q14, scaled back in the same fma)
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int c = 0; c < CH; c++)
 #pragma unroll
-      for (int c = 0; c < CH; c++) o[k * CH + c] = acc[c][k] + 0.5f;
+      for (int hlf = 0; hlf < 2; hlf++) {
+        const f32x2 v = LZ ? __builtin_elementwise_fma(acc[c][hlf], f32x2{kQ14Inv, kQ14Inv}, f32x2{0.5f, 0.5f}) : acc[c][hlf] + f32x2{0.5f, 0.5f};
+        o[(2 * hlf) * CH + c] = v[0]; o[(2 * hlf + 1) * CH + c] = v[1];
+      }
     uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
-    if (vec_ok && x0 + 4 <= dw) {
+    if (P.vec_ok && x0 + 4 <= dw) {
       if constexpr (CH == 3) {
         stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
       } else if constexpr (CH == 2) {
@@ -518,6 +687,23 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
     }
   }
 }
+// single plane, single frame: scalar arguments, source side first (kernarg preload: see VPF_ONE_SRC_PARAMS in vpf_internal.h)
+template <int CH, bool LZ, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_resize_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                          uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                          float scx, float scy, uint32_t tile_rows, uint32_t nr_cap, uint32_t rowq, uint32_t lshift,
+                                                          int vec_ok) {
+  TileTask<CH, LZ, WPB>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, tile_rows, nr_cap, rowq, lshift}, blockIdx.x, blockIdx.y);
+}
+// the template-template forms k_planes_mp wants
+template <int CH> struct TileLz4 : TileTask<CH, true, 4> {};
+template <int CH> struct TileLz8 : TileTask<CH, true, 8> {};
+template <int CH> struct TileBl4 : TileTask<CH, false, 4> {};
+template <int CH> struct TileBl8 : TileTask<CH, false, 8> {};
+template <int CH> struct RowPair1 : RowPairTask<CH, 1> {};
+template <int CH> struct RowPair2 : RowPairTask<CH, 2> {};
+template <int CH> struct RowPair3 : RowPairTask<CH, 3> {};
+template <int CH> struct RowPair4 : RowPairTask<CH, 4> {};
 
 // ------------------------------------------------------------------------------------------
 // Exact 2x bilinear down-scale (4K -> 1080p ...): s = 2 d + 0.5 exactly, so every destination pixel is the fx = fy = 0.5
@@ -526,9 +712,20 @@ __global__ __launch_bounds__(256) void k_resize_tile(const uint8_t* __restrict__
 // Requires dw % 4 == 0, 8-B aligned source rows, 4-B (8-B for CH == 2) aligned destination rows.
 // ------------------------------------------------------------------------------------------
 template <int CH>
+struct HalfTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
+template <int CH>
 __global__ __launch_bounds__(256) void k_resize_half(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                                      uint32_t dw, uint32_t dh) {
-  const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  HalfTask<CH>::run(src, sp, dst, dp, PlaneGeom{2 * dw, 2 * dh, dw, dh, 2.f, 2.f, 1, 0, 0, 0, 0}, blockIdx.x, blockIdx.y);
+}
+template <int CH>
+VPF_DEV void HalfTask<CH>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx,
+                               uint32_t by) {
+  const uint32_t dw = G.dw, dh = G.dh;
+  const uint32_t gx = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
   const uint32_t x0 = gx * 4;
   if (x0 >= dw || y >= dh) return;
   uint32_t ra[2 * CH], rb[2 * CH];  // 8 source pixels of rows 2y and 2y + 1
@@ -578,11 +775,20 @@ static uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* sr
 // bilinear blend of four 8-bit taps is exactly (p00 + p01 + p10 + p11 + 2) >> 2 (see k_convert_half), taken per channel
 // from the de-interleaved dwords with two v_dot4_u32_u8 whose weights (64 on two bytes) pick a horizontal pair of each row.
 // Requires sw % 32 == 0 and 16-B aligned source / destination rows.
+struct Half3R16Task {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
 __global__ __launch_bounds__(256) void k_resize_half3_r16(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                                           uint32_t sw, uint32_t chunks_x, uint32_t n_tasks) {
+  Half3R16Task::run(src, sp, dst, dp, PlaneGeom{sw, 0, sw >> 1, 0, 2.f, 2.f, 1, chunks_x, n_tasks, 0, 0}, blockIdx.x, 0);
+}
+VPF_DEV void Half3R16Task::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx,
+                               uint32_t /*by*/) {
   __shared__ u32x4 tile[4 * 192];  // 3 KiB per wave
+  const uint32_t sw = G.sw, chunks_x = G.a0, n_tasks = G.a1;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t wt = blockIdx.x * 4 + wv;
+  const uint32_t wt = bx * 4 + wv;
   if (wt >= n_tasks) return;
   const uint32_t y = wt / chunks_x, chunk = wt - y * chunks_x;
   u32x4* t = tile + wv * 192;
@@ -627,25 +833,71 @@ __global__ __launch_bounds__(256) void k_resize_half3_r16(const uint8_t* __restr
   }
 }
 
+// Shape of a tiled launch: destination rows per tile (ty) and waves per workgroup (wpb).  A taller tile computes fewer horizontal
+// dots per destination pixel ((ty - 1) scy + taps + 2 source rows for ty destination rows) but there are fewer of them; what a
+// launch costs is (rounds of workgroups the chip needs) x (time one workgroup takes from its first load to its last store), the
+// latter a chain of dependent steps: weights, then ceil(source rows / waves) row steps per wave, then the vertical passes.  The
+// constants below are fitted to rocprofv3 kernel durations (profiles/r02_tile_shape_sweep.txt); VPF_TUNE_RESIZE_TILE overrides the
+// choice for such sweeps (ty | wpb << 8) — every shape writes the same pixels.
+struct TileShape { bool ok; uint32_t ty, nr, lds, rowq, lshift; int wpb; };
+static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, const uint32_t* dh, const float* scxs, const float* scys, uint32_t frames) {
+  TileShape best{false, 0, 0, 0, 0, 0, 4};
+  const double taps = lz ? 6.0 : 2.0;
+  int ch_max = 0;
+  uint32_t rowq = 0;  // 16-B units a tile row can span (+ alignment slack), the widest plane decides
+  float scy = 0.f;
+  for (int p = 0; p < np; p++) {
+    ch_max = ch[p] > ch_max ? ch[p] : ch_max;
+    const uint32_t q = (uint32_t)((((double)scxs[p] * 63.0 + taps + 3.0) * ch[p] + 32.0) / 16.0) + 1;
+    rowq = q > rowq ? q : rowq;
+    scy = scys[p] > scy ? scys[p] : scy;
+  }
+  if (rowq > kLzStripQ || scy > 48.0f) return best;
+  uint32_t lshift = 0;
+  while ((1u << lshift) < rowq) lshift++;
+  const int forced = tuning(VPF_TUNE_RESIZE_TILE);
+  double best_cost = 1e30;
+  for (int wpb = 4; wpb <= 8; wpb += 4)
+    for (uint32_t ty = 4; ty <= 64; ty += 4) {
+      if (forced && ((uint32_t)(forced & 0xff) != ty || (forced >> 8) != wpb)) continue;
+      const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
+      const uint32_t lds = nr * rowq * 16 + nr * ch_max * 64 * 4 + ty * 8 * 4 + (lz ? 4 * 64 * 4 : 0);  // RAW | H | WY | WX (Lanczos)
+      if (lds > 64u * 1024u) continue;
+      const uint32_t srows = (64u * wpb) >> lshift;  // source rows staged per pass
+      if (!srows || (nr + srows - 1) / srows > (uint32_t)kTileStagePasses) continue;
+      double wgs = 0;
+      for (int p = 0; p < np; p++) wgs += (double)((dw[p] + 63) / 64) * ((dh[p] + ty - 1) / ty);
+      wgs *= frames;
+      uint32_t resident = (160u * 1024u) / lds;
+      if (resident > 32u / wpb) resident = 32u / wpb;  // 8 waves per SIMD
+      const double rounds = __builtin_ceil(wgs / (256.0 * resident));
+      const double row_steps = __builtin_ceil((double)nr / wpb), vpasses = __builtin_ceil((double)ty / (4.0 * wpb));
+      // one workgroup, microseconds: fixed part (dispatch, staging, weights, barriers) + row steps + vertical passes; the more
+      // workgroups share a CU's SIMDs, the slower each step
+      const double share = 1.0 + 0.15 * (resident * wpb / 4.0 - 1.0);
+      const double t_wg = 1.5 + (0.05 * row_steps + (lz ? 0.22 : 0.10) * vpasses * ch_max / 3.0) * share;
+      const double cost = rounds * t_wg;
+      if (cost < best_cost) { best_cost = cost; best = TileShape{true, ty, nr, lds, rowq, lshift, wpb}; }
+    }
+  return best;
+}
+
+// tiled separable launch of ONE plane of ONE frame (Lanczos always; bilinear when up-scaling, where the horizontal lerp is shared by
+// several destination rows): needs 16-B aligned source rows and a 64-column span that fits the 2-KiB strip.  Returns false when it
+// does not apply.
 static bool launch_resize_tile(hipStream_t st, bool lz, int ch, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp,
                                uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp, float scx, float scy) {
-  const double taps = lz ? 6.0 : 2.0;
   if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9 || (((uintptr_t)src | sp) & 15)) return false;
-  if (((double)scx * 63.0 + taps + 3.0) * ch + 32.0 > 16.0 * kLzStripQ || scy > 48.0f) return false;
-  constexpr uint32_t kRowsCap = 56;  // H rows per tile: 56 x 3 x 64 floats = 42 KiB
-  uint32_t ty = (uint32_t)((double)(kRowsCap - taps - 2.0) / (double)scy) + 1;
-  ty = ty > 64 ? 64 : ty;
-  // small outputs: prefer more, shorter tiles (>= ~8 workgroups per CU) over maximal row reuse
-  while (ty >= 16 && (size_t)((dw + 63) / 64) * ((dh + ty - 1) / ty) < 2048) ty = (ty + 1) / 2;
-  if (ty > 4) ty &= ~3u;  // phase 2 hands out rows four per wave
-  const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
-  const uint32_t lds = 4 * kLzStripQ * 16 + nr * ch * 64 * 4 + ty * 8 * 4 + (lz ? 7 * 64 * 4 : 0);  // strips | H | WY | WX (Lanczos)
-  dim3 tgrid((dw + 63) / 64, (dh + ty - 1) / ty);
+  const TileShape t = plan_tile(lz, 1, &ch, &dw, &dh, &scx, &scy, 1);
+  if (!t.ok) return false;
+  dim3 tgrid((dw + 63) / 64, (dh + t.ty - 1) / t.ty);
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
-#define VPF_TILE(C, L) VPF_LAUNCH((k_resize_tile<C, L>), tgrid, dim3(256), lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, ty, nr, vec_ok)
+#define VPF_TILE3(C, L, W) VPF_LAUNCH((k_resize_tile<C, L, W>), tgrid, dim3(64 * W), t.lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, t.ty, t.nr, t.rowq, t.lshift, vec_ok)
+#define VPF_TILE(C, L) do { if (t.wpb == 8) VPF_TILE3(C, L, 8); else VPF_TILE3(C, L, 4); } while (0)
   if (lz) { if (ch == 1) VPF_TILE(1, true); else if (ch == 2) VPF_TILE(2, true); else VPF_TILE(3, true); }
   else { if (ch == 1) VPF_TILE(1, false); else if (ch == 2) VPF_TILE(2, false); else VPF_TILE(3, false); }
 #undef VPF_TILE
+#undef VPF_TILE3
   return true;
 }
 
@@ -722,10 +974,22 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
 template <int CH>
 struct FloatPx { float c[CH]; };  // one pixel of an RGB_32F (CH = 3) / planar float (CH = 1) surface: 4-B aligned, loaded as one 4 * CH-byte access
 template <int CH, int INTERP>
+struct FloatGatherTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
+template <int CH, int INTERP>
 __global__ __launch_bounds__(256) void k_resize_f32(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                     uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
                                                     float scx, float scy) {
-  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  FloatGatherTask<CH, INTERP>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, 0, 0, 0, 0, 0}, blockIdx.x, blockIdx.y);
+}
+template <int CH, int INTERP>
+VPF_DEV void FloatGatherTask<CH, INTERP>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                              uint32_t bx, uint32_t by) {
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh;
+  const float scx = G.scx, scy = G.scy;
+  const uint32_t x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
   float* o = reinterpret_cast<float*>(dst + (size_t)y * dp) + (size_t)CH * x;
   if constexpr (INTERP == VPF_INTERP_LANCZOS3) {
@@ -804,13 +1068,191 @@ hipError_t launch_resize_f32(hipStream_t st, int ch, int interp, uint32_t sw, ui
 }
 
 // ------------------------------------------------------------------------------------------
+// vpf_resize_batch: every plane of a frame and up to 32 same-shape frames in as few dispatches as possible.  A 720p plane is 2-3 us
+// of work, the same order as a kernel boundary, and an NV12 / YUV420 frame is two or three such planes: one launch per plane per
+// frame leaves the chip idle most of the time.  The plane geometry decides the kernel family exactly as in launch_resize; when every
+// plane of the format lands in the same (tiled or row-pair) family they all go into ONE launch (k_planes_mp), otherwise each plane
+// gets one launch over all frames (k_plane_batch).  Same task bodies as the single-frame kernels -> identical pixels.
+// ------------------------------------------------------------------------------------------
+static bool planes_aligned(const BatchArgs& a, uint32_t n, int k, uintptr_t src_mask, uintptr_t dst_mask) {
+  for (uint32_t i = 0; i < n; i++)
+    if ((((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & src_mask) || (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & dst_mask)) return false;
+  return true;
+}
+template <class Task>
+static void launch_plane_batch(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgs& a, int k, const PlaneGeom& g) {
+  VPF_LAUNCH((k_plane_batch<Task>), grid, dim3(Task::kThreads), lds, st, a, k, g);
+}
+template <template <int> class TaskCH>
+static void launch_planes_mp(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgs& a, const PlaneTable& t) {
+  VPF_LAUNCH((k_planes_mp<TaskCH>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
+}
+template <template <int, int> class T2, int I>
+static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, const ResizeJob& j, const PlaneGeom& g) {
+  if (j.ch == 1) launch_plane_batch<T2<1, I>>(st, grid, 0, a, j.k, g);
+  else if (j.ch == 2) launch_plane_batch<T2<2, I>>(st, grid, 0, a, j.k, g);
+  else launch_plane_batch<T2<3, I>>(st, grid, 0, a, j.k, g);
+}
+
+hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
+  enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
+  const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
+  if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return hipErrorInvalidValue;
+  Fam fam[3];
+  int eff[3];
+  PlaneGeom g[3];
+  uint32_t rowb[3] = {0, 0, 0};
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
+    const bool odd_int = j.sw % j.dw == 0 && j.sh % j.dh == 0 && ((j.sw / j.dw) & 1) && ((j.sh / j.dh) & 1) && j.sw < (1u << 22) && j.sh < (1u << 22) &&
+                         tune != 40 && tune != 9;  // every filter returns the centre sample (see launch_resize)
+    eff[p] = interp;
+    if (f32) {
+      if (interp != VPF_INTERP_NEAREST && odd_int) eff[p] = VPF_INTERP_NEAREST;
+      g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, 0, 0, 0, 0};
+      fam[p] = FAM_GATHER;
+      continue;
+    }
+    if (interp == VPF_INTERP_LANCZOS3 && odd_int) eff[p] = VPF_INTERP_NEAREST;
+    const int vec_ok = planes_aligned(a, n, j.k, 0, j.ch == 2 ? 7 : 3) ? 1 : 0;
+    g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, vec_ok, 0, 0, 0, 0};
+    const bool src16 = tune != 9 && planes_aligned(a, n, j.k, 15, 0);
+    if (eff[p] == VPF_INTERP_LINEAR && j.sw == 2 * j.dw && j.sh == 2 * j.dh && j.dw % 4 == 0 && tune != 40 && tune != 9 &&
+        planes_aligned(a, n, j.k, 7, j.ch == 2 ? 7 : 3)) {
+      if (j.ch == 3 && j.sw % 32 == 0 && planes_aligned(a, n, j.k, 15, 15)) {
+        const uint32_t chunks = (j.sw + 1023) / 1024;
+        g[p].a0 = chunks; g[p].a1 = chunks * j.dh;
+        fam[p] = FAM_HALF3;
+      } else {
+        fam[p] = FAM_HALF;
+      }
+    } else if (eff[p] == VPF_INTERP_LANCZOS3) {
+      fam[p] = src16 ? FAM_TILE : FAM_LZ_GATHER;
+    } else if (eff[p] == VPF_INTERP_LINEAR && (scy < 1.0f || tune == 43) && tune != 40 && src16) {
+      fam[p] = FAM_TILE;
+    } else if (eff[p] == VPF_INTERP_LINEAR && src16 && (rowb[p] = lds_strip_bytes(j.ch, j.sw, j.dw, a.f[0].s[j.k], a.f[0].sp[j.k], kResizeRowBytes)) != 0) {
+      fam[p] = FAM_ROWPAIR;
+    } else {
+      fam[p] = FAM_GATHER;
+    }
+  }
+  // ---- every plane tiled: one launch for the whole format
+  bool all_tile = !f32, all_rowpair = !f32;
+  for (int p = 0; p < njobs; p++) {
+    all_tile = all_tile && fam[p] == FAM_TILE && eff[p] == eff[0];
+    all_rowpair = all_rowpair && fam[p] == FAM_ROWPAIR;
+  }
+  TileShape ts{false, 0, 0, 0, 0, 0, 4};
+  if (all_tile) {
+    int ch[3]; uint32_t dw[3], dh[3]; float sx[3], sy[3];
+    for (int p = 0; p < njobs; p++) { ch[p] = jobs[p].ch; dw[p] = jobs[p].dw; dh[p] = jobs[p].dh; sx[p] = g[p].scx; sy[p] = g[p].scy; }
+    ts = plan_tile(eff[0] == VPF_INTERP_LANCZOS3, njobs, ch, dw, dh, sx, sy, n);
+    if (!ts.ok) {  // the span does not fit a strip: every plane falls back to its gather form
+      all_tile = false;
+      for (int p = 0; p < njobs; p++) fam[p] = eff[p] == VPF_INTERP_LANCZOS3 ? FAM_LZ_GATHER : FAM_GATHER;
+    }
+  } else {
+    for (int p = 0; p < njobs; p++)
+      if (fam[p] == FAM_TILE) {  // mixed families: this plane is tiled on its own
+        const float sx = g[p].scx, sy = g[p].scy;
+        const TileShape t1 = plan_tile(eff[p] == VPF_INTERP_LANCZOS3, 1, &jobs[p].ch, &jobs[p].dw, &jobs[p].dh, &sx, &sy, n);
+        if (!t1.ok) { fam[p] = eff[p] == VPF_INTERP_LANCZOS3 ? FAM_LZ_GATHER : FAM_GATHER; continue; }
+        g[p].a0 = t1.ty; g[p].a1 = t1.nr; g[p].a2 = t1.rowq; g[p].a3 = t1.lshift;
+        rowb[p] = t1.lds | ((uint32_t)t1.wpb << 24);  // carried to the launch below
+      }
+  }
+  if (all_tile || all_rowpair) {
+    PlaneTable t{};
+    t.np = (uint32_t)njobs;
+    uint32_t gx = 0, gy = 0, it = 1, rb = 0;
+    for (int p = 0; p < njobs; p++) {
+      t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
+      if (all_tile) {
+        t.g[p].a0 = ts.ty; t.g[p].a1 = ts.nr; t.g[p].a2 = ts.rowq; t.g[p].a3 = ts.lshift;
+        const uint32_t bx = (jobs[p].dw + 63) / 64;
+        gx = bx > gx ? bx : gx;
+        gy += (jobs[p].dh + ts.ty - 1) / ts.ty;
+      } else {
+        rb = rowb[p] > rb ? rowb[p] : rb;
+        const uint32_t bx = ((jobs[p].dw + 3) / 4 + 63) / 64;
+        gx = bx > gx ? bx : gx;
+        gy += (jobs[p].dh + 3) / 4;
+      }
+    }
+    const dim3 grid(gx, gy, n);
+    if (all_tile) {
+      const bool lz = eff[0] == VPF_INTERP_LANCZOS3;
+      if (lz && ts.wpb == 8) launch_planes_mp<TileLz8>(st, grid, ts.lds, a, t);
+      else if (lz) launch_planes_mp<TileLz4>(st, grid, ts.lds, a, t);
+      else if (ts.wpb == 8) launch_planes_mp<TileBl8>(st, grid, ts.lds, a, t);
+      else launch_planes_mp<TileBl4>(st, grid, ts.lds, a, t);
+    } else {
+      for (int p = 0; p < njobs; p++) t.g[p].a0 = rb / 16;  // one strip size for the launch (the widest plane's)
+      it = (rb + 1023) / 1024;
+      const uint32_t lds = 4 * 2 * rb + 16;
+      if (it == 1) launch_planes_mp<RowPair1>(st, grid, lds, a, t);
+      else if (it == 2) launch_planes_mp<RowPair2>(st, grid, lds, a, t);
+      else if (it == 3) launch_planes_mp<RowPair3>(st, grid, lds, a, t);
+      else launch_planes_mp<RowPair4>(st, grid, lds, a, t);
+    }
+    return hipGetLastError();
+  }
+  // ---- otherwise: one launch per plane over all frames
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    const dim3 grid1((j.dw + 63) / 64, (j.dh + 3) / 4, n), grid4(((j.dw + 3) / 4 + 63) / 64, (j.dh + 3) / 4, n);
+    if (f32) {
+#define VPF_F32B(C) do { if (eff[p] == VPF_INTERP_LANCZOS3) launch_plane_batch<FloatGatherTask<C, VPF_INTERP_LANCZOS3>>(st, grid1, 0, a, j.k, g[p]); \
+                         else if (eff[p] == VPF_INTERP_LINEAR) launch_plane_batch<FloatGatherTask<C, VPF_INTERP_LINEAR>>(st, grid1, 0, a, j.k, g[p]); \
+                         else launch_plane_batch<FloatGatherTask<C, VPF_INTERP_NEAREST>>(st, grid1, 0, a, j.k, g[p]); } while (0)
+      if (j.ch == 3) VPF_F32B(3); else VPF_F32B(1);
+#undef VPF_F32B
+    } else if (fam[p] == FAM_HALF3) {
+      launch_plane_batch<Half3R16Task>(st, dim3((g[p].a1 + 3) / 4, 1, n), 0, a, j.k, g[p]);
+    } else if (fam[p] == FAM_HALF) {
+      const dim3 hgrid((j.dw / 4 + 63) / 64, (j.dh + 3) / 4, n);
+      if (j.ch == 1) launch_plane_batch<HalfTask<1>>(st, hgrid, 0, a, j.k, g[p]);
+      else if (j.ch == 2) launch_plane_batch<HalfTask<2>>(st, hgrid, 0, a, j.k, g[p]);
+      else launch_plane_batch<HalfTask<3>>(st, hgrid, 0, a, j.k, g[p]);
+    } else if (fam[p] == FAM_TILE) {
+      const uint32_t lds = rowb[p] & 0xffffffu, wpb = rowb[p] >> 24;
+      const dim3 tgrid((j.dw + 63) / 64, (j.dh + g[p].a0 - 1) / g[p].a0, n);
+      const bool lz = eff[p] == VPF_INTERP_LANCZOS3;
+#define VPF_TILEB(C) do { if (lz && wpb == 8) launch_plane_batch<TileTask<C, true, 8>>(st, tgrid, lds, a, j.k, g[p]); \
+                          else if (lz) launch_plane_batch<TileTask<C, true, 4>>(st, tgrid, lds, a, j.k, g[p]); \
+                          else if (wpb == 8) launch_plane_batch<TileTask<C, false, 8>>(st, tgrid, lds, a, j.k, g[p]); \
+                          else launch_plane_batch<TileTask<C, false, 4>>(st, tgrid, lds, a, j.k, g[p]); } while (0)
+      if (j.ch == 1) VPF_TILEB(1); else if (j.ch == 2) VPF_TILEB(2); else VPF_TILEB(3);
+#undef VPF_TILEB
+    } else if (fam[p] == FAM_ROWPAIR) {
+      g[p].a0 = rowb[p] / 16;
+      const uint32_t it = (rowb[p] + 1023) / 1024, lds = 4 * 2 * rowb[p] + 16;
+#define VPF_RPB(C) do { if (it == 1) launch_plane_batch<RowPairTask<C, 1>>(st, grid4, lds, a, j.k, g[p]); else if (it == 2) launch_plane_batch<RowPairTask<C, 2>>(st, grid4, lds, a, j.k, g[p]); \
+                        else if (it == 3) launch_plane_batch<RowPairTask<C, 3>>(st, grid4, lds, a, j.k, g[p]); else launch_plane_batch<RowPairTask<C, 4>>(st, grid4, lds, a, j.k, g[p]); } while (0)
+      if (j.ch == 1) VPF_RPB(1); else if (j.ch == 2) VPF_RPB(2); else VPF_RPB(3);
+#undef VPF_RPB
+    } else if (fam[p] == FAM_LZ_GATHER) {
+      if (j.ch == 1) launch_plane_batch<LanczosGatherTask<1>>(st, grid1, 0, a, j.k, g[p]);
+      else if (j.ch == 2) launch_plane_batch<LanczosGatherTask<2>>(st, grid1, 0, a, j.k, g[p]);
+      else launch_plane_batch<LanczosGatherTask<3>>(st, grid1, 0, a, j.k, g[p]);
+    } else if (eff[p] == VPF_INTERP_LINEAR) {
+      launch_gather_ch<GatherTask, VPF_INTERP_LINEAR>(st, grid4, a, j, g[p]);
+    } else {
+      launch_gather_ch<GatherTask, VPF_INTERP_NEAREST>(st, grid4, a, j, g[p]);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------
 // remap: dst(x,y) = bilinear(src, xmap[y][x], ymap[y][x]); out-of-range -> dst untouched [A9].
 // One lane per destination pixel: the map reads (8 B/px) are coalesced, texels are gathers.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
-                                                const float* __restrict__ xmap, uint32_t xp,
-                                                const float* __restrict__ ymap, uint32_t yp, uint8_t* dst, uint32_t dp,
-                                                uint32_t dw, uint32_t dh) {
+VPF_DEV void remap3_task(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh, const float* __restrict__ xmap, uint32_t xp,
+                         const float* __restrict__ ymap, uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh) {
   const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
   const float sx = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(xmap) + (size_t)y * xp)[x];
@@ -824,6 +1266,19 @@ __global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src,
 #pragma unroll
   for (int c = 0; c < 3; c++)
     o[c] = (uint8_t)sat_trunc(bilerp(r0[3 * x0 + c], r0[3 * x1 + c], r1[3 * x0 + c], r1[3 * x1 + c], fx, fy));
+}
+
+__global__ __launch_bounds__(256) void k_remap3(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                const float* __restrict__ xmap, uint32_t xp,
+                                                const float* __restrict__ ymap, uint32_t yp, uint8_t* dst, uint32_t dp,
+                                                uint32_t dw, uint32_t dh) {
+  remap3_task(src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh);
+}
+// the same map applied to up to 32 frames in one dispatch (vpf_remap_batch): blockIdx.z = frame
+__global__ __launch_bounds__(256) void k_remap3_b(const BatchArgs args, uint32_t sw, uint32_t sh, const float* __restrict__ xmap, uint32_t xp,
+                                                  const float* __restrict__ ymap, uint32_t yp, uint32_t dw, uint32_t dh) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  remap3_task(f.s[0], f.sp[0], sw, sh, xmap, xp, ymap, yp, f.d[0], f.dp[0], dw, dh);
 }
 
 // fast remap: lane = 4 consecutive destination pixels, wave = 256 pixels of one row.  Maps come in as two 16-B loads, the
@@ -908,9 +1363,8 @@ VPF_DEV void remap_blend4(const uint8_t* __restrict__ src, const uint32_t* o0, c
 // map loads 25.2 (+ NT stores 23.6).  Assigning each XCD a horizontal band of the picture (so that vertically adjacent
 // tiles share an L2) was slower as well: 23.4 vs 21.9; so was padding the grid width to a multiple of 8 (a column of tiles per
 // XCD): 23.0 vs 22.2.
-__global__ __launch_bounds__(256, 8) void k_remap3_p4(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
-                                                   const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
-                                                   uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
+VPF_DEV void remap3_p4_task(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh, const float* __restrict__ xmap, uint32_t xp,
+                            const float* __restrict__ ymap, uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const uint32_t x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
@@ -944,6 +1398,36 @@ __global__ __launch_bounds__(256, 8) void k_remap3_p4(const uint8_t* __restrict_
     for (int j = 0; j < 12; j++)
       if (ok[j / 3]) out[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
   }
+}
+
+__global__ __launch_bounds__(256, 8) void k_remap3_p4(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                   const float* __restrict__ xmap, uint32_t xp, const float* __restrict__ ymap,
+                                                   uint32_t yp, uint8_t* dst, uint32_t dp, uint32_t dw, uint32_t dh, int vec_ok) {
+  remap3_p4_task(src, sp, sw, sh, xmap, xp, ymap, yp, dst, dp, dw, dh, vec_ok);
+}
+__global__ __launch_bounds__(256, 8) void k_remap3_p4_b(const BatchArgs args, uint32_t sw, uint32_t sh, const float* __restrict__ xmap, uint32_t xp,
+                                                     const float* __restrict__ ymap, uint32_t yp, uint32_t dw, uint32_t dh, int vec_ok) {
+  const FrameDesc& f = args.f[blockIdx.z];  // the maps are shared: frame i + 1 finds them in L2 / Infinity Cache
+  remap3_p4_task(f.s[0], f.sp[0], sw, sh, xmap, xp, ymap, yp, f.d[0], f.dp[0], dw, dh, vec_ok);
+}
+
+// one map applied to n <= kMaxBatch frames in one dispatch
+hipError_t launch_remap_batch(hipStream_t st, uint32_t sw, uint32_t sh, const float* xmap, uint32_t xp, const float* ymap, uint32_t yp, uint32_t dw,
+                              uint32_t dh, uint32_t n, const BatchArgs& a) {
+  const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
+  bool fast = tune != 9 && (dw % 4 == 0) && !(((uintptr_t)xmap | xp | (uintptr_t)ymap | yp) & 15) && sw >= 4;
+  int vec_ok = 1;
+  for (uint32_t i = 0; i < n; i++) {
+    const FrameDesc& f = a.f[i];
+    fast = fast && !(((uintptr_t)f.s[0] | f.sp[0]) & 3) && f.sp[0] < (1u << 24) && (uint64_t)sh * f.sp[0] < (1ull << 32);
+    vec_ok &= ((((uintptr_t)f.d[0] | f.dp[0]) & 3) == 0);
+  }
+  if (fast) {
+    VPF_LAUNCH(k_remap3_p4_b, dim3((dw / 4 + 63) / 64, (dh + 3) / 4, n), dim3(256), 0, st, a, sw, sh, xmap, xp, ymap, yp, dw, dh, vec_ok);
+    return hipGetLastError();
+  }
+  VPF_LAUNCH(k_remap3_b, dim3((dw + 63) / 64, (dh + 3) / 4, n), dim3(256), 0, st, a, sw, sh, xmap, xp, ymap, yp, dw, dh);
+  return hipGetLastError();
 }
 
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp, const float* xmap,

@@ -412,6 +412,30 @@ TaskExecStatus ResizeSurface::Run() {
   return TASK_EXEC_SUCCESS;
 }
 
+// additive: n same-shape surfaces into n caller-owned surfaces of the task's size, every plane of every frame in as few dispatches
+// as possible (vpf_resize_batch); asynchronous on the task's stream like ConvertSurface::RunBatch
+TaskExecStatus ResizeSurface::RunBatch(Surface* const* ins, Surface* const* outs, uint32_t n) {
+  const HipMark tick("ResizeSurface::RunBatch");
+  if (!ins || !outs || !n || !ins[0]) return TASK_EXEC_FAIL;
+  const uint32_t sw = ins[0]->Width(), sh = ins[0]->Height();
+  std::vector<vpf_frame_io> io(n);
+  for (uint32_t i = 0; i < n; i++) {
+    Surface *s = ins[i], *d = outs[i];
+    if (!s || !d || s->Empty() || d->Empty() || s->PixelFormat() != pImpl->fmt || d->PixelFormat() != pImpl->fmt || s->Width() != sw || s->Height() != sh ||
+        d->Width() != pImpl->w || d->Height() != pImpl->h)
+      return TASK_EXEC_FAIL;
+    fill_planes(s, io[i].src);
+    fill_planes(d, io[i].dst);
+  }
+  const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
+  const vpf_status st = vpf_resize_batch(&ex, pImpl->fmt, pImpl->interp, vpf_size{sw, sh}, vpf_size{pImpl->w, pImpl->h}, n, io.data());
+  if (st != VPF_OK) {
+    std::cerr << "Failed to resize surfaces. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
+  return TASK_EXEC_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------ RemapSurface
 struct RemapSurface::Impl {
   Pixel_Format fmt;
@@ -460,6 +484,31 @@ TaskExecStatus RemapSurface::Run() {
     return TASK_EXEC_FAIL;
   }
   SetOutput(pImpl->out.get(), 0U);
+  return TASK_EXEC_SUCCESS;
+}
+
+// additive: the task's maps applied to n same-shape surfaces into n caller-owned surfaces of the map's size in one dispatch per 32
+// frames (vpf_remap_batch).  Destination pixels whose source falls outside the picture keep what the caller's surface held.
+TaskExecStatus RemapSurface::RunBatch(Surface* const* ins, Surface* const* outs, uint32_t n) {
+  const HipMark tick("RemapSurface::RunBatch");
+  if (!ins || !outs || !n || !ins[0]) return TASK_EXEC_FAIL;
+  const uint32_t sw = ins[0]->Width(), sh = ins[0]->Height();
+  std::vector<vpf_frame_io> io(n);
+  for (uint32_t i = 0; i < n; i++) {
+    Surface *s = ins[i], *d = outs[i];
+    if (!s || !d || s->Empty() || d->Empty() || s->PixelFormat() != pImpl->fmt || d->PixelFormat() != pImpl->fmt || s->Width() != sw || s->Height() != sh ||
+        d->Width() != pImpl->w || d->Height() != pImpl->h)
+      return TASK_EXEC_FAIL;
+    fill_planes(s, io[i].src);
+    fill_planes(d, io[i].dst);
+  }
+  const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
+  const vpf_status st = vpf_remap_batch(&ex, pImpl->fmt, vpf_size{sw, sh}, (const float*)pImpl->xmap->GpuMem(), pImpl->w * 4, (const float*)pImpl->ymap->GpuMem(),
+                                        pImpl->w * 4, vpf_size{pImpl->w, pImpl->h}, n, io.data());
+  if (st != VPF_OK) {
+    std::cerr << "Failed to remap surfaces. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
+    return TASK_EXEC_FAIL;
+  }
   return TASK_EXEC_SUCCESS;
 }
 

@@ -61,6 +61,9 @@ public:
   static ResizeSurface* Make(uint32_t width, uint32_t height, Pixel_Format format, HipContext ctx, HipStream str);
   ~ResizeSurface() override;
   TaskExecStatus Run() final;  // blocking: the task registers a stream-sync callback (Tasks.cpp:1455-1456)
+  // additive: n same-shape surfaces -> n caller-owned surfaces of the task's size, every plane of every frame in as few dispatches
+  // as possible (vpf_resize_batch); asynchronous on the task's stream
+  TaskExecStatus RunBatch(Surface* const* inputs, Surface* const* outputs, uint32_t n);
   // 0 nearest, 1 bilinear (default: BASELINE.json north_star), 2 Lanczos-3 (what the reference asks NPP for, :1190)
   void SetInterpolation(int interp);
   int GetInterpolation() const;
@@ -78,6 +81,8 @@ public:
                             Pixel_Format format, HipContext ctx, HipStream str);
   ~RemapSurface() override;
   TaskExecStatus Run() final;
+  // additive: the task's maps applied to n same-shape surfaces -> n caller-owned surfaces of the map's size, one dispatch per 32 frames
+  TaskExecStatus RunBatch(Surface* const* inputs, Surface* const* outputs, uint32_t n);
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;

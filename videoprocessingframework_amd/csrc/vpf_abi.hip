@@ -82,8 +82,8 @@ void note_kernel(const char* k) {
   if (trace_on() && g_roctx_mark) g_roctx_mark(k);
 }
 
-static std::atomic<int> g_tune_variant{0};
-int tuning(int key) { return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : 0; }
+static std::atomic<int> g_tune_variant{0}, g_tune_tile{0};
+int tuning(int key) { return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : (key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : 0); }
 
 // ------------------------------------------------------------------------------------------
 // format helpers
@@ -245,53 +245,99 @@ vpf_status vpf_convert(const vpf_exec* exec, int sf, int df, int cs, int cr, vpf
   return vpf_convert_batch(exec, sf, df, cs, cr, size, 1, &io);
 }
 
-vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, const vpf_plane src[3], vpf_size ds,
-                      const vpf_plane dst[3]) {
-  const Mark mark("vpf_resize");
-  if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR && interp != VPF_INTERP_LANCZOS3) return VPF_ERR_UNSUPPORTED;
+// planes of `fmt` as resize jobs: (interleaved channels, plane index, plane size in pixels)
+static int resize_jobs(int fmt, vpf_size ss, vpf_size ds, ResizeJob jobs[3], bool* f32) {
+  const uint32_t scw = (ss.width + 1) / 2, sch = (ss.height + 1) / 2, dcw = (ds.width + 1) / 2, dch = (ds.height + 1) / 2;
+  *f32 = fmt == VPF_FMT_RGB_32F || fmt == VPF_FMT_RGB_32F_PLANAR;
+  const ResizeJob full1 = {1, 0, ss.width, ss.height, ds.width, ds.height};
   switch (fmt) {
-    case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_Y: case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
-    case VPF_FMT_YUV420: case VPF_FMT_YCBCR: case VPF_FMT_NV12: case VPF_FMT_RGB_32F: case VPF_FMT_RGB_32F_PLANAR: break;
-    default: return VPF_ERR_UNSUPPORTED;
+    case VPF_FMT_RGB: case VPF_FMT_BGR: case VPF_FMT_RGB_32F: jobs[0] = ResizeJob{3, 0, ss.width, ss.height, ds.width, ds.height}; return 1;
+    case VPF_FMT_Y: jobs[0] = full1; return 1;
+    case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR: case VPF_FMT_RGB_32F_PLANAR:
+      for (int k = 0; k < 3; k++) { jobs[k] = full1; jobs[k].k = k; }
+      return 3;
+    case VPF_FMT_YUV420: case VPF_FMT_YCBCR:
+      jobs[0] = full1;
+      for (int k = 1; k < 3; k++) jobs[k] = ResizeJob{1, k, scw, sch, dcw, dch};
+      return 3;
+    case VPF_FMT_NV12:  // luma plane + the UV plane as a 2-channel image (== C3 -> R2 -> C4 of Tasks.cpp:1303-1318)
+      jobs[0] = full1;
+      jobs[1] = ResizeJob{2, 1, scw, sch, dcw, dch};
+      return 2;
+    default: return 0;
   }
-  if (!exec || !dims_ok(ss) || !dims_ok(ds) || !planes_ok(fmt, ss.width, src) ||
-      !planes_ok(fmt, ds.width, dst))
-    return VPF_ERR_BAD_ARG;
-  if (fmt == VPF_FMT_RGB_32F || fmt == VPF_FMT_RGB_32F_PLANAR)  // float samples: rows must be 4-B aligned
-    for (int k = 0; k < num_planes(fmt); k++)
-      if ((((uintptr_t)src[k].ptr | src[k].pitch | (uintptr_t)dst[k].ptr | dst[k].pitch) & 3)) return VPF_ERR_BAD_ARG;
+}
+
+vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size ss, vpf_size ds, uint32_t n, const vpf_frame_io* frames) {
+  const Mark mark("vpf_resize_batch");
+  if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR && interp != VPF_INTERP_LANCZOS3) return VPF_ERR_UNSUPPORTED;
+  ResizeJob jobs[3];
+  bool f32 = false;
+  const int nj = resize_jobs(fmt, ss, ds, jobs, &f32);
+  if (!nj) return VPF_ERR_UNSUPPORTED;
+  if (!exec || !frames || !n || !dims_ok(ss) || !dims_ok(ds)) return VPF_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!planes_ok(fmt, ss.width, frames[i].src) || !planes_ok(fmt, ds.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
+    if (f32)  // float samples: rows must be 4-B aligned
+      for (int k = 0; k < num_planes(fmt); k++)
+        if ((((uintptr_t)frames[i].src[k].ptr | frames[i].src[k].pitch | (uintptr_t)frames[i].dst[k].ptr | frames[i].dst[k].pitch) & 3)) return VPF_ERR_BAD_ARG;
+  }
   DeviceGuard guard(exec->device);
   if (guard.err != hipSuccess) return status_of(guard.err);
   hipStream_t st = static_cast<hipStream_t>(exec->stream);
-  auto one = [&](int ch, int k, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
-    return launch_resize(st, ch, interp, sw, sh, static_cast<const uint8_t*>(src[k].ptr), src[k].pitch, dw, dh,
-                         static_cast<uint8_t*>(dst[k].ptr), dst[k].pitch);
-  };
-  const uint32_t scw = (ss.width + 1) / 2, sch = (ss.height + 1) / 2, dcw = (ds.width + 1) / 2, dch = (ds.height + 1) / 2;
-  hipError_t e = hipSuccess;
-  auto onef = [&](int ch, int k) {
-    return launch_resize_f32(st, ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(src[k].ptr), src[k].pitch, ds.width,
-                             ds.height, static_cast<uint8_t*>(dst[k].ptr), dst[k].pitch);
-  };
-  switch (fmt) {
-    case VPF_FMT_RGB_32F: e = onef(3, 0); break;
-    case VPF_FMT_RGB_32F_PLANAR:
-      for (int k = 0; k < 3 && e == hipSuccess; k++) e = onef(1, k);
-      break;
-    case VPF_FMT_RGB: case VPF_FMT_BGR: e = one(3, 0, ss.width, ss.height, ds.width, ds.height); break;
-    case VPF_FMT_Y: e = one(1, 0, ss.width, ss.height, ds.width, ds.height); break;
-    case VPF_FMT_YUV444: case VPF_FMT_RGB_PLANAR:
-      for (int k = 0; k < 3 && e == hipSuccess; k++) e = one(1, k, ss.width, ss.height, ds.width, ds.height);
-      break;
-    case VPF_FMT_YUV420: case VPF_FMT_YCBCR:
-      e = one(1, 0, ss.width, ss.height, ds.width, ds.height);
-      for (int k = 1; k < 3 && e == hipSuccess; k++) e = one(1, k, scw, sch, dcw, dch);
-      break;
-    default:  // NV12: luma plane + the UV plane as a 2-channel image (== C3 -> R2 -> C4 of Tasks.cpp:1303-1318)
-      e = one(1, 0, ss.width, ss.height, ds.width, ds.height);
-      if (e == hipSuccess) e = one(2, 1, scw, sch, dcw, dch);
+  const int np = num_planes(fmt);
+  if (n == 1 && nj == 1) {  // one plane of one frame: the scalar-argument kernel entries (kernarg preload)
+    const vpf_plane &s0 = frames[0].src[0], &d0 = frames[0].dst[0];
+    const hipError_t e = f32 ? launch_resize_f32(st, jobs[0].ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(s0.ptr), s0.pitch, ds.width, ds.height,
+                                                 static_cast<uint8_t*>(d0.ptr), d0.pitch)
+                             : launch_resize(st, jobs[0].ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(s0.ptr), s0.pitch, ds.width, ds.height,
+                                             static_cast<uint8_t*>(d0.ptr), d0.pitch);
+    return status_of(e);
   }
-  return status_of(e);
+  for (uint32_t base = 0; base < n; base += kMaxBatch) {
+    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
+    BatchArgs a;
+    for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, np, frames[base + i].dst, np);
+    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    const hipError_t e = launch_resize_jobs(st, f32, interp, nj, jobs, m, a);
+    if (e != hipSuccess) return status_of(e);
+  }
+  return VPF_OK;
+}
+
+vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, const vpf_plane src[3], vpf_size ds,
+                      const vpf_plane dst[3]) {
+  if (interp != VPF_INTERP_NEAREST && interp != VPF_INTERP_LINEAR && interp != VPF_INTERP_LANCZOS3) return VPF_ERR_UNSUPPORTED;
+  ResizeJob probe[3];
+  bool f32 = false;
+  if (!resize_jobs(fmt, vpf_size{2, 2}, vpf_size{2, 2}, probe, &f32)) return VPF_ERR_UNSUPPORTED;
+  if (!src || !dst) return VPF_ERR_BAD_ARG;
+  vpf_frame_io io;
+  std::memset(&io, 0, sizeof(io));
+  for (int k = 0; k < num_planes(fmt); k++) { io.src[k] = src[k]; io.dst[k] = dst[k]; }
+  return vpf_resize_batch(exec, fmt, interp, ss, ds, 1, &io);
+}
+
+vpf_status vpf_remap_batch(const vpf_exec* exec, int fmt, vpf_size ss, const float* xmap, uint32_t xp, const float* ymap, uint32_t yp, vpf_size ds,
+                           uint32_t n, const vpf_frame_io* frames) {
+  const Mark mark("vpf_remap_batch");
+  if (fmt != VPF_FMT_RGB && fmt != VPF_FMT_BGR) return VPF_ERR_UNSUPPORTED;
+  if (!exec || !frames || !n || !dims_ok(ss) || !dims_ok(ds) || !xmap || !ymap || xp < 4 * ds.width || yp < 4 * ds.width || (xp & 3) || (yp & 3) ||
+      ((uintptr_t)xmap & 3) || ((uintptr_t)ymap & 3))
+    return VPF_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n; i++)
+    if (!planes_ok(fmt, ss.width, frames[i].src) || !planes_ok(fmt, ds.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
+  DeviceGuard guard(exec->device);
+  if (guard.err != hipSuccess) return status_of(guard.err);
+  for (uint32_t base = 0; base < n; base += kMaxBatch) {
+    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
+    BatchArgs a;
+    for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, 1, frames[base + i].dst, 1);
+    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    const hipError_t e = launch_remap_batch(static_cast<hipStream_t>(exec->stream), ss.width, ss.height, xmap, xp, ymap, yp, ds.width, ds.height, m, a);
+    if (e != hipSuccess) return status_of(e);
+  }
+  return VPF_OK;
 }
 
 vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size ss, const vpf_plane* src, const float* xmap, uint32_t xp,
@@ -369,6 +415,11 @@ int vpf_trace_push(const char* name) {
 void vpf_trace_pop(int opened) { if (opened) trace_pop(); }
 
 int vpf_set_tuning(int key, int value) {
+  if (key == VPF_TUNE_RESIZE_TILE) {
+    const int ty = value & 0xff, wpb = value >> 8;
+    if (value != 0 && (ty < 4 || ty > 64 || (ty & 3) || (wpb != 4 && wpb != 8))) return -1;
+    return g_tune_tile.exchange(value);
+  }
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
     case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: return g_tune_variant.exchange(value);

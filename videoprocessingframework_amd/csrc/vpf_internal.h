@@ -66,9 +66,18 @@ hipError_t launch_resize(hipStream_t st, int channels, int interp, uint32_t sw, 
                          uint32_t spitch, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dpitch);
 hipError_t launch_resize_f32(hipStream_t st, int channels, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
                              uint32_t spitch, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dpitch);
+// one plane of a resize: `ch` interleaved channels (for float surfaces: floats per pixel), `k` = plane index in FrameDesc
+struct ResizeJob {
+  int ch, k;
+  uint32_t sw, sh, dw, dh;
+};
+// all planes of a format over n <= kMaxBatch same-shape frames in as few launches as possible (k_resize.hip)
+hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a);
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t spitch,
                         const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch, uint32_t dw,
                         uint32_t dh, uint8_t* dst, uint32_t dpitch);
+hipError_t launch_remap_batch(hipStream_t st, uint32_t sw, uint32_t sh, const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch,
+                              uint32_t dw, uint32_t dh, uint32_t n, const BatchArgs& a);
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw,
                                  uint32_t sh, uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh);
 
