@@ -815,7 +815,7 @@ static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, cons
           const double v = floor(acc + 0.5);
           o[ch * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         } else { /* kernel arithmetic: horizontal pass exact in Q14 integers (order-free), then an fp32 fma chain over the six rows
-                    (row 0 first) on the integer sums, scaled back by 2^-14 together with the + 0.5 of the rounding */
+                    (row 0 first) on the integer sums, scaled back by 2^-14 (exact) and rounded to nearest even like the YUV -> RGB family */
           float acc = 0.f;
           for (int ky = 0; ky < 6; ky++) {
             const uint8_t* r = prow(s, (uint32_t)ty[yy].idx[ky]);
@@ -823,7 +823,7 @@ static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, cons
             for (int kx = 0; kx < 6; kx++) h += tx[x].q[kx] * (int32_t)r[ch * tx[x].idx[kx] + c];
             acc = __builtin_fmaf(ty[yy].wf[ky], (float)h, acc); /* |h| < 2^24: the conversion is exact */
           }
-          o[ch * x + c] = sat_trunc(__builtin_fmaf(acc, 6.103515625e-05f, 0.5f));
+          o[ch * x + c] = sat_rne(acc * 6.103515625e-05f); /* exact scaling, then ONE rounding: saturate, ties to even (v_cvt_pk_u8_f32) */
         }
       }
   }

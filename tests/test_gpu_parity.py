@@ -341,13 +341,17 @@ def test_resize_float_surfaces(capi, oracle, fmt):
         src = oracle.synth(f, sw, sh, 1045)
         for interp in (capi.INTERP_NEAREST, capi.INTERP_LINEAR, capi.INTERP_LANCZOS3):
             _, want = oracle.resize(f, interp, sw, sh, src, dw, dh, oracle.FP32)
-            for align in (256, 4):
+            for align, variant in ((256, 0), (4, 0), (256, 43), (256, 9)):  # tiled Lanczos / gather (unaligned) / tiled bilinear too / forced gather
                 s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(f, dw, dh), align)
-                capi.resize(capi.make_exec(stream_handle()), f, interp, sw, sh, s.desc(), dw, dh, d.desc())
+                prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+                try:
+                    capi.resize(capi.make_exec(stream_handle()), f, interp, sw, sh, s.desc(), dw, dh, d.desc())
+                finally:
+                    capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
                 torch.cuda.synchronize()
                 got, intact = d.download()
                 assert intact
-                assert_planes_equal(got, want, f"float resize {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} a{align}")
+                assert_planes_equal(got, want, f"float resize {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} a{align} v{variant}")
             _, ex = oracle.resize(f, interp, sw, sh, src, dw, dh, oracle.EXACT)
             for g, e in zip(got, ex):  # fp32 source coordinates carry ~1e-7 * x of error; samples are in [0, 1)
                 if interp == capi.INTERP_NEAREST:  # a coordinate that rounds across a sample boundary picks a neighbour

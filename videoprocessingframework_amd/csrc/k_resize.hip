@@ -22,6 +22,8 @@
 //                                         kernels' byte-move and direct-pack paths (bilinear, fused)
 //   packed RGB taps                       both taps of a row = 6 contiguous bytes: fetched as ONE 12-B window from the
 //                                         aligned address below (global or LDS) and cut out with v_alignbyte_b32
+#include <cstring>
+
 #include "vpf_device.h"
 
 namespace vpf {
@@ -238,6 +240,13 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 VPF_DEV int32_t dot2(uint32_t a, uint32_t b, int32_t c) {  // a.lo * b.lo + a.hi * b.hi + c on int16 halves
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+// the first dot of a chain: the VOP3P encoding takes the inline constant 0 as its addend (the compiler only emits the accumulate-in-place
+// VOP2 form v_dot2c_i32_i16, which wants a zeroed register per chain: three v_mov_b32 per source row of the tiled kernel)
+VPF_DEV int32_t dot2z(uint32_t a, uint32_t b) {
+  int32_t r;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 constexpr float kQ14Inv = 6.103515625e-05f;  // 2^-14
 
 template <int CH>
@@ -289,7 +298,7 @@ VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_
   }
   uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
 #pragma unroll
-  for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_trunc(__builtin_fmaf(acc[c], kQ14Inv, 0.5f));
+  for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_rne(acc[c] * kQ14Inv);  // the scaling is exact (power of two); one rounding, ties to even
 }
 
 // ------------------------------------------------------------------------------------------
@@ -397,10 +406,48 @@ VPF_DEV void RowPairTask<CH, IT>::run(const uint8_t* __restrict__ src, uint32_t 
     }
   }
   float o[4 * CH];
+  Tap txs[4];
+  bool general = row1;  // wave-uniform: every pixel of the wave blends four taps (no exact-alignment shortcut applies)
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint32_t x = (x0 + k < dw) ? x0 + k : dw - 1;
-    const Tap tx = make_tap<VPF_INTERP_LINEAR>(x, scx, sw);
+    txs[k] = make_tap<VPF_INTERP_LINEAR>((x0 + k < dw) ? x0 + k : dw - 1, scx, sw);
+    general = general && __builtin_amdgcn_ballot_w64(txs[k].f != 0.f) != 0;
+  }
+  if (general) {
+    // The common case, on the packed-fp32 pipe: the four taps of all four pixels are fetched first, then every blend step runs on
+    // PIXEL PAIRS (v_pk_add_f32 / v_pk_fma_f32: two independent IEEE operations per instruction at the issue cost of one —
+    // profiles/r02_probe_valu_rate.txt), 3.5 instead of 7 VALU slots per pixel and channel.  Each component goes through exactly
+    // bilerp()'s operations in bilerp()'s order -> bit-identical to the scalar form below and to the other kernels.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float p00[4][CH], p01[4][CH], p10[4][CH], p11[4][CH];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t a = CH * txs[k].i0 - base, b = CH * txs[k].i1 - base;
+      if constexpr (CH == 3) {  // both taps of a row are 6 contiguous bytes: one 12-B LDS window + v_alignbyte_b32 (see strip_window_taps)
+        strip_window_taps(r0, a, p00[k], p01[k]);
+        strip_window_taps(r1, a, p10[k], p11[k]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { p00[k][c] = (float)r0[a + c]; p01[k][c] = (float)r0[b + c]; p10[k][c] = (float)r1[a + c]; p11[k][c] = (float)r1[b + c]; }
+      }
+    }
+    const f32x2 fy2 = {ty.f, ty.f}, half2 = {0.5f, 0.5f};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int k0 = 2 * j, k1 = 2 * j + 1;
+      const f32x2 fx2 = {txs[k0].f, txs[k1].f};
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const f32x2 a00 = {p00[k0][c], p00[k1][c]}, a01 = {p01[k0][c], p01[k1][c]}, a10 = {p10[k0][c], p10[k1][c]}, a11 = {p11[k0][c], p11[k1][c]};
+        const f32x2 top = __builtin_elementwise_fma(fx2, a01 - a00, a00), bot = __builtin_elementwise_fma(fx2, a11 - a10, a10);
+        const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
+        o[k0 * CH + c] = v[0]; o[k1 * CH + c] = v[1];
+      }
+    }
+  } else {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const Tap tx = txs[k];
     const uint32_t a = CH * tx.i0 - base, b = CH * tx.i1 - base;
     const bool tap1 = __builtin_amdgcn_ballot_w64(tx.f != 0.f) != 0;  // wave-uniform
     if constexpr (CH == 3) {
@@ -434,6 +481,7 @@ VPF_DEV void RowPairTask<CH, IT>::run(const uint8_t* __restrict__ src, uint32_t 
         }
       }
     }
+  }
   }
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
@@ -567,59 +615,68 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
   // Phase 1, horizontal: wave w takes source rows w, w + WPB, ...; rows are independent of one another (no barrier inside the loop)
   // wave-uniform: no lane's taps were clamped at an image edge (clamped taps repeat a pixel and break the run)
   const bool contiguous = LZ && __builtin_amdgcn_ballot_w64(xo[NT - 1] - xo[0] != (uint32_t)(CH * (NT - 1))) == 0;
-  for (uint32_t r = wv; r < nrows; r += WPB) {
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq);
-    if constexpr (LZ) {
-      // In integers, two taps per v_dot2_i32_i16.  No tap clamped anywhere in the wave (everything but the tiles on the left / right
-      // image edge): a lane's 6 x CH taps are contiguous bytes -> aligned dword reads, v_alignbyte_b32 to drop the lead, one
-      // v_perm_b32 per tap pair to spread two bytes into int16 halves, then the dots; same exact sums as the byte-by-byte form below
-      // and as the gather kernel.
-      int32_t h[CH];
-      if (contiguous) {
-        constexpr int NE = (6 * CH + 3) / 4;  // dwords of the lead-free run
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(b + (xo[0] & ~3u));
-        const uint32_t lead = xo[0] & 3u;
-        uint32_t d[NE + 1], e[NE];
+  if (LZ && contiguous) {
+    // In integers, two taps per v_dot2_i32_i16.  No tap clamped anywhere in the wave (everything but the tiles on the left / right
+    // image edge): a lane's 6 x CH taps are contiguous bytes -> aligned dword reads, v_alignbyte_b32 to drop the lead, one v_perm_b32
+    // per tap pair to spread two bytes into int16 halves, then the dots; same exact sums as the byte-by-byte form below and as the
+    // gather kernel.  Two source rows per iteration: both rows' LDS reads are in flight before the first is used.
+    constexpr int NE = (6 * CH + 3) / 4;  // dwords of the lead-free run
+    const uint32_t lead = xo[0] & 3u, qoff = xo[0] & ~3u;
+    auto fetch = [&](uint32_t r, uint32_t* d) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq) + qoff);
 #pragma unroll
-        for (int i = 0; i <= NE; i++) d[i] = q[i];
+      for (int i = 0; i <= NE; i++) d[i] = q[i];
+    };
+    auto hdots = [&](uint32_t r, const uint32_t* d) {
+      uint32_t e[NE];
 #pragma unroll
-        for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead);
+      for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead);
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-          uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c
-          if constexpr (CH == 3) {  // bytes c, 3 + c | 6 + c, 9 + c | 12 + c, 15 + c of the run
-            p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
-            p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
-            p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
-          } else if constexpr (CH == 2) {  // bytes c, 2 + c of dwords 0, 1, 2
-            const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
-            p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
-          } else {  // bytes 0, 1 | 2, 3 | 4, 5
-            p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
-          }
-          h[c] = dot2(p2, qx[2], dot2(p1, qx[1], dot2(p0, qx[0], 0)));
+      for (int c = 0; c < CH; c++) {
+        uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c
+        if constexpr (CH == 3) {  // bytes c, 3 + c | 6 + c, 9 + c | 12 + c, 15 + c of the run
+          p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+          p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
+          p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+        } else if constexpr (CH == 2) {  // bytes c, 2 + c of dwords 0, 1, 2
+          const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
+          p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
+        } else {  // bytes 0, 1 | 2, 3 | 4, 5
+          p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
         }
-      } else {
+        H[(r * CH + c) * 64 + lane] = (float)dot2(p2, qx[2], dot2(p1, qx[1], dot2z(p0, qx[0])));  // exact: |h| < 2^24
+      }
+    };
+    for (uint32_t r = wv; r < nrows; r += 2 * WPB) {
+      uint32_t da[NE + 1], db[NE + 1];
+      const bool two = r + WPB < nrows;  // wave-uniform
+      fetch(r, da);
+      if (two) fetch(r + WPB, db);
+      hdots(r, da);
+      if (two) hdots(r + WPB, db);
+    }
+  } else {
+    for (uint32_t r = wv; r < nrows; r += WPB) {
+      const uint8_t* b = reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq);
+      if constexpr (LZ) {  // a tile on the left / right image edge: clamped taps, byte by byte
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           int32_t a = 0;
 #pragma unroll
           for (int k = 0; k < 3; k++) a = dot2((uint32_t)b[xo[2 * k] + c] | ((uint32_t)b[xo[2 * k + 1] + c] << 16), qx[k], a);
-          h[c] = a;
+          H[(r * CH + c) * 64 + lane] = (float)a;
         }
-      }
+      } else if (CH == 3) {
+        float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
+        strip_window_taps(b, xo[0], t0, t1);
 #pragma unroll
-      for (int c = 0; c < CH; c++) H[(r * CH + c) * 64 + lane] = (float)h[c];  // exact: |h| < 2^24
-    } else if (CH == 3) {
-      float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
-      strip_window_taps(b, xo[0], t0, t1);
+        for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx, t1[c] - t0[c], t0[c]);
+      } else {
 #pragma unroll
-      for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx, t1[c] - t0[c], t0[c]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < CH; c++) {
-        const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
-        H[(r * CH + c) * 64 + lane] = __builtin_fmaf(wx, p1 - p0, p0);
+        for (int c = 0; c < CH; c++) {
+          const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
+          H[(r * CH + c) * 64 + lane] = __builtin_fmaf(wx, p1 - p0, p0);
+        }
       }
     }
   }
@@ -664,26 +721,186 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
         acc[c][1] = __builtin_elementwise_fma(fy2, b1 - t1, t1);
       }
     }
-    float o[4 * CH];  // pixel-major, + 0.5 for the truncating pack (Lanczos: the sums are Q14, scaled back in the same fma)
+    // pixel-major.  Bilinear: + 0.5, then the truncating pack of every bilinear kernel.  Lanczos: the Q14 sums are scaled back (exact:
+    // a power of two) and rounded + saturated + byte-packed by v_cvt_pk_u8_f32 (ties to even, one instruction per byte instead of
+    // clamp + convert + shift / or: the pack was a tenth of the kernel's instructions)
+    float o[4 * CH];
 #pragma unroll
     for (int c = 0; c < CH; c++)
 #pragma unroll
       for (int hlf = 0; hlf < 2; hlf++) {
-        const f32x2 v = LZ ? __builtin_elementwise_fma(acc[c][hlf], f32x2{kQ14Inv, kQ14Inv}, f32x2{0.5f, 0.5f}) : acc[c][hlf] + f32x2{0.5f, 0.5f};
+        const f32x2 v = LZ ? acc[c][hlf] * f32x2{kQ14Inv, kQ14Inv} : acc[c][hlf] + f32x2{0.5f, 0.5f};
         o[(2 * hlf) * CH + c] = v[0]; o[(2 * hlf + 1) * CH + c] = v[1];
       }
+    auto pk4 = [](float a, float b, float c, float d) { return LZ ? pack4<1>(a, b, c, d) : pack4_trunc(a, b, c, d); };
     uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
     if (P.vec_ok && x0 + 4 <= dw) {
       if constexpr (CH == 3) {
-        stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+        stg3<true>(out, pk4(o[0], o[1], o[2], o[3]), pk4(o[4], o[5], o[6], o[7]), pk4(o[8], o[9], o[10], o[11]));
       } else if constexpr (CH == 2) {
-        stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
+        stg<true, u32x2>(out, u32x2{pk4(o[0], o[1], o[2], o[3]), pk4(o[4], o[5], o[6], o[7])});
       } else {
-        stg<true, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
+        stg<true, uint32_t>(out, pk4(o[0], o[1], o[2], o[3]));
       }
     } else {
       const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
-      for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[i]);
+      for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(LZ ? sat_rne(o[i]) : sat_trunc(o[i]));
+    }
+  }
+}
+// The same tiling for 32-bit float surfaces (RGB_32F: CH = 3 interleaved, RGB_32F_PLANAR: CH = 1 per plane; reference
+// NppResizeSurfacePacked32F3C_Impl / NppResizeSurface32FPlanar_Impl, Tasks.cpp:1334-1445).  Samples are floats, so both passes are
+// fp32 fma chains in FloatGatherTask's order (tap 0 first, row 0 first, accumulators starting at 0; bilinear: its two lerps): results
+// are bit-identical to the gather form; nothing is rounded or clamped.  Geometry fields as for TileTask, with 4-byte samples; the
+// window is staged in rounds of kTileStagePasses units per thread (a float row is four times as long as a byte row).
+template <int CH, bool LZ, int WPB>
+struct TileTaskF32 {
+  static constexpr int kThreads = 64 * WPB;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P, uint32_t bx, uint32_t by);
+};
+template <int CH, bool LZ, int WPB>
+VPF_DEV void TileTaskF32<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P,
+                                           uint32_t bx, uint32_t by) {
+  // dynamic LDS: RAW[nr_cap][rowq x 16 B] source floats | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats | WX[7][64] floats (Lanczos)
+  constexpr int NT = LZ ? 6 : 2;
+  constexpr uint32_t T = 64 * WPB;
+  const uint32_t sw = P.sw, sh = P.sh, dw = P.dw, dh = P.dh, tile_rows = P.a0, nr_cap = P.a1, rowq = P.a2, lshift = P.a3;
+  const float scx = P.scx, scy = P.scy;
+  u32x4* const RAW = dyn_strip;
+  float* const H = reinterpret_cast<float*>(dyn_strip + (size_t)nr_cap * rowq);
+  float* const WY = H + (size_t)nr_cap * CH * 64;
+  float* const WX = WY + (size_t)tile_rows * 8;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t xf = bx * 64, xl = (xf + 63 < dw - 1) ? xf + 63 : dw - 1;
+  if (xf >= dw) return;
+  const uint32_t x = xf + lane, xc = x < dw ? x : dw - 1;
+  const uint32_t y0 = by * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
+  auto clampi = [](int32_t i, int32_t hi) { return (uint32_t)(i < 0 ? 0 : (i > hi ? hi : i)); };
+  int32_t R0, R1;
+  uint32_t first, last;
+  if constexpr (LZ) {
+    R0 = ltap_i0(y0, scy) - 2; R1 = ltap_i0(yl, scy) + 3;
+    first = clampi(ltap_i0(xf, scx) - 2, (int32_t)sw - 1); last = clampi(ltap_i0(xl, scx) + 3, (int32_t)sw - 1);
+  } else {
+    R0 = (int32_t)make_tap<VPF_INTERP_LINEAR>(y0, scy, sh).i0; R1 = (int32_t)make_tap<VPF_INTERP_LINEAR>(yl, scy, sh).i1;
+    first = make_tap<VPF_INTERP_LINEAR>(xf, scx, sw).i0; last = make_tap<VPF_INTERP_LINEAR>(xl, scx, sw).i1;
+  }
+  const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
+  const uint32_t base = (4 * CH * first) & ~15u, nq = (4 * CH * (last + 1) - base + 15) / 16;
+  const uint32_t scol = threadIdx.x & ((1u << lshift) - 1u), srow0 = threadIdx.x >> lshift, srows = T >> lshift;
+  for (uint32_t rb = 0; rb < nrows; rb += kTileStagePasses * srows) {  // usually one round; the units of a round are all in flight together
+    u32x4 stage[kTileStagePasses];
+#pragma unroll
+    for (int k = 0; k < kTileStagePasses; k++) {
+      const uint32_t r = rb + srow0 + k * srows;
+      if (r < nrows && scol < nq) stage[k] = ldg<false, u32x4>(src + (size_t)clampi(R0 + (int32_t)r, (int32_t)sh - 1) * sp + base + 16 * scol);
+    }
+#pragma unroll
+    for (int k = 0; k < kTileStagePasses; k++) {
+      const uint32_t r = rb + srow0 + k * srows;
+      if (r < nrows && scol < nq) RAW[r * rowq + scol] = stage[k];
+    }
+  }
+  const uint32_t vt = LZ ? threadIdx.x - 64 : threadIdx.x;
+  if (vt < tile_rows) {
+    const uint32_t y = y0 + vt, yc = y < dh ? y : dh - 1;
+    if constexpr (LZ) {
+      const LTap t = make_ltap(yc, scy);
+#pragma unroll
+      for (int k = 0; k < 6; k++) WY[vt * 8 + k] = t.w[k];
+      WY[vt * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
+    } else {
+      const Tap t = make_tap<VPF_INTERP_LINEAR>(yc, scy, sh);
+      WY[vt * 8] = t.f;
+      WY[vt * 8 + 6] = __int_as_float((int32_t)t.i0 - R0);
+      WY[vt * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
+    }
+  }
+  if constexpr (LZ) {
+    if (wv == 0) {
+      const LTap tx = make_ltap(xc, scx);
+#pragma unroll
+      for (int k = 0; k < 6; k++) WX[k * 64 + lane] = tx.w[k];
+      WX[6 * 64 + lane] = __int_as_float(tx.i0);
+    }
+  }
+  __syncthreads();
+  uint32_t xo[NT];  // float index of tap k's first channel inside the staged row
+  float wx[NT];
+  if constexpr (LZ) {
+    const int32_t i0 = __float_as_int(WX[6 * 64 + lane]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { xo[k] = (clampi(i0 + k - 2, (int32_t)sw - 1) * 4 * CH - base) >> 2; wx[k] = WX[k * 64 + lane]; }
+  } else {
+    const Tap tx = make_tap<VPF_INTERP_LINEAR>(xc, scx, sw);
+    xo[0] = (tx.i0 * 4 * CH - base) >> 2; xo[1] = (tx.i1 * 4 * CH - base) >> 2; wx[0] = tx.f; wx[1] = 0.f;
+  }
+  for (uint32_t r = wv; r < nrows; r += WPB) {
+    const float* b = reinterpret_cast<const float*>(RAW + (size_t)r * rowq);
+    float v[NT][CH];  // all taps requested before the first is used
+#pragma unroll
+    for (int k = 0; k < NT; k++)
+#pragma unroll
+      for (int c = 0; c < CH; c++) v[k][c] = b[xo[k] + c];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      float ra;
+      if constexpr (LZ) {
+        ra = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) ra = __builtin_fmaf(wx[k], v[k][c], ra);
+      } else {
+        ra = __builtin_fmaf(wx[0], v[1][c] - v[0][c], v[0][c]);
+      }
+      H[(r * CH + c) * 64 + lane] = ra;
+    }
+  }
+  __syncthreads();
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const uint32_t cg = lane & 15, rsub = lane >> 4, x0 = xf + 4 * cg;
+  for (uint32_t yb = 0; yb < tile_rows; yb += 4 * WPB) {
+    const uint32_t yy = yb + wv * 4 + rsub, y = y0 + yy;
+    if (yy >= tile_rows || y >= dh || x0 >= dw) continue;
+    const uint32_t r0 = (uint32_t)__float_as_int(WY[yy * 8 + 6]);
+    f32x2 acc[CH][2];
+    if constexpr (LZ) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c][0] = acc[c][1] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 6; ky++) {
+        const float wy = WY[yy * 8 + ky];
+        const f32x2 wy2 = {wy, wy};
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(&H[((r0 + ky) * CH + c) * 64 + 4 * cg]);
+          acc[c][0] = __builtin_elementwise_fma(wy2, f32x2{hv[0], hv[1]}, acc[c][0]);
+          acc[c][1] = __builtin_elementwise_fma(wy2, f32x2{hv[2], hv[3]}, acc[c][1]);
+        }
+      }
+    } else {
+      const uint32_t r1 = (uint32_t)__float_as_int(WY[yy * 8 + 7]);
+      const float fy = WY[yy * 8];
+      const f32x2 fy2 = {fy, fy};
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const f32x4 top = *reinterpret_cast<const f32x4*>(&H[(r0 * CH + c) * 64 + 4 * cg]);
+        const f32x4 bot = *reinterpret_cast<const f32x4*>(&H[(r1 * CH + c) * 64 + 4 * cg]);
+        const f32x2 t0 = {top[0], top[1]}, t1 = {top[2], top[3]}, b0 = {bot[0], bot[1]}, b1 = {bot[2], bot[3]};
+        acc[c][0] = __builtin_elementwise_fma(fy2, b0 - t0, t0);
+        acc[c][1] = __builtin_elementwise_fma(fy2, b1 - t1, t1);
+      }
+    }
+    float* out = reinterpret_cast<float*>(dst + (size_t)y * dp) + (size_t)CH * x0;
+    float o[4 * CH];  // pixel-major
+#pragma unroll
+    for (int c = 0; c < CH; c++) { o[c] = acc[c][0][0]; o[CH + c] = acc[c][0][1]; o[2 * CH + c] = acc[c][1][0]; o[3 * CH + c] = acc[c][1][1]; }
+    if (P.vec_ok && x0 + 4 <= dw) {  // 16-B aligned rows: CH 16-B stores per lane
+#pragma unroll
+      for (int q = 0; q < CH; q++) stg<true, f32x4>(out + 4 * q, f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]});
+    } else {
+      const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
+      for (uint32_t i = 0; i < nv; i++) out[i] = o[i];
     }
   }
 }
@@ -840,7 +1057,8 @@ VPF_DEV void Half3R16Task::run(const uint8_t* __restrict__ src, uint32_t sp, uin
 // constants below are fitted to rocprofv3 kernel durations (profiles/r02_tile_shape_sweep.txt); VPF_TUNE_RESIZE_TILE overrides the
 // choice for such sweeps (ty | wpb << 8) — every shape writes the same pixels.
 struct TileShape { bool ok; uint32_t ty, nr, lds, rowq, lshift; int wpb; };
-static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, const uint32_t* dh, const float* scxs, const float* scys, uint32_t frames) {
+static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, const uint32_t* dh, const float* scxs, const float* scys, uint32_t frames,
+                           int elem = 1 /* bytes per sample: 1, or 4 for float surfaces */) {
   TileShape best{false, 0, 0, 0, 0, 0, 4};
   const double taps = lz ? 6.0 : 2.0;
   int ch_max = 0;
@@ -848,11 +1066,11 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
   float scy = 0.f;
   for (int p = 0; p < np; p++) {
     ch_max = ch[p] > ch_max ? ch[p] : ch_max;
-    const uint32_t q = (uint32_t)((((double)scxs[p] * 63.0 + taps + 3.0) * ch[p] + 32.0) / 16.0) + 1;
+    const uint32_t q = (uint32_t)((((double)scxs[p] * 63.0 + taps + 3.0) * ch[p] * elem + 32.0) / 16.0) + 1;
     rowq = q > rowq ? q : rowq;
     scy = scys[p] > scy ? scys[p] : scy;
   }
-  if (rowq > kLzStripQ || scy > 48.0f) return best;
+  if (rowq > kLzStripQ * (uint32_t)elem || scy > 48.0f) return best;
   uint32_t lshift = 0;
   while ((1u << lshift) < rowq) lshift++;
   const int forced = tuning(VPF_TUNE_RESIZE_TILE);
@@ -861,10 +1079,10 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
     for (uint32_t ty = 4; ty <= 64; ty += 4) {
       if (forced && ((uint32_t)(forced & 0xff) != ty || (forced >> 8) != wpb)) continue;
       const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
-      const uint32_t lds = nr * rowq * 16 + nr * ch_max * 64 * 4 + ty * 8 * 4 + (lz ? 4 * 64 * 4 : 0);  // RAW | H | WY | WX (Lanczos)
+      const uint32_t lds = nr * rowq * 16 + nr * ch_max * 64 * 4 + ty * 8 * 4 + (lz ? (elem == 4 ? 7 : 4) * 64 * 4 : 0);  // RAW | H | WY | WX (Lanczos)
       if (lds > 64u * 1024u) continue;
       const uint32_t srows = (64u * wpb) >> lshift;  // source rows staged per pass
-      if (!srows || (nr + srows - 1) / srows > (uint32_t)kTileStagePasses) continue;
+      if (!srows || (elem == 1 && (nr + srows - 1) / srows > (uint32_t)kTileStagePasses)) continue;  // (the float task stages in rounds)
       double wgs = 0;
       for (int p = 0; p < np; p++) wgs += (double)((dw[p] + 63) / 64) * ((dh[p] + ty - 1) / ty);
       wgs *= frames;
@@ -1057,6 +1275,27 @@ hipError_t launch_resize_f32(hipStream_t st, int ch, int interp, uint32_t sw, ui
   if (interp != VPF_INTERP_NEAREST && sw % dw == 0 && sh % dh == 0 && ((sw / dw) & 1) && ((sh / dh) & 1) && sw < (1u << 22) && sh < (1u << 22) &&
       tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9)
     interp = VPF_INTERP_NEAREST;  // odd integer factors: every filter returns the centre sample (see launch_resize)
+  // Lanczos: the tiled separable form (16-B aligned source rows; 1080p -> 720p 22.7 -> 15.7 us, 720p -> 1080p 42.7 -> 19.5 us); the
+  // gather form below otherwise.  Bilinear stays on the gather form: tiled, a 720p -> 1080p up-scale took 17.0 us against 10.1 (four
+  // times the bytes of an 8-bit surface go through LDS for little reuse); the bilinear branch of TileTaskF32 is reachable with tuning 43.
+  if ((interp == VPF_INTERP_LANCZOS3 || (interp == VPF_INTERP_LINEAR && scy < 1.0f && tuning(VPF_TUNE_NV12_RGB_VARIANT) == 43)) && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 &&
+      tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15)) {
+    const bool lz = interp == VPF_INTERP_LANCZOS3;
+    const TileShape t = plan_tile(lz, 1, &ch, &dw, &dh, &scx, &scy, 1, 4);
+    if (t.ok) {
+      const PlaneGeom g{sw, sh, dw, dh, scx, scy, (int)((((uintptr_t)dst | dp) & 15) == 0), t.ty, t.nr, t.rowq, t.lshift};
+      const dim3 tgrid((dw + 63) / 64, (dh + t.ty - 1) / t.ty);
+      BatchArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.f[0].s[0] = src; a.f[0].sp[0] = sp; a.f[0].d[0] = dst; a.f[0].dp[0] = dp;
+#define VPF_TF(C, L, W) VPF_LAUNCH((k_plane_batch<TileTaskF32<C, L, W>>), tgrid, dim3(64 * W), t.lds, st, a, 0, g)
+#define VPF_TFW(C, L) do { if (t.wpb == 8) VPF_TF(C, L, 8); else VPF_TF(C, L, 4); } while (0)
+      if (ch == 3) { if (lz) VPF_TFW(3, true); else VPF_TFW(3, false); } else { if (lz) VPF_TFW(1, true); else VPF_TFW(1, false); }
+#undef VPF_TFW
+#undef VPF_TF
+      return hipGetLastError();
+    }
+  }
 #define VPF_F32(C, I) VPF_LAUNCH((k_resize_f32<C, I>), grid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy)
   if (ch == 3) {
     if (interp == VPF_INTERP_LANCZOS3) VPF_F32(3, VPF_INTERP_LANCZOS3); else if (interp == VPF_INTERP_LINEAR) VPF_F32(3, VPF_INTERP_LINEAR); else VPF_F32(3, VPF_INTERP_NEAREST);
@@ -1202,6 +1441,22 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const dim3 grid1((j.dw + 63) / 64, (j.dh + 3) / 4, n), grid4(((j.dw + 3) / 4 + 63) / 64, (j.dh + 3) / 4, n);
+    if (f32 && (eff[p] == VPF_INTERP_LANCZOS3 || (eff[p] == VPF_INTERP_LINEAR && g[p].scy < 1.0f && tune == 43)) && tune != 9 && tune != 40 && planes_aligned(a, n, j.k, 15, 0)) {
+      const bool lz = eff[p] == VPF_INTERP_LANCZOS3;
+      const float sx = g[p].scx, sy = g[p].scy;
+      const TileShape t = plan_tile(lz, 1, &j.ch, &j.dw, &j.dh, &sx, &sy, n, 4);
+      if (t.ok) {
+        g[p].vec_ok = planes_aligned(a, n, j.k, 0, 15) ? 1 : 0;
+        g[p].a0 = t.ty; g[p].a1 = t.nr; g[p].a2 = t.rowq; g[p].a3 = t.lshift;
+        const dim3 tgrid((j.dw + 63) / 64, (j.dh + t.ty - 1) / t.ty, n);
+#define VPF_TFB(C, L) do { if (t.wpb == 8) launch_plane_batch<TileTaskF32<C, L, 8>>(st, tgrid, t.lds, a, j.k, g[p]); else launch_plane_batch<TileTaskF32<C, L, 4>>(st, tgrid, t.lds, a, j.k, g[p]); } while (0)
+        if (j.ch == 3) { if (lz) VPF_TFB(3, true); else VPF_TFB(3, false); } else { if (lz) VPF_TFB(1, true); else VPF_TFB(1, false); }
+#undef VPF_TFB
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        continue;
+      }
+    }
     if (f32) {
 #define VPF_F32B(C) do { if (eff[p] == VPF_INTERP_LANCZOS3) launch_plane_batch<FloatGatherTask<C, VPF_INTERP_LANCZOS3>>(st, grid1, 0, a, j.k, g[p]); \
                          else if (eff[p] == VPF_INTERP_LINEAR) launch_plane_batch<FloatGatherTask<C, VPF_INTERP_LINEAR>>(st, grid1, 0, a, j.k, g[p]); \
