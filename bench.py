@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from videoprocessingframework_amd import capi, sharding  # noqa: E402  (capi raises if libvpfhip.so is missing: no fallback)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
 
 
 def _pitched(rows, row_bytes, dev, gen=None, align=256):
@@ -89,7 +89,7 @@ class Workload:
             self.px_per_step = ring * w * h
             self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
             self.launches_per_step = (ring + 31) // 32 if mode == "batch" else ring
-            self.kernel = ("k_nv12_rgb_p16 (16 px/lane, LDS-transposed 1 KiB NT stores; 4 workgroups/CU when batched)" if self.dst_fmt == capi.RGB
+            self.kernel = ("k_nv12_rgb_p16<RGB, NT stores, 4 workgroups/CU, NV12> (16 px/lane, LDS-transposed 1 KiB non-temporal stores)" if self.dst_fmt == capi.RGB
                            else "k_nv12_planar_r16 (one row x 1024 px per wave, 16 px/lane, three 1-KiB non-temporal plane stores)")
         elif name in ("resize_4k_720p", "fused_4k_720p"):
             self.w, self.h, self.dw, self.dh = 3840, 2160, 1280, 720

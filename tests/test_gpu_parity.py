@@ -769,7 +769,7 @@ def test_tuning_hook_rejects_values_outside_the_product(capi):
     for v in (1, 7, 15, 22, 23, 26, 27, 38, 41, 100, -1):
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v) == -1
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 0      # unchanged
-    assert capi.set_tuning(2, 0) == -1                                    # unknown key
+    assert capi.set_tuning(7, 0) == -1                                    # unknown key
     for v in (4, 8, 9, 12, 30, 37, 40, 43, 44):
         capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v)
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == v
