@@ -1059,12 +1059,13 @@ VPF_DEV void Half3R16Task::run(const uint8_t* __restrict__ src, uint32_t sp, uin
   }
 }
 
-// Shape of a tiled launch: destination rows per tile (ty) and waves per workgroup (wpb).  A taller tile computes fewer horizontal
-// dots per destination pixel ((ty - 1) scy + taps + 2 source rows for ty destination rows) but there are fewer of them; what a
-// launch costs is (rounds of workgroups the chip needs) x (time one workgroup takes from its first load to its last store), the
-// latter a chain of dependent steps: weights, then ceil(source rows / waves) row steps per wave, then the vertical passes.  The
-// constants below are fitted to rocprofv3 kernel durations (profiles/r02_tile_shape_sweep.txt); VPF_TUNE_RESIZE_TILE overrides the
-// choice for such sweeps (ty | wpb << 8) — every shape writes the same pixels.
+// Shape of a tiled launch: destination rows per tile (ty) and waves per workgroup (wpb).  A taller tile computes fewer horizontal dots per
+// destination pixel ((ty - 1) scy + taps + 2 source rows for ty destination rows) but there are fewer of them to fill the chip with.
+// Rule read off rocprofv3 kernel durations over (ty, wpb) for six size pairs (profiles/r02_tile_shape_sweep.txt): 8 waves per workgroup
+// always (each wave walks fewer source rows one after the other), and the TALLEST tile that fits LDS and still leaves >= ~900 workgroups
+// (about one full round of the chip at 4 workgroups per CU) — e.g. 1080p -> 720p: ty 16 (900 workgroups, 7.5 us; ty 32: 7.7, ty 8: 9.7),
+// 720p -> 1080p: ty 32 (7.2 us; ty 64: 9.4), 1080p -> 4K: ty 64 (15.5 us; ty 32: 18.9), batches: the tallest that fits.
+// VPF_TUNE_RESIZE_TILE overrides the choice for such sweeps (ty | wpb << 8) — every shape writes the same pixels.
 struct TileShape { bool ok; uint32_t ty, nr, lds, rowq, lshift; int wpb; };
 static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, const uint32_t* dh, const float* scxs, const float* scys, uint32_t frames,
                            int elem = 1 /* bytes per sample: 1, or 4 for float surfaces */) {
@@ -1083,9 +1084,9 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
   uint32_t lshift = 0;
   while ((1u << lshift) < rowq) lshift++;
   const int forced = tuning(VPF_TUNE_RESIZE_TILE);
-  double best_cost = 1e30;
-  for (int wpb = 4; wpb <= 8; wpb += 4)
-    for (uint32_t ty = 4; ty <= 64; ty += 4) {
+  uint32_t best_wgs = 0;
+  for (int wpb = forced ? 4 : 8; wpb <= 8; wpb += 4)
+    for (uint32_t ty = forced ? 4 : 8; ty <= 64; ty += 4) {
       if (forced && ((uint32_t)(forced & 0xff) != ty || (forced >> 8) != wpb)) continue;
       const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
       const uint32_t lds = nr * rowq * 16 + nr * ch_max * 64 * 4 + ty * 8 * 4 + (lz ? (elem == 4 ? 7 : 4) * 64 * 4 : 0);  // RAW | H | WY | WX (Lanczos)
@@ -1095,16 +1096,9 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
       double wgs = 0;
       for (int p = 0; p < np; p++) wgs += (double)((dw[p] + 63) / 64) * ((dh[p] + ty - 1) / ty);
       wgs *= frames;
-      uint32_t resident = (160u * 1024u) / lds;
-      if (resident > 32u / wpb) resident = 32u / wpb;  // 8 waves per SIMD
-      const double rounds = __builtin_ceil(wgs / (256.0 * resident));
-      const double row_steps = __builtin_ceil((double)nr / wpb), vpasses = __builtin_ceil((double)ty / (4.0 * wpb));
-      // one workgroup, microseconds: fixed part (dispatch, staging, weights, barriers) + row steps + vertical passes; the more
-      // workgroups share a CU's SIMDs, the slower each step
-      const double share = 1.0 + 0.15 * (resident * wpb / 4.0 - 1.0);
-      const double t_wg = 1.5 + (0.05 * row_steps + (lz ? 0.22 : 0.10) * vpasses * ch_max / 3.0) * share;
-      const double cost = rounds * t_wg;
-      if (cost < best_cost) { best_cost = cost; best = TileShape{true, ty, nr, lds, rowq, lshift, wpb}; }
+      const uint32_t w = wgs > 4e9 ? 0xffffffffu : (uint32_t)wgs;
+      // candidates come in order of growing ty: take a taller tile while it still leaves >= 900 workgroups; below that, the most workgroups win
+      if (!best.ok || w >= 900u || w > best_wgs) { best = TileShape{true, ty, nr, lds, rowq, lshift, wpb}; best_wgs = w; }
     }
   return best;
 }
