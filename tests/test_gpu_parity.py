@@ -858,3 +858,45 @@ def test_tiled_resize_shapes_write_identical_pixels(capi, oracle, shape):
     finally:
         capi.set_tuning(capi.TUNE_RESIZE_TILE, 0)
     assert capi.set_tuning(capi.TUNE_RESIZE_TILE, 7) == -1 and capi.set_tuning(capi.TUNE_RESIZE_TILE, 16 | (5 << 8)) == -1
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
+def test_fuzz_resize_batch(capi, oracle, seed):
+    """random format (multi-plane formats exercise the one-launch-for-all-planes kernels, odd sizes give the chroma planes their own
+    scale factors), filter, size pair (incl. exact 2x, odd integer factors, up-scales), frame count, alignment and kernel family: every
+    frame of the batch equals the oracle"""
+    rng = np.random.default_rng(13000 + seed)
+    for _ in range(3):
+        fmt = str(rng.choice(["RGB", "BGR", "Y", "NV12", "YUV420", "YUV444", "RGB_PLANAR", "YCBCR"]))
+        interp = int(rng.integers(0, 3))
+        kind = int(rng.integers(5))
+        if kind == 0:      # exact 2x
+            dw, dh = int(rng.integers(2, 200)) * 2, int(rng.integers(1, 30)) * 2
+            sw, sh = 2 * dw, 2 * dh
+        elif kind == 1:    # odd integer factor
+            k = int(rng.choice([3, 5]))
+            dw, dh = int(rng.integers(2, 120)), int(rng.integers(2, 25))
+            sw, sh = k * dw, k * dh
+        elif kind == 2:    # up-scale
+            sw, sh = int(rng.integers(8, 200)), int(rng.integers(6, 40))
+            dw, dh = int(sw * rng.uniform(1.0, 3.0)), int(sh * rng.uniform(1.0, 3.0))
+        else:              # general down-scale
+            sw, sh = int(rng.integers(32, 900)), int(rng.integers(10, 90))
+            dw, dh = max(2, int(sw / rng.uniform(1.0, 4.0))), max(2, int(sh / rng.uniform(1.0, 4.0)))
+        n = int(rng.choice([1, 2, 3, 5]))
+        align, variant = int(rng.choice([256, 256, 16, 4, 1])), int(rng.choice([0, 0, 0, 40, 43, 9]))
+        f, of = getattr(capi, fmt), getattr(oracle, fmt)
+        srcs = [oracle.synth(of, sw, sh, int(rng.integers(1 << 30))) for _ in range(n)]
+        S = [DevPlanes(p, align) for p in srcs]
+        D = [DevPlanes(oracle.alloc(of, dw, dh), align) for _ in range(n)]
+        prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        try:
+            capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+        finally:
+            capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+        torch.cuda.synchronize()
+        for i in range(n):
+            got, intact = D[i].download()
+            assert intact
+            _, want = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.FP32)
+            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} frame {i}")

@@ -9,6 +9,8 @@ from videoprocessingframework_amd import capi
 dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 NAMES = {0: "nearest", 1: "bilinear", 2: "lanczos3"}
+if len(sys.argv) > 1:  # e.g. 43: the tiled kernel for bilinear down-scales too (A/B against the row-pair kernel)
+    capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, int(sys.argv[1]))
 
 
 def surf(fmt, w, h, rand):

@@ -2229,8 +2229,8 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
     if (ok8) {
       const uint32_t rowbytes = (((uint32_t)(255.0 * (double)scx) + 2 + 8 + 8) * 3 + 16 + 15) & ~15u;  // a wave's source span + alignment + tap-window slack
       int r = 0;
-      if ((double)scy * 3.0 + 3.0 <= (double)kStripRows) r = 4;
-      else if ((double)scy + 3.0 <= (double)kStripRows) r = 2;
+      if ((double)scy * 3.0 + 3.01 <= (double)kStripRows) r = 4;  // rows a wave's R destination rows can touch: <= (R - 1) scy + 3 (+ fp32 slack)
+      else if ((double)scy + 3.01 <= (double)kStripRows) r = 2;
       if (dh < 64) r = r ? 2 : 0;  // short pictures: more, smaller tasks
       const uint32_t lds1 = 4u * kStripRows * rowbytes;
       // conversions per destination pixel: scx x ((r - 1) scy + 2) / r source pixels against the four taps of the per-tap kernel —
