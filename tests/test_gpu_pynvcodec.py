@@ -555,3 +555,24 @@ def test_resizer_and_remaper_execute_batch(oracle):
         want = oracle.remap(oracle.RGB, w, h, planes[i], xm, ym)[1][0].reshape(-1)
         assert np.array_equal(download(outs[i])[inside], want[inside]), i
         assert np.array_equal(download(rm.Execute(srcs[i]))[inside], want[inside])
+
+
+def test_resizer_and_remaper_async_opt_out(oracle):
+    """additive SetAsync(True): Execute() stops waiting for the stream (default: blocking, like the reference's cuda_stream_sync callback);
+    same pixels once the stream is synchronised"""
+    w, h, dw, dh = 640, 360, 300, 200
+    planes = oracle.synth(oracle.RGB, w, h, 91)
+    src = upload(PF.RGB, w, h, planes)
+    rs = nvc.PySurfaceResizer(dw, dh, PF.RGB, GPU)
+    assert rs.GetAsync() is False
+    rs.SetAsync(True)
+    assert rs.GetAsync() is True
+    out = rs.Execute(src)
+    torch.cuda.synchronize()
+    assert np.array_equal(download(out), host_frame(oracle.resize(oracle.RGB, 1, w, h, planes, dw, dh, oracle.FP32)[1]))
+    yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
+    rm = nvc.PySurfaceRemaper((xx * 2).astype(np.float32), (yy * 1.5).astype(np.float32), PF.RGB, GPU)
+    rm.SetAsync(True)
+    out = rm.Execute(src)
+    torch.cuda.synchronize()
+    assert np.array_equal(download(out), oracle.remap(oracle.RGB, w, h, planes, (xx * 2).astype(np.float32), (yy * 1.5).astype(np.float32))[1][0].reshape(-1))

@@ -163,6 +163,8 @@ public:
   }
   Pixel_Format GetFormat() const { return fmt_; }
   void SetInterpolation(int i) { rs_->SetInterpolation(i); }
+  void SetAsync(bool on) { rs_->SetAsync(on); }
+  bool GetAsync() const { return rs_->GetAsync(); }
   int GetInterpolation() const { return rs_->GetInterpolation(); }
   std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src) {
     if (!src) return empty_surface(fmt_);
@@ -194,6 +196,8 @@ public:
     rm_.reset(RemapSurface::Make(x.data(), y.data(), (uint32_t)x.shape(1), (uint32_t)x.shape(0), f, ctx, str));
   }
   Pixel_Format GetFormat() const { return fmt_; }
+  void SetAsync(bool on) { rm_->SetAsync(on); }
+  bool GetAsync() const { return rm_->GetAsync(); }
   std::shared_ptr<Surface> Execute(std::shared_ptr<Surface> src) {
     if (!src) return empty_surface(fmt_);
     rm_->SetInput(src.get(), 0U);
@@ -531,6 +535,9 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def("SetInterpolation", &PySurfaceResizer::SetInterpolation, py::arg("interp"),
            "additive: 0 nearest, 1 bilinear (default), 2 Lanczos-3 (the filter the reference requests from NPP)")
       .def("GetInterpolation", &PySurfaceResizer::GetInterpolation)
+      .def("SetAsync", &PySurfaceResizer::SetAsync, py::arg("on"),
+           "additive: Execute() no longer waits for the stream (like PySurfaceConverter); default False = the reference's blocking behaviour")
+      .def("GetAsync", &PySurfaceResizer::GetAsync)
       .def("Execute", &PySurfaceResizer::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>())
       .def("ExecuteBatch", &PySurfaceResizer::ExecuteBatch, py::arg("src"), py::arg("dst"), py::call_guard<py::gil_scoped_release>(),
            "additive: n same-shape surfaces into n caller-owned surfaces, all planes of all frames in as few dispatches as possible; asynchronous on the resizer's stream");
@@ -542,6 +549,8 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](FMap& x, FMap& y, Pixel_Format f, size_t ctx, size_t str) { return new PySurfaceRemaper(x, y, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("x_map"), py::arg("y_map"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceRemaper::GetFormat)
+      .def("SetAsync", &PySurfaceRemaper::SetAsync, py::arg("on"), "additive: Execute() no longer waits for the stream; default False = the reference's blocking behaviour")
+      .def("GetAsync", &PySurfaceRemaper::GetAsync)
       .def("Execute", &PySurfaceRemaper::Execute, py::arg("src"), py::keep_alive<0, 1>(), py::call_guard<py::gil_scoped_release>())
       .def("ExecuteBatch", &PySurfaceRemaper::ExecuteBatch, py::arg("src"), py::arg("dst"), py::call_guard<py::gil_scoped_release>(),
            "additive: the remaper's maps applied to n surfaces into n caller-owned surfaces, one dispatch per 32 frames; asynchronous on the remaper's stream");

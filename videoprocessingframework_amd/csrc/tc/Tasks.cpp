@@ -361,7 +361,10 @@ struct ResizeSurface::Impl {
   StreamRef sref;
   std::unique_ptr<Surface> out;
   int interp = VPF_INTERP_LINEAR;
+  bool async = false;
 };
+void ResizeSurface::SetAsync(bool on) { pImpl->async = on; }
+bool ResizeSurface::GetAsync() const { return pImpl->async; }
 void ResizeSurface::SetInterpolation(int interp) {
   if (interp < VPF_INTERP_NEAREST || interp > VPF_INTERP_LANCZOS3) throw std::invalid_argument("ResizeSurface: unknown interpolation");
   pImpl->interp = interp;
@@ -403,7 +406,7 @@ TaskExecStatus ResizeSurface::Run() {
   const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
   const vpf_status st = vpf_resize(&ex, pImpl->fmt, pImpl->interp, vpf_size{in->Width(), in->Height()}, src,
                                    vpf_size{pImpl->w, pImpl->h}, dst);
-  hip_stream_sync(&pImpl->sref);  // the reference task is blocking (cuda_stream_sync callback)
+  if (!pImpl->async) hip_stream_sync(&pImpl->sref);  // the reference task is blocking (cuda_stream_sync callback); SetAsync(true) opts out
   if (st != VPF_OK) {
     std::cerr << "Failed to resize surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
     return TASK_EXEC_FAIL;
@@ -443,7 +446,10 @@ struct RemapSurface::Impl {
   StreamRef sref;
   std::unique_ptr<CudaBuffer> xmap, ymap;
   std::unique_ptr<Surface> out;
+  bool async = false;
 };
+void RemapSurface::SetAsync(bool on) { pImpl->async = on; }
+bool RemapSurface::GetAsync() const { return pImpl->async; }
 RemapSurface::RemapSurface(const float* x_map, const float* y_map, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str)
     : Task("HipRemapSurface", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl() {
   if (f != RGB && f != BGR) throw std::runtime_error("pixel format not supported");  // Tasks.cpp:1615-1620
@@ -478,7 +484,7 @@ TaskExecStatus RemapSurface::Run() {
   const vpf_status st = vpf_remap(&ex, pImpl->fmt, vpf_size{in->Width(), in->Height()}, src,
                                   (const float*)pImpl->xmap->GpuMem(), pImpl->w * 4, (const float*)pImpl->ymap->GpuMem(),
                                   pImpl->w * 4, vpf_size{pImpl->w, pImpl->h}, dst);
-  hip_stream_sync(&pImpl->sref);
+  if (!pImpl->async) hip_stream_sync(&pImpl->sref);  // blocking like the reference (Tasks.cpp:1630-1640); SetAsync(true) opts out
   if (st != VPF_OK) {
     std::cerr << "Failed to remap surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
     return TASK_EXEC_FAIL;

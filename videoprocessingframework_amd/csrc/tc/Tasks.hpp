@@ -67,6 +67,10 @@ public:
   // 0 nearest, 1 bilinear (default: BASELINE.json north_star), 2 Lanczos-3 (what the reference asks NPP for, :1190)
   void SetInterpolation(int interp);
   int GetInterpolation() const;
+  // additive: Run() stops waiting for the stream (it then behaves like ConvertSurface: asynchronous on the task's stream, the caller
+  // orders later work on that stream or synchronises itself).  Default false = the reference's blocking behaviour.
+  void SetAsync(bool on);
+  bool GetAsync() const;
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
@@ -83,6 +87,8 @@ public:
   TaskExecStatus Run() final;
   // additive: the task's maps applied to n same-shape surfaces -> n caller-owned surfaces of the map's size, one dispatch per 32 frames
   TaskExecStatus RunBatch(Surface* const* inputs, Surface* const* outputs, uint32_t n);
+  void SetAsync(bool on);  // additive: see ResizeSurface::SetAsync
+  bool GetAsync() const;
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
