@@ -33,7 +33,11 @@ def build(force: bool = False) -> str:
     """Compile the oracle (and oracle/_ref when /root/reference exists) with oracle/Makefile."""
     src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("vpf_oracle.c", "vpf_oracle.h", "Makefile"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
-        subprocess.check_call(["make", "-C", _HERE, "libvpforacle.so"], stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # pytest-xdist workers must not link the same file at the same time
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
+                subprocess.check_call(["make", "-C", _HERE, "libvpforacle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src/TC/TC_CORE/src"):
         ref = os.path.join(_HERE, "_ref")
         shim_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_shim.cpp", "ref_tc_shim.cpp", "Makefile"))

@@ -860,6 +860,38 @@ def test_tiled_resize_shapes_write_identical_pixels(capi, oracle, shape):
     assert capi.set_tuning(capi.TUNE_RESIZE_TILE, 7) == -1 and capi.set_tuning(capi.TUNE_RESIZE_TILE, 16 | (5 << 8)) == -1
 
 
+@pytest.mark.parametrize("band", [1, 2, 4, 8])
+def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
+    """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 8 / 4 / 2 for launches with >= 2048
+    workgroups, 1 otherwise).  Every value writes the oracle's pixels: general and > 2x down-scales, shared and disjoint source rows,
+    heights that are not a multiple of the band, one-row pictures, ragged widths, fx == 0 columns (even integer factor on x only), an
+    up-scale forced onto the row-pair family (variant 40: repeated source rows), multi-plane formats, and a 33-frame batch"""
+    cases = [("RGB", 640, 360, 427, 240, 0, 3), ("RGB", 1920, 96, 416, 37, 0, 2), ("NV12", 1280, 72, 854, 48, 0, 3), ("YUV420", 642, 90, 300, 31, 0, 2),
+             ("RGB", 300, 5, 200, 1, 0, 2), ("Y", 997, 61, 333, 47, 0, 2), ("RGB", 512, 90, 128, 61, 0, 2), ("RGB", 200, 50, 333, 77, 40, 2),
+             ("NV12", 200, 50, 320, 96, 40, 2), ("RGB", 640, 360, 224, 224, 0, 33), ("RGB", 1919, 64, 1280, 43, 0, 2)]
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, band) >= 0
+    try:
+        for fmt, sw, sh, dw, dh, variant, n in cases:
+            f, of = getattr(capi, fmt), getattr(oracle, fmt)
+            srcs = [oracle.synth(of, sw, sh, 7100 + i) for i in range(min(n, 3))]
+            S = [DevPlanes(srcs[i % len(srcs)]) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+            prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+            try:
+                capi.resize_batch(capi.make_exec(stream_handle()), f, 1, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+            finally:
+                capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+            torch.cuda.synchronize()
+            wants = [oracle.resize(of, 1, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+            for i in range(n):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, wants[i % len(srcs)], f"band {band} {fmt} {sw}x{sh}->{dw}x{dh} v{variant} frame {i} of {n}")
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 16) == -1
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
 def test_fuzz_resize_batch(capi, oracle, seed):
     """random format (multi-plane formats exercise the one-launch-for-all-planes kernels, odd sizes give the chroma planes their own
@@ -889,14 +921,17 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         srcs = [oracle.synth(of, sw, sh, int(rng.integers(1 << 30))) for _ in range(n)]
         S = [DevPlanes(p, align) for p in srcs]
         D = [DevPlanes(oracle.alloc(of, dw, dh), align) for _ in range(n)]
+        band = int(rng.choice([0, 1, 2, 4, 8]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+        capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
         try:
             capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
         finally:
             capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+            capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
         torch.cuda.synchronize()
         for i in range(n):
             got, intact = D[i].download()
             assert intact
             _, want = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.FP32)
-            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} frame {i}")
+            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} frame {i}")

@@ -11,6 +11,9 @@ ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 NAMES = {0: "nearest", 1: "bilinear", 2: "lanczos3"}
 if len(sys.argv) > 1:  # e.g. 43: the tiled kernel for bilinear down-scales too (A/B against the row-pair kernel)
     capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, int(sys.argv[1]))
+BAND = int(os.environ.get("VPF_BENCH_BAND", "0"))        # rows per wave of the row-pair kernels (0 = policy)
+ONLY = os.environ.get("VPF_BENCH_ONLY", "")              # "bilinear": skip the Lanczos lines and the remap section
+capi.set_tuning(capi.TUNE_RESIZE_BAND, BAND)
 
 
 def surf(fmt, w, h, rand):
@@ -49,18 +52,23 @@ for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420
         batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
         planes = [(capi.planes(s[1]), capi.planes(d[1])) for s, d in zip(S, D)]
         nbytes = S[0][2] + D[0][2]
-        for interp in (1, 2):
+        for interp in ((1,) if ONLY == "bilinear" else (1, 2)):
             if fmt != capi.RGB and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
                 continue
             tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
             ts = timed(lambda: [capi.resize(ex, fmt, interp, sw, sh, s, dw, dh, d) for s, d in planes], 3) / ring
+            extra = ""
+            if os.environ.get("VPF_BENCH_ONE"):  # batches of ONE frame: the multi-plane / band kernels at single-frame launch sizes
+                ones = [capi.make_batch([(s[1], d[1])]) for s, d in zip(S, D)]
+                t1 = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in ones], 3) / ring
+                extra = f" | batches of one {t1:6.2f} us/frame ({nbytes / t1 / 8e6:.2f})"
             print(f"[resize_batch] {fname:6s} {sw}x{sh}->{dw}x{dh} {NAMES[interp]:8s}: batched {tb:6.2f} us/frame = {nbytes / tb / 1e6:5.2f} TB/s ({nbytes / tb / 8e6:.2f} of 8 TB/s)"
-                  f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f})  ring {ring}", flush=True)
+                  f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f}){extra}  ring {ring}", flush=True)
         del S, D, batch, planes
         torch.cuda.empty_cache()
 
 # remap: one pair of maps, many frames
-for (w, h) in ((1920, 1080), (3840, 2160)):
+for (w, h) in (() if ONLY else ((1920, 1080), (3840, 2160))):
     ring = 32
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
     nx, ny = (xx - (w - 1) / 2) / ((w - 1) / 2), (yy - (h - 1) / 2) / ((h - 1) / 2)

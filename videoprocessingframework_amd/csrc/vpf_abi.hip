@@ -82,8 +82,10 @@ void note_kernel(const char* k) {
   if (trace_on() && g_roctx_mark) g_roctx_mark(k);
 }
 
-static std::atomic<int> g_tune_variant{0}, g_tune_tile{0};
-int tuning(int key) { return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : (key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : 0); }
+static std::atomic<int> g_tune_variant{0}, g_tune_tile{0}, g_tune_band{0};
+int tuning(int key) {
+  return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : key == VPF_TUNE_RESIZE_BAND ? g_tune_band.load() : 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // format helpers
@@ -420,6 +422,7 @@ int vpf_set_tuning(int key, int value) {
     if (value != 0 && (ty < 4 || ty > 64 || (ty & 3) || (wpb != 4 && wpb != 8))) return -1;
     return g_tune_tile.exchange(value);
   }
+  if (key == VPF_TUNE_RESIZE_BAND) return (value == 0 || value == 1 || value == 2 || value == 4 || value == 8) ? g_tune_band.exchange(value) : -1;
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
     case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: return g_tune_variant.exchange(value);
