@@ -892,6 +892,34 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 16) == -1
 
 
+@pytest.mark.parametrize("rows", [1, 2, 7, 24, 64])
+def test_lanczos_march_kernel_writes_the_tiled_kernel_pixels(capi, oracle, rows):
+    """VPF_TUNE_RESIZE_MARCH = destination rows per wave of the barrier-free Lanczos kernel (policy: batches that leave >= 6144 waves;
+    1 = never).  Every value writes the oracle's pixels: down- and up-scales, chunks on the left / right image edge (replicated margin
+    pixels) and pictures narrower than one chunk, bands cut by the bottom edge, vertical factors above 6 (source rows nobody blends),
+    multi-plane formats (chroma planes with their own factors), heights below one band, a 33-frame batch"""
+    cases = [("RGB", 640, 360, 427, 240, 3), ("RGB", 320, 180, 1280, 720, 2), ("NV12", 1280, 72, 854, 48, 3), ("YUV420", 642, 90, 300, 31, 2),
+             ("RGB", 300, 50, 200, 7, 2), ("Y", 997, 61, 333, 47, 2), ("RGB", 96, 54, 700, 33, 2), ("RGB", 640, 360, 224, 224, 33), ("RGB", 1919, 64, 1280, 43, 2),
+             ("YUV444", 100, 60, 333, 201, 2), ("RGB", 20, 12, 45, 31, 2)]
+    assert capi.set_tuning(capi.TUNE_RESIZE_MARCH, rows) >= 0
+    try:
+        for fmt, sw, sh, dw, dh, n in cases:
+            f, of = getattr(capi, fmt), getattr(oracle, fmt)
+            srcs = [oracle.synth(of, sw, sh, 7300 + i) for i in range(min(n, 3))]
+            S = [DevPlanes(srcs[i % len(srcs)]) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+            capi.resize_batch(capi.make_exec(stream_handle()), f, 2, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+            torch.cuda.synchronize()
+            wants = [oracle.resize(of, 2, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+            for i in range(n):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, wants[i % len(srcs)], f"march rows {rows} {fmt} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_MARCH, 0)
+    assert capi.set_tuning(capi.TUNE_RESIZE_MARCH, 65) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MARCH, -1) == -1
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
 def test_fuzz_resize_batch(capi, oracle, seed):
     """random format (multi-plane formats exercise the one-launch-for-all-planes kernels, odd sizes give the chroma planes their own
@@ -924,14 +952,17 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         band = int(rng.choice([0, 1, 2, 4, 8]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
+        march = int(rng.choice([0, 1, 2, 5, 16, 64]))  # rows per wave of the Lanczos march kernel (small batches would never reach it by policy)
+        capi.set_tuning(capi.TUNE_RESIZE_MARCH, march)
         try:
             capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
         finally:
             capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
             capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
+            capi.set_tuning(capi.TUNE_RESIZE_MARCH, 0)
         torch.cuda.synchronize()
         for i in range(n):
             got, intact = D[i].download()
             assert intact
             _, want = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.FP32)
-            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} frame {i}")
+            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} march{march} frame {i}")

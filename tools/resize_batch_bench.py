@@ -14,6 +14,7 @@ if len(sys.argv) > 1:  # e.g. 43: the tiled kernel for bilinear down-scales too 
 BAND = int(os.environ.get("VPF_BENCH_BAND", "0"))        # rows per wave of the row-pair kernels (0 = policy)
 ONLY = os.environ.get("VPF_BENCH_ONLY", "")              # "bilinear": skip the Lanczos lines and the remap section
 capi.set_tuning(capi.TUNE_RESIZE_BAND, BAND)
+capi.set_tuning(capi.TUNE_RESIZE_MARCH, int(os.environ.get("VPF_BENCH_MARCH", "0")))  # rows per wave of the Lanczos march kernel (0 = policy, 1 = never)
 
 
 def surf(fmt, w, h, rand):
@@ -49,13 +50,19 @@ for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420
         ring = max(32, min(256, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // 32 * 32))
         S = [surf(fmt, sw, sh, True) for _ in range(ring)]
         D = [surf(fmt, dw, dh, False) for _ in range(ring)]
+        NB = int(os.environ.get("VPF_BENCH_N", "0"))  # frames per batch (0: the whole ring, in dispatches of 32)
+        if NB:
+            batches = [capi.make_batch([(s[1], d[1]) for s, d in list(zip(S, D))[i:i + NB]]) for i in range(0, ring, NB)]
         batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
         planes = [(capi.planes(s[1]), capi.planes(d[1])) for s, d in zip(S, D)]
         nbytes = S[0][2] + D[0][2]
-        for interp in ((1,) if ONLY == "bilinear" else (1, 2)):
+        for interp in ((1,) if ONLY == "bilinear" else (2,) if ONLY == "lanczos" else (1, 2)):
             if fmt != capi.RGB and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
                 continue
-            tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
+            if NB:
+                tb = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in batches], 5) / ring
+            else:
+                tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
             ts = timed(lambda: [capi.resize(ex, fmt, interp, sw, sh, s, dw, dh, d) for s, d in planes], 3) / ring
             extra = ""
             if os.environ.get("VPF_BENCH_ONE"):  # batches of ONE frame: the multi-plane / band kernels at single-frame launch sizes

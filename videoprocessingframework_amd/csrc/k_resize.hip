@@ -22,6 +22,7 @@
 //                                         kernels' byte-move and direct-pack paths (bilinear, fused)
 //   packed RGB taps                       both taps of a row = 6 contiguous bytes: fetched as ONE 12-B window from the
 //                                         aligned address below (global or LDS) and cut out with v_alignbyte_b32
+#include <algorithm>
 #include <cstring>
 
 #include "vpf_device.h"
@@ -562,6 +563,48 @@ VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH>& T, float* H) {  //
     }
   }
 }
+// Destination rows ya..yb (at most R) of a band whose source rows r_lo.. sit in LDS `rowbytes` apart: the two current source rows'
+// horizontal lerps stay in registers and move up (Hb -> Ha) as the destination rows walk down.  put(y, o) receives o[] = pixel-major, + 0.5 added.
+template <int CH, int R, class Put>
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, float scy, uint32_t sh, const ColTaps<CH>& T, Put&& put) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float Ha[4 * CH], Hb[4 * CH];       // horizontal lerps of source rows ida (upper tap) and idb (lower tap)
+  uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    if (ya + i > yb) break;
+    const Tap t = make_tap<VPF_INTERP_LINEAR>(ya + i, scy, sh);
+    const uint32_t i0 = __builtin_amdgcn_readfirstlane(t.i0), i1 = __builtin_amdgcn_readfirstlane(t.i1);
+    const float fy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t.f)));
+    if (i0 != ida) {
+      if (i0 == idb) {
+#pragma unroll
+        for (int q = 0; q < 4 * CH; q++) Ha[q] = Hb[q];
+      } else {
+        band_hlerp4<CH>(strips + (size_t)(i0 - r_lo) * rowbytes, T, Ha);
+      }
+      ida = i0;
+    }
+    if (i1 != idb) {
+      if (i1 == ida) {
+#pragma unroll
+        for (int q = 0; q < 4 * CH; q++) Hb[q] = Ha[q];
+      } else {
+        band_hlerp4<CH>(strips + (size_t)(i1 - r_lo) * rowbytes, T, Hb);
+      }
+      idb = i1;
+    }
+    float o[4 * CH];
+    const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
+#pragma unroll
+    for (int q = 0; q < 4 * CH; q += 2) {
+      const f32x2 top = {Ha[q], Ha[q + 1]}, bot = {Hb[q], Hb[q + 1]};
+      const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
+      o[q] = v[0]; o[q + 1] = v[1];
+    }
+    put(ya + i, o);
+  }
+}
 template <int CH, int R>
 struct RowBandTask {
   static constexpr int kThreads = 256;
@@ -595,43 +638,9 @@ VPF_DEV void RowBandTask<CH, R>::run(const uint8_t* __restrict__ src, uint32_t s
   const ColTaps<CH> T = make_col_taps<CH>(base, x0, dw, sw, scx);
   const bool vec4 = G.vec_ok && x0 + 4 <= dw;
   const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  float Ha[4 * CH], Hb[4 * CH];       // horizontal lerps of source rows ida (upper tap) and idb (lower tap)
-  uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    if (ya + i > yb) break;
-    const Tap t = make_tap<VPF_INTERP_LINEAR>(ya + i, scy, sh);
-    const uint32_t i0 = __builtin_amdgcn_readfirstlane(t.i0), i1 = __builtin_amdgcn_readfirstlane(t.i1);
-    const float fy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t.f)));
-    if (i0 != ida) {
-      if (i0 == idb) {
-#pragma unroll
-        for (int q = 0; q < 4 * CH; q++) Ha[q] = Hb[q];
-      } else {
-        band_hlerp4<CH>(reinterpret_cast<const uint8_t*>(strips + (size_t)(i0 - r_lo) * rowq), T, Ha);
-      }
-      ida = i0;
-    }
-    if (i1 != idb) {
-      if (i1 == ida) {
-#pragma unroll
-        for (int q = 0; q < 4 * CH; q++) Hb[q] = Ha[q];
-      } else {
-        band_hlerp4<CH>(reinterpret_cast<const uint8_t*>(strips + (size_t)(i1 - r_lo) * rowq), T, Hb);
-      }
-      idb = i1;
-    }
-    float o[4 * CH];
-    const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
-#pragma unroll
-    for (int q = 0; q < 4 * CH; q += 2) {
-      const f32x2 top = {Ha[q], Ha[q + 1]}, bot = {Hb[q], Hb[q + 1]};
-      const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
-      o[q] = v[0]; o[q + 1] = v[1];
-    }
-    store_blend4<CH>(dst + (size_t)(ya + i) * dp + (size_t)CH * x0, o, vec4, nv);
-  }
+  band_blend_rows<CH, R>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo, ya, yb, scy, sh, T, [&](uint32_t y, const float* o) {
+    store_blend4<CH>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -884,6 +893,183 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
     }
   }
 }
+// ------------------------------------------------------------------------------------------
+// Lanczos-3 "march" (batches): a WAVE owns 256 destination columns and walks down a band of G.a1 destination rows on its own — no
+// workgroup barrier, no H plane in LDS.  The horizontal Q14 sums of the six source rows under the current destination row live in
+// REGISTERS (a ring of six rows x 4 pixels x CH values per lane; the walk is unrolled six source rows deep so that every slot number
+// is a compile-time constant and the ring never moves), so a source row's horizontal pass is evaluated once per band — (R - 1) scy + 6
+// evaluations for R destination rows, 1.7 per row at a 1.5x down-scale with R = 24 — and the vertical pass reads nothing but
+// registers and six broadcast weights.  Source rows reach the wave through a private LDS strip, kMarchGroup rows per memory round
+// trip; the pixels an image edge clamps to are REPLICATED into the strip's margins while staging, so every lane's taps are contiguous
+// bytes everywhere (the tiled kernel walks edge tiles byte by byte).  Column weights are computed once per band and lane (4 sets),
+// the band's vertical weight sets by the first R lanes in one go (v_readlane_b32 hands row y's set to the wave).
+// Same exact integer sums and the same vertical fma chain (tap 0 first, accumulator from 0, x 2^-14, v_cvt_pk_u8_f32) as TileTask /
+// LanczosGatherTask / the oracle -> same bytes.  VALU instructions per destination pixel at 1080p -> 720p: 2.31 (TileLz8) -> see
+// profiles/r02_pmc_resize_batch.txt.
+// ------------------------------------------------------------------------------------------
+constexpr int kMarchGroup = 4;       // source rows staged per round trip
+constexpr uint32_t kMarchPad = 16;   // bytes in front of a strip's first real byte: room for up to 3 replicated pixels (and 16-B aligned stores)
+template <int CH>
+struct LanczosMarchTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
+template <int CH>
+VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                       uint32_t bx, uint32_t by) {
+  constexpr int PX = 4, NV = PX * CH;
+  constexpr int NE = (6 * CH + 3) / 4;  // dwords of a pixel's lead-free run of 6 x CH tap bytes
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, R = G.a1;
+  const float scx = G.scx, scy = G.scy;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t ya = (by * 4 + wv) * R, xs = bx * 256;
+  if (ya >= dh || xs >= dw) return;
+  const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  // columns: virtual source pixels [first_v, last_v] (taps before pixel 0 / after pixel sw - 1 exist in the strip as copies of the edge pixel)
+  const int32_t first_v = __builtin_amdgcn_readfirstlane(ltap_i0(xs, scx) - 2), last_v = __builtin_amdgcn_readfirstlane(ltap_i0(xe, scx) + 3);
+  const uint32_t first_r = first_v < 0 ? 0u : (uint32_t)first_v, last_r = last_v > (int32_t)sw - 1 ? sw - 1 : (uint32_t)last_v;
+  const uint32_t base = (CH * first_r) & ~15u, nq = (CH * (last_r + 1) - base + 15) / 16;
+  u32x4* const strips = dyn_strip + (size_t)wv * kMarchGroup * rowq;
+  const uint32_t x0 = xs + lane * PX;
+  uint32_t qx[PX][3], qoff[PX], lead[PX];
+#pragma unroll
+  for (int k = 0; k < PX; k++) {
+    const uint32_t xc = x0 + k < dw ? x0 + k : dw - 1;  // lanes / pixels past the right edge compute a duplicate, never stored
+    const QTap t = quantize_ltap(make_ltap(xc, scx));
+#pragma unroll
+    for (int j = 0; j < 3; j++) qx[k][j] = pack_i16(t.q[2 * j], t.q[2 * j + 1]);
+    const uint32_t off = (uint32_t)((int32_t)CH * (t.i0 - 2) - (int32_t)base + (int32_t)kMarchPad);  // >= 7: i0 - 2 >= -3 where base == 0
+    qoff[k] = off & ~3u; lead[k] = off & 3u;
+  }
+  // rows: lane l holds the vertical tap set of destination row ya + l (R <= 64)
+  const LTap tyl = make_ltap(ya + lane < dh ? ya + lane : dh - 1, scy);
+  const int32_t jlast = __builtin_amdgcn_readlane(tyl.i0, yb - ya) + 3;  // last virtual source row of the band
+  int32_t hnext = __builtin_amdgcn_readlane(tyl.i0, 0) - 2;             // next virtual source row to evaluate
+  int32_t staged_lo = hnext, staged_hi = hnext - 1;                     // virtual rows in the strips: slot = row - staged_lo
+  float ring[6][NV];                                                     // horizontal sums of virtual rows hnext - 6 .. hnext - 1
+
+  // Source rows travel global memory -> registers -> LDS in groups of kMarchGroup, one group AHEAD of the arithmetic: fetch() requests
+  // a group, commit() (called when the horizontal pass runs out of staged rows) moves it to the strips and requests the next one,
+  // which then has the horizontal passes of kMarchGroup rows and the vertical passes in between to arrive.
+  Span<2> pf[kMarchGroup];
+  int32_t pf_lo = 0, pf_hi = -1;
+  auto fetch = [&](int32_t lo) {
+    pf_lo = lo;
+    pf_hi = lo + kMarchGroup - 1 < jlast ? lo + kMarchGroup - 1 : jlast;
+#pragma unroll
+    for (int g = 0; g < kMarchGroup; g++)
+      if (lo + g <= pf_hi) {
+        const int32_t r = lo + g;
+        pf[g].load(src + (size_t)(r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r)) * sp, base, nq, lane);
+      }
+  };
+  auto commit = [&]() {
+    staged_lo = pf_lo; staged_hi = pf_hi;
+#pragma unroll
+    for (int g = 0; g < kMarchGroup; g++)
+      if (staged_lo + g <= staged_hi) pf[g].store(strips + (size_t)g * rowq + kMarchPad / 16, nq, lane);
+    if (staged_hi < jlast) fetch(staged_hi + 1);
+    if (first_v < 0 || last_v > (int32_t)sw - 1) {  // wave-uniform: this chunk touches an image edge
+      wave_lds_sync();
+#pragma unroll
+      for (int g = 0; g < kMarchGroup; g++)
+        if (staged_lo + g <= staged_hi) {
+          uint8_t* b = reinterpret_cast<uint8_t*>(strips + (size_t)g * rowq);
+          if (first_v < 0 && lane < (uint32_t)(-first_v) * CH) b[kMarchPad + CH * first_v + (int32_t)lane] = b[kMarchPad + lane % CH];  // base == 0 here
+          const int32_t nr = last_v - ((int32_t)sw - 1);
+          if (nr > 0 && lane < (uint32_t)nr * CH) b[kMarchPad + CH * sw - base + lane] = b[kMarchPad + CH * (sw - 1) - base + lane % CH];
+        }
+    }
+    wave_lds_sync();
+  };
+  fetch(hnext);
+  // one source row's horizontal pass: 4 pixels x CH exact Q14 sums -> h[]
+  auto hrow = [&](uint32_t slot, float* h) {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(strips + (size_t)slot * rowq);
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(b + qoff[k]);
+      uint32_t d[NE + 1], e[NE];
+#pragma unroll
+      for (int i = 0; i <= NE; i++) d[i] = q[i];
+#pragma unroll
+      for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead[k]);
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c (see TileTask)
+        if constexpr (CH == 3) {
+          p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+          p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
+          p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+        } else if constexpr (CH == 2) {
+          const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
+          p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
+        } else {
+          p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
+        }
+        h[k * CH + c] = (float)dot2(p2, qx[k][2], dot2(p1, qx[k][1], dot2z(p0, qx[k][0])));  // exact: |h| < 2^24
+      }
+    }
+  };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool vec4 = G.vec_ok && x0 + 4 <= dw;
+  // The walk runs over SOURCE rows, six per trip of the loop, so that the ring slot a row's sums go to — and with it the slots of the
+  // six taps of every destination row that ends on this source row (taps hnext - 5 .. hnext = slots S + 1 .. S + 6 mod 6) — are
+  // compile-time constants: the ring stays where it is in the register file (a run-time slot number made the compiler rotate 72
+  // registers per source row).  A destination row is emitted as soon as its last source row has been evaluated.
+  uint32_t y = ya;
+  int32_t jy = __builtin_amdgcn_readlane(tyl.i0, 0) + 3;  // last virtual source row under destination row y
+  auto emit = [&](const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5) {
+    const uint32_t li = y - ya;
+    float wy[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) wy[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tyl.w[k]), li));
+    const float* tap[6] = {t0, t1, t2, t3, t4, t5};
+    f32x2 acc[NV / 2];
+#pragma unroll
+    for (int q = 0; q < NV / 2; q++) acc[q] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 6; ky++) {
+      const f32x2 w2 = {wy[ky], wy[ky]};
+#pragma unroll
+      for (int q = 0; q < NV / 2; q++) acc[q] = __builtin_elementwise_fma(w2, f32x2{tap[ky][2 * q], tap[ky][2 * q + 1]}, acc[q]);
+    }
+    if (x0 < dw) {
+      float o[NV];  // pixel-major
+#pragma unroll
+      for (int q = 0; q < NV / 2; q++) {
+        const f32x2 v = acc[q] * f32x2{kQ14Inv, kQ14Inv};
+        o[2 * q] = v[0]; o[2 * q + 1] = v[1];
+      }
+      uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
+      if (vec4) {
+        if constexpr (CH == 3) {
+          stg3<true>(out, pack4<1>(o[0], o[1], o[2], o[3]), pack4<1>(o[4], o[5], o[6], o[7]), pack4<1>(o[8], o[9], o[10], o[11]));
+        } else if constexpr (CH == 2) {
+          stg<true, u32x2>(out, u32x2{pack4<1>(o[0], o[1], o[2], o[3]), pack4<1>(o[4], o[5], o[6], o[7])});
+        } else {
+          stg<true, uint32_t>(out, pack4<1>(o[0], o[1], o[2], o[3]));
+        }
+      } else {
+        const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
+        for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_rne(o[i]);
+      }
+    }
+    y++;
+    if (y <= yb) jy = __builtin_amdgcn_readlane(tyl.i0, y - ya) + 3;
+  };
+#define VPF_MARCH_STEP(S)                                                                                                                   \
+  if (hnext > jlast) break;                                                                                                                \
+  if (hnext > staged_hi) commit();                                                                                                         \
+  hrow((uint32_t)(hnext - staged_lo), ring[S]);                                                                                            \
+  while (y <= yb && jy == hnext) emit(ring[((S) + 1) % 6], ring[((S) + 2) % 6], ring[((S) + 3) % 6], ring[((S) + 4) % 6], ring[((S) + 5) % 6], ring[S]); \
+  hnext++;
+  for (;;) {
+    VPF_MARCH_STEP(0) VPF_MARCH_STEP(1) VPF_MARCH_STEP(2) VPF_MARCH_STEP(3) VPF_MARCH_STEP(4) VPF_MARCH_STEP(5)
+  }
+#undef VPF_MARCH_STEP
+}
+
 // The same tiling for 32-bit float surfaces (RGB_32F: CH = 3 interleaved, RGB_32F_PLANAR: CH = 1 per plane; reference
 // NppResizeSurfacePacked32F3C_Impl / NppResizeSurface32FPlanar_Impl, Tasks.cpp:1334-1445).  Samples are floats, so both passes are
 // fp32 fma chains in FloatGatherTask's order (tap 0 first, row 0 first, accumulators starting at 0; bilinear: its two lerps): results
@@ -1060,6 +1246,7 @@ template <int CH> struct RowPair4 : RowPairTask<CH, 4> {};
 template <int CH> struct RowBand2 : RowBandTask<CH, 2> {};
 template <int CH> struct RowBand4 : RowBandTask<CH, 4> {};
 template <int CH> struct RowBand8 : RowBandTask<CH, 8> {};
+template <int CH> struct LzMarch : LanczosMarchTask<CH> {};
 
 // ------------------------------------------------------------------------------------------
 // Exact 2x bilinear down-scale (4K -> 1080p ...): s = 2 d + 0.5 exactly, so every destination pixel is the fx = fy = 0.5
@@ -1498,6 +1685,55 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
   return {1, 0};
 }
 
+// Lanczos march (LanczosMarchTask): destination rows per wave (R) and strip size, or rows == 0 when the tiled kernel keeps the launch.
+// Every plane's 256-column source span must fit a 2-KiB strip and the vertical factor must stay below 6 (no skipped source rows).
+// The kernel is VALU-bound with three waves per SIMD resident (167 VGPRs), i.e. three 4-wave workgroups per CU, and every wave of a
+// plane does the same work, so a launch lasts about ceil(workgroups / 768) rounds of one wave's time, and a wave's time grows with R as
+// a fixed part (column and row weight sets) + ((R - 1) scy + 6) horizontal passes + R vertical passes (measured: 166 and 80 VALU
+// instructions per 256 columns of packed RGB).  R is the value that minimises rounds x wave time — 32 frames 1080p -> 720p: R = 20
+// (1440 workgroups, two rounds filled to 94 %) where R = 16 spends a third round on half the chip and R = 19 (38 bands = 9.5
+// workgroups per column of chunks) a third round on a twelfth of it (3.52 us / frame against 3.10, profiles/r02_lanczos_march.txt).
+// The tiled kernel keeps what the march does not win (A/B over batch sizes 2 .. 32 and six size pairs, profiles/r02_lanczos_march.txt):
+// launches under ~700 workgroups (its 64-column tiles spread a small job wider), multi-plane formats under ~1400 (the 1- and
+// 2-channel planes pay the per-band weight sets for a third / two thirds of the pixels), and up-scales whose best R is below 20 (the
+// six extra source rows of a short band cost more than the tiled kernel's barriers).
+constexpr uint32_t kMarchGroupSlots = 768;  // 256 CUs x 3 workgroups
+struct MarchShape { uint32_t rows, rowq; };
+static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
+  const int forced = tuning(VPF_TUNE_RESIZE_MARCH);
+  if (forced == 1) return {0, 0};
+  uint32_t rowq = 0;
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    const double scx = (double)j.sw / (double)j.dw, sy = (double)j.sh / (double)j.dh;
+    const uint32_t span_px = (uint32_t)(255.0 * scx) + 8;  // taps of 256 columns: floor(255 scx) + 6 (+ fp32 slack)
+    if ((uint32_t)j.ch * span_px > 2018u || sy > 5.9) return {0, 0};
+    const uint32_t q = (kMarchPad + 15u + (uint32_t)j.ch * span_px + 8u + 15u) / 16u;
+    rowq = q > rowq ? q : rowq;
+  }
+  if (forced) return {(uint32_t)forced, rowq};
+  uint32_t best = 0;
+  double best_cost = 0.0;
+  uint64_t best_groups = 0;
+  for (uint32_t r = 6; r <= 64; r++) {
+    uint64_t groups = 0;
+    double work = 0.0;
+    for (int p = 0; p < njobs; p++) {
+      const ResizeJob& j = jobs[p];
+      const uint64_t g = (uint64_t)((j.dw + 255) / 256) * (((j.dh + r - 1) / r + 3) / 4) * n;
+      const double sy = (double)j.sh / (double)j.dh;
+      groups += g;
+      work += (double)g * (700.0 + ((double)(r - 1) * sy + 6.0) * (40.0 + 42.0 * j.ch) + (double)r * (20.0 + 20.0 * j.ch));
+    }
+    const double cost = (double)((groups + kMarchGroupSlots - 1) / kMarchGroupSlots) * work / (double)groups;
+    if (!best || cost < best_cost) { best = r; best_cost = cost; best_groups = groups; }
+  }
+  double scy_min = 1e9;
+  for (int p = 0; p < njobs; p++) scy_min = std::min(scy_min, (double)jobs[p].sh / (double)jobs[p].dh);
+  if (best_groups < 700 || (njobs > 1 && best_groups < 1400) || njobs == 3 || (scy_min < 1.0 && best < 20)) return {0, 0};  // three 1-channel planes: no gain measured (2.74 vs 2.54 us, 8.16 vs 8.19)
+  return {best, rowq};
+}
+
 hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
   enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
@@ -1558,6 +1794,23 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
   for (int p = 0; p < njobs; p++) {
     all_tile = all_tile && fam[p] == FAM_TILE && eff[p] == eff[0];
     all_rowpair = all_rowpair && fam[p] == FAM_ROWPAIR;
+  }
+  if (all_tile && eff[0] == VPF_INTERP_LANCZOS3 && tune != 40) {  // a batch of Lanczos planes: the barrier-free march kernel when the launch is large enough
+    const MarchShape ms = plan_march(njobs, jobs, n);
+    if (ms.rows) {
+      PlaneTable t{};
+      t.np = (uint32_t)njobs;
+      uint32_t gx = 0, gy = 0;
+      for (int p = 0; p < njobs; p++) {
+        t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
+        t.g[p].a0 = ms.rowq; t.g[p].a1 = ms.rows;
+        const uint32_t bx = (jobs[p].dw + 255) / 256;
+        gx = bx > gx ? bx : gx;
+        gy += (jobs[p].dh + 4 * ms.rows - 1) / (4 * ms.rows);
+      }
+      launch_planes_mp<LzMarch>(st, dim3(gx, gy, n), 4u * kMarchGroup * ms.rowq * 16u, a, t);
+      return hipGetLastError();
+    }
   }
   TileShape ts{false, 0, 0, 0, 0, 0, 4};
   if (all_tile) {
@@ -2348,14 +2601,8 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
   if (x0 >= dw) return;
   const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
   const ColTaps<3> T = make_col_taps<3>(3 * base_px, x0, dw, sw, scx);  // once for the R rows
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const uint32_t y = ya + i;
-    if (y > yb) break;
-    const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
-    const bool row1 = __builtin_amdgcn_readfirstlane(__float_as_uint(ty.f)) != 0u;
-    float o[12];  // pixel-major R G B, + 0.5 added
-    rowpair_blend4<3>(strip + (size_t)(ty.i0 - r_lo) * rowbytes, strip + (size_t)(ty.i1 - r_lo) * rowbytes, row1, ty.f, T, o);
+  // the band walk of RowBandTask: every strip row's horizontal lerp is evaluated once and shared by the destination rows that blend it
+  band_blend_rows<3, R>(strip, rowbytes, r_lo, ya, yb, scy, sh, T, [&](uint32_t y, const float* o) {  // o: pixel-major R G B, + 0.5 added
     if constexpr (DST == FC_PLANAR) {
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) {
@@ -2375,7 +2622,7 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
         }
       }
     }
-  }
+  });
 }
 template <int SRC, int DST, int R>
 __global__ __launch_bounds__(256) void k_convert_strip(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
@@ -2423,9 +2670,11 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
     if (ok8) {
       const uint32_t rowbytes = (((uint32_t)(255.0 * (double)scx) + 2 + 8 + 8) * 3 + 16 + 15) & ~15u;  // a wave's source span + alignment + tap-window slack
       int r = 0;
-      if ((double)scy * 3.0 + 3.01 <= (double)kStripRows) r = 4;  // rows a wave's R destination rows can touch: <= (R - 1) scy + 3 (+ fp32 slack)
+      if ((double)scy * 7.0 + 3.01 <= (double)kStripRows) r = 8;  // rows a wave's R destination rows can touch: <= (R - 1) scy + 3 (+ fp32 slack)
+      else if ((double)scy * 3.0 + 3.01 <= (double)kStripRows) r = 4;
       else if ((double)scy + 3.01 <= (double)kStripRows) r = 2;
       if (dh < 64) r = r ? 2 : 0;  // short pictures: more, smaller tasks
+      if (r == 8 && (uint64_t)((dw + 255) / 256) * ((dh + 31) / 32) * n < 2048) r = 4;  // keep the chip covered
       const uint32_t lds1 = 4u * kStripRows * rowbytes;
       // conversions per destination pixel: scx x ((r - 1) scy + 2) / r source pixels against the four taps of the per-tap kernel —
       // measured break-even near 2x (4K -> 1600x900, 2.4x: 9.5 us here vs 5.2 us per-tap; 1080p -> 720p: 2.36 vs 3.21; 1080p -> 4K: 15.0 vs 23.6)
@@ -2433,7 +2682,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       if (r && lds1 <= 64u * 1024u && conv_per_px <= 3.0) {
         dim3 sgrid((dw + 255) / 256, (dh + 4 * r - 1) / (4 * r), n);
 #define VPF_STRIP1(S, D, RR) VPF_LAUNCH((k_convert_strip<S, D, RR>), sgrid, dim3(256), lds1, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes / 16)
-#define VPF_STRIP(S, D) do { if (r == 4) VPF_STRIP1(S, D, 4); else VPF_STRIP1(S, D, 2); } while (0)
+#define VPF_STRIP(S, D) do { if (r == 8) VPF_STRIP1(S, D, 8); else if (r == 4) VPF_STRIP1(S, D, 4); else VPF_STRIP1(S, D, 2); } while (0)
 #define VPF_STRIPD(S) do { if (dst_fc == FC_RGB) VPF_STRIP(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_STRIP(S, FC_BGR); else VPF_STRIP(S, FC_PLANAR); } while (0)
         if (src_fc == FC_NV12) VPF_STRIPD(FC_NV12); else VPF_STRIPD(FC_YUV420);
 #undef VPF_STRIPD

@@ -82,9 +82,9 @@ void note_kernel(const char* k) {
   if (trace_on() && g_roctx_mark) g_roctx_mark(k);
 }
 
-static std::atomic<int> g_tune_variant{0}, g_tune_tile{0}, g_tune_band{0};
+static std::atomic<int> g_tune_variant{0}, g_tune_tile{0}, g_tune_band{0}, g_tune_march{0};
 int tuning(int key) {
-  return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : key == VPF_TUNE_RESIZE_BAND ? g_tune_band.load() : 0;
+  return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : key == VPF_TUNE_RESIZE_BAND ? g_tune_band.load() : key == VPF_TUNE_RESIZE_MARCH ? g_tune_march.load() : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,6 +422,7 @@ int vpf_set_tuning(int key, int value) {
     if (value != 0 && (ty < 4 || ty > 64 || (ty & 3) || (wpb != 4 && wpb != 8))) return -1;
     return g_tune_tile.exchange(value);
   }
+  if (key == VPF_TUNE_RESIZE_MARCH) return (value >= 0 && value <= 64) ? g_tune_march.exchange(value) : -1;
   if (key == VPF_TUNE_RESIZE_BAND) return (value == 0 || value == 1 || value == 2 || value == 4 || value == 8) ? g_tune_band.exchange(value) : -1;
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
