@@ -1638,13 +1638,18 @@ static bool planes_aligned(const BatchArgs& a, uint32_t n, int k, uintptr_t src_
     if ((((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & src_mask) || (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & dst_mask)) return false;
   return true;
 }
+// (the selection log / roctx mark carries __PRETTY_FUNCTION__: it names the task the generic entry was instantiated with)
 template <class Task>
 static void launch_plane_batch(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgs& a, int k, const PlaneGeom& g) {
-  VPF_LAUNCH((k_plane_batch<Task>), grid, dim3(Task::kThreads), lds, st, a, k, g);
+  if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((k_plane_batch<Task>), grid, dim3(Task::kThreads), lds, st, a, k, g);
 }
 template <template <int> class TaskCH>
 static void launch_planes_mp(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgs& a, const PlaneTable& t) {
-  VPF_LAUNCH((k_planes_mp<TaskCH>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
+  if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((k_planes_mp<TaskCH>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
 }
 template <template <int, int> class T2, int I>
 static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, const ResizeJob& j, const PlaneGeom& g) {
