@@ -216,7 +216,7 @@ VPF_API int vpf_set_tuning(int key, int value);
                                   (rows 4..64 in steps of 4, waves 4 or 8); same pixels whatever the shape */
 #define VPF_TUNE_RESIZE_MARCH 4 /* Lanczos-3 batches: destination rows per wave of the barrier-free "march" kernel: 0 = policy, 1 = never (tiled kernel),
                                    2..64 = that many wherever the kernel applies; same pixels whatever the value */
-#define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4 or 8; same pixels whatever the value */
+#define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4, 8 or 16; same pixels whatever the value */
 
 #ifdef __cplusplus
 }

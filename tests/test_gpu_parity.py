@@ -860,9 +860,9 @@ def test_tiled_resize_shapes_write_identical_pixels(capi, oracle, shape):
     assert capi.set_tuning(capi.TUNE_RESIZE_TILE, 7) == -1 and capi.set_tuning(capi.TUNE_RESIZE_TILE, 16 | (5 << 8)) == -1
 
 
-@pytest.mark.parametrize("band", [1, 2, 4, 8])
+@pytest.mark.parametrize("band", [1, 2, 4, 8, 16])
 def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
-    """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 8 / 4 / 2 for launches with >= 2048
+    """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 16 / 8 / 4 / 2 for launches with >= 2048
     workgroups, 1 otherwise).  Every value writes the oracle's pixels: general and > 2x down-scales, shared and disjoint source rows,
     heights that are not a multiple of the band, one-row pictures, ragged widths, fx == 0 columns (even integer factor on x only), an
     up-scale forced onto the row-pair family (variant 40: repeated source rows), multi-plane formats, and a 33-frame batch"""
@@ -889,7 +889,7 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
                 assert_planes_equal(got, wants[i % len(srcs)], f"band {band} {fmt} {sw}x{sh}->{dw}x{dh} v{variant} frame {i} of {n}")
     finally:
         capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
-    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 16) == -1
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 32) == -1
 
 
 @pytest.mark.parametrize("fmt,interp,sizes", [("RGB", 1, (1920, 1080, 1280, 720)), ("RGB", 2, (1920, 1080, 1280, 720)), ("NV12", 1, (1920, 1080, 1280, 720)),
@@ -970,7 +970,7 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         srcs = [oracle.synth(of, sw, sh, int(rng.integers(1 << 30))) for _ in range(n)]
         S = [DevPlanes(p, align) for p in srcs]
         D = [DevPlanes(oracle.alloc(of, dw, dh), align) for _ in range(n)]
-        band = int(rng.choice([0, 1, 2, 4, 8]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
+        band = int(rng.choice([0, 1, 2, 4, 8, 16]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
         march = int(rng.choice([0, 1, 2, 5, 16, 64]))  # rows per wave of the Lanczos march kernel (small batches would never reach it by policy)

@@ -538,7 +538,7 @@ VPF_DEV void RowPairTask<CH, IT>::run(const uint8_t* __restrict__ src, uint32_t 
 // RowPairTask and of the oracle (zero weights need no special case: fma(0, finite, t) == t and every staged byte is finite).
 // Used where the launch still has plenty of workgroups (batches); a single small frame keeps one row per wave.
 // ------------------------------------------------------------------------------------------
-constexpr int kBandSlots = 8;  // source rows a wave's strips can hold
+constexpr int kBandSlots = 8;  // source rows a wave's strips can hold (twice as many when a strip is a single 1-KiB staging pass: IT = 1)
 template <int CH>
 VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH>& T, float* H) {  // H[k * CH + c] = horizontal lerp of pixel k, channel c
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -605,13 +605,14 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
     put(ya + i, o);
   }
 }
-template <int CH, int R>
+template <int CH, int R, int IT = 2 /* 1-KiB staging passes per strip */>
 struct RowBandTask {
   static constexpr int kThreads = 256;
+  static constexpr int kSlots = kBandSlots * 2 / IT;
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
-template <int CH, int R>
-VPF_DEV void RowBandTask<CH, R>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+template <int CH, int R, int IT>
+VPF_DEV void RowBandTask<CH, R, IT>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
                                      uint32_t bx, uint32_t by) {
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, slots = G.a1;
   const float scx = G.scx, scy = G.scy;
@@ -623,14 +624,14 @@ VPF_DEV void RowBandTask<CH, R>::run(const uint8_t* __restrict__ src, uint32_t s
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
   const uint32_t r_lo = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(ya, scy, sh).i0);
-  const uint32_t r_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(yb, scy, sh).i1);  // the launcher guarantees r_hi - r_lo < slots <= kBandSlots
+  const uint32_t r_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(yb, scy, sh).i1);  // the launcher guarantees r_hi - r_lo < slots <= kSlots
   u32x4* const strips = dyn_strip + (size_t)wv * slots * rowq;
-  Span<2> rows[kBandSlots];
+  Span<IT> rows[kSlots];
 #pragma unroll
-  for (int k = 0; k < kBandSlots; k++)
+  for (int k = 0; k < kSlots; k++)
     if (r_lo + k <= r_hi) rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane);
 #pragma unroll
-  for (int k = 0; k < kBandSlots; k++)
+  for (int k = 0; k < kSlots; k++)
     if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, nq, lane);
   wave_lds_sync();
   const uint32_t x0 = xs + lane * 4;
@@ -1246,6 +1247,8 @@ template <int CH> struct RowPair4 : RowPairTask<CH, 4> {};
 template <int CH> struct RowBand2 : RowBandTask<CH, 2> {};
 template <int CH> struct RowBand4 : RowBandTask<CH, 4> {};
 template <int CH> struct RowBand8 : RowBandTask<CH, 8> {};
+template <int CH> struct RowBand8n : RowBandTask<CH, 8, 1> {};    // narrow strips (<= 1 KiB): 16 slots
+template <int CH> struct RowBand16n : RowBandTask<CH, 16, 1> {};
 template <int CH> struct LzMarch : LanczosMarchTask<CH> {};
 
 // ------------------------------------------------------------------------------------------
@@ -1658,36 +1661,39 @@ static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, cons
   else launch_plane_batch<T2<3, I>>(st, grid, 0, a, j.k, g);
 }
 
-// Destination rows per wave for a row-pair launch (RowBandTask) and the strips per wave its LDS is sized for: the largest of 8 / 4 / 2
-// whose bands fit kBandSlots source rows and 64 KB of LDS (`rb` bytes per strip, at most two 1-KiB staging passes) while the launch keeps
-// at least kBandMinGroups workgroups (a single small frame stays at one row per wave: it needs the parallelism more than the shared
-// work).  Vertical factors above 2 skip source rows (a contiguous band would read rows nobody blends) and odd integer factors on both
-// axes move bytes (RowPairTask's centre-sample shortcut): both keep one row per wave.  VPF_TUNE_RESIZE_BAND forces a value where it applies.
+// Destination rows per wave for a row-pair launch (RowBandTask) and the strips per wave its LDS is sized for: the largest of 16 / 8 / 4 / 2
+// whose bands fit the strip slots (8; 16 when a strip is at most 1 KiB = one staging pass, the 1- and 2-channel planes and the up-scales)
+// and 64 KB of LDS (`rb` bytes per strip, at most two 1-KiB staging passes) while the launch keeps at least kBandMinGroups workgroups (a
+// single small frame stays at one row per wave: it needs the parallelism more than the shared work).  Vertical factors above 2 skip
+// source rows (a contiguous band would read rows nobody blends) and odd integer factors on both axes move bytes (RowPairTask's
+// centre-sample shortcut): both keep one row per wave.  VPF_TUNE_RESIZE_BAND forces a value where it applies.
 constexpr uint32_t kBandMinGroups = 2048;
-struct BandShape { int rows; uint32_t slots; };
+struct BandShape { int rows; uint32_t slots; bool narrow; };
 static uint32_t band_slots(int r, float scy) {  // source rows a band of r destination rows can touch: i1(last) - i0(first) + 1 <= floor((r - 1) scy) + 3 (+ fp32 slack)
   return (uint32_t)((double)(r - 1) * (double)scy + 0.01) + 3u;
 }
 static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32_t n) {
   const int forced = tuning(VPF_TUNE_RESIZE_BAND);
-  if (forced == 1 || rb > 2048) return {1, 0};
+  if (forced == 1 || rb > 2048) return {1, 0, false};
   float scy = 0.f;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
-    if (j.sw % j.dw == 0 && j.sh % j.dh == 0 && ((j.sw / j.dw) & 1) && ((j.sh / j.dh) & 1)) return {1, 0};
+    if (j.sw % j.dw == 0 && j.sh % j.dh == 0 && ((j.sw / j.dw) & 1) && ((j.sh / j.dh) & 1)) return {1, 0, false};
     const float s = (float)j.sh / (float)j.dh;
     scy = s > scy ? s : scy;
   }
-  if (scy > 2.0f) return {1, 0};
-  for (int r = 8; r >= 2; r >>= 1) {
+  if (scy > 2.0f) return {1, 0, false};
+  for (int r = 16; r >= 2; r >>= 1) {
     if (forced && forced != r) continue;
+    const bool narrow = r >= 8 && rb <= 1024;  // the IT = 1 instantiations (8 and 16 rows)
+    if (r == 16 && !narrow) continue;
     const uint32_t slots = band_slots(r, scy);
-    if (slots > (uint32_t)kBandSlots || 4u * slots * rb + 16u > 64u * 1024u) continue;
+    if (slots > (uint32_t)(narrow ? 2 * kBandSlots : kBandSlots) || 4u * slots * rb + 16u > 64u * 1024u) continue;
     uint64_t groups = 0;
     for (int p = 0; p < njobs; p++) groups += (uint64_t)(((jobs[p].dw + 3) / 4 + 63) / 64) * ((jobs[p].dh + 4 * r - 1) / (4 * r)) * n;
-    if (forced || groups >= kBandMinGroups) return {r, slots};
+    if (forced || groups >= kBandMinGroups) return {r, slots, narrow};
   }
-  return {1, 0};
+  return {1, 0, false};
 }
 
 // Lanczos march (LanczosMarchTask): destination rows per wave (R) and strip size, or rows == 0 when the tiled kernel keeps the launch.
@@ -1841,7 +1847,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     t.np = (uint32_t)njobs;
     uint32_t gx = 0, gy = 0, it = 1, rb = 0;
     for (int p = 0; p < njobs && all_rowpair; p++) rb = rowb[p] > rb ? rowb[p] : rb;
-    const BandShape bs = all_rowpair ? band_rows(njobs, jobs, rb, n) : BandShape{1, 0};
+    const BandShape bs = all_rowpair ? band_rows(njobs, jobs, rb, n) : BandShape{1, 0, false};
     const int band = bs.rows;
     for (int p = 0; p < njobs; p++) {
       t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
@@ -1867,7 +1873,9 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; }  // one strip size for the launch (the widest plane's)
       it = (rb + 1023) / 1024;
       const uint32_t lds = band > 1 ? 4 * bs.slots * rb + 16 : 4 * 2 * rb + 16;
-      if (band == 8) launch_planes_mp<RowBand8>(st, grid, lds, a, t);
+      if (band == 16) launch_planes_mp<RowBand16n>(st, grid, lds, a, t);
+      else if (band == 8 && bs.narrow) launch_planes_mp<RowBand8n>(st, grid, lds, a, t);
+      else if (band == 8) launch_planes_mp<RowBand8>(st, grid, lds, a, t);
       else if (band == 4) launch_planes_mp<RowBand4>(st, grid, lds, a, t);
       else if (band == 2) launch_planes_mp<RowBand2>(st, grid, lds, a, t);
       else if (it == 1) launch_planes_mp<RowPair1>(st, grid, lds, a, t);
@@ -1928,7 +1936,8 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
         g[p].a1 = bs.slots;
         const dim3 bgrid(grid4.x, (j.dh + 4 * band - 1) / (4 * band), n);
         const uint32_t blds = 4 * bs.slots * rowb[p] + 16;
-#define VPF_RBB(C) do { if (band == 8) launch_plane_batch<RowBandTask<C, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 4) launch_plane_batch<RowBandTask<C, 4>>(st, bgrid, blds, a, j.k, g[p]); \
+#define VPF_RBB(C) do { if (band == 16) launch_plane_batch<RowBandTask<C, 16, 1>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.narrow) launch_plane_batch<RowBandTask<C, 8, 1>>(st, bgrid, blds, a, j.k, g[p]); \
+                        else if (band == 8) launch_plane_batch<RowBandTask<C, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 4) launch_plane_batch<RowBandTask<C, 4>>(st, bgrid, blds, a, j.k, g[p]); \
                         else launch_plane_batch<RowBandTask<C, 2>>(st, bgrid, blds, a, j.k, g[p]); } while (0)
         if (j.ch == 1) VPF_RBB(1); else if (j.ch == 2) VPF_RBB(2); else VPF_RBB(3);
 #undef VPF_RBB
