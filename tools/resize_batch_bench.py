@@ -26,6 +26,9 @@ def surf(fmt, w, h, rand):
     if fmt == capi.RGB:
         t, p = alloc(h, 3 * w)
         return [t], [(t.data_ptr(), p)], 3 * w * h
+    if fmt == capi.Y:
+        t, p = alloc(h, w)
+        return [t], [(t.data_ptr(), p)], w * h
     if fmt == capi.NV12:
         t, p = alloc(h * 3 // 2, w)
         return [t], [(t.data_ptr(), p), (t.data_ptr() + h * p, p)], w * h * 3 // 2
@@ -45,7 +48,8 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")):
+FORMATS = ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")) + (((capi.Y, "Y"),) if os.environ.get("VPF_BENCH_Y") else ())
+for fmt, fname in FORMATS:
     for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (1920, 1080, 416, 416), (3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (1280, 720, 1920, 1080)):
         ring = max(32, min(256, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // 32 * 32))
         S = [surf(fmt, sw, sh, True) for _ in range(ring)]
@@ -57,7 +61,7 @@ for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420
         planes = [(capi.planes(s[1]), capi.planes(d[1])) for s, d in zip(S, D)]
         nbytes = S[0][2] + D[0][2]
         for interp in ((1,) if ONLY == "bilinear" else (2,) if ONLY == "lanczos" else (1, 2)):
-            if fmt != capi.RGB and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
+            if fmt not in (capi.RGB, capi.Y) and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
                 continue
             if NB:
                 tb = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in batches], 5) / ring

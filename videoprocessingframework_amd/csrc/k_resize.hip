@@ -895,9 +895,9 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
   }
 }
 // ------------------------------------------------------------------------------------------
-// Lanczos-3 "march" (batches): a WAVE owns 256 destination columns and walks down a band of G.a1 destination rows on its own — no
+// Lanczos-3 "march" (batches): a WAVE owns 256 destination columns (512 of a 1-channel plane) and walks down a band of G.a1 destination rows on its own — no
 // workgroup barrier, no H plane in LDS.  The horizontal Q14 sums of the six source rows under the current destination row live in
-// REGISTERS (a ring of six rows x 4 pixels x CH values per lane; the walk is unrolled six source rows deep so that every slot number
+// REGISTERS (a ring of six rows x 4 pixels x CH values per lane — 8 pixels when CH = 1; the walk is unrolled six source rows deep so that every slot number
 // is a compile-time constant and the ring never moves), so a source row's horizontal pass is evaluated once per band — (R - 1) scy + 6
 // evaluations for R destination rows, 1.7 per row at a 1.5x down-scale with R = 24 — and the vertical pass reads nothing but
 // registers and six broadcast weights.  Source rows reach the wave through a private LDS strip, kMarchGroup rows per memory round
@@ -910,22 +910,25 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
 // ------------------------------------------------------------------------------------------
 constexpr int kMarchGroup = 4;       // source rows staged per round trip
 constexpr uint32_t kMarchPad = 16;   // bytes in front of a strip's first real byte: room for up to 3 replicated pixels (and 16-B aligned stores)
+constexpr int march_px(int ch) { return ch == 1 ? 8 : 4; }  // destination pixels per lane: a 1-channel plane takes 512 columns per wave (the per-band and per-row fixed work of a wave is the same whatever the channel count)
 template <int CH>
 struct LanczosMarchTask {
   static constexpr int kThreads = 256;
+  static constexpr int kPx = march_px(CH);
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
 template <int CH>
 VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
                                        uint32_t bx, uint32_t by) {
-  constexpr int PX = 4, NV = PX * CH;
+  constexpr int PX = kPx, NV = PX * CH;
+  constexpr uint32_t W = 64 * PX;  // destination columns per wave
   constexpr int NE = (6 * CH + 3) / 4;  // dwords of a pixel's lead-free run of 6 x CH tap bytes
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, R = G.a1;
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t ya = (by * 4 + wv) * R, xs = bx * 256;
+  const uint32_t ya = (by * 4 + wv) * R, xs = bx * W;
   if (ya >= dh || xs >= dw) return;
-  const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
   // columns: virtual source pixels [first_v, last_v] (taps before pixel 0 / after pixel sw - 1 exist in the strip as copies of the edge pixel)
   const int32_t first_v = __builtin_amdgcn_readfirstlane(ltap_i0(xs, scx) - 2), last_v = __builtin_amdgcn_readfirstlane(ltap_i0(xe, scx) + 3);
   const uint32_t first_r = first_v < 0 ? 0u : (uint32_t)first_v, last_r = last_v > (int32_t)sw - 1 ? sw - 1 : (uint32_t)last_v;
@@ -1013,7 +1016,7 @@ VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t
     }
   };
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const bool vec4 = G.vec_ok && x0 + 4 <= dw;
+  const bool vec4 = G.vec_ok && x0 + PX <= dw;
   // The walk runs over SOURCE rows, six per trip of the loop, so that the ring slot a row's sums go to — and with it the slots of the
   // six taps of every destination row that ends on this source row (taps hnext - 5 .. hnext = slots S + 1 .. S + 6 mod 6) — are
   // compile-time constants: the ring stays where it is in the register file (a run-time slot number made the compiler rotate 72
@@ -1049,10 +1052,11 @@ VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t
         } else if constexpr (CH == 2) {
           stg<true, u32x2>(out, u32x2{pack4<1>(o[0], o[1], o[2], o[3]), pack4<1>(o[4], o[5], o[6], o[7])});
         } else {
-          stg<true, uint32_t>(out, pack4<1>(o[0], o[1], o[2], o[3]));
+#pragma unroll
+          for (int q = 0; q < PX / 4; q++) stg<true, uint32_t>(out + 4 * q, pack4<1>(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]));
         }
       } else {
-        const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
+        const uint32_t nv = (dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX) * CH;
         for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_rne(o[i]);
       }
     }
@@ -1704,10 +1708,10 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
 // instructions per 256 columns of packed RGB).  R is the value that minimises rounds x wave time — 32 frames 1080p -> 720p: R = 20
 // (1440 workgroups, two rounds filled to 94 %) where R = 16 spends a third round on half the chip and R = 19 (38 bands = 9.5
 // workgroups per column of chunks) a third round on a twelfth of it (3.52 us / frame against 3.10, profiles/r02_lanczos_march.txt).
-// The tiled kernel keeps what the march does not win (A/B over batch sizes 2 .. 32 and six size pairs, profiles/r02_lanczos_march.txt):
-// launches under ~700 workgroups (its 64-column tiles spread a small job wider), multi-plane formats under ~1400 (the 1- and
-// 2-channel planes pay the per-band weight sets for a third / two thirds of the pixels), and up-scales whose best R is below 20 (the
-// six extra source rows of a short band cost more than the tiled kernel's barriers).
+// The tiled kernel keeps what the march does not win (A/B over batch sizes 2 .. 32, profiles/r02_lanczos_march.txt and
+// r02_lanczos_march_planes.txt): launches under ~600 workgroups (its 64-column tiles spread a small job wider; ~1000 when every plane
+// has one channel, where a wave's fixed work weighs three times as much per byte), three-plane formats (YUV420: 2.5 - 2.8 us / frame
+// either way), and up-scales whose best R is below 20 (the six extra source rows of a short band cost more than the tiled kernel's barriers).
 constexpr uint32_t kMarchGroupSlots = 768;  // 256 CUs x 3 workgroups
 struct MarchShape { uint32_t rows, rowq; };
 static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
@@ -1717,7 +1721,7 @@ static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const double scx = (double)j.sw / (double)j.dw, sy = (double)j.sh / (double)j.dh;
-    const uint32_t span_px = (uint32_t)(255.0 * scx) + 8;  // taps of 256 columns: floor(255 scx) + 6 (+ fp32 slack)
+    const uint32_t span_px = (uint32_t)((64.0 * march_px(j.ch) - 1.0) * scx) + 8;  // taps of a wave's columns: floor((W - 1) scx) + 6 (+ fp32 slack)
     if ((uint32_t)j.ch * span_px > 2018u || sy > 5.9) return {0, 0};
     const uint32_t q = (kMarchPad + 15u + (uint32_t)j.ch * span_px + 8u + 15u) / 16u;
     rowq = q > rowq ? q : rowq;
@@ -1731,17 +1735,21 @@ static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
     double work = 0.0;
     for (int p = 0; p < njobs; p++) {
       const ResizeJob& j = jobs[p];
-      const uint64_t g = (uint64_t)((j.dw + 255) / 256) * (((j.dh + r - 1) / r + 3) / 4) * n;
+      const uint32_t wcols = 64u * march_px(j.ch);
+      const uint64_t g = (uint64_t)((j.dw + wcols - 1) / wcols) * (((j.dh + r - 1) / r + 3) / 4) * n;
       const double sy = (double)j.sh / (double)j.dh;
       groups += g;
-      work += (double)g * (700.0 + ((double)(r - 1) * sy + 6.0) * (40.0 + 42.0 * j.ch) + (double)r * (20.0 + 20.0 * j.ch));
+      const double vals = j.ch * march_px(j.ch) / 4.0;  // values per lane and row, in units of a 4-pixel 1-channel row
+      work += (double)g * (700.0 + ((double)(r - 1) * sy + 6.0) * (40.0 + 42.0 * vals) + (double)r * (20.0 + 20.0 * vals));
     }
     const double cost = (double)((groups + kMarchGroupSlots - 1) / kMarchGroupSlots) * work / (double)groups;
     if (!best || cost < best_cost) { best = r; best_cost = cost; best_groups = groups; }
   }
   double scy_min = 1e9;
   for (int p = 0; p < njobs; p++) scy_min = std::min(scy_min, (double)jobs[p].sh / (double)jobs[p].dh);
-  if (best_groups < 700 || (njobs > 1 && best_groups < 1400) || njobs == 3 || (scy_min < 1.0 && best < 20)) return {0, 0};  // three 1-channel planes: no gain measured (2.74 vs 2.54 us, 8.16 vs 8.19)
+  bool wide = false;  // some plane has 2 or 3 channels
+  for (int p = 0; p < njobs; p++) wide = wide || jobs[p].ch >= 2;
+  if (best_groups < (wide ? 600u : 1000u) || njobs == 3 || (scy_min < 1.0 && best < 20)) return {0, 0};
   return {best, rowq};
 }
 
@@ -1815,7 +1823,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       for (int p = 0; p < njobs; p++) {
         t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
         t.g[p].a0 = ms.rowq; t.g[p].a1 = ms.rows;
-        const uint32_t bx = (jobs[p].dw + 255) / 256;
+        const uint32_t wcols = 64u * march_px(jobs[p].ch), bx = (jobs[p].dw + wcols - 1) / wcols;
         gx = bx > gx ? bx : gx;
         gy += (jobs[p].dh + 4 * ms.rows - 1) / (4 * ms.rows);
       }

@@ -288,7 +288,8 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
   if (guard.err != hipSuccess) return status_of(guard.err);
   hipStream_t st = static_cast<hipStream_t>(exec->stream);
   const int np = num_planes(fmt);
-  if (n == 1 && nj == 1) {  // one plane of one frame: the scalar-argument kernel entries (kernarg preload)
+  const bool forced_family = tuning(VPF_TUNE_RESIZE_MARCH) >= 2 || tuning(VPF_TUNE_RESIZE_BAND) >= 2;  // measurement runs: the batch kernels on one frame
+  if (n == 1 && nj == 1 && !forced_family) {  // one plane of one frame: the scalar-argument kernel entries (kernarg preload)
     const vpf_plane &s0 = frames[0].src[0], &d0 = frames[0].dst[0];
     const hipError_t e = f32 ? launch_resize_f32(st, jobs[0].ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(s0.ptr), s0.pitch, ds.width, ds.height,
                                                  static_cast<uint8_t*>(d0.ptr), d0.pitch)
