@@ -868,7 +868,9 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     up-scale forced onto the row-pair family (variant 40: repeated source rows), multi-plane formats, and a 33-frame batch"""
     cases = [("RGB", 640, 360, 427, 240, 0, 3), ("RGB", 1920, 96, 416, 37, 0, 2), ("NV12", 1280, 72, 854, 48, 0, 3), ("YUV420", 642, 90, 300, 31, 0, 2),
              ("RGB", 300, 5, 200, 1, 0, 2), ("Y", 997, 61, 333, 47, 0, 2), ("RGB", 512, 90, 128, 61, 0, 2), ("RGB", 200, 50, 333, 77, 40, 2),
-             ("NV12", 200, 50, 320, 96, 40, 2), ("RGB", 640, 360, 224, 224, 0, 33), ("RGB", 1919, 64, 1280, 43, 0, 2)]
+             ("NV12", 200, 50, 320, 96, 40, 2), ("RGB", 640, 360, 224, 224, 0, 33), ("RGB", 1919, 64, 1280, 43, 0, 2),
+             ("RGB", 320, 180, 1280, 720, 0, 2), ("YUV420", 96, 54, 160, 90, 0, 3),                                # up-scales (the band family by policy when forced)
+             ("RGB", 1, 1, 9, 7, 0, 2), ("RGB", 2, 3, 300, 5, 0, 2), ("Y", 3, 2, 5, 70, 0, 2), ("NV12", 4, 4, 18, 10, 0, 2), ("RGB", 5, 2, 3, 1, 0, 2)]  # tiny pictures
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, band) >= 0
     try:
         for fmt, sw, sh, dw, dh, variant, n in cases:
@@ -921,7 +923,9 @@ def test_lanczos_march_kernel_writes_the_tiled_kernel_pixels(capi, oracle, rows)
     multi-plane formats (chroma planes with their own factors), heights below one band, a 33-frame batch"""
     cases = [("RGB", 640, 360, 427, 240, 3), ("RGB", 320, 180, 1280, 720, 2), ("NV12", 1280, 72, 854, 48, 3), ("YUV420", 642, 90, 300, 31, 2),
              ("RGB", 300, 50, 200, 7, 2), ("Y", 997, 61, 333, 47, 2), ("RGB", 96, 54, 700, 33, 2), ("RGB", 640, 360, 224, 224, 33), ("RGB", 1919, 64, 1280, 43, 2),
-             ("YUV444", 100, 60, 333, 201, 2), ("RGB", 20, 12, 45, 31, 2)]
+             ("YUV444", 100, 60, 333, 201, 2), ("RGB", 20, 12, 45, 31, 2),
+             # pictures smaller than the filter: every tap of some columns / rows is a replicated edge pixel
+             ("RGB", 1, 1, 9, 7, 2), ("RGB", 2, 3, 300, 5, 2), ("Y", 3, 2, 5, 70, 2), ("NV12", 4, 4, 18, 10, 2), ("RGB", 5, 1, 3, 1, 2), ("Y", 700, 2, 64, 1, 2)]
     assert capi.set_tuning(capi.TUNE_RESIZE_MARCH, rows) >= 0
     try:
         for fmt, sw, sh, dw, dh, n in cases:
