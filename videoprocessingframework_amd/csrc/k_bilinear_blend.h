@@ -1,0 +1,272 @@
+// k_bilinear_blend.h — what the bilinear kernels of k_resize.hip (row-pair, row-band, tiled) and the fused convert + resize kernels of
+// k_convert_resize.hip share: the sampling convention, wave-private LDS strips, and the blend of taps that sit in such strips.
+//
+// Sampling convention (SURVEY.md §8c [A8]): s = (d + 0.5) * (S / D) - 0.5 clamped to [0, S-1];
+// i0 = floor(s), i1 = min(i0 + 1, S - 1), f = s - i0;
+//   top = fma(fx, p01 - p00, p00); bot = fma(fx, p11 - p10, p10); out = sat_trunc(fma(fy, bot - top, top) + 0.5)
+#ifndef VPF_K_BILINEAR_BLEND_H_
+#define VPF_K_BILINEAR_BLEND_H_
+#include "vpf_device.h"
+
+namespace vpf {
+
+struct Tap {
+  uint32_t i0, i1;
+  float f;
+};
+template <int INTERP>
+VPF_DEV Tap make_tap(uint32_t d, float scale, uint32_t S) {
+  Tap t;
+  if constexpr (INTERP == VPF_INTERP_NEAREST) {
+    uint32_t i = (uint32_t)(((float)d + 0.5f) * scale);
+    t.i0 = t.i1 = (i > S - 1) ? S - 1 : i;
+    t.f = 0.f;
+  } else {
+    float s = __builtin_fmaf((float)d + 0.5f, scale, -0.5f);
+    s = fmaxf(s, 0.f);
+    s = fminf(s, (float)(S - 1));
+    t.i0 = (uint32_t)(int)s;
+    t.i1 = (t.i0 + 1 < S) ? t.i0 + 1 : S - 1;
+    t.f = s - (float)t.i0;
+  }
+  return t;
+}
+VPF_DEV float bilerp(float p00, float p01, float p10, float p11, float fx, float fy) {
+  const float top = __builtin_fmaf(fx, p01 - p00, p00);
+  const float bot = __builtin_fmaf(fx, p11 - p10, p10);
+  return __builtin_fmaf(fy, bot - top, top) + 0.5f;
+}
+
+constexpr uint32_t kResizeRowBytes = 4096;  // largest strip (IT = 4 dense 1-KiB loads per source row)
+// The strips live in dynamic LDS sized for THIS launch's scale factor (strip bytes = span rounded up to 256):
+// a 3x down-scale of packed RGB needs 2.5 KiB per row instead of the 4 KiB worst case, so 8 workgroups fit a CU
+// instead of 5 and the load latency of one wave hides behind the arithmetic of more neighbours.
+extern __shared__ u32x4 dyn_strip[];
+
+// Copy `nq` 16-byte units of a source row (starting at the 16-B aligned byte offset `base`) into an LDS strip.
+// All loads are issued before the first LDS write (MAXIT is a compile-time bound), so the wave pays ONE memory
+// latency per strip, not one per 1 KiB.
+template <int MAXIT>
+struct Span {
+  u32x4 v[MAXIT];
+  VPF_DEV void load(const uint8_t* row, uint32_t base, uint32_t nq, uint32_t lane) {
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++)
+      if (lane + 64 * k < nq) v[k] = ldg<false, u32x4>(row + base + 16 * (lane + 64 * k));
+  }
+  VPF_DEV void store(u32x4* lds, uint32_t nq, uint32_t lane) const {
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++)
+      if (lane + 64 * k < nq) lds[lane + 64 * k] = v[k];
+  }
+};
+VPF_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the two 3-byte taps that start `a` bytes into an LDS strip (any alignment): 12-B window from the dword below + v_alignbyte_b32
+VPF_DEV void strip_window_taps(const uint8_t* strip, uint32_t a, float* t0, float* t1) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(strip + (a & ~3u));
+  const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+  t0[0] = ubyte<0>(lo); t0[1] = ubyte<1>(lo); t0[2] = ubyte<2>(lo);
+  t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);
+}
+
+// The column side of four consecutive destination pixels of a row-pair blend: tap offsets inside the LDS strips and weights.  They depend on
+// the destination columns only, so a wave that blends several destination rows computes them once (RowBandTask, convert_strip_task).
+template <int CH>
+struct ColTaps {
+  uint32_t a[4], b[4];  // byte offsets of tap 0 / tap 1 from the strips' first byte
+  float f[4];
+  bool allfx;  // wave-uniform: for each of the four pixels some lane has fx != 0 (no exact-alignment shortcut applies on x)
+};
+template <int CH>
+VPF_DEV ColTaps<CH> make_col_taps(uint32_t base, uint32_t x0, uint32_t dw, uint32_t sw, float scx) {
+  ColTaps<CH> T;
+  T.allfx = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const Tap t = make_tap<VPF_INTERP_LINEAR>((x0 + k < dw) ? x0 + k : dw - 1, scx, sw);
+    T.a[k] = CH * t.i0 - base; T.b[k] = CH * t.i1 - base; T.f[k] = t.f;
+    T.allfx = T.allfx && __builtin_amdgcn_ballot_w64(t.f != 0.f) != 0;
+  }
+  return T;
+}
+
+// Four consecutive destination pixels of one row blended from two source rows that sit in LDS as byte strips (`base` of make_col_taps =
+// byte offset of the strips' first byte inside the source row): the arithmetic of the row-pair kernels, shared by the plain resize
+// (RowPairTask, RowBandTask) and the fused convert + resize (convert_strip_task), whose strips hold freshly converted RGB.
+// o[] = pixel-major, + 0.5 already added.  row1 = (fy != 0), wave-uniform.
+template <int CH>
+VPF_DEV void rowpair_blend4(const uint8_t* r0, const uint8_t* r1, bool row1, float fy, const ColTaps<CH>& T, float* o) {
+  if (row1 && T.allfx) {
+    // The common case, on the packed-fp32 pipe: the four taps of all four pixels are fetched first, then every blend step runs on
+    // PIXEL PAIRS (v_pk_add_f32 / v_pk_fma_f32: two independent IEEE operations per instruction at the issue cost of one —
+    // profiles/r02_probe_valu_rate.txt), 3.5 instead of 7 VALU slots per pixel and channel.  Each component goes through exactly
+    // bilerp()'s operations in bilerp()'s order -> bit-identical to the scalar form below and to the other kernels.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float p00[4][CH], p01[4][CH], p10[4][CH], p11[4][CH];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t a = T.a[k], b = T.b[k];
+      if constexpr (CH == 3) {  // both taps of a row are 6 contiguous bytes: one 12-B LDS window + v_alignbyte_b32 (see strip_window_taps)
+        strip_window_taps(r0, a, p00[k], p01[k]);
+        strip_window_taps(r1, a, p10[k], p11[k]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { p00[k][c] = (float)r0[a + c]; p01[k][c] = (float)r0[b + c]; p10[k][c] = (float)r1[a + c]; p11[k][c] = (float)r1[b + c]; }
+      }
+    }
+    const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int k0 = 2 * j, k1 = 2 * j + 1;
+      const f32x2 fx2 = {T.f[k0], T.f[k1]};
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const f32x2 a00 = {p00[k0][c], p00[k1][c]}, a01 = {p01[k0][c], p01[k1][c]}, a10 = {p10[k0][c], p10[k1][c]}, a11 = {p11[k0][c], p11[k1][c]};
+        const f32x2 top = __builtin_elementwise_fma(fx2, a01 - a00, a00), bot = __builtin_elementwise_fma(fx2, a11 - a10, a10);
+        const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
+        o[k0 * CH + c] = v[0]; o[k1 * CH + c] = v[1];
+      }
+    }
+  } else {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t a = T.a[k], b = T.b[k];
+    const float fx = T.f[k];
+    const bool tap1 = __builtin_amdgcn_ballot_w64(fx != 0.f) != 0;  // wave-uniform
+    if constexpr (CH == 3) {
+      // packed RGB: both taps of a row are 6 contiguous bytes -> three aligned dword reads + v_alignbyte_b32 instead of six
+      // ds_read_u8 (the kernel spends as long issuing LDS reads as VALU work).  At the right image edge i1 == i0 and the
+      // window's second tap is whatever follows the row — its weight is exactly 0 there (fma(0, finite, p) == p).
+      float t0[3], t1[3], u0[3], u1[3];
+      strip_window_taps(r0, a, t0, t1);
+      if (row1) strip_window_taps(r1, a, u0, u1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float top = tap1 ? __builtin_fmaf(fx, t1[c] - t0[c], t0[c]) : t0[c];
+        if (row1) {
+          const float bot = tap1 ? __builtin_fmaf(fx, u1[c] - u0[c], u0[c]) : u0[c];
+          o[k * 3 + c] = __builtin_fmaf(fy, bot - top, top) + 0.5f;
+        } else {
+          o[k * 3 + c] = top + 0.5f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const float p00 = (float)r0[a + c];
+        const float top = tap1 ? __builtin_fmaf(fx, (float)r0[b + c] - p00, p00) : p00;
+        if (row1) {
+          const float p10 = (float)r1[a + c];
+          const float bot = tap1 ? __builtin_fmaf(fx, (float)r1[b + c] - p10, p10) : p10;
+          o[k * CH + c] = __builtin_fmaf(fy, bot - top, top) + 0.5f;
+        } else {
+          o[k * CH + c] = top + 0.5f;
+        }
+      }
+    }
+  }
+  }
+}
+// four blended pixels (o[] of rowpair_blend4) -> bytes of one destination row
+template <int CH>
+VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /* valid pixels, 1..4 */) {
+  if (vec4) {
+    if constexpr (CH == 3) {
+      stg3<true>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7]), pack4_trunc_inrange(o[8], o[9], o[10], o[11]));
+    } else if constexpr (CH == 2) {
+      stg<true, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
+    } else {
+      stg<true, uint32_t>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]));
+    }
+  } else {
+    for (uint32_t i = 0; i < nv * CH; i++) out[i] = (uint8_t)(uint32_t)o[i];
+  }
+}
+
+constexpr int kBandSlots = 8;  // source rows a wave's strips can hold (twice as many when a strip is a single 1-KiB staging pass: IT = 1)
+template <int CH>
+VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH>& T, float* H) {  // H[k * CH + c] = horizontal lerp of pixel k, channel c
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float p0[4][CH], p1[4][CH];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if constexpr (CH == 3) {
+      strip_window_taps(r, T.a[k], p0[k], p1[k]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; c++) { p0[k][c] = (float)r[T.a[k] + c]; p1[k][c] = (float)r[T.b[k] + c]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const f32x2 fx2 = {T.f[2 * j], T.f[2 * j + 1]};
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const f32x2 a0 = {p0[2 * j][c], p0[2 * j + 1][c]}, a1 = {p1[2 * j][c], p1[2 * j + 1][c]};
+      const f32x2 h = __builtin_elementwise_fma(fx2, a1 - a0, a0);
+      H[2 * j * CH + c] = h[0]; H[(2 * j + 1) * CH + c] = h[1];
+    }
+  }
+}
+// Destination rows ya..yb (at most R) of a band whose source rows r_lo.. sit in LDS `rowbytes` apart: the two current source rows'
+// horizontal lerps stay in registers and move up (Hb -> Ha) as the destination rows walk down.  put(y, o) receives o[] = pixel-major, + 0.5 added.
+template <int CH, int R, class Put>
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, float scy, uint32_t sh, const ColTaps<CH>& T, Put&& put) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  float Ha[4 * CH], Hb[4 * CH];       // horizontal lerps of source rows ida (upper tap) and idb (lower tap)
+  uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    if (ya + i > yb) break;
+    const Tap t = make_tap<VPF_INTERP_LINEAR>(ya + i, scy, sh);
+    const uint32_t i0 = __builtin_amdgcn_readfirstlane(t.i0), i1 = __builtin_amdgcn_readfirstlane(t.i1);
+    const float fy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t.f)));
+    if (i0 != ida) {
+      if (i0 == idb) {
+#pragma unroll
+        for (int q = 0; q < 4 * CH; q++) Ha[q] = Hb[q];
+      } else {
+        band_hlerp4<CH>(strips + (size_t)(i0 - r_lo) * rowbytes, T, Ha);
+      }
+      ida = i0;
+    }
+    if (i1 != idb) {
+      if (i1 == ida) {
+#pragma unroll
+        for (int q = 0; q < 4 * CH; q++) Hb[q] = Ha[q];
+      } else {
+        band_hlerp4<CH>(strips + (size_t)(i1 - r_lo) * rowbytes, T, Hb);
+      }
+      idb = i1;
+    }
+    float o[4 * CH];
+    const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
+#pragma unroll
+    for (int q = 0; q < 4 * CH; q += 2) {
+      const f32x2 top = {Ha[q], Ha[q + 1]}, bot = {Hb[q], Hb[q + 1]};
+      const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
+      o[q] = v[0]; o[q + 1] = v[1];
+    }
+    put(ya + i, o);
+  }
+}
+
+// strip bytes a wave needs for its source span (<= 255*scale + 3 pixels, + 16-B alignment slack on both ends),
+// rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
+static inline uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
+  if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9) return 0;  // forced generic
+  if (((uintptr_t)src | sp) & 15) return 0;
+  const double scale = (double)sw / (double)dw;
+  const double need = (255.0 * scale + 4.0) * ch + 32.0;
+  if (need > (double)row_bytes_cap) return 0;
+  return ((uint32_t)need + 255u) & ~255u;
+}
+
+}  // namespace vpf
+#endif  // VPF_K_BILINEAR_BLEND_H_
