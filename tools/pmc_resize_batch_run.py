@@ -12,10 +12,11 @@ if os.environ.get("VPF_PMC_MARCH"):  # 1: keep the tiled Lanczos kernel
 dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 N = 32
-sp, dp = (3 * sw + 255) // 256 * 256, (3 * dw + 255) // 256 * 256
+CHN = 1 if os.environ.get("VPF_PMC_FMT") == "Y" else 3  # VPF_PMC_FMT=Y: one 1-channel plane instead of packed RGB
+sp, dp = (CHN * sw + 255) // 256 * 256, (CHN * dw + 255) // 256 * 256
 src = [torch.randint(0, 256, (sh, sp), dtype=torch.uint8, device=dev) for _ in range(N)]
 dst = [torch.zeros((dh, dp), dtype=torch.uint8, device=dev) for _ in range(N)]
 batch = capi.make_batch([([(s.data_ptr(), sp)], [(d.data_ptr(), dp)]) for s, d in zip(src, dst)])
 for _ in range(6):
-    capi.resize_batch(ex, capi.RGB, interp, sw, sh, dw, dh, batch)
+    capi.resize_batch(ex, capi.Y if CHN == 1 else capi.RGB, interp, sw, sh, dw, dh, batch)
 torch.cuda.synchronize()

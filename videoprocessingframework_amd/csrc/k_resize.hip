@@ -650,7 +650,8 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
 // evaluations for R destination rows, 1.7 per row at a 1.5x down-scale with R = 24 — and the vertical pass reads nothing but
 // registers and six broadcast weights.  Source rows reach the wave through a private LDS strip, kMarchGroup rows per memory round
 // trip; the pixels an image edge clamps to are REPLICATED into the strip's margins while staging, so every lane's taps are contiguous
-// bytes everywhere (the tiled kernel walks edge tiles byte by byte).  Column weights are computed once per band and lane (4 sets),
+// bytes everywhere (the tiled kernel walks edge tiles byte by byte).  Column weight sets are computed once per WORKGROUP (its four waves
+// own the same columns: each computes a quarter and shares it through LDS — the only barrier of the kernel, before the walk starts),
 // the band's vertical weight sets by the first R lanes in one go (v_readlane_b32 hands row y's set to the wave).
 // Same exact integer sums and the same vertical fma chain (tap 0 first, accumulator from 0, x 2^-14, v_cvt_pk_u8_f32) as TileTask /
 // LanczosGatherTask / the oracle -> same bytes.  VALU instructions per destination pixel at 1080p -> 720p: 2.31 (TileLz8) -> see
@@ -675,7 +676,7 @@ VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t ya = (by * 4 + wv) * R, xs = bx * W;
-  if (ya >= dh || xs >= dw) return;
+  if (xs >= dw) return;  // workgroup-uniform (the barrier below is reached by all four waves or by none)
   const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
   // columns: virtual source pixels [first_v, last_v] (taps before pixel 0 / after pixel sw - 1 exist in the strip as copies of the edge pixel)
   const int32_t first_v = __builtin_amdgcn_readfirstlane(ltap_i0(xs, scx) - 2), last_v = __builtin_amdgcn_readfirstlane(ltap_i0(xe, scx) + 3);
@@ -683,15 +684,25 @@ VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t
   const uint32_t base = (CH * first_r) & ~15u, nq = (CH * (last_r + 1) - base + 15) / 16;
   u32x4* const strips = dyn_strip + (size_t)wv * kMarchGroup * rowq;
   const uint32_t x0 = xs + lane * PX;
+  // Column weight sets (~130 VALU instructions each, PX per lane): the four waves of a workgroup own the SAME columns (consecutive bands
+  // of one chunk), so each computes PX / 4 of the sets and hands them to the others through LDS
+  u32x4* const wsets = dyn_strip + (size_t)4 * kMarchGroup * rowq;  // [PX][64] x {q0|q1, q2|q3, q4|q5, byte offset of tap 0 in a strip}
+#pragma unroll
+  for (int j = 0; j < PX / 4; j++) {
+    const uint32_t k = wv * (PX / 4) + j;
+    const uint32_t xc = x0 + k < dw ? x0 + k : dw - 1;  // lanes / pixels past the right edge compute a duplicate, never stored
+    const QTap t = quantize_ltap(make_ltap(xc, scx));
+    const uint32_t off = (uint32_t)((int32_t)CH * (t.i0 - 2) - (int32_t)base + (int32_t)kMarchPad);  // >= 7: i0 - 2 >= -3 where base == 0
+    wsets[k * 64 + lane] = u32x4{pack_i16(t.q[0], t.q[1]), pack_i16(t.q[2], t.q[3]), pack_i16(t.q[4], t.q[5]), off};
+  }
+  __syncthreads();
+  if (ya >= dh) return;
   uint32_t qx[PX][3], qoff[PX], lead[PX];
 #pragma unroll
   for (int k = 0; k < PX; k++) {
-    const uint32_t xc = x0 + k < dw ? x0 + k : dw - 1;  // lanes / pixels past the right edge compute a duplicate, never stored
-    const QTap t = quantize_ltap(make_ltap(xc, scx));
-#pragma unroll
-    for (int j = 0; j < 3; j++) qx[k][j] = pack_i16(t.q[2 * j], t.q[2 * j + 1]);
-    const uint32_t off = (uint32_t)((int32_t)CH * (t.i0 - 2) - (int32_t)base + (int32_t)kMarchPad);  // >= 7: i0 - 2 >= -3 where base == 0
-    qoff[k] = off & ~3u; lead[k] = off & 3u;
+    const u32x4 w = wsets[k * 64 + lane];
+    qx[k][0] = w[0]; qx[k][1] = w[1]; qx[k][2] = w[2];
+    qoff[k] = w[3] & ~3u; lead[k] = w[3] & 3u;
   }
   // rows: lane l holds the vertical tap set of destination row ya + l (R <= 64)
   const LTap tyl = make_ltap(ya + lane < dh ? ya + lane : dh - 1, scy);
@@ -735,7 +746,8 @@ VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t
     wave_lds_sync();
   };
   fetch(hnext);
-  // one source row's horizontal pass: 4 pixels x CH exact Q14 sums -> h[]
+  // one source row's horizontal pass: PX pixels x CH exact Q14 sums -> h[]  (requesting the LDS reads of several pixels together
+  // changes nothing measurable: the compiler already keeps 6 - 8 reads in flight and waits with descending lgkmcnt)
   auto hrow = [&](uint32_t slot, float* h) {
     const uint8_t* b = reinterpret_cast<const uint8_t*>(strips + (size_t)slot * rowq);
 #pragma unroll
@@ -1449,7 +1461,7 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
 // r02_lanczos_march_planes.txt): launches under ~600 workgroups (its 64-column tiles spread a small job wider; ~1000 when every plane
 // has one channel, where a wave's fixed work weighs three times as much per byte), three-plane formats (YUV420: 2.5 - 2.8 us / frame
 // either way), and up-scales whose best R is below 20 (the six extra source rows of a short band cost more than the tiled kernel's barriers).
-constexpr uint32_t kMarchGroupSlots = 768;  // 256 CUs x 3 workgroups
+constexpr uint32_t kMarchGroupSlots = 768;  // 256 CUs x 3 workgroups (counting 4 % fewer made the 16-frame launches slower: 4K -> 1080p 7.7 -> 8.5 us / frame)
 struct MarchShape { uint32_t rows, rowq; };
 static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
   const int forced = tuning(VPF_TUNE_RESIZE_MARCH);
@@ -1564,7 +1576,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
         gx = bx > gx ? bx : gx;
         gy += (jobs[p].dh + 4 * ms.rows - 1) / (4 * ms.rows);
       }
-      launch_planes_mp<LzMarch>(st, dim3(gx, gy, n), 4u * kMarchGroup * ms.rowq * 16u, a, t);
+      launch_planes_mp<LzMarch>(st, dim3(gx, gy, n), 4u * kMarchGroup * ms.rowq * 16u + 8u * 64u * 16u /* column weight sets */, a, t);
       return hipGetLastError();
     }
   }
