@@ -113,11 +113,28 @@ class Workload:
                 self.launches_per_step = 2 * ring
             self.kernel = ("k_convert_resize_lds (exact-alignment shortcuts at 3x)" if name == "fused_4k_720p"
                            else "k_nv12_rgb_p16 + k_resize (odd integer factor: centre-sample kernel)")
+        elif name in ("rgb_resize_1080p_720p_bilinear", "rgb_resize_1080p_720p_lanczos"):  # vpf_resize_batch: every frame of the ring, 32 per dispatch
+            self.w, self.h, self.dw, self.dh = 1920, 1080, 1280, 720
+            self.interp = capi.INTERP_LINEAR if name.endswith("bilinear") else capi.INTERP_LANCZOS3
+            frames = []
+            for _ in range(ring):
+                src, sp = _pitched(self.h, 3 * self.w, dev, gen)
+                dst, dp = _pitched(self.dh, 3 * self.dw, dev)
+                self.keep += [src, dst]
+                frames.append(([(src.data_ptr(), sp)], [(dst.data_ptr(), dp)]))
+            self.batch = capi.make_batch(frames)
+            self.px_per_step = ring * self.w * self.h
+            self.bytes_per_step = ring * 3 * (self.w * self.h + self.dw * self.dh)  # algorithmic: source read once, destination written once
+            self.launches_per_step = (ring + 31) // 32
+            self.kernel = "RowBandTask (4 destination rows per wave)" if name.endswith("bilinear") else "LanczosMarchTask (register ring, no barriers)"
         else:
             raise SystemExit(f"unknown workload {name}")
 
     def step(self):
         ex = self.ex
+        if self.name.startswith("rgb_resize_"):
+            capi.resize_batch(ex, capi.RGB, self.interp, self.w, self.h, self.dw, self.dh, self.batch)
+            return
         if self.name in ("nv12_rgb_4k", "nv12_planar_1080p"):
             if self.mode == "batch":
                 capi.convert_batch(ex, capi.NV12, self.dst_fmt, capi.BT_709, capi.MPEG, self.w, self.h, self.batch)
@@ -260,7 +277,9 @@ def other_configs(dev, main_wl):
             ("4k_nv12_rgb_one_dispatch_per_frame", "nv12_rgb_4k", 32, "single", 10),         # unmodified per-Execute() API
             ("1080p_nv12_rgb_planar_batched", "nv12_planar_1080p", 128, "batch", 10),          # configs[1]
             ("4k_nv12_rgb_then_resize_720p_per_frame", "resize_4k_720p", 16, "single", 4),     # configs[2], API-faithful
-            ("4k_nv12_to_720p_rgb_fused_batched", "fused_4k_720p", 32, "batch", 10)):          # configs[2], fused
+            ("4k_nv12_to_720p_rgb_fused_batched", "fused_4k_720p", 32, "batch", 10),           # configs[2], fused
+            ("1080p_rgb_to_720p_bilinear_batched", "rgb_resize_1080p_720p_bilinear", 64, "batch", 10),   # vpf_resize_batch, north_star's filter
+            ("1080p_rgb_to_720p_lanczos3_batched", "rgb_resize_1080p_720p_lanczos", 64, "batch", 10)):   # vpf_resize_batch, the reference resizer's filter
         wl = Workload(name, dev, ring, 0, mode)
         _, ev = timed(wl, steps, 2, False)
         res[key] = {"Gpix_s_src": round(wl.px_per_step * steps / ev / 1e9, 1),
