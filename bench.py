@@ -89,7 +89,7 @@ class Workload:
             self.px_per_step = ring * w * h
             self.bytes_per_step = ring * (w * h * 3 // 2 + 3 * w * h)  # algorithmic: 1.5 B/px read + 3 B/px written
             self.launches_per_step = (ring + 31) // 32 if mode == "batch" else ring
-            self.kernel = ("k_nv12_rgb_p16<RGB, NT stores, 4 workgroups/CU, NV12> (16 px/lane, LDS-transposed 1 KiB non-temporal stores)" if self.dst_fmt == capi.RGB
+            self.kernel = ("k_nv12_rgb_p16x<RGB, NT stores, 4 workgroups/CU, NV12> (16 px x 2 rows per lane, blocks numbered straight through the picture, LDS-transposed non-temporal stores)" if self.dst_fmt == capi.RGB
                            else "k_nv12_planar_r16 (one row x 1024 px per wave, 16 px/lane, three 1-KiB non-temporal plane stores)")
         elif name in ("resize_4k_720p", "fused_4k_720p"):
             self.w, self.h, self.dw, self.dh = 3840, 2160, 1280, 720
@@ -347,7 +347,7 @@ def main():
         labso.vpf_lab_nv12_rgb.argtypes = [C.POINTER(capi.Exec), C.c_int, C.c_int, C.c_int, C.c_int, capi.Size, C.c_uint32, C.POINTER(capi.FrameIO)]
         for wlname in ("nv12_rgb_4k", "nv12_planar_1080p"):
             for mode in ("batch", "single"):
-                for v in (4, 8, 30, 37, -38, -41, -43, -15, -22, -23):   # negative: lab variant |v|
+                for v in (4, 8, 30, 45, 46, 37, -38, -41, -43, -15, -22, -23):   # negative: lab variant |v|
                     wl = Workload(wlname, dev, a.ring if wlname == "nv12_rgb_4k" else 4 * a.ring, max(v, 0), mode)
                     if v < 0:
                         frames_all = [capi.make_batch([(s_, d_) for s_, d_ in wl.frames[i:i + 32]]) for i in range(0, len(wl.frames), 32)]

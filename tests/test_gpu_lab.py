@@ -13,7 +13,7 @@ from gpu_util import DevPlanes, assert_planes_equal, stream_handle
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAB = os.path.join(ROOT, "tools", "lab", "libvpfhip_lab.so")
-CONVERSIONS = [1, 2, 3, 5, 6, 7, 10, 11, 13, 14, 16, 17, 18, 19, 20, 21, 27, 28, 29, 31, 32, 33, 34, 35, 36, 38, 41, 42, 43]
+CONVERSIONS = [1, 2, 3, 5, 6, 7, 10, 11, 13, 14, 16, 17, 18, 19, 20, 21, 27, 28, 29, 31, 32, 33, 34, 35, 36, 38, 41, 42, 43, 45, 46]
 PROBES = [15, 22, 23, 24, 25, 26]
 
 
@@ -51,4 +51,4 @@ def test_lab_conversion_forms_write_the_product_pixels(lab, capi, oracle, varian
 
 def test_lab_knows_which_variants_are_probes(lab):
     assert all(lab.vpf_lab_is_conversion(v) == 0 for v in PROBES)
-    assert all(lab.vpf_lab_is_conversion(v) == -1 for v in (0, 4, 8, 9, 12, 30, 37, 40, 44, 99))   # product kernels are not in the lab
+    assert all(lab.vpf_lab_is_conversion(v) == -1 for v in (0, 4, 8, 9, 12, 30, 37, 40, 44, 99))  # (the lab's own 45 / 46 are the prototype of the product's p16x)   # product kernels are not in the lab

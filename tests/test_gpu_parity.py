@@ -57,17 +57,19 @@ def test_nv12_to_rgb_matrices(capi, oracle, cs, cr, dst):
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), cs, cr, w, h, src)
 
 
-@pytest.mark.parametrize("variant", [4, 8, 9, 12, 30, 37, 40, 44])
+@pytest.mark.parametrize("variant", [4, 8, 9, 12, 30, 37, 40, 44, 45, 46])
 @pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
 def test_nv12_to_rgb_every_kernel_variant(capi, oracle, variant, dst):
     """every NV12 -> RGB kernel libvpfhip contains (the only values vpf_set_tuning accepts: p4 / p16 with non-temporal or allocating
-    stores / p16 capped at 4 workgroups per CU / planar r16 / generic) agrees bit for bit; the experimental forms live in tools/lab"""
-    for (w, h) in [(1920, 32), (3840, 8), (848, 464), (1280, 18)]:
+    stores / p16 capped at 4 workgroups per CU / p16x = blocks numbered straight through the picture / planar r16 / generic) agrees
+    bit for bit; the experimental forms live in tools/lab.  Widths around the p16x conditions: 1024 (64 blocks per row: a wave = a
+    row pair), 1040 (65: every wave crosses a row boundary at a different lane), 1008 (below 1024: falls back to p16)"""
+    for (w, h) in [(1920, 32), (3840, 8), (848, 464), (1280, 18), (1024, 6), (1040, 10), (1008, 4), (4096, 2), (5008, 6)]:
         src = oracle.synth(oracle.NV12, w, h, 1001)
         _convert(capi, oracle, capi.NV12, getattr(capi, dst), 1, 0, w, h, src, variant=variant, exact_tol=False)
 
 
-@pytest.mark.parametrize("variant", [8, 12, 30, 37, 44])
+@pytest.mark.parametrize("variant", [8, 12, 30, 37, 44, 45, 46])
 def test_nv12_to_rgb_variant_falls_back_when_not_applicable(capi, oracle, variant):
     """a 16-B-aligned-only kernel requested on ragged widths / odd bases / the other output class must silently take a
     general kernel with identical pixels (the tuning knob is a hint, never a correctness switch)"""
@@ -157,19 +159,20 @@ def test_full_size_4k_and_1080p(capi, oracle):
 
 
 def test_batch_matches_single(capi, oracle):
-    """vpf_convert_batch over 70 frames (3 dispatches of <=32) == 37 single conversions; outputs independent"""
-    w, h, n = 640, 36, 70
-    srcs = [oracle.synth(oracle.NV12, w, h, 2000 + i) for i in range(n)]
-    S = [DevPlanes(s) for s in srcs]
-    D = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
-    batch = capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)])
-    capi.convert_batch(capi.make_exec(stream_handle()), capi.NV12, capi.RGB, 1, 0, w, h, batch)
-    torch.cuda.synchronize()
-    for i in range(n):
-        got, intact = D[i].download()
-        assert intact
-        _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, srcs[i])
-        assert_planes_equal(got, want, f"batch frame {i}")
+    """vpf_convert_batch over 70 frames (3 dispatches of <=32) == 70 single conversions; outputs independent.  640 px: the chunk-per-row
+    p16 kernel; 1040 px (65 blocks per row pair): p16x, every wave crossing a row boundary at a different lane"""
+    for (w, h, n) in ((640, 36, 70), (1040, 10, 37)):
+        srcs = [oracle.synth(oracle.NV12, w, h, 2000 + i) for i in range(n)]
+        S = [DevPlanes(s) for s in srcs]
+        D = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
+        batch = capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)])
+        capi.convert_batch(capi.make_exec(stream_handle()), capi.NV12, capi.RGB, 1, 0, w, h, batch)
+        torch.cuda.synchronize()
+        for i in range(n):
+            got, intact = D[i].download()
+            assert intact
+            _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, srcs[i])
+            assert_planes_equal(got, want, f"batch {w}x{h} frame {i}")
 
 
 def test_single_frame_entry_equals_batch_entry(capi, oracle):
@@ -178,7 +181,7 @@ def test_single_frame_entry_equals_batch_entry(capi, oracle):
     for the fused kernels (exact 3x, exact 2x, general ratio)."""
     ex = capi.make_exec(stream_handle())
     pairs = [("NV12", "RGB", 640, 36), ("NV12", "BGR", 1056, 8), ("NV12", "RGB_PLANAR", 640, 36), ("NV12", "RGB_PLANAR", 2048, 1536),
-             ("NV12", "RGB", 1366, 10), ("YUV420", "RGB", 640, 36), ("YUV420", "RGB_PLANAR", 640, 36), ("YUV444", "BGR", 640, 12),
+             ("NV12", "RGB", 1366, 10), ("NV12", "RGB", 1040, 10), ("YUV420", "BGR", 2064, 6), ("YUV420", "RGB", 640, 36), ("YUV420", "RGB_PLANAR", 640, 36), ("YUV444", "BGR", 640, 12),
              ("RGB", "RGB_PLANAR", 640, 12), ("RGB_PLANAR", "BGR", 640, 12), ("RGB", "BGR", 640, 12), ("RGB", "YUV420", 640, 12),
              ("BGR", "YUV444", 640, 12), ("NV12", "YUV420", 640, 12), ("YUV420", "NV12", 640, 12), ("RGB", "Y", 640, 12),
              ("RGB", "RGB_32F", 640, 12), ("P10", "NV12", 640, 12)]
@@ -567,9 +570,9 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
         cs = 0 if s in ("RGB", "BGR", "RGB_PLANAR") else int(rng.integers(2))
         cr = int(rng.integers(2))
         if s == "NV12" and d in ("RGB", "BGR", "RGB_PLANAR"):
-            variant = int(rng.choice([0, 0, 4, 8, 9, 12, 30, 37, 40, 44]))
+            variant = int(rng.choice([0, 0, 4, 8, 9, 12, 30, 37, 40, 44, 45, 46]))
         elif s == "YUV420" and d in ("RGB", "BGR", "RGB_PLANAR"):
-            variant = int(rng.choice([0, 0, 8, 12, 30, 37, 44, 4, 40, 9]))
+            variant = int(rng.choice([0, 0, 8, 12, 30, 37, 44, 45, 46, 4, 40, 9]))
         else:
             variant = int(rng.choice([0, 0, 0, 40, 9]))
         src = oracle.synth(getattr(oracle, s), w, h, int(rng.integers(1 << 30)), "ABC"[int(rng.integers(3))])
@@ -770,7 +773,7 @@ def test_tuning_hook_rejects_values_outside_the_product(capi):
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v) == -1
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 0      # unchanged
     assert capi.set_tuning(7, 0) == -1                                    # unknown key
-    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44):
+    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46):
         capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v)
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == v
 

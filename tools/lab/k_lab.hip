@@ -231,6 +231,61 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_s16(const BatchArgs args, cons
 // bench.py --sweep to locate the ceilings): MODE 0 = the loads only (one dword per wave stored so they are not
 // dead), MODE 1 = the stores only.
 // ---------------------------------------------------------------------------------------------
+// p16 with the frame's 16-px x 2-row blocks numbered straight through the picture: a wave takes 64 consecutive blocks wherever the row
+// ends (3840 px = 240 blocks per row pair = 3.75 waves: the product kernel leaves a quarter of every fourth wave idle).  Loads are per
+// lane; the LDS-transposed stores compute the destination of every 16-B unit from the lane that produced it.  Requires w % 16 == 0.
+template <int DST, int BALLAST_KB>
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16x(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h, uint32_t bpr /* blocks per row pair */,
+                                                        uint32_t n_blocks) {
+  __shared__ u32x4 tile[4 * 2 * 192 + BALLAST_KB * 64];
+  const FrameDesc& f = args.f[blockIdx.y];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t b0 = (blockIdx.x * 4 + wv) * 64;
+  if (b0 >= n_blocks) return;
+  const uint32_t blk = b0 + lane;
+  const bool act = blk < n_blocks;
+  const uint32_t rp = blk / bpr, x = (blk - rp * bpr) * 16;
+  u32x4 y[2], uv;
+  if (act) {
+    y[0] = ldg<true, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+    y[1] = ldg<true, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+    uv = ldg<true, u32x4>(f.s[1] + (size_t)rp * f.sp[1] + x);
+  }
+  uint32_t o[2][12];
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j]));
+      const Chroma k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const Quad q = convert4(c, y[half][j], k0, k1);
+        pack_rgb12<DST, 1>(q, o[half][3 * j], o[half][3 * j + 1], o[half][3 * j + 2]);
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    u32x4* t = tile + (wv * 2 + half) * 192;
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) t[lane * 3 + j] = u32x4{o[half][4 * j], o[half][4 * j + 1], o[half][4 * j + 2], o[half][4 * j + 3]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const uint32_t idx = k * 64 + lane, src_lane = idx / 3, part = idx - 3 * src_lane;  // 16-B unit idx came from lane idx / 3
+      const uint32_t ublk = b0 + src_lane;
+      if (ublk < n_blocks) {
+        const uint32_t urp = ublk / bpr, ux = (ublk - urp * bpr) * 16;
+        stg<true, u32x4>(f.d[0] + (size_t)(2 * urp + half) * f.dp[0] + 3 * (size_t)ux + 16 * part, t[idx]);
+      }
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_probe_p16(const BatchArgs args, uint32_t w, uint32_t h, uint32_t chunks_x, uint32_t n_tasks) {
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -393,6 +448,14 @@ static hipError_t lab_launch(hipStream_t st, int variant, const Yuv2RgbCoef& c, 
       hipLaunchKernelGGL((k_nv12_rgb_r16<DST, true, 0>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, chunks16, tasks);
       return hipGetLastError();
     }
+    if (variant == 45 || variant == 46) {  // row-crossing p16 (46: 16 KiB of LDS ballast like the product's batch kernel)
+      if constexpr (DST == FC_PLANAR) { return hipErrorInvalidValue; } else {
+        const uint32_t bpr = w / 16, nb = bpr * (h / 2);
+        if (variant == 45) hipLaunchKernelGGL((k_nv12_rgb_p16x<DST, 0>), dim3((nb + 255) / 256, n), dim3(256), 0, st, a, c, w, h, bpr, nb);
+        else hipLaunchKernelGGL((k_nv12_rgb_p16x<DST, 16>), dim3((nb + 255) / 256, n), dim3(256), 0, st, a, c, w, h, bpr, nb);
+        return hipGetLastError();
+      }
+    }
     if (variant == 43) {
       const uint32_t segs = (3 * w + 1023) / 1024, tasks = segs * h;
       hipLaunchKernelGGL((k_nv12_rgb_s16<DST, true>), dim3((tasks + 3) / 4, n), dim3(256), 0, st, a, c, w, h, segs, tasks);
@@ -413,7 +476,7 @@ __attribute__((visibility("default"))) int vpf_lab_is_conversion(int variant) {
   switch (variant) {
     case 15: case 22: case 23: case 24: case 25: case 26: return 0;
     case 1: case 2: case 3: case 5: case 6: case 7: case 10: case 11: case 13: case 14: case 16: case 17: case 18: case 19: case 20: case 21:
-    case 27: case 28: case 29: case 31: case 32: case 33: case 34: case 35: case 36: case 38: case 41: case 42: case 43: return 1;
+    case 27: case 28: case 29: case 31: case 32: case 33: case 34: case 35: case 36: case 38: case 41: case 42: case 43: case 45: case 46: return 1;
     default: return -1;
   }
 }

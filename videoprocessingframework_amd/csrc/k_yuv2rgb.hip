@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void k_nv12_rgb_p16_one(VPF_ONE_SRC_PARAMS, ui
   p16_task<DST, 1, true, NTS, true, 4, 0, false, SRC>(VPF_ONE_FRAME, c, w, h, chunks_x, n_tasks);
 }
 
+// the same conversion with the blocks numbered straight through the picture (p16x_task): the default for packed outputs of frames at least 1024 px wide
+template <int DST, bool NTS, int BALLAST_KB, int SRC>
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16x(const BatchArgs args, const Yuv2RgbCoef c, uint32_t bpr, uint32_t n_blocks) {
+  p16x_task<DST, NTS, BALLAST_KB, SRC>(args.f[blockIdx.y], c, bpr, n_blocks);
+}
+template <int DST, bool NTS, int SRC>
+__global__ __launch_bounds__(256) void k_nv12_rgb_p16x_one(VPF_ONE_SRC_PARAMS, uint32_t bpr, uint32_t n_blocks, VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
+  p16x_task<DST, NTS, 0, SRC>(VPF_ONE_FRAME, c, bpr, n_blocks);
+}
+
 template <bool NTS, int SRC = FC_NV12>
 __global__ __launch_bounds__(256) void k_nv12_planar_r16(const BatchArgs args, const Yuv2RgbCoef c, uint32_t w, uint32_t h,
                                                          uint32_t chunks_x, uint32_t n_tasks) {
@@ -205,11 +215,12 @@ static bool aligned_all(const BatchArgs& a, uint32_t n, int nsrc, int ndst, uint
 // Kernel selection for 4:2:0 sources.  `variant` is the tuning hint (include/vpf_hip.h): 0 = policy below; a named kernel
 // (4 / 8 / 12 / 30 / 37 / 44) is honoured where it applies and falls back down the same chain where it does not; 40 = the
 // narrower p4 path, 9 = the any-input generic kernel.  Every kernel here writes the same pixels.
+//   p16x (45 | 46: 4 workgroups / CU)                                               packed outputs, w >= 1024: blocks numbered straight through the picture
 //   p16  (8: non-temporal stores | 12: allocating stores | 30: 4 workgroups / CU)   packed outputs; w % 16 == 0, h even, 16-B aligned
 //   r16  (37: non-temporal | 44: allocating stores)                                 planar outputs; same conditions
 //   p4   (4)                                                                        4-B aligned planes, any size
 //   generic (9)                                                                     anything
-// Policy (profiles/r01_bench_sweep.log, tools/lab): packed -> p16, with the 4-workgroup cap when the launch is a batch (>= 4 frames:
+// Policy (profiles/r01_bench_sweep.log, r02_bench_sweep.log, tools/lab): packed -> p16x (p16 below 1024 px), with the 4-workgroup cap when the launch is a batch (>= 4 frames:
 // a narrower chip-wide write frontier is worth 1-2 %; short single-frame launches want all the waves they can get); planar -> r16
 // (three 1-KiB plane stores per wave), except a lone frame of >= 3 Mpx where the row-pair p16 form wins (kernel 7.3 vs 7.9 us at 4K,
 // but 4.3 vs 3.6 at 1080p: tools/gpu_planar_single.sh).  The alternatives that were measured and dropped (more row pairs per task,
@@ -222,7 +233,9 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   const bool p16_ok = even && (w % 16 == 0) && aligned_all(a, n, nsrc, ndst, 16, 16, SRC == FC_NV12 ? 16 : 8);
   const bool p4_ok = aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
   const bool big_single = n < 4 && (size_t)w * h >= (size_t)3 << 20;
-  if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? (big_single ? 8 : 37) : (n >= 4 ? 30 : 8)) : 4;
+  const bool p16x_ok = p16_ok && DST != FC_PLANAR && w >= 1024 && (uint64_t)(w / 16) * (h / 2) < (1u << 30);
+  if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? (big_single ? 8 : 37) : (n >= 4 ? (p16x_ok ? 46 : 30) : 8)) : 4;  // (single frames: p16x measured level with p16, 0.710 vs 0.717)
+  if ((variant == 45 || variant == 46) && !p16x_ok) variant = variant == 46 ? 30 : 8;  // narrow frames / planar outputs: the chunk-per-row form
   const bool is_p16 = variant == 8 || variant == 12 || variant == 30, is_r16 = variant == 37 || variant == 44;
   if ((is_p16 || is_r16) && !p16_ok) variant = 4;
   if (is_r16 && DST != FC_PLANAR) variant = 4;
@@ -236,6 +249,16 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
     else if (variant == 37) VPF_LAUNCH((k_nv12_planar_r16<true, SRC>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);
     else VPF_LAUNCH((k_nv12_planar_r16<false, SRC>), grid, dim3(256), 0, st, a, c, w, h, chunks, tasks);  // allocating stores
     return hipGetLastError();
+  }
+  if (variant == 45 || variant == 46) {
+    if constexpr (DST != FC_PLANAR) {
+      const uint32_t bpr = w / 16, nb = bpr * (h / 2);
+      dim3 grid((nb + 255) / 256, n);
+      if (n == 1) VPF_LAUNCH((k_nv12_rgb_p16x_one<DST, true, SRC>), grid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(f0), bpr, nb, VPF_ONE_DST_ARGS(f0), c);
+      else if (variant == 45) VPF_LAUNCH((k_nv12_rgb_p16x<DST, true, 0, SRC>), grid, dim3(256), 0, st, a, c, bpr, nb);
+      else VPF_LAUNCH((k_nv12_rgb_p16x<DST, true, 16, SRC>), grid, dim3(256), 0, st, a, c, bpr, nb);  // 40 KiB of LDS -> 4 workgroups / CU
+      return hipGetLastError();
+    }
   }
   if (variant == 8 || variant == 12 || variant == 30) {
     const uint32_t chunks = (w + 1023) / 1024, tasks = chunks * (h / 2);

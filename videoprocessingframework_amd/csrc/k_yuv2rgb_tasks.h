@@ -184,6 +184,65 @@ VPF_DEV void p16_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t w, uint
   }
 }
 
+// p16 with the frame's 16-px x 2-row blocks numbered STRAIGHT THROUGH the picture ("p16x"): a wave takes 64 consecutive blocks wherever
+// the row ends.  With p16's chunk-per-row tasks a 3840-px row pair is 3.75 waves — every fourth wave works with 48 of its 64 lanes, 6 % fewer
+// bytes in flight chip-wide — and the straight numbering is worth exactly that on the HBM-bound batch: 0.78 -> 0.82 of 8 TB/s
+// (profiles/r02_bench_sweep.log, lab 45 / 46 before it moved here).  Loads are per lane (own row pair, own column); the LDS-transposed
+// stores compute the destination of every 16-B unit from the lane that produced it.  A wave crosses at most one row boundary:
+// requires bpr = w / 16 >= 64 (w >= 1024), w % 16 == 0, h even, 16-B aligned planes / pitches.  Packed outputs only.
+template <int DST, bool NTS, int BALLAST_KB, int SRC>
+VPF_DEV void p16x_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t bpr /* blocks per row pair */, uint32_t n_blocks) {
+  __shared__ u32x4 tile[4 * 2 * 192 + BALLAST_KB * 64];
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t b0 = (blockIdx.x * 4 + wv) * 64;
+  if (b0 >= n_blocks) return;
+  const uint32_t rp0 = __builtin_amdgcn_readfirstlane(b0 / bpr), c0 = b0 - rp0 * bpr;  // the wave's first block: row pair, column (in blocks)
+  auto place = [&](uint32_t l, uint32_t& rp, uint32_t& x) {  // block b0 + l: at most one row boundary inside a wave (bpr >= 64)
+    const uint32_t col = c0 + l, over = col >= bpr ? 1u : 0u;
+    rp = rp0 + over; x = (col - over * bpr) * 16;
+  };
+  const bool act = b0 + lane < n_blocks;
+  uint32_t rp, x;
+  place(lane, rp, x);
+  u32x4 y[2], uv;
+  if (act) {
+    y[0] = ldg<true, u32x4>(f.s[0] + (size_t)(2 * rp) * f.sp[0] + x);
+    y[1] = ldg<true, u32x4>(f.s[0] + (size_t)(2 * rp + 1) * f.sp[0] + x);
+    uv = load_uv16<SRC, true>(f, rp, x);
+  }
+  uint32_t o[2][12];
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Chroma k0 = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j]));
+      const Chroma k1 = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const Quad q = convert4(c, y[half][j], k0, k1);
+        pack_rgb12<DST, 1>(q, o[half][3 * j], o[half][3 * j + 1], o[half][3 * j + 2]);
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    u32x4* t = tile + (wv * 2 + half) * 192;
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) t[lane * 3 + j] = u32x4{o[half][4 * j], o[half][4 * j + 1], o[half][4 * j + 2], o[half][4 * j + 3]};
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const uint32_t idx = k * 64 + lane, src_lane = idx / 3, part = idx - 3 * src_lane;  // 16-B unit idx was produced by lane idx / 3
+      if (b0 + src_lane < n_blocks) {
+        uint32_t urp, ux;
+        place(src_lane, urp, ux);
+        stg<NTS, u32x4>(f.d[0] + (size_t)(2 * urp + half) * f.dp[0] + 3 * (size_t)ux + 16 * part, t[idx]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // r16 (planar outputs): a wave owns ONE row x 1024 px: lane = 16 px, Y dwordx4 + UV dwordx4 (the row below re-reads the same
 // UV line from L2, not HBM), three dense 1-KiB dwordx4 stores (R, G, B planes) — 3 stores per wave instead of the 6 a

@@ -427,7 +427,7 @@ int vpf_set_tuning(int key, int value) {
   if (key == VPF_TUNE_RESIZE_BAND) return (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? g_tune_band.exchange(value) : -1;
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
-    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: return g_tune_variant.exchange(value);
+    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: return g_tune_variant.exchange(value);
     default: return -1;  // unknown value: nothing changes
   }
 }
