@@ -161,18 +161,18 @@ def test_full_size_4k_and_1080p(capi, oracle):
 def test_batch_matches_single(capi, oracle):
     """vpf_convert_batch over 70 frames (3 dispatches of <=32) == 70 single conversions; outputs independent.  640 px: the chunk-per-row
     p16 kernel; 1040 px (65 blocks per row pair): p16x, every wave crossing a row boundary at a different lane"""
-    for (w, h, n) in ((640, 36, 70), (1040, 10, 37)):
+    for (w, h, n, dst) in ((640, 36, 70, "RGB"), (1040, 10, 37, "RGB"), (1040, 10, 37, "RGB_PLANAR"), (2064, 6, 5, "RGB_PLANAR")):
         srcs = [oracle.synth(oracle.NV12, w, h, 2000 + i) for i in range(n)]
         S = [DevPlanes(s) for s in srcs]
-        D = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
+        D = [DevPlanes(oracle.alloc(getattr(oracle, dst), w, h)) for _ in range(n)]
         batch = capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)])
-        capi.convert_batch(capi.make_exec(stream_handle()), capi.NV12, capi.RGB, 1, 0, w, h, batch)
+        capi.convert_batch(capi.make_exec(stream_handle()), capi.NV12, getattr(capi, dst), 1, 0, w, h, batch)
         torch.cuda.synchronize()
         for i in range(n):
             got, intact = D[i].download()
             assert intact
-            _, want = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, srcs[i])
-            assert_planes_equal(got, want, f"batch {w}x{h} frame {i}")
+            _, want = oracle.convert(oracle.NV12, getattr(oracle, dst), 1, 0, w, h, srcs[i])
+            assert_planes_equal(got, want, f"batch {dst} {w}x{h} frame {i}")
 
 
 def test_single_frame_entry_equals_batch_entry(capi, oracle):
@@ -181,7 +181,7 @@ def test_single_frame_entry_equals_batch_entry(capi, oracle):
     for the fused kernels (exact 3x, exact 2x, general ratio)."""
     ex = capi.make_exec(stream_handle())
     pairs = [("NV12", "RGB", 640, 36), ("NV12", "BGR", 1056, 8), ("NV12", "RGB_PLANAR", 640, 36), ("NV12", "RGB_PLANAR", 2048, 1536),
-             ("NV12", "RGB", 1366, 10), ("NV12", "RGB", 1040, 10), ("YUV420", "BGR", 2064, 6), ("YUV420", "RGB", 640, 36), ("YUV420", "RGB_PLANAR", 640, 36), ("YUV444", "BGR", 640, 12),
+             ("NV12", "RGB", 1366, 10), ("NV12", "RGB", 1040, 10), ("YUV420", "BGR", 2064, 6), ("NV12", "RGB_PLANAR", 1040, 10), ("YUV420", "RGB", 640, 36), ("YUV420", "RGB_PLANAR", 640, 36), ("YUV444", "BGR", 640, 12),
              ("RGB", "RGB_PLANAR", 640, 12), ("RGB_PLANAR", "BGR", 640, 12), ("RGB", "BGR", 640, 12), ("RGB", "YUV420", 640, 12),
              ("BGR", "YUV444", 640, 12), ("NV12", "YUV420", 640, 12), ("YUV420", "NV12", 640, 12), ("RGB", "Y", 640, 12),
              ("RGB", "RGB_32F", 640, 12), ("P10", "NV12", 640, 12)]

@@ -218,6 +218,7 @@ static bool aligned_all(const BatchArgs& a, uint32_t n, int nsrc, int ndst, uint
 //   p16x (45 | 46: 4 workgroups / CU)                                               packed outputs, w >= 1024: blocks numbered straight through the picture
 //   p16  (8: non-temporal stores | 12: allocating stores | 30: 4 workgroups / CU)   packed outputs; w % 16 == 0, h even, 16-B aligned
 //   r16  (37: non-temporal | 44: allocating stores)                                 planar outputs; same conditions
+//        (the straight numbering applied to r16 measured 1 % SLOWER on the 1080p planar batch, 0.779 vs 0.787 in same-box A/B: not kept)
 //   p4   (4)                                                                        4-B aligned planes, any size
 //   generic (9)                                                                     anything
 // Policy (profiles/r01_bench_sweep.log, r02_bench_sweep.log, tools/lab): packed -> p16x (p16 below 1024 px), with the 4-workgroup cap when the launch is a batch (>= 4 frames:
