@@ -443,9 +443,11 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
   int32_t R0, R1;
   uint32_t first, last, xo[NT];
   float wx = 0.f;  // bilinear: fx
+  int32_t fv = 0, lv = 0;  // Lanczos: the tile's VIRTUAL source columns [fv, lv]; columns before 0 / after sw - 1 are copies of the edge pixel
   if constexpr (LZ) {
     R0 = ltap_i0(y0, scy) - 2; R1 = ltap_i0(yl, scy) + 3;
-    first = clampi(ltap_i0(xf, scx) - 2, (int32_t)sw - 1); last = clampi(ltap_i0(xl, scx) + 3, (int32_t)sw - 1);
+    fv = ltap_i0(xf, scx) - 2; lv = ltap_i0(xl, scx) + 3;
+    first = clampi(fv, (int32_t)sw - 1); last = clampi(lv, (int32_t)sw - 1);
   } else {
     R0 = (int32_t)make_tap<VPF_INTERP_LINEAR>(y0, scy, sh).i0; R1 = (int32_t)make_tap<VPF_INTERP_LINEAR>(yl, scy, sh).i1;
     first = make_tap<VPF_INTERP_LINEAR>(xf, scx, sw).i0; last = make_tap<VPF_INTERP_LINEAR>(xl, scx, sw).i1;
@@ -489,17 +491,33 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
       WX[3 * 64 + lane] = (uint32_t)tx.i0;
     }
   }
+  constexpr uint32_t PADQ = LZ ? 1 : 0;  // Lanczos rows start one 16-B unit into their LDS row: room for up to 3 replicated pixels on the left
 #pragma unroll
   for (int k = 0; k < kTileStagePasses; k++) {
     const uint32_t r = srow0 + k * srows;
-    if (r < nrows && scol < nq) RAW[r * rowq + scol] = stage[k];
+    if (r < nrows && scol < nq) RAW[r * rowq + scol + PADQ] = stage[k];
+  }
+  if constexpr (LZ) {
+    // Tiles on the left / right image edge: the pixels clamped taps fall on are REPLICATED into the margins of every staged row, so that
+    // every lane's six taps are contiguous bytes in every tile (the byte-by-byte walk these tiles used to take made them the slowest
+    // workgroups of a single-frame launch, which lasts as long as its slowest workgroup)
+    if (fv < 0 || lv > (int32_t)sw - 1) {  // workgroup-uniform
+      __syncthreads();
+      const int32_t nl = fv < 0 ? -fv * CH : 0, nr = lv > (int32_t)sw - 1 ? (lv - ((int32_t)sw - 1)) * CH : 0;  // bytes to add on each side (<= 3 px)
+      for (uint32_t t = threadIdx.x; t < nrows * 16; t += T) {
+        uint8_t* b = reinterpret_cast<uint8_t*>(RAW + (size_t)(t >> 4) * rowq) + 16;
+        const int32_t i = (int32_t)(t & 15);
+        if (i < nl) b[CH * fv + i] = b[i % CH];                                                    // base == 0 on the left edge
+        if (i < nr) b[CH * sw - base + (uint32_t)i] = b[CH * (sw - 1) - base + (uint32_t)i % CH];
+      }
+    }
   }
   __syncthreads();
   uint32_t qx[3] = {0, 0, 0};  // Lanczos: the column's six Q14 weights as three int16 pairs (taps 0|1, 2|3, 4|5)
   if constexpr (LZ) {
     const int32_t i0 = (int32_t)WX[3 * 64 + lane];
 #pragma unroll
-    for (int k = 0; k < 6; k++) xo[k] = clampi(i0 + k - 2, (int32_t)sw - 1) * CH - base;
+    for (int k = 0; k < 6; k++) xo[k] = (uint32_t)((i0 + k - 2) * CH - (int32_t)base + 16);  // contiguous by construction
 #pragma unroll
     for (int k = 0; k < 3; k++) qx[k] = WX[k * 64 + lane];
   } else {
@@ -507,11 +525,9 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
     xo[0] = tx.i0 * CH - base; xo[1] = tx.i1 * CH - base; wx = tx.f;
   }
   // Phase 1, horizontal: wave w takes source rows w, w + WPB, ...; rows are independent of one another (no barrier inside the loop)
-  // wave-uniform: no lane's taps were clamped at an image edge (clamped taps repeat a pixel and break the run)
-  const bool contiguous = LZ && __builtin_amdgcn_ballot_w64(xo[NT - 1] - xo[0] != (uint32_t)(CH * (NT - 1))) == 0;
-  if (LZ && contiguous) {
-    // In integers, two taps per v_dot2_i32_i16.  No tap clamped anywhere in the wave (everything but the tiles on the left / right
-    // image edge): a lane's 6 x CH taps are contiguous bytes -> aligned dword reads, v_alignbyte_b32 to drop the lead, one v_perm_b32
+  if constexpr (LZ) {
+    // In integers, two taps per v_dot2_i32_i16.  A lane's 6 x CH taps are contiguous bytes (edge tiles: replicated margins, above)
+    // -> aligned dword reads, v_alignbyte_b32 to drop the lead, one v_perm_b32
     // per tap pair to spread two bytes into int16 halves, then the dots; same exact sums as the byte-by-byte form below and as the
     // gather kernel.  Two source rows per iteration: both rows' LDS reads are in flight before the first is used.
     constexpr int NE = (6 * CH + 3) / 4;  // dwords of the lead-free run
@@ -552,15 +568,7 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
   } else {
     for (uint32_t r = wv; r < nrows; r += WPB) {
       const uint8_t* b = reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq);
-      if constexpr (LZ) {  // a tile on the left / right image edge: clamped taps, byte by byte
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-          int32_t a = 0;
-#pragma unroll
-          for (int k = 0; k < 3; k++) a = dot2((uint32_t)b[xo[2 * k] + c] | ((uint32_t)b[xo[2 * k + 1] + c] << 16), qx[k], a);
-          H[(r * CH + c) * 64 + lane] = (float)a;
-        }
-      } else if (CH == 3) {
+      if constexpr (CH == 3) {
         float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
         strip_window_taps(b, xo[0], t0, t1);
 #pragma unroll
@@ -1149,7 +1157,7 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
   float scy = 0.f;
   for (int p = 0; p < np; p++) {
     ch_max = ch[p] > ch_max ? ch[p] : ch_max;
-    const uint32_t q = (uint32_t)((((double)scxs[p] * 63.0 + taps + 3.0) * ch[p] * elem + 32.0) / 16.0) + 1;
+    const uint32_t q = (uint32_t)((((double)scxs[p] * 63.0 + taps + 3.0) * ch[p] * elem + 32.0) / 16.0) + 1 + ((lz && elem == 1) ? 2 : 0);  // 8-bit Lanczos: + pad unit + right margin
     rowq = q > rowq ? q : rowq;
     scy = scys[p] > scy ? scys[p] : scy;
   }
