@@ -873,6 +873,7 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
              ("RGB", 300, 5, 200, 1, 0, 2), ("Y", 997, 61, 333, 47, 0, 2), ("RGB", 512, 90, 128, 61, 0, 2), ("RGB", 200, 50, 333, 77, 40, 2),
              ("NV12", 200, 50, 320, 96, 40, 2), ("RGB", 640, 360, 224, 224, 0, 33), ("RGB", 1919, 64, 1280, 43, 0, 2),
              ("RGB", 320, 180, 1280, 720, 0, 2), ("YUV420", 96, 54, 160, 90, 0, 3),                                # up-scales (the band family by policy when forced)
+             ("Y", 1500, 40, 1000, 27, 0, 2), ("YUV444", 600, 40, 500, 31, 0, 2), ("NV12", 1200, 40, 2040, 68, 0, 2),  # 1-channel planes that 512-column chunks fill well: 8 px per lane
              ("RGB", 1, 1, 9, 7, 0, 2), ("RGB", 2, 3, 300, 5, 0, 2), ("Y", 3, 2, 5, 70, 0, 2), ("NV12", 4, 4, 18, 10, 0, 2), ("RGB", 5, 2, 3, 1, 0, 2)]  # tiny pictures
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, band) >= 0
     try:

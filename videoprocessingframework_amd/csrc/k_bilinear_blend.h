@@ -75,20 +75,21 @@ VPF_DEV void strip_window_taps(const uint8_t* strip, uint32_t a, float* t0, floa
   t1[0] = ubyte<3>(lo); t1[1] = ubyte<0>(hi); t1[2] = ubyte<1>(hi);
 }
 
-// The column side of four consecutive destination pixels of a row-pair blend: tap offsets inside the LDS strips and weights.  They depend on
-// the destination columns only, so a wave that blends several destination rows computes them once (RowBandTask, convert_strip_task).
-template <int CH>
+// The column side of PX (four; eight in the row-band kernel's 1-channel instantiation) consecutive destination pixels of a row-pair blend:
+// tap offsets inside the LDS strips and weights.  They depend on the destination columns only, so a wave that blends several destination
+// rows computes them once (RowBandTask, convert_strip_task).
+template <int CH, int PX = 4>
 struct ColTaps {
-  uint32_t a[4], b[4];  // byte offsets of tap 0 / tap 1 from the strips' first byte
-  float f[4];
-  bool allfx;  // wave-uniform: for each of the four pixels some lane has fx != 0 (no exact-alignment shortcut applies on x)
+  uint32_t a[PX], b[PX];  // byte offsets of tap 0 / tap 1 from the strips' first byte
+  float f[PX];
+  bool allfx;  // wave-uniform: for each of the pixels some lane has fx != 0 (no exact-alignment shortcut applies on x)
 };
-template <int CH>
-VPF_DEV ColTaps<CH> make_col_taps(uint32_t base, uint32_t x0, uint32_t dw, uint32_t sw, float scx) {
-  ColTaps<CH> T;
+template <int CH, int PX = 4>
+VPF_DEV ColTaps<CH, PX> make_col_taps(uint32_t base, uint32_t x0, uint32_t dw, uint32_t sw, float scx) {
+  ColTaps<CH, PX> T;
   T.allfx = true;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < PX; k++) {
     const Tap t = make_tap<VPF_INTERP_LINEAR>((x0 + k < dw) ? x0 + k : dw - 1, scx, sw);
     T.a[k] = CH * t.i0 - base; T.b[k] = CH * t.i1 - base; T.f[k] = t.f;
     T.allfx = T.allfx && __builtin_amdgcn_ballot_w64(t.f != 0.f) != 0;
@@ -173,16 +174,18 @@ VPF_DEV void rowpair_blend4(const uint8_t* r0, const uint8_t* r1, bool row1, flo
   }
   }
 }
-// four blended pixels (o[] of rowpair_blend4) -> bytes of one destination row
-template <int CH>
-VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /* valid pixels, 1..4 */) {
+// PX blended pixels (o[] of rowpair_blend4 / band_blend_rows) -> bytes of one destination row (PX = 8: 1-channel planes only)
+template <int CH, int PX = 4>
+VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /* valid pixels, 1..PX */) {
+  static_assert(PX == 4 || (PX == 8 && CH == 1), "8 pixels per lane: 1-channel planes");
   if (vec4) {
     if constexpr (CH == 3) {
       stg3<true>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7]), pack4_trunc_inrange(o[8], o[9], o[10], o[11]));
     } else if constexpr (CH == 2) {
       stg<true, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
     } else {
-      stg<true, uint32_t>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]));
+#pragma unroll
+      for (int q = 0; q < PX / 4; q++) stg<true, uint32_t>(out + 4 * q, pack4_trunc_inrange(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]));
     }
   } else {
     for (uint32_t i = 0; i < nv * CH; i++) out[i] = (uint8_t)(uint32_t)o[i];
@@ -190,12 +193,12 @@ VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /
 }
 
 constexpr int kBandSlots = 8;  // source rows a wave's strips can hold (twice as many when a strip is a single 1-KiB staging pass: IT = 1)
-template <int CH>
-VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH>& T, float* H) {  // H[k * CH + c] = horizontal lerp of pixel k, channel c
+template <int CH, int PX = 4>
+VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, float* H) {  // H[k * CH + c] = horizontal lerp of pixel k, channel c
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  float p0[4][CH], p1[4][CH];
+  float p0[PX][CH], p1[PX][CH];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < PX; k++) {
     if constexpr (CH == 3) {
       strip_window_taps(r, T.a[k], p0[k], p1[k]);
     } else {
@@ -204,7 +207,7 @@ VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH>& T, float* H) {  //
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < PX / 2; j++) {
     const f32x2 fx2 = {T.f[2 * j], T.f[2 * j + 1]};
 #pragma unroll
     for (int c = 0; c < CH; c++) {
@@ -216,10 +219,10 @@ VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH>& T, float* H) {  //
 }
 // Destination rows ya..yb (at most R) of a band whose source rows r_lo.. sit in LDS `rowbytes` apart: the two current source rows'
 // horizontal lerps stay in registers and move up (Hb -> Ha) as the destination rows walk down.  put(y, o) receives o[] = pixel-major, + 0.5 added.
-template <int CH, int R, class Put>
-VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, float scy, uint32_t sh, const ColTaps<CH>& T, Put&& put) {
+template <int CH, int R, int PX = 4, class Put>
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, float scy, uint32_t sh, const ColTaps<CH, PX>& T, Put&& put) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  float Ha[4 * CH], Hb[4 * CH];       // horizontal lerps of source rows ida (upper tap) and idb (lower tap)
+  float Ha[PX * CH], Hb[PX * CH];       // horizontal lerps of source rows ida (upper tap) and idb (lower tap)
   uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
 #pragma unroll
   for (int i = 0; i < R; i++) {
@@ -230,25 +233,25 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
     if (i0 != ida) {
       if (i0 == idb) {
 #pragma unroll
-        for (int q = 0; q < 4 * CH; q++) Ha[q] = Hb[q];
+        for (int q = 0; q < PX * CH; q++) Ha[q] = Hb[q];
       } else {
-        band_hlerp4<CH>(strips + (size_t)(i0 - r_lo) * rowbytes, T, Ha);
+        band_hlerp4<CH, PX>(strips + (size_t)(i0 - r_lo) * rowbytes, T, Ha);
       }
       ida = i0;
     }
     if (i1 != idb) {
       if (i1 == ida) {
 #pragma unroll
-        for (int q = 0; q < 4 * CH; q++) Hb[q] = Ha[q];
+        for (int q = 0; q < PX * CH; q++) Hb[q] = Ha[q];
       } else {
-        band_hlerp4<CH>(strips + (size_t)(i1 - r_lo) * rowbytes, T, Hb);
+        band_hlerp4<CH, PX>(strips + (size_t)(i1 - r_lo) * rowbytes, T, Hb);
       }
       idb = i1;
     }
-    float o[4 * CH];
+    float o[PX * CH];
     const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
 #pragma unroll
-    for (int q = 0; q < 4 * CH; q += 2) {
+    for (int q = 0; q < PX * CH; q += 2) {
       const f32x2 top = {Ha[q], Ha[q + 1]}, bot = {Hb[q], Hb[q + 1]};
       const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
       o[q] = v[0]; o[q + 1] = v[1];
@@ -257,13 +260,13 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
   }
 }
 
-// strip bytes a wave needs for its source span (<= 255*scale + 3 pixels, + 16-B alignment slack on both ends),
-// rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
-static inline uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap) {
+// strip bytes a wave needs for the source span of its `cols` destination columns (<= (cols - 1) * scale + 3 pixels, + 16-B alignment slack
+// on both ends), rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
+static inline uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap, uint32_t cols = 256) {
   if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9) return 0;  // forced generic
   if (((uintptr_t)src | sp) & 15) return 0;
   const double scale = (double)sw / (double)dw;
-  const double need = (255.0 * scale + 4.0) * ch + 32.0;
+  const double need = ((double)(cols - 1) * scale + 4.0) * ch + 32.0;
   if (need > (double)row_bytes_cap) return 0;
   return ((uint32_t)need + 255u) & ~255u;
 }

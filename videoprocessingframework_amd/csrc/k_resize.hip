@@ -353,22 +353,28 @@ VPF_DEV void RowPairTask<CH, IT>::run(const uint8_t* __restrict__ src, uint32_t 
 // RowPairTask and of the oracle (zero weights need no special case: fma(0, finite, t) == t and every staged byte is finite).
 // Used where the launch still has plenty of workgroups (batches); a single small frame keeps one row per wave.
 // ------------------------------------------------------------------------------------------
-template <int CH, int R, int IT = 2 /* 1-KiB staging passes per strip */>
+// destination pixels per lane: 4, or 8 = 512 columns per wave on 1-channel planes in the `P1 = 8` instantiations (a wave's per-row fixed
+// work is the same whatever the channel count; the launcher picks them when 512-column chunks fill the planes' rows well)
+constexpr int band_px(int ch, int p1) { return ch == 1 ? p1 : 4; }
+template <int CH, int R, int IT = 2 /* 1-KiB staging passes per strip */, int P1 = 4 /* pixels per lane on 1-channel planes */>
 struct RowBandTask {
   static constexpr int kThreads = 256;
   static constexpr int kSlots = kBandSlots * 2 / IT;
+  static constexpr int kPx = band_px(CH, P1);
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
-template <int CH, int R, int IT>
-VPF_DEV void RowBandTask<CH, R, IT>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
-                                     uint32_t bx, uint32_t by) {
+template <int CH, int R, int IT, int P1>
+VPF_DEV void RowBandTask<CH, R, IT, P1>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                         uint32_t bx, uint32_t by) {
+  constexpr int PX = kPx;
+  constexpr uint32_t W = 64 * PX;  // destination columns per wave
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, slots = G.a1;
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t ya = (by * 4 + wv) * R;
-  if (ya >= dh || bx * 256 >= dw) return;
+  if (ya >= dh || bx * W >= dw) return;
   const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1;
-  const uint32_t xs = bx * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  const uint32_t xs = bx * W, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
   const uint32_t r_lo = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(ya, scy, sh).i0);
@@ -382,13 +388,13 @@ VPF_DEV void RowBandTask<CH, R, IT>::run(const uint8_t* __restrict__ src, uint32
   for (int k = 0; k < kSlots; k++)
     if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, nq, lane);
   wave_lds_sync();
-  const uint32_t x0 = xs + lane * 4;
+  const uint32_t x0 = xs + lane * PX;
   if (x0 >= dw) return;
-  const ColTaps<CH> T = make_col_taps<CH>(base, x0, dw, sw, scx);
-  const bool vec4 = G.vec_ok && x0 + 4 <= dw;
-  const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
-  band_blend_rows<CH, R>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo, ya, yb, scy, sh, T, [&](uint32_t y, const float* o) {
-    store_blend4<CH>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
+  const ColTaps<CH, PX> T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);
+  const bool vec4 = G.vec_ok && x0 + PX <= dw;
+  const uint32_t nv = dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX;
+  band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo, ya, yb, scy, sh, T, [&](uint32_t y, const float* o) {
+    store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
   });
 }
 
@@ -1021,6 +1027,8 @@ template <int CH> struct RowBand4 : RowBandTask<CH, 4> {};
 template <int CH> struct RowBand8 : RowBandTask<CH, 8> {};
 template <int CH> struct RowBand8n : RowBandTask<CH, 8, 1> {};    // narrow strips (<= 1 KiB): 16 slots
 template <int CH> struct RowBand16n : RowBandTask<CH, 16, 1> {};
+template <int CH> struct RowBand8w : RowBandTask<CH, 8, 1, 8> {};   // ... and 8 pixels per lane on 1-channel planes
+template <int CH> struct RowBand16w : RowBandTask<CH, 16, 1, 8> {};
 template <int CH> struct LzMarch : LanczosMarchTask<CH> {};
 
 // ------------------------------------------------------------------------------------------
@@ -1433,9 +1441,29 @@ struct BandShape { int rows; uint32_t slots; bool narrow; };
 static uint32_t band_slots(int r, float scy) {  // source rows a band of r destination rows can touch: i1(last) - i0(first) + 1 <= floor((r - 1) scy) + 3 (+ fp32 slack)
   return (uint32_t)((double)(r - 1) * (double)scy + 0.01) + 3u;
 }
-static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32_t n) {
+// pixels per lane for the 1-channel planes of a band launch: 8 (512 columns per wave) when such chunks fill every 1-channel row to >= 80 %
+// (1280 px: 3 chunks, 83 %; the 640-px chroma planes of a 720p YUV420 frame: 2 chunks, 62 % -> 4)
+static int band_p1(int njobs, const ResizeJob* jobs) {
+  for (int p = 0; p < njobs; p++)
+    if (jobs[p].ch == 1 && (double)jobs[p].dw < 0.8 * 512.0 * ((jobs[p].dw + 511) / 512)) return 4;
+  return 8;
+}
+// strip bytes of the widest plane for a band launch (RowBandTask: 64 * band_px(ch, p1) columns per wave); 0 when some plane has no LDS path
+static uint32_t band_strip_bytes(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a, int p1) {
+  uint32_t rbmax = 0;
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    bool al = true;
+    for (uint32_t i = 0; i < n; i++) al = al && !(((uintptr_t)a.f[i].s[j.k] | a.f[i].sp[j.k]) & 15);
+    const uint32_t rb = al ? lds_strip_bytes(j.ch, j.sw, j.dw, a.f[0].s[j.k], a.f[0].sp[j.k], kResizeRowBytes, 64u * band_px(j.ch, p1)) : 0;
+    if (!rb) return 0;
+    rbmax = rb > rbmax ? rb : rbmax;
+  }
+  return rbmax;
+}
+static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32_t n, int p1 = 4) {
   const int forced = tuning(VPF_TUNE_RESIZE_BAND);
-  if (forced == 1 || rb > 2048) return {1, 0, false};
+  if (forced == 1 || rb == 0 || rb > 2048) return {1, 0, false};
   float scy = 0.f;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
@@ -1451,10 +1479,23 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
     const uint32_t slots = band_slots(r, scy);
     if (slots > (uint32_t)(narrow ? 2 * kBandSlots : kBandSlots) || 4u * slots * rb + 16u > 64u * 1024u) continue;
     uint64_t groups = 0;
-    for (int p = 0; p < njobs; p++) groups += (uint64_t)(((jobs[p].dw + 3) / 4 + 63) / 64) * ((jobs[p].dh + 4 * r - 1) / (4 * r)) * n;
+    for (int p = 0; p < njobs; p++) groups += (uint64_t)((jobs[p].dw + 64u * band_px(jobs[p].ch, p1) - 1) / (64u * band_px(jobs[p].ch, p1))) * ((jobs[p].dh + 4 * r - 1) / (4 * r)) * n;
     if (forced || groups >= kBandMinGroups) return {r, slots, narrow};
   }
   return {1, 0, false};
+}
+// the whole decision: 8 pixels per lane on the 1-channel planes only with the 16-slot (narrow-strip) instantiations that exist for it
+struct BandPlan { int rows; uint32_t slots; bool narrow; int p1; uint32_t rb; };
+static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
+  const int p1 = band_p1(njobs, jobs);
+  if (p1 == 8) {
+    const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 8);
+    const BandShape bs = band_rows(njobs, jobs, rb, n, 8);
+    if (bs.rows >= 8 && bs.narrow) return {bs.rows, bs.slots, true, 8, rb};
+  }
+  const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 4);
+  const BandShape bs = band_rows(njobs, jobs, rb, n, 4);
+  return {bs.rows, bs.slots, bs.narrow, 4, rb};
 }
 
 // Lanczos march (LanczosMarchTask): destination rows per wave (R) and strip size, or rows == 0 when the tiled kernel keeps the launch.
@@ -1521,15 +1562,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
   // bilinear up-scales: the tiled kernel for a single frame, the row-band kernel (8 or 4 destination rows per wave, each source row's
   // horizontal lerp evaluated once per band, no barriers) when the launch is large enough for it — 1080p -> 4K batched 11.9 -> 6.9 us / frame
   bool band_up = !f32 && interp == VPF_INTERP_LINEAR && tune != 43 && tune != 9;
-  if (band_up) {
-    uint32_t rbmax = 0;
-    for (int p = 0; p < njobs && band_up; p++) {
-      const uint32_t rb = planes_aligned(a, n, jobs[p].k, 15, 0) ? lds_strip_bytes(jobs[p].ch, jobs[p].sw, jobs[p].dw, a.f[0].s[jobs[p].k], a.f[0].sp[jobs[p].k], kResizeRowBytes) : 0;
-      band_up = rb != 0;
-      rbmax = rb > rbmax ? rb : rbmax;
-    }
-    band_up = band_up && band_rows(njobs, jobs, rbmax, n).rows >= 4;
-  }
+  if (band_up) band_up = plan_band(njobs, jobs, n, a).rows >= 4;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
@@ -1612,8 +1645,9 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     t.np = (uint32_t)njobs;
     uint32_t gx = 0, gy = 0, it = 1, rb = 0;
     for (int p = 0; p < njobs && all_rowpair; p++) rb = rowb[p] > rb ? rowb[p] : rb;
-    const BandShape bs = all_rowpair ? band_rows(njobs, jobs, rb, n) : BandShape{1, 0, false};
+    const BandPlan bs = all_rowpair ? plan_band(njobs, jobs, n, a) : BandPlan{1, 0, false, 4, 0};
     const int band = bs.rows;
+    if (band > 1) rb = bs.rb;
     for (int p = 0; p < njobs; p++) {
       t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
       if (all_tile) {
@@ -1622,7 +1656,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
         gx = bx > gx ? bx : gx;
         gy += (jobs[p].dh + ts.ty - 1) / ts.ty;
       } else {
-        const uint32_t bx = ((jobs[p].dw + 3) / 4 + 63) / 64;
+        const uint32_t wcols = band > 1 ? 64u * band_px(jobs[p].ch, bs.p1) : 256u, bx = (jobs[p].dw + wcols - 1) / wcols;
         gx = bx > gx ? bx : gx;
         gy += (jobs[p].dh + 4 * band - 1) / (4 * band);
       }
@@ -1638,7 +1672,9 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; }  // one strip size for the launch (the widest plane's)
       it = (rb + 1023) / 1024;
       const uint32_t lds = band > 1 ? 4 * bs.slots * rb + 16 : 4 * 2 * rb + 16;
-      if (band == 16) launch_planes_mp<RowBand16n>(st, grid, lds, a, t);
+      if (band == 16 && bs.p1 == 8) launch_planes_mp<RowBand16w>(st, grid, lds, a, t);
+      else if (band == 8 && bs.p1 == 8) launch_planes_mp<RowBand8w>(st, grid, lds, a, t);
+      else if (band == 16) launch_planes_mp<RowBand16n>(st, grid, lds, a, t);
       else if (band == 8 && bs.narrow) launch_planes_mp<RowBand8n>(st, grid, lds, a, t);
       else if (band == 8) launch_planes_mp<RowBand8>(st, grid, lds, a, t);
       else if (band == 4) launch_planes_mp<RowBand4>(st, grid, lds, a, t);
@@ -1695,13 +1731,15 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
 #undef VPF_TILEB
     } else if (fam[p] == FAM_ROWPAIR) {
       g[p].a0 = rowb[p] / 16;
-      const BandShape bs = band_rows(1, &j, rowb[p], n);
+      const BandPlan bs = plan_band(1, &j, n, a);
       const int band = bs.rows;
       if (band > 1) {
-        g[p].a1 = bs.slots;
-        const dim3 bgrid(grid4.x, (j.dh + 4 * band - 1) / (4 * band), n);
-        const uint32_t blds = 4 * bs.slots * rowb[p] + 16;
-#define VPF_RBB(C) do { if (band == 16) launch_plane_batch<RowBandTask<C, 16, 1>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.narrow) launch_plane_batch<RowBandTask<C, 8, 1>>(st, bgrid, blds, a, j.k, g[p]); \
+        g[p].a0 = bs.rb / 16; g[p].a1 = bs.slots;
+        const uint32_t wcols = 64u * band_px(j.ch, bs.p1);
+        const dim3 bgrid((j.dw + wcols - 1) / wcols, (j.dh + 4 * band - 1) / (4 * band), n);
+        const uint32_t blds = 4 * bs.slots * bs.rb + 16;
+#define VPF_RBB(C) do { if (band == 16 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 16, 1, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 8, 1, 8>>(st, bgrid, blds, a, j.k, g[p]); \
+                        else if (band == 16) launch_plane_batch<RowBandTask<C, 16, 1>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.narrow) launch_plane_batch<RowBandTask<C, 8, 1>>(st, bgrid, blds, a, j.k, g[p]); \
                         else if (band == 8) launch_plane_batch<RowBandTask<C, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 4) launch_plane_batch<RowBandTask<C, 4>>(st, bgrid, blds, a, j.k, g[p]); \
                         else launch_plane_batch<RowBandTask<C, 2>>(st, bgrid, blds, a, j.k, g[p]); } while (0)
         if (j.ch == 1) VPF_RBB(1); else if (j.ch == 2) VPF_RBB(2); else VPF_RBB(3);
