@@ -536,6 +536,55 @@ def test_abi_is_hip_graph_capturable(capi, oracle):
     assert_planes_equal(got, c, "graph replay")
 
 
+def test_batch_entries_are_hip_graph_capturable(capi, oracle):
+    """vpf_convert_batch -> vpf_resize_batch (row-band / march kernels forced, as a large batch would pick them) -> vpf_remap_batch captured
+    into one hipGraph and replayed: the batch entries, too, neither synchronise nor allocate (their frame tables travel in the kernarg)"""
+    w, h, dw, dh, n = 640, 360, 427, 240, 5
+    srcs = [oracle.synth(oracle.NV12, w, h, 1080 + i) for i in range(n)]
+    yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
+    xm, ym = (xx * 0.9 + 3.25).astype(np.float32), (yy * 0.9 + 1.5).astype(np.float32)
+    st = torch.cuda.Stream()
+    for interp, band, march in ((1, 4, 0), (2, 0, 16)):
+        with torch.cuda.stream(st):
+            S = [DevPlanes(p) for p in srcs]
+            M = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
+            R = [DevPlanes(oracle.alloc(oracle.RGB, dw, dh)) for _ in range(n)]
+            O = [DevPlanes(oracle.alloc(oracle.RGB, dw, dh, fill=7)) for _ in range(n)]
+            dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+            ex = capi.make_exec(st.cuda_stream)
+            b1 = capi.make_batch([(s.desc(), m.desc()) for s, m in zip(S, M)])
+            b2 = capi.make_batch([(m.desc(), r.desc()) for m, r in zip(M, R)])
+            b3 = capi.make_batch([(r.desc(), o.desc()) for r, o in zip(R, O)])
+
+            def chain():
+                capi.convert_batch(ex, capi.NV12, capi.RGB, 1, 0, w, h, b1)
+                capi.resize_batch(ex, capi.RGB, interp, w, h, dw, dh, b2)
+                capi.remap_batch(ex, capi.RGB, dw, dh, dx.data_ptr(), 4 * dw, dy.data_ptr(), 4 * dw, dw, dh, b3)
+
+            capi.set_tuning(capi.TUNE_RESIZE_BAND, band); capi.set_tuning(capi.TUNE_RESIZE_MARCH, march)
+            try:
+                chain(); st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    chain()
+            finally:
+                capi.set_tuning(capi.TUNE_RESIZE_BAND, 0); capi.set_tuning(capi.TUNE_RESIZE_MARCH, 0)
+            for d in M + R:
+                for t in d.bufs:
+                    t.fill_(0xCD)
+            g.replay(); st.synchronize()
+            for i in range(n):
+                _, a = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, srcs[i])
+                _, b = oracle.resize(oracle.RGB, interp, w, h, a, dw, dh, oracle.FP32)
+                got, intact = R[i].download()
+                assert intact
+                assert_planes_equal(got, b, f"graph replay, resize_batch interp {interp} frame {i}")
+                _, want = oracle.remap(oracle.RGB, dw, dh, b, xm, ym, dst=oracle.alloc(oracle.RGB, dw, dh, fill=7))  # out-of-range: untouched
+                got, intact = O[i].download()
+                assert intact
+                assert_planes_equal(got, want, f"graph replay, remap_batch frame {i}")
+
+
 # ---------------------------------------------------------------------------------------------
 # randomised shape / pitch / alignment fuzz (deterministic seeds): every converter family, bit-exact
 # ---------------------------------------------------------------------------------------------
