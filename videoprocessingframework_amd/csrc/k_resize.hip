@@ -1444,9 +1444,13 @@ static uint32_t band_slots(int r, float scy) {  // source rows a band of r desti
 // pixels per lane for the 1-channel planes of a band launch: 8 (512 columns per wave) when such chunks fill every 1-channel row to >= 80 %
 // (1280 px: 3 chunks, 83 %; the 640-px chroma planes of a 720p YUV420 frame: 2 chunks, 62 % -> 4)
 static int band_p1(int njobs, const ResizeJob* jobs) {
-  for (int p = 0; p < njobs; p++)
-    if (jobs[p].ch == 1 && (double)jobs[p].dw < 0.8 * 512.0 * ((jobs[p].dw + 511) / 512)) return 4;
-  return 8;
+  bool any = false;
+  for (int p = 0; p < njobs; p++) {
+    if (jobs[p].ch != 1) continue;
+    any = true;
+    if ((double)jobs[p].dw < 0.8 * 512.0 * ((jobs[p].dw + 511) / 512)) return 4;
+  }
+  return any ? 8 : 4;
 }
 // strip bytes of the widest plane for a band launch (RowBandTask: 64 * band_px(ch, p1) columns per wave); 0 when some plane has no LDS path
 static uint32_t band_strip_bytes(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a, int p1) {
