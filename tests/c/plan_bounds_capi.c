@@ -1,0 +1,11 @@
+/* tests/c/plan_bounds_capi.c — the launchers' LDS sizing formulas (csrc/vpf_plan_bounds.h) behind C symbols, for tests/test_plan_bounds_cpu.py */
+#include "vpf_plan_bounds.h"
+
+uint32_t pb_strip_bytes(int ch, uint32_t sw, uint32_t dw, uint32_t cap, uint32_t cols) { return vpf_bound_strip_bytes(ch, sw, dw, cap, cols); }
+uint32_t pb_band_slots(int r, float scy) { return vpf_bound_band_slots(r, scy); }
+uint32_t pb_march_rowq(int ch, uint32_t sw, uint32_t dw, uint32_t wcols) { return vpf_bound_march_rowq(ch, sw, dw, wcols); }
+uint32_t pb_march_pad(void) { return VPF_MARCH_PAD; }
+uint32_t pb_fused_rowbytes(float scx) { return vpf_bound_fused_rowbytes(scx); }
+int pb_fused_rows_fit(int r, float scy, int strip_rows) { return vpf_bound_fused_rows_fit(r, scy, strip_rows); }
+uint32_t pb_tile_rows(uint32_t ty, float scy, int taps) { return vpf_bound_tile_rows(ty, scy, taps); }
+uint32_t pb_tile_rowq(float scx, int taps, int ch, int elem) { return vpf_bound_tile_rowq(scx, taps, ch, elem); }

@@ -1,0 +1,181 @@
+"""The LDS sizing bounds of the strip-staging resize kernels (csrc/vpf_plan_bounds.h — the header the launchers include) against the
+kernels' exact fp32 tap arithmetic, on the CPU.  A bound one byte or one row short would be silent memory corruption on the device;
+here every formula is compiled with gcc as it stands and checked over thousands of (source size, destination size, position) cases.
+
+Tap arithmetic restated from k_bilinear_blend.h make_tap / k_resize.hip ltap_i0 (fma in fp32: the product of two floats is exact in
+float64, the sum with -0.5 as well at these magnitudes, one rounding to float32 — what v_fma_f32 does)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def pb(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("pb") / "libplanbounds.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so])
+    L = C.CDLL(so)
+    for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_march_rowq", [C.c_int] + [C.c_uint32] * 3),
+                       ("pb_march_pad", []), ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
+                       ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int])):
+        getattr(L, name).argtypes, getattr(L, name).restype = args, C.c_uint32
+    L.pb_fused_rows_fit.argtypes, L.pb_fused_rows_fit.restype = [C.c_int, C.c_float, C.c_int], C.c_int
+    return L
+
+
+def _s(d, scale):
+    """fma((float)d + 0.5f, scale, -0.5f) for an array of destination indices"""
+    d = np.asarray(d)
+    return ((d.astype(F) + F(0.5)).astype(np.float64) * np.float64(scale) - 0.5).astype(F)
+
+
+def lin_taps(d, S, D):
+    """make_tap<LINEAR>: (i0, i1) of destination indices d"""
+    scale = F(F(S) / F(D))
+    s = np.minimum(np.maximum(_s(d, scale), F(0)), F(S - 1))
+    i0 = s.astype(np.int64)
+    return i0, np.minimum(i0 + 1, S - 1)
+
+
+def lz_i0(d, S, D):
+    """ltap_i0: floor of the unclamped source coordinate (the six taps are i0 - 2 .. i0 + 3)"""
+    return np.floor(_s(d, F(F(S) / F(D)))).astype(np.int64)
+
+
+def size_pairs(rng, n, lo=0.2, hi=4.0):
+    out = [(1920, 1280), (1080, 720), (3840, 1920), (1280, 1920), (720, 1080), (1920, 3840), (1920, 416), (2160, 1080), (64, 1000), (7, 300), (1, 9)]
+    for d in (255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048):   # chunk boundaries, exact ratios, one off
+        for num, den in ((1, 1), (2, 1), (3, 2), (3, 1), (1, 2), (2, 3), (4, 3), (5, 1)):
+            if lo <= num / den <= hi:
+                out += [(max(1, d * num // den), d), (max(1, d * num // den + 1), d), (max(1, d * num // den - 1), d)]
+    while len(out) < n:
+        d = int(rng.integers(1, 3000))
+        s = max(1, int(d * rng.uniform(lo, hi)))
+        out.append((s, d))
+    return out
+
+
+def test_band_slots_cover_every_band(pb):
+    """RowBandTask / convert_strip_task stage the contiguous rows [i0(first row of the band), i1(last row)] into `slots` strips"""
+    rng = np.random.default_rng(1)
+    for sh, dh in size_pairs(rng, 1500, 0.2, 2.0):
+        scy = F(F(sh) / F(dh))
+        y = np.arange(dh)
+        i0, i1 = lin_taps(y, sh, dh)
+        for r in (2, 4, 8, 16):
+            ya = np.arange(0, dh, r)
+            yb = np.minimum(ya + r - 1, dh - 1)
+            need = int((i1[yb] - i0[ya] + 1).max())
+            assert need <= pb.pb_band_slots(r, scy), (sh, dh, r, need)
+            if pb.pb_fused_rows_fit(r if r <= 8 else 8, scy, 8):
+                rr = r if r <= 8 else 8
+                ya = np.arange(0, dh, rr)
+                assert int((i1[np.minimum(ya + rr - 1, dh - 1)] - i0[ya] + 1).max()) <= 8, (sh, dh, rr)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_bilinear_strips_hold_the_span_and_the_tap_window(pb, ch):
+    """RowPairTask / RowBandTask: strip = bytes [base, ch * (last + 1)) of the row, base = (ch * first) & ~15; packed RGB reads every tap pair
+    as a 12-B window from the dword below (over-read of 6 bytes past the last tap)"""
+    rng = np.random.default_rng(2)
+    for sw, dw in size_pairs(rng, 1500, 0.05, 16.0):
+        for cols in (256, 512):
+            rb = pb.pb_strip_bytes(ch, sw, dw, 4096, cols)
+            if not rb:
+                continue
+            xs = np.arange(0, dw, cols)
+            xe = np.minimum(xs + cols - 1, dw - 1)
+            first, last = lin_taps(xs, sw, dw)[0], lin_taps(xe, sw, dw)[1]
+            base = (ch * first) & ~15
+            span = ch * (last + 1) - base
+            assert int(((span + 15) // 16 * 16).max()) <= rb, (sw, dw, cols)        # what the staging loop writes (whole 16-B units)
+            x = np.arange(dw)
+            i0 = lin_taps(x, sw, dw)[0]
+            a = ch * i0 - base[x // cols]
+            reach = (a & ~3) + 12 if ch == 3 else a + 2 * ch                           # window of three dwords / two byte taps
+            assert int(reach.max()) <= rb, (sw, dw, cols)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_march_strips_hold_margins_span_and_over_read(pb, ch):
+    """LanczosMarchTask: strip = pad | bytes [base, ch * (last_r + 1)) | replicated right margin; every lane reads (6 * ch + 3) / 4 + 1 dwords
+    from the dword below its first tap"""
+    rng = np.random.default_rng(3)
+    pad, ne = pb.pb_march_pad(), (6 * ch + 3) // 4
+    w = 512 if ch == 1 else 256
+    for sw, dw in size_pairs(rng, 1500, 0.05, 8.0):
+        rowq = pb.pb_march_rowq(ch, sw, dw, w)
+        if not rowq:
+            continue
+        xs = np.arange(0, dw, w)
+        xe = np.minimum(xs + w - 1, dw - 1)
+        first_v, last_v = lz_i0(xs, sw, dw) - 2, lz_i0(xe, sw, dw) + 3
+        assert first_v.min() >= -3 and (last_v - (sw - 1)).max() <= 3                 # at most three replicated pixels on either side
+        first_r, last_r = np.maximum(first_v, 0), np.minimum(last_v, sw - 1)
+        base = (ch * first_r) & ~15
+        nq = (ch * (last_r + 1) - base + 15) // 16
+        assert int(nq.max()) <= 128 and int((pad // 16 + nq).max()) <= rowq, (sw, dw)  # two 1-KiB staging passes; staged units fit behind the pad
+        assert int((pad + ch * first_v - base).min()) >= 0, (sw, dw)                  # left margin stays inside the pad
+        assert int((pad + ch * (last_v + 1) - base).max()) <= rowq * 16, (sw, dw)     # right margin
+        x = np.arange(dw)
+        off = pad + ch * (lz_i0(x, sw, dw) - 2) - base[x // w]
+        assert int(off.min()) >= 0 and int(((off & ~3) + 4 * (ne + 1)).max()) <= rowq * 16, (sw, dw)
+
+
+def test_fused_strip_rows_hold_the_converted_window(pb):
+    """convert_strip_task: a strip row holds packed RGB of source pixels [first & ~7, ...) in groups of 8 up to the last tap; taps are read as
+    12-B windows"""
+    rng = np.random.default_rng(4)
+    for sw, dw in size_pairs(rng, 1500, 0.2, 3.0):
+        if sw % 8:
+            continue
+        rowbytes = pb.pb_fused_rowbytes(F(F(sw) / F(dw)))
+        xs = np.arange(0, dw, 256)
+        xe = np.minimum(xs + 255, dw - 1)
+        first, last = lin_taps(xs, sw, dw)[0], lin_taps(xe, sw, dw)[1]
+        base_px = first & ~7
+        conv_end = base_px + (last - base_px) // 8 * 8 + 8                             # conversion runs in groups of 8 pixels through `last`
+        assert int((3 * (conv_end - base_px)).max()) <= rowbytes, (sw, dw)
+        x = np.arange(dw)
+        a = 3 * (lin_taps(x, sw, dw)[0] - base_px[x // 256])
+        assert int(((a & ~3) + 12).max()) <= rowbytes, (sw, dw)
+
+
+@pytest.mark.parametrize("taps", [2, 6])
+def test_tile_windows(pb, taps):
+    """TileTask: source rows [R0, R1] of a tile of ty destination rows, and the 16-B units of a staged source row"""
+    rng = np.random.default_rng(5)
+    for s_, d_ in size_pairs(rng, 800, 0.1, 8.0):
+        scale = F(F(s_) / F(d_))
+        for ty in (4, 8, 16, 24, 32, 64):
+            y0 = np.arange(0, d_, ty)
+            yl = np.minimum(y0 + ty - 1, d_ - 1)
+            if taps == 6:
+                need = (lz_i0(yl, s_, d_) + 3) - (lz_i0(y0, s_, d_) - 2) + 1
+            else:
+                need = lin_taps(yl, s_, d_)[1] - lin_taps(y0, s_, d_)[0] + 1
+            assert int(need.max()) <= pb.pb_tile_rows(ty, scale, taps), (s_, d_, ty)
+        for ch in (1, 2, 3):
+            rowq = pb.pb_tile_rowq(scale, taps, ch, 1)
+            xf = np.arange(0, d_, 64)
+            xl = np.minimum(xf + 63, d_ - 1)
+            if taps == 6:
+                fv, lv = lz_i0(xf, s_, d_) - 2, lz_i0(xl, s_, d_) + 3
+                first, last = np.clip(fv, 0, s_ - 1), np.clip(lv, 0, s_ - 1)
+                base = (ch * first) & ~15
+                nq = (ch * (last + 1) - base + 15) // 16
+                assert int((1 + nq).max()) <= rowq, (s_, d_, ch)                                   # pad unit + staged units
+                assert int((16 + ch * (lv + 1) - base).max()) <= rowq * 16, (s_, d_, ch)           # replicated right margin
+                x = np.arange(d_)
+                off = 16 + ch * (lz_i0(x, s_, d_) - 2) - base[x // 64]
+                assert int(off.min()) >= 0 and int(((off & ~3) + 4 * ((6 * ch + 3) // 4 + 1)).max()) <= rowq * 16, (s_, d_, ch)
+            else:
+                first, last = lin_taps(xf, s_, d_)[0], lin_taps(xl, s_, d_)[1]
+                base = (ch * first) & ~15
+                assert int(((ch * (last + 1) - base + 15) // 16).max()) <= rowq, (s_, d_, ch)

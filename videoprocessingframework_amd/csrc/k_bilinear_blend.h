@@ -7,6 +7,7 @@
 #ifndef VPF_K_BILINEAR_BLEND_H_
 #define VPF_K_BILINEAR_BLEND_H_
 #include "vpf_device.h"
+#include "vpf_plan_bounds.h"
 
 namespace vpf {
 
@@ -260,15 +261,12 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
   }
 }
 
-// strip bytes a wave needs for the source span of its `cols` destination columns (<= (cols - 1) * scale + 3 pixels, + 16-B alignment slack
-// on both ends), rounded up to 256; 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
+// strip bytes a wave needs for the source span of its `cols` destination columns (vpf_bound_strip_bytes, checked on the CPU);
+// 0 when the LDS path does not apply (forced generic, unaligned source, span above the cap)
 static inline uint32_t lds_strip_bytes(int ch, uint32_t sw, uint32_t dw, const void* src, uint32_t sp, uint32_t row_bytes_cap, uint32_t cols = 256) {
   if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9) return 0;  // forced generic
   if (((uintptr_t)src | sp) & 15) return 0;
-  const double scale = (double)sw / (double)dw;
-  const double need = ((double)(cols - 1) * scale + 4.0) * ch + 32.0;
-  if (need > (double)row_bytes_cap) return 0;
-  return ((uint32_t)need + 255u) & ~255u;
+  return vpf_bound_strip_bytes(ch, sw, dw, row_bytes_cap, cols);
 }
 
 }  // namespace vpf

@@ -526,11 +526,11 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
     for (uint32_t i = 0; i < n && ok8; i++)
       for (int k = 0; k < (src_fc == FC_NV12 ? 2 : 3); k++) ok8 = ok8 && !(((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & 7);
     if (ok8) {
-      const uint32_t rowbytes = (((uint32_t)(255.0 * (double)scx) + 2 + 8 + 8) * 3 + 16 + 15) & ~15u;  // a wave's source span + alignment + tap-window slack
+      const uint32_t rowbytes = vpf_bound_fused_rowbytes(scx);  // a wave's source span + alignment + tap-window slack (vpf_plan_bounds.h)
       int r = 0;
-      if ((double)scy * 7.0 + 3.01 <= (double)kStripRows) r = 8;  // rows a wave's R destination rows can touch: <= (R - 1) scy + 3 (+ fp32 slack)
-      else if ((double)scy * 3.0 + 3.01 <= (double)kStripRows) r = 4;
-      else if ((double)scy + 3.01 <= (double)kStripRows) r = 2;
+      if (vpf_bound_fused_rows_fit(8, scy, kStripRows)) r = 8;  // rows a wave's R destination rows can touch: <= (R - 1) scy + 3 (+ fp32 slack)
+      else if (vpf_bound_fused_rows_fit(4, scy, kStripRows)) r = 4;
+      else if (vpf_bound_fused_rows_fit(2, scy, kStripRows)) r = 2;
       if (dh < 64) r = r ? 2 : 0;  // short pictures: more, smaller tasks
       if (r == 8 && (uint64_t)((dw + 255) / 256) * ((dh + 31) / 32) * n < 2048) r = 4;  // keep the chip covered
       const uint32_t lds1 = 4u * kStripRows * rowbytes;

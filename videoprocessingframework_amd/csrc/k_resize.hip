@@ -672,7 +672,7 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
 // profiles/r02_pmc_resize_batch.txt.
 // ------------------------------------------------------------------------------------------
 constexpr int kMarchGroup = 4;       // source rows staged per round trip
-constexpr uint32_t kMarchPad = 16;   // bytes in front of a strip's first real byte: room for up to 3 replicated pixels (and 16-B aligned stores)
+constexpr uint32_t kMarchPad = VPF_MARCH_PAD;  // bytes in front of a strip's first real byte: room for up to 3 replicated pixels (and 16-B aligned stores)
 constexpr int march_px(int ch) { return ch == 1 ? 8 : 4; }  // destination pixels per lane: a 1-channel plane takes 512 columns per wave (the per-band and per-row fixed work of a wave is the same whatever the channel count)
 template <int CH>
 struct LanczosMarchTask {
@@ -1165,7 +1165,7 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
   float scy = 0.f;
   for (int p = 0; p < np; p++) {
     ch_max = ch[p] > ch_max ? ch[p] : ch_max;
-    const uint32_t q = (uint32_t)((((double)scxs[p] * 63.0 + taps + 3.0) * ch[p] * elem + 32.0) / 16.0) + 1 + ((lz && elem == 1) ? 2 : 0);  // 8-bit Lanczos: + pad unit + right margin
+    const uint32_t q = vpf_bound_tile_rowq(scxs[p], lz ? 6 : 2, ch[p], elem);  // (8-bit Lanczos: + pad unit + right margin; vpf_plan_bounds.h)
     rowq = q > rowq ? q : rowq;
     scy = scys[p] > scy ? scys[p] : scy;
   }
@@ -1177,7 +1177,7 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
   for (int wpb = forced ? 4 : 8; wpb <= 8; wpb += 4)
     for (uint32_t ty = forced ? 4 : 8; ty <= 64; ty += 4) {
       if (forced && ((uint32_t)(forced & 0xff) != ty || (forced >> 8) != wpb)) continue;
-      const uint32_t nr = (uint32_t)((double)(ty - 1) * (double)scy) + (uint32_t)taps + 2;
+      const uint32_t nr = vpf_bound_tile_rows(ty, scy, lz ? 6 : 2);
       const uint32_t lds = nr * rowq * 16 + nr * ch_max * 64 * 4 + ty * 8 * 4 + (lz ? (elem == 4 ? 7 : 4) * 64 * 4 : 0);  // RAW | H | WY | WX (Lanczos)
       if (lds > 64u * 1024u) continue;
       const uint32_t srows = (64u * wpb) >> lshift;  // source rows staged per pass
@@ -1438,9 +1438,7 @@ static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, cons
 // centre-sample shortcut): both keep one row per wave.  VPF_TUNE_RESIZE_BAND forces a value where it applies.
 constexpr uint32_t kBandMinGroups = 2048;
 struct BandShape { int rows; uint32_t slots; bool narrow; };
-static uint32_t band_slots(int r, float scy) {  // source rows a band of r destination rows can touch: i1(last) - i0(first) + 1 <= floor((r - 1) scy) + 3 (+ fp32 slack)
-  return (uint32_t)((double)(r - 1) * (double)scy + 0.01) + 3u;
-}
+static uint32_t band_slots(int r, float scy) { return vpf_bound_band_slots(r, scy); }  // (vpf_plan_bounds.h: checked on the CPU against the tap arithmetic)
 // pixels per lane for the 1-channel planes of a band launch: 8 (512 columns per wave) when such chunks fill every 1-channel row to >= 80 %
 // (1280 px: 3 chunks, 83 %; the 640-px chroma planes of a 720p YUV420 frame: 2 chunks, 62 % -> 4)
 static int band_p1(int njobs, const ResizeJob* jobs) {
@@ -1522,10 +1520,9 @@ static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
   uint32_t rowq = 0;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
-    const double scx = (double)j.sw / (double)j.dw, sy = (double)j.sh / (double)j.dh;
-    const uint32_t span_px = (uint32_t)((64.0 * march_px(j.ch) - 1.0) * scx) + 8;  // taps of a wave's columns: floor((W - 1) scx) + 6 (+ fp32 slack)
-    if ((uint32_t)j.ch * span_px > 2018u || sy > 5.9) return {0, 0};
-    const uint32_t q = (kMarchPad + 15u + (uint32_t)j.ch * span_px + 8u + 15u) / 16u;
+    const double sy = (double)j.sh / (double)j.dh;
+    const uint32_t q = vpf_bound_march_rowq(j.ch, j.sw, j.dw, 64u * march_px(j.ch));  // (vpf_plan_bounds.h: checked on the CPU against the tap arithmetic)
+    if (!q || sy > 5.9) return {0, 0};
     rowq = q > rowq ? q : rowq;
   }
   if (forced) return {(uint32_t)forced, rowq};
