@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 2, visit N: march policy over batch sizes (Lanczos lines, all formats), optional forced rows per wave
+# round 2, visit N: the batch kernels on ONE frame per dispatch (forced rows per wave) against the single-frame kernels: bilinear up-scales
 mkdir -p gpurun_out && cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "march or fuzz_resize_batch or resize_batch_equals or policy_picks" -n 4 2>&1 | tail -3 > gpurun_out/r02_n_pytest.txt
-for m in ${MARCH_SWEEP:-0}; do for nb in ${NB_SWEEP:-0 16 8 4}; do echo "== frames per batch $nb (0 = 32), march $m (0 = policy)"; VPF_BENCH_MARCH=$m VPF_BENCH_N=$nb VPF_BENCH_Y=1 VPF_BENCH_ONLY=lanczos timeout 300 python tools/resize_batch_bench.py 2>&1 | grep "resize_batch" | grep -v 416x416 | cut -c1-100; done; done > gpurun_out/r02_n_policy.txt
-cat gpurun_out/r02_n_pytest.txt gpurun_out/r02_n_policy.txt
+{ echo "== single-frame kernels"; VPF_BENCH_ONLY=bilinear timeout 300 python tools/resize_batch_bench.py 2>&1 | grep "resize_batch. RGB" | grep "3840x2160\$\|->3840x2160\|->1920x1080" | sed 's/batched.*| one/one/' | cut -c1-140;
+  for b in 8 16; do echo "== band rows $b"; VPF_BENCH_BAND=$b VPF_BENCH_ONLY=bilinear timeout 300 python tools/resize_batch_bench.py 2>&1 | grep "resize_batch. RGB" | grep "\->3840x2160\|->1920x1080" | sed 's/batched.*| one/one/' | cut -c1-140; done; } > gpurun_out/r02_n_single_up.txt
+cat gpurun_out/r02_n_single_up.txt
