@@ -213,7 +213,7 @@ static bool aligned_all(const BatchArgs& a, uint32_t n, int nsrc, int ndst, uint
 }
 
 // Kernel selection for 4:2:0 sources.  `variant` is the tuning hint (include/vpf_hip.h): 0 = policy below; a named kernel
-// (4 / 8 / 12 / 30 / 37 / 44) is honoured where it applies and falls back down the same chain where it does not; 40 = the
+// (4 / 8 / 12 / 30 / 37 / 44 / 45 / 46) is honoured where it applies and falls back down the same chain where it does not; 40 = the
 // narrower p4 path, 9 = the any-input generic kernel.  Every kernel here writes the same pixels.
 //   p16x (45 | 46: 4 workgroups / CU)                                               packed outputs, w >= 1024: blocks numbered straight through the picture
 //   p16  (8: non-temporal stores | 12: allocating stores | 30: 4 workgroups / CU)   packed outputs; w % 16 == 0, h even, 16-B aligned
