@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from videoprocessingframework_amd import capi
 
 dev = torch.device("cuda", 0)
-W, H, RING, STEPS = 3840, 2160, 16, 5
+W, H, RING, STEPS = int(os.environ.get("VPF_BENCH_W", "3840")), int(os.environ.get("VPF_BENCH_H", "2160")), 16, 5  # frame size: 4K unless VPF_BENCH_W / _H say otherwise
 cw, ch = W // 2, H // 2
 
 

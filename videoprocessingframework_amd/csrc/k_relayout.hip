@@ -345,6 +345,8 @@ __global__ __launch_bounds__(256) void k_gray_r16_one(VPF_ONE_SRC_PARAMS, uint32
 
 // NV12 <-> YUV420, rows split by role: a luma wave copies 1 KiB (one load, one store); a chroma wave moves 2 KiB of
 // interleaved UV <-> 1 KiB of U + 1 KiB of V.  Requires w % 32 == 0, h even, every plane and pitch 16-B aligned.
+// (Numbering the blocks straight through the planes, which is worth 1 % on k_nv12_rgb_p16x, changes nothing here: 0.78 vs 0.79 of 8 TB/s
+// at 4K, 0.72 vs 0.72 at 1080p in same-box A/B, round 2.)
 template <bool TO_PLANAR>
 VPF_DEV void nv12_yuv420_r16_task(const FrameDesc& f, uint32_t w, uint32_t h, uint32_t chunks_y, uint32_t luma_tasks, uint32_t chunks_c, uint32_t n_tasks) {
   __shared__ u32x4 tile[TO_PLANAR ? 1 : 4 * 128];
