@@ -177,6 +177,16 @@ def resize(fmt, interp, sw, sh, src, dw, dh, mode=FP32, dst=None):
     return st, dst
 
 
+def lanczos_taps(S: int, D: int):
+    """FP32-mode Lanczos-3 taps of one axis: (i0[D], q[6 D]) — floor of the source coordinate and the six Q14 weights per sample"""
+    i0, q = np.zeros(D, np.int32), np.zeros(6 * D, np.int32)
+    L = lib()
+    L.vpfo_lanczos_taps_q14.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    if L.vpfo_lanczos_taps_q14(S, D, i0.ctypes.data, q.ctypes.data) != 0:
+        raise ValueError("vpfo_lanczos_taps_q14")
+    return i0, q
+
+
 def remap(fmt, sw, sh, src, xmap, ymap, mode=FP32, dst=None):
     dh, dw = xmap.shape
     xmap = np.ascontiguousarray(xmap, dtype=np.float32)

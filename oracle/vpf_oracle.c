@@ -706,8 +706,9 @@ static int resize_plane(int mode, int interp, int ch, uint32_t sw, uint32_t sh, 
  *   s = (d + 0.5) * S/D - 0.5;  i0 = floor(s);  f = s - i0;  taps i0-2 .. i0+3 (indices clamped to the image),
  *   w_k = L(f - (k - 2)),  L(t) = sinc(t) sinc(t/3),  weights normalised to sum 1, no widening when minifying.
  * EXACT: double + libm.  FP32: the kernels' arithmetic — sin(pi f), sin(pi f/3), cos(pi f/3) from fixed fma polynomials (so host
- * and device agree bit for bit), the six taps from angle-addition identities; on 8-bit surfaces the horizontal pass then runs in
- * Q14 integers (lanczos_weights_q14) and the vertical pass as an fp32 fma chain; float surfaces stay fp32 throughout.
+ * and device agree bit for bit), the six taps from angle-addition identities; on 8-bit surfaces BOTH passes then run in integers on
+ * Q14 weights (lanczos_weights_q14) with the row sums rounded to Q6 in between (see resize_plane_lanczos; round 3 — the vertical pass
+ * was an fp32 fma chain before, which an integer matrix unit cannot reproduce); float surfaces stay fp32 throughout.
  * ------------------------------------------------------------------------------------------ */
 static inline float lz_sinpi_poly(float g) { /* sin(pi g), g in [0, 0.5]; odd Taylor polynomial in x = pi g, degree 11 */
   const float x = 3.14159274f * g, x2 = x * x;
@@ -751,7 +752,7 @@ static void lanczos_weights_fp32(float f, float w[6]) {
   const float inv = 1.0f / sum;
   for (int k = 0; k < 6; k++) w[k] *= inv;
 }
-/* The kernels run the HORIZONTAL pass of Lanczos on 8-bit surfaces in integers (v_dot2_i32_i16): the six normalised fp32 weights
+/* The kernels run Lanczos on 8-bit surfaces in integers (v_mfma_i32_16x16x64_i8 / v_dot2_i32_i16): the six normalised fp32 weights
  * become Q14 fixed point, q_k = rint(w_k * 16384) (ties to even), and tap 2 absorbs the rounding residue so that the six sum to
  * exactly 16384 (a flat picture stays flat).  H = sum q_k * p_k is then exact in 32 bits, whatever the order. */
 static void lanczos_weights_q14(const float w[6], int32_t q[6]) {
@@ -759,6 +760,8 @@ static void lanczos_weights_q14(const float w[6], int32_t q[6]) {
   for (int k = 0; k < 6; k++) { q[k] = (int32_t)nearbyintf(w[k] * 16384.0f); sum += q[k]; }
   q[2] += 16384 - sum;
 }
+/* arithmetic shift right (floor division by 2^n) spelled so that it does not depend on the compiler's choice for negative operands */
+static inline int32_t asr32(int32_t v, int n) { return v >= 0 ? v >> n : -(int32_t)(((uint32_t)(-(v + 1)) >> n) + 1u); }
 static void lanczos_weights_exact(double f, double w[6]) {
   double sum = 0;
   for (int k = 0; k < 6; k++) {
@@ -792,6 +795,21 @@ static void make_ltaps(int mode, uint32_t S, uint32_t D, ltap* t) {
     }
   }
 }
+/* the FP32-mode taps of one axis, for tests that model a kernel's data flow on the CPU: i0[d] = floor of the source coordinate (taps
+ * i0 - 2 .. i0 + 3, to be clamped by the caller), q[6 d + k] = Q14 weights */
+int vpfo_lanczos_taps_q14(uint32_t S, uint32_t D, int32_t* i0, int32_t* q) {
+  if (!S || !D || !i0 || !q) return VPFO_BAD_ARG;
+  const float scf = (float)S / (float)D;
+  for (uint32_t d = 0; d < D; d++) {
+    const float s = __builtin_fmaf((float)d + 0.5f, scf, -0.5f);
+    const float fl = floorf(s);
+    float wf[6];
+    i0[d] = (int32_t)fl;
+    lanczos_weights_fp32(s - fl, wf);
+    lanczos_weights_q14(wf, q + 6 * d);
+  }
+  return VPFO_OK;
+}
 static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw, uint32_t dh,
                                 const vpfo_plane* d) {
   ltap* tx = (ltap*)malloc(sizeof(ltap) * dw);
@@ -814,16 +832,19 @@ static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, cons
           }
           const double v = floor(acc + 0.5);
           o[ch * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-        } else { /* kernel arithmetic: horizontal pass exact in Q14 integers (order-free), then an fp32 fma chain over the six rows
-                    (row 0 first) on the integer sums, scaled back by 2^-14 (exact) and rounded to nearest even like the YUV -> RGB family */
-          float acc = 0.f;
+        } else { /* kernel arithmetic, all integers and therefore order-free (the MFMA kernel sums 64 terms per instruction, the gather
+                    kernel six): H = sum q_x p exact (Q14); Hr = (H + 128) >> 8 = H rounded half up to Q6, which fits 16 bits (Lanczos
+                    overshoot included: -4.5k .. 20.8k); V = sum q_y Hr exact in 32 bits (Q20); out = clamp((V + 2^19) >> 20).  The two
+                    roundings move the result by < 0.02 LSB + the Q14 weight quantisation: within 1 LSB of EXACT (test_oracle_kat.py). */
+          int32_t v = 0;
           for (int ky = 0; ky < 6; ky++) {
             const uint8_t* r = prow(s, (uint32_t)ty[yy].idx[ky]);
             int32_t h = 0;
             for (int kx = 0; kx < 6; kx++) h += tx[x].q[kx] * (int32_t)r[ch * tx[x].idx[kx] + c];
-            acc = __builtin_fmaf(ty[yy].wf[ky], (float)h, acc); /* |h| < 2^24: the conversion is exact */
+            v += ty[yy].q[ky] * asr32(h + 128, 8);
           }
-          o[ch * x + c] = sat_rne(acc * 6.103515625e-05f); /* exact scaling, then ONE rounding: saturate, ties to even (v_cvt_pk_u8_f32) */
+          v = asr32(v + (1 << 19), 20);
+          o[ch * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         }
       }
   }

@@ -537,14 +537,14 @@ def test_abi_is_hip_graph_capturable(capi, oracle):
 
 
 def test_batch_entries_are_hip_graph_capturable(capi, oracle):
-    """vpf_convert_batch -> vpf_resize_batch (row-band / march kernels forced, as a large batch would pick them) -> vpf_remap_batch captured
+    """vpf_convert_batch -> vpf_resize_batch (row-band / matrix-core kernels with forced shapes, as a large batch would pick them) -> vpf_remap_batch captured
     into one hipGraph and replayed: the batch entries, too, neither synchronise nor allocate (their frame tables travel in the kernarg)"""
     w, h, dw, dh, n = 640, 360, 427, 240, 5
     srcs = [oracle.synth(oracle.NV12, w, h, 1080 + i) for i in range(n)]
     yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
     xm, ym = (xx * 0.9 + 3.25).astype(np.float32), (yy * 0.9 + 1.5).astype(np.float32)
     st = torch.cuda.Stream()
-    for interp, band, march in ((1, 4, 0), (2, 0, 16)):
+    for interp, band, mfma in ((1, 4, 0), (2, 0, (8 << 8) | 2)):
         with torch.cuda.stream(st):
             S = [DevPlanes(p) for p in srcs]
             M = [DevPlanes(oracle.alloc(oracle.RGB, w, h)) for _ in range(n)]
@@ -561,14 +561,14 @@ def test_batch_entries_are_hip_graph_capturable(capi, oracle):
                 capi.resize_batch(ex, capi.RGB, interp, w, h, dw, dh, b2)
                 capi.remap_batch(ex, capi.RGB, dw, dh, dx.data_ptr(), 4 * dw, dy.data_ptr(), 4 * dw, dw, dh, b3)
 
-            capi.set_tuning(capi.TUNE_RESIZE_BAND, band); capi.set_tuning(capi.TUNE_RESIZE_MARCH, march)
+            capi.set_tuning(capi.TUNE_RESIZE_BAND, band); capi.set_tuning(capi.TUNE_RESIZE_MFMA, mfma)
             try:
                 chain(); st.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st):
                     chain()
             finally:
-                capi.set_tuning(capi.TUNE_RESIZE_BAND, 0); capi.set_tuning(capi.TUNE_RESIZE_MARCH, 0)
+                capi.set_tuning(capi.TUNE_RESIZE_BAND, 0); capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
             for d in M + R:
                 for t in d.bufs:
                     t.fill_(0xCD)
@@ -969,18 +969,20 @@ def test_batched_resize_at_full_size_with_the_kernels_the_policy_picks(capi, ora
         assert_planes_equal(got, wants[i % 2], f"policy batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} frame {i}")
 
 
-@pytest.mark.parametrize("rows", [1, 2, 7, 24, 64])
-def test_lanczos_march_kernel_writes_the_tiled_kernel_pixels(capi, oracle, rows):
-    """VPF_TUNE_RESIZE_MARCH = destination rows per wave of the barrier-free Lanczos kernel (policy: batches that leave >= 6144 waves;
-    1 = never).  Every value writes the oracle's pixels: down- and up-scales, chunks on the left / right image edge (replicated margin
-    pixels) and pictures narrower than one chunk, bands cut by the bottom edge, vertical factors above 6 (source rows nobody blends),
-    multi-plane formats (chroma planes with their own factors), heights below one band, a 33-frame batch"""
+@pytest.mark.parametrize("shape", [1, (4 << 8) | 1, (4 << 8) | 3, (8 << 8) | 1, (8 << 8) | 2, (8 << 8) | 64, 5])
+def test_lanczos_mfma_kernel_shapes_write_the_oracle_pixels(capi, oracle, shape):
+    """VPF_TUNE_RESIZE_MFMA = N-tiles per wave << 8 | 16-row destination tiles per band of the matrix-core Lanczos kernel (1 = never: the
+    gather form).  Every value writes the oracle's pixels: down- and up-scales, strips on the left / right image edge (clamped taps merged
+    on the edge sample) and pictures narrower than one strip or one N-tile, bands cut by the bottom edge, factors the kernel's 64-B
+    window / four-tile ring cannot hold (-> gather form), multi-plane formats (chroma planes with their own factors and channel counts),
+    heights below one tile, a 33-frame batch"""
     cases = [("RGB", 640, 360, 427, 240, 3), ("RGB", 320, 180, 1280, 720, 2), ("NV12", 1280, 72, 854, 48, 3), ("YUV420", 642, 90, 300, 31, 2),
              ("RGB", 300, 50, 200, 7, 2), ("Y", 997, 61, 333, 47, 2), ("RGB", 96, 54, 700, 33, 2), ("RGB", 640, 360, 224, 224, 33), ("RGB", 1919, 64, 1280, 43, 2),
-             ("YUV444", 100, 60, 333, 201, 2), ("RGB", 20, 12, 45, 31, 2),
-             # pictures smaller than the filter: every tap of some columns / rows is a replicated edge pixel
+             ("YUV444", 100, 60, 333, 201, 2), ("RGB", 20, 12, 45, 31, 2), ("RGB", 1280, 200, 640, 100, 2), ("NV12", 640, 400, 320, 200, 2), ("RGB", 500, 300, 233, 140, 2),
+             ("Y", 2000, 100, 701, 43, 2), ("NV12", 854, 480, 1280, 720, 2), ("RGB", 1000, 37, 1000, 37, 2),
+             # pictures smaller than the filter: every tap of some columns / rows is a clamped edge sample
              ("RGB", 1, 1, 9, 7, 2), ("RGB", 2, 3, 300, 5, 2), ("Y", 3, 2, 5, 70, 2), ("NV12", 4, 4, 18, 10, 2), ("RGB", 5, 1, 3, 1, 2), ("Y", 700, 2, 64, 1, 2)]
-    assert capi.set_tuning(capi.TUNE_RESIZE_MARCH, rows) >= 0
+    assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, shape) >= 0
     try:
         for fmt, sw, sh, dw, dh, n in cases:
             f, of = getattr(capi, fmt), getattr(oracle, fmt)
@@ -993,10 +995,10 @@ def test_lanczos_march_kernel_writes_the_tiled_kernel_pixels(capi, oracle, rows)
             for i in range(n):
                 got, intact = D[i].download()
                 assert intact
-                assert_planes_equal(got, wants[i % len(srcs)], f"march rows {rows} {fmt} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+                assert_planes_equal(got, wants[i % len(srcs)], f"mfma shape {shape:#x} {fmt} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
     finally:
-        capi.set_tuning(capi.TUNE_RESIZE_MARCH, 0)
-    assert capi.set_tuning(capi.TUNE_RESIZE_MARCH, 65) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MARCH, -1) == -1
+        capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
+    assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, (3 << 8) | 2) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, -1) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, (8 << 8) | 65) == -1
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
@@ -1031,17 +1033,17 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         band = int(rng.choice([0, 1, 2, 4, 8, 16]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
-        march = int(rng.choice([0, 1, 2, 5, 16, 64]))  # rows per wave of the Lanczos march kernel (small batches would never reach it by policy)
-        capi.set_tuning(capi.TUNE_RESIZE_MARCH, march)
+        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64]))  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
+        capi.set_tuning(capi.TUNE_RESIZE_MFMA, march)
         try:
             capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
         finally:
             capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
             capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
-            capi.set_tuning(capi.TUNE_RESIZE_MARCH, 0)
+            capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
         torch.cuda.synchronize()
         for i in range(n):
             got, intact = D[i].download()
             assert intact
             _, want = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.FP32)
-            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} march{march} frame {i}")
+            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} mfma{march:#x} frame {i}")

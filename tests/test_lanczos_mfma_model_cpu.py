@@ -1,0 +1,39 @@
+"""The bookkeeping of the MFMA Lanczos kernel (tests/lanczos_mfma_model.py: windows, K-slot layout, signed-byte splits and their
+constants, ring slots, tile triggers) against the oracle's definition of 8-bit Lanczos-3, on the CPU."""
+import numpy as np
+import pytest
+
+from lanczos_mfma_model import Model
+
+
+def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3):
+    fmt = {1: oracle.Y, 3: oracle.RGB}.get(ch)
+    rng = np.random.default_rng(seed)
+    if ch == 2:   # a 2-channel plane = the chroma plane of an NV12 picture twice as large
+        src = [rng.integers(0, 256, (2 * sh, 2 * sw), dtype=np.uint8), rng.integers(0, 256, (sh, 2 * sw), dtype=np.uint8)]
+        _, want = oracle.resize(oracle.NV12, oracle.LANCZOS3, 2 * sw, 2 * sh, src, 2 * dw, 2 * dh, oracle.FP32)
+        plane, want = src[1], want[1]
+    else:
+        src = [rng.integers(0, 256, (sh, sw * ch), dtype=np.uint8)]
+        _, want = oracle.resize(fmt, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.FP32)
+        plane, want = src[0], want[0]
+    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band)
+    got = m.run(plane)
+    assert np.array_equal(got, want), f"ch{ch} {sw}x{sh}->{dw}x{dh} nt{nt} band{band}: {np.argwhere(got != want)[:5]}"
+    return m
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_model_equals_the_oracle(oracle, ch):
+    for (sw, sh, dw, dh, nt, band) in ((96, 54, 64, 36, 4, 32), (64, 36, 96, 54, 8, 16), (128, 72, 64, 36, 2, 48), (50, 41, 50, 41, 4, 32),
+                                       (37, 29, 53, 71, 4, 64), (7, 5, 40, 33, 8, 16), (120, 90, 57, 43, 8, 32), (40, 200, 40, 97, 4, 96),
+                                       (3, 3, 9, 9, 4, 16), (1, 1, 5, 4, 4, 16), (200, 17, 95, 40, 8, 16)):
+        _run(oracle, ch, sw, sh, dw, dh, nt, band)
+
+
+def test_model_flat_and_extremes(oracle):
+    """0 / 255 pictures exercise the signed-byte offsets: every constant that is off shows up as a uniform error"""
+    for val in (0, 255, 128, 127):
+        src = np.full((40, 60 * 3), val, np.uint8)
+        m = Model(3, 60, 40, 41, 27, oracle.lanczos_taps(60, 41), oracle.lanczos_taps(40, 27), nt=4, band_rows=16)
+        assert (m.run(src) == val).all()

@@ -19,11 +19,12 @@ F = np.float32
 def pb(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("pb") / "libplanbounds.so")
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"),
-                           os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so])
+                           os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so, "-lm"])
     L = C.CDLL(so)
     for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_march_rowq", [C.c_int] + [C.c_uint32] * 3),
                        ("pb_march_pad", []), ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
-                       ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int])):
+                       ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]),
+                       ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32])):
         getattr(L, name).argtypes, getattr(L, name).restype = args, C.c_uint32
     L.pb_fused_rows_fit.argtypes, L.pb_fused_rows_fit.restype = [C.c_int, C.c_float, C.c_int], C.c_int
     return L
@@ -179,3 +180,45 @@ def test_tile_windows(pb, taps):
                 first, last = lin_taps(xf, s_, d_)[0], lin_taps(xl, s_, d_)[1]
                 base = (ch * first) & ~15
                 assert int(((ch * (last + 1) - base + 15) // 16).max()) <= rowq, (s_, d_, ch)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_lanczos_mfma_windows_ring_and_strip(pb, ch):
+    """k_lanczos_mfma.hip: the launcher walks the tiles with the kernel's own fp32 coordinate arithmetic (vpf_bound_lzm_span /
+    vpf_bound_lzm_rows_ok).  Against an independent numpy evaluation of every destination BYTE: a non-zero span means every tap of the 16
+    destination bytes of every N-tile lies in the 64-B window that starts at the 16-B aligned byte below the tile's first tap (K = 64 of the
+    MFMA) and every strip of nt tiles fits the span (the LDS pitch is >= span and 32 mod 256); a zero span means some tile really does not
+    fit (the check is exact up to the last pixel's unused channels); rows_ok means a 16-row destination tile finds its source rows in four
+    consecutive 16-row source tiles.  And the headline ratios — exactly 2.0 with three channels among them — pass."""
+    rng = np.random.default_rng(77 + ch)
+    n_ok = n_no = 0
+    for (S, D) in size_pairs(rng, 500, 0.2, 3.2):
+        dwb = D * ch
+        b = np.arange(dwb)
+        px, c = b // ch, b % ch
+        i0 = lz_i0(np.arange(D), S, D)
+        lo = np.clip(i0 - 2, 0, S - 1)[px] * ch + c      # lowest / highest source byte a destination byte touches
+        hi = np.clip(i0 + 3, 0, S - 1)[px] * ch + c
+        first_b = np.minimum((b // 16) * 16, dwb - 1)
+        ws = (np.clip(i0 - 2, 0, S - 1)[first_b // ch] * ch) & ~15
+        fits = bool((lo >= ws).all() and (hi - ws < 64).all())
+        for nt in (4, 8):
+            span = pb.pb_lzm_span(ch, S, D, nt)
+            if span:
+                assert fits, (S, D, int((hi - ws).max()))
+                pitch = pb.pb_lzm_pitch(span)
+                assert pitch % 256 == 32 and pitch >= span
+                wst = ws[::16]                                 # window start per tile
+                for s0 in range(0, len(wst), nt):              # strips
+                    assert wst[min(s0 + nt, len(wst)) - 1] - wst[s0] + 64 <= span, (S, D, nt, s0)
+            else:
+                assert (hi - ws).max() + ch - 1 >= 64, (S, D)  # conservative by at most the last pixel's unused channels
+        n_ok += bool(pb.pb_lzm_span(ch, S, D, 8)); n_no += not pb.pb_lzm_span(ch, S, D, 8)
+        if pb.pb_lzm_rows_ok(S, D):
+            y0 = np.arange(0, D, 16)
+            y1 = np.minimum(y0 + 15, D - 1)
+            tmin, tmax = np.clip(i0[y0] - 2, 0, S - 1) >> 4, np.clip(i0[y1] + 3, 0, S - 1) >> 4
+            assert (tmax - tmin <= 3).all(), (S, D)
+    assert n_ok > 100 and n_no > 20
+    for (S, D) in ((1920, 1280), (3840, 1920), (1280, 1920), (1920, 3840), (1080, 720), (2160, 1080), (720, 1080), (960, 640), (640, 960)):
+        assert pb.pb_lzm_span(ch, S, D, 8) and pb.pb_lzm_span(ch, S, D, 4) and pb.pb_lzm_rows_ok(S, D), (S, D)

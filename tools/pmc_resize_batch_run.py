@@ -7,8 +7,8 @@ from videoprocessingframework_amd import capi
 
 sw, sh, dw, dh = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (1920, 1080, 1280, 720)
 interp = int(sys.argv[5]) if len(sys.argv) > 5 else 2
-if os.environ.get("VPF_PMC_MARCH"):  # 1: keep the tiled Lanczos kernel
-    capi.set_tuning(capi.TUNE_RESIZE_MARCH, int(os.environ["VPF_PMC_MARCH"]))
+if os.environ.get("VPF_PMC_MFMA"):  # 1: keep the tiled Lanczos kernel
+    capi.set_tuning(capi.TUNE_RESIZE_MFMA, int(os.environ["VPF_PMC_MFMA"], 0))
 dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 N = 32

@@ -14,7 +14,7 @@ if len(sys.argv) > 1:  # e.g. 43: the tiled kernel for bilinear down-scales too 
 BAND = int(os.environ.get("VPF_BENCH_BAND", "0"))        # rows per wave of the row-pair kernels (0 = policy)
 ONLY = os.environ.get("VPF_BENCH_ONLY", "")              # "bilinear": skip the Lanczos lines and the remap section
 capi.set_tuning(capi.TUNE_RESIZE_BAND, BAND)
-capi.set_tuning(capi.TUNE_RESIZE_MARCH, int(os.environ.get("VPF_BENCH_MARCH", "0")))  # rows per wave of the Lanczos march kernel (0 = policy, 1 = never)
+capi.set_tuning(capi.TUNE_RESIZE_MFMA, int(os.environ.get("VPF_BENCH_MFMA", "0"), 0))  # Lanczos matrix-core kernel: 0 policy, 1 never, nt << 8 | tiles per band
 
 
 def surf(fmt, w, h, rand):

@@ -21,7 +21,7 @@ INC = os.path.join(ROOT, "include")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libvpfhip.so")
 
-KERNEL_TUS = ["vpf_abi.hip", "k_yuv2rgb.hip", "k_relayout.hip", "k_rgb2yuv.hip", "k_resize.hip", "k_remap.hip", "k_convert_resize.hip"]
+KERNEL_TUS = ["vpf_abi.hip", "k_yuv2rgb.hip", "k_relayout.hip", "k_rgb2yuv.hip", "k_resize.hip", "k_lanczos_mfma.hip", "k_remap.hip", "k_convert_resize.hip"]
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-fvisibility=hidden",
              "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]

@@ -23,7 +23,7 @@ OK, ERR_UNSUPPORTED, ERR_BAD_ARG, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
 TUNE_NV12_RGB_VARIANT = 1
 TUNE_RESIZE_TILE = 2
 TUNE_RESIZE_BAND = 3
-TUNE_RESIZE_MARCH = 4
+TUNE_RESIZE_MFMA = 5
 
 EXPORTS = [
     "vpf_convert", "vpf_convert_batch", "vpf_convert_supported", "vpf_resize", "vpf_remap", "vpf_convert_resize",

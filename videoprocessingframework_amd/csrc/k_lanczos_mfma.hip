@@ -1,0 +1,415 @@
+// k_lanczos_mfma.hip — Lanczos-3 resize of 8-bit planes on the integer matrix cores (gfx950: v_mfma_i32_16x16x64_i8).
+//
+// Replaces nppiResize_8u_C3R / _C1R with NPPI_INTER_LANCZOS — the filter the reference's resizer asks for
+// (NppResizeSurfacePacked3C_Impl::Run / NppResizeSurfacePlanar_Impl::Run, src/TC/src/Tasks.cpp:1162-1203,1217-1261).
+//
+// A separable resize is two banded matrix products: H = S Wx (every source row against the column weights) and O = Wy H.  With six
+// taps per output sample the bands are narrow, and on the vector ALU the filter is issue-bound long before it is memory-bound (round 2:
+// 0.22-0.50 of the HBM roofline, half of it v_perm_b32 / v_dot2 tap extraction).  The matrix cores do not care that most of a band is
+// zero — an i8 MFMA retires 16 x 16 x 64 products in 16 cycles — and, decisive here, they take the SOURCE BYTES AS THEY LIE IN MEMORY as
+// an operand: no unpacking, no per-channel shuffles.  The whole filter is integer arithmetic (the test oracle restates it: resize_plane_lanczos,
+// FP32 mode), so the order in which an MFMA adds its 64 products does not matter and every kernel of the family writes the same bytes:
+//   H  = sum_k qx[k] s[k]          Q14 weights (sum 16384), exact
+//   Hr = (H + 128) >> 8            Q6, fits 16 bits with the Lanczos overshoot
+//   V  = sum_k qy[k] Hr[k]         exact in 32 bits (Q20)
+//   out = clamp((V + 2^19) >> 20, 0, 255)
+//
+// Work decomposition (tests/lanczos_mfma_model.py is an executable model of exactly this bookkeeping, checked against the oracle on the CPU):
+//   * a WAVE owns a strip of NT "N-tiles" of 16 destination BYTES (byte b = pixel b / CH, channel b % CH: packed RGB needs no special
+//     case) and a band of destination rows, and marches down the source in tiles of 16 rows.  No workgroup barrier anywhere.
+//   * pass 1, per source tile T and N-tile j:  D[16 rows][16 bytes] = A B with A = the 64 source bytes of each row that start at the
+//     tile's window ws_j (one ds_read_b128 per lane: lane (i, g) reads row i, bytes 16 g .. 16 g + 15; bytes are staged with 0x80 xor-ed
+//     in = s - 128 as a signed byte) and B = the column weights, each Q14 weight as two signed bytes (w = 256 wh + wl -> two MFMAs HI, LO).
+//     Clamped taps simply add their weights on the edge pixel's slot, so image edges cost nothing.  Per lane:
+//     h'' = ((HI + 128) << 8) + LO + 128 (the 128s ride in as the MFMAs' C operand) holds Hr - 8192 = 256 hb + lb in bytes 2 / 1, and
+//     four v_perm_b32 + one xor pack the four rows a lane holds into one dword of hb and one of lb.
+//   * the D layout of pass 1 (lane (n, g) holds rows 4 g .. 4 g + 3 of column n) IS the A layout of pass 2 (lane (n, g) holds K slots
+//     16 g .. 16 g + 15 of row n) once the K slots are numbered to match: K slot (g, 4 p + r) <-> source row 16 T + 4 g + r of the tile in
+//     ring slot p = T & 3.  The ring (the packed bytes of the last four source tiles, 2 x 4 VGPRs per N-tile) never moves: pass 1 is
+//     instantiated per ring slot and the vertical weight operand is built for the slot numbering.
+//   * pass 2, per destination tile of 16 rows and N-tile: D[16 bytes][16 rows] = A B with A = the ring, B = the row weights split like the
+//     column weights: HH, MID = HL + LH, LL -> V = 65536 HH + 256 MID + LL (+ 2^27 for the 8192s, + 2^19 to round; both in LL's C operand);
+//     a lane ends up with four horizontally adjacent output bytes -> one dword -> a wave-private LDS tile -> dense 16-B row stores.
+//   * weights: the column sets of a strip are evaluated once per wave (one pixel per lane), merged at the image edges, split into bytes
+//     and SCATTERED into the operand image in LDS with ds_write_b8 (6 x CH x 2 byte stores per pixel); the row sets of 64 destination
+//     rows (four tiles) the same way every fourth tile.
+// VGPRs: 2 x 4 x NT column weights + 2 x 4 x NT ring + staging prefetch: NT = 8 -> two waves per SIMD.
+#include <algorithm>
+#include <type_traits>
+
+#include "k_resize_common.h"
+#include "vpf_plan_bounds.h"
+
+namespace vpf {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// taps i0 - 2 .. i0 + 3 clamped to [0, size - 1]; the weights of taps that fall on the same sample are summed into the LAST of them and
+// the others marked dead (pos = -1): every live tap of a set has its own source sample
+struct MTap {
+  int32_t pos[6];
+  int32_t q[6];
+};
+VPF_DEV MTap merge_taps(const QTap& t, uint32_t size) {
+  MTap m;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int32_t i = t.i0 + k - 2;
+    m.pos[k] = i < 0 ? 0 : (i > (int32_t)size - 1 ? (int32_t)size - 1 : i);
+    m.q[k] = t.q[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++)
+    if (m.pos[k] == m.pos[k + 1]) { m.q[k + 1] += m.q[k]; m.pos[k] = -1; }
+  return m;
+}
+// w = 256 hi + lo, lo in [-128, 127] (|w| < 32512: merged Lanczos weights stay below 1.3 x 16384)
+VPF_DEV void split_i8(int32_t w, int32_t& hi, int32_t& lo) {
+  lo = ((w + 128) & 0xff) - 128;
+  hi = (w - lo) >> 8;
+}
+// keeps the compiler from re-associating a chain of (a << n) + b into shift, shift, add3: an EMPTY asm (no instruction, so none of the
+// MFMA -> VALU wait states the compiler pads for its own instructions — and not for the contents of an asm — can go missing)
+VPF_DEV uint32_t opaque(uint32_t v) {
+  asm("" : "+v"(v));
+  return v;
+}
+VPF_DEV uint32_t sat_pk_u8_i16(uint32_t two_i16) {  // {sat_u8(hi half), sat_u8(lo half)} in the low 16 bits
+  uint32_t r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(two_i16));
+  return r;
+}
+
+// PF = staging loads a lane keeps in flight = ceil(16-B units per staged row / 4)
+template <int CH, int NT, int PF>
+struct LanczosMfmaTask {
+  static constexpr int kThreads = 256;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+};
+
+constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles
+constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
+constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of LDS per wave
+  const uint32_t run = 16u * pitch + kLzmWmBytes + 16u * lzm_out_pitch(nt), setup = 2u * (uint32_t)nt * 1024u;
+  return run > setup ? run : setup;
+}
+
+template <int CH, int NT, int PF>
+VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
+                                              const PlaneGeom& G, uint32_t bx, uint32_t by) {
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, P = G.a0, R = G.a1;
+  const float scx = G.scx, scy = G.scy;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t dwb = dw * CH, ob0 = (bx * 4 + wv) * (16u * NT), ya = by * R;
+  if (ob0 >= dwb || ya >= dh) return;  // wave-uniform; the kernel has no workgroup barrier
+  const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
+  uint8_t* const lds = reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)wv * G.a2;
+  uint8_t* const stage = lds;                         // [16 rows][P]
+  uint8_t* const wm = lds + 16u * P;                  // [4 tiles][2 planes][64 lanes][16 B]
+  uint8_t* const ot = wm + kLzmWmBytes;               // [16 rows][lzm_out_pitch]
+  constexpr uint32_t PO = lzm_out_pitch(NT);
+
+  // ---- windows: ws_j = 16-B aligned source byte below the first tap of tile j's first pixel (tiles past the row end copy the last window)
+  auto window = [&](uint32_t b) -> uint32_t {
+    const uint32_t bb = b < dwb - 1 ? b : dwb - 1;
+    int32_t p0 = ltap_i0(bb / CH, scx) - 2;
+    p0 = p0 < 0 ? 0 : (p0 > (int32_t)sw - 1 ? (int32_t)sw - 1 : p0);
+    return ((uint32_t)CH * (uint32_t)p0) & ~15u;
+  };
+  const uint32_t S0 = __builtin_amdgcn_readfirstlane(window(ob0));
+  uint32_t wrel[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) wrel[j] = __builtin_amdgcn_readfirstlane(window(ob0 + 16u * j)) - S0;
+
+  // ---- column weights -> pass-1 B operands.  Operand image in LDS: [plane][tile j][lane 16 g + n][16 bytes]; zero it, scatter the bytes
+  {
+    u32x4* z = reinterpret_cast<u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 2 * NT; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+    const uint32_t px_first = ob0 / CH, ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb, px_last = (ob1 - 1) / CH;
+    for (uint32_t px = px_first + lane; px <= px_last; px += 64) {
+      const MTap m = merge_taps(quantize_ltap(make_ltap(px, scx)), sw);
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const uint32_t b = px * CH + c;
+        if (b < ob0 || b >= ob1) continue;
+        const uint32_t j = (b - ob0) >> 4, n = (b - ob0) & 15;
+        const uint32_t wsj = window(ob0 + 16u * j);
+        uint8_t* const cell = lds + (j * 64 + n) * 16;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          if (m.pos[k] < 0) continue;
+          const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 (vpf_bound_lzm_cols_ok)
+          int32_t hi, lo;
+          split_i8(m.q[k], hi, lo);
+          uint8_t* const a = cell + (kk >> 4) * 256 + (kk & 15);
+          a[0] = (uint8_t)hi;
+          a[NT * 1024] = (uint8_t)lo;
+        }
+      }
+    }
+  }
+  wave_lds_sync();
+  v4i b1h[NT], b1l[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    b1h[j] = *reinterpret_cast<const v4i*>(lds + (j * 64 + lane) * 16);
+    b1l[j] = *reinterpret_cast<const v4i*>(lds + NT * 1024 + (j * 64 + lane) * 16);
+  }
+  wave_lds_sync();
+
+  // ---- the march
+  // 16-B units of a staged row (<= 4 PF, <= P / 16: host), cut at the row's last unit: the last window of a strip at the right image
+  // edge reaches past the row (those bytes carry no weight and are never loaded: the LDS keeps whatever it held)
+  const uint32_t nq_win = (wrel[NT - 1] + 64u) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
+  const uint32_t nq = nq_win < nq_row ? nq_win : nq_row;
+  const uint32_t npf = __builtin_amdgcn_readfirstlane((nq + 3u) / 4u);  // staging loads per lane and tile (wave-uniform, <= PF)
+  const uint32_t srow = lane >> 2, sq = lane & 3;  // staging: lane -> (row of the tile, unit (lane & 3) + 4 k)
+  int32_t t_first;                                 // first source tile of the band: ring slot of tile T = (T - t_first) & 3
+  {
+    int32_t r = ltap_i0(ya, scy) - 2;
+    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+    t_first = __builtin_amdgcn_readfirstlane(r >> 4);
+  }
+  // the units a lane stages: (lane & 3) + 4 k, clamped to the last one instead of predicated (all loads issue back to back; the clamped
+  // duplicates land in LDS units >= nq, which carry no weight — 4 PF units always fit the pitch)
+  uint32_t soff[PF];
+#pragma unroll
+  for (int k = 0; k < PF; k++) soff[k] = 16u * (sq + 4u * k < nq ? sq + 4u * k : nq - 1u);
+  u32x4 pf[PF];
+  auto fetch = [&](int32_t T) {
+    int32_t r = 16 * T + (int32_t)srow;
+    r = r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r;
+    const uint8_t* row = src + (size_t)r * sp + S0;
+#pragma unroll
+    for (int k = 0; k < PF; k++)
+      if ((uint32_t)k < npf) pf[k] = ldg<false, u32x4>(row + soff[k]);
+  };
+  v4i ringH[NT], ringL[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) { ringH[j] = v4i{0, 0, 0, 0}; ringL[j] = v4i{0, 0, 0, 0}; }
+  const v4i c128 = {128, 128, 128, 128};
+  const uint32_t arow = (lane & 15) * P + 16u * (lane >> 4);  // A operand of pass 1: lane (i, g) -> row i, bytes 16 g ..
+  uint8_t* const sdst = stage + srow * P + 16u * sq;
+
+  // pass 1 of source tile T into ring slot SLOT = (T - t_first) & 3 (a compile-time constant: the march below is unrolled four deep so
+  // that the ring never moves in the register file)
+  auto pass1 = [&](int32_t T, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+    for (int k = 0; k < PF; k++)
+      if ((uint32_t)k < npf)
+        *reinterpret_cast<u32x4*>(sdst + 64u * k) = pf[k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    fetch(T + 1);  // one tile ahead (the tile past the band's last is a harmless clamped re-read)
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const v4i a = *reinterpret_cast<const v4i*>(stage + arow + wrel[j]);
+      const v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1h[j], c128, 0, 0, 0);
+      const v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1l[j], c128, 0, 0, 0);
+      uint32_t h[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[r] << 8) + (uint32_t)lo[r];
+      const uint32_t p01 = __builtin_amdgcn_perm(h[1], h[0], 0x06050201u), p23 = __builtin_amdgcn_perm(h[3], h[2], 0x06050201u);
+      ringH[j][SLOT] = (int32_t)__builtin_amdgcn_perm(p23, p01, 0x07050301u);
+      ringL[j][SLOT] = (int32_t)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+    }
+    wave_lds_sync();  // the next tile's staging stores must not pass these reads
+  };
+
+  // pass 2 + store of one destination tile: rows y0 .. y0 + 15, weight operands of tile t of the current group
+  const v4i cll = {(1 << 27) + (1 << 19), (1 << 27) + (1 << 19), (1 << 27) + (1 << 19), (1 << 27) + (1 << 19)};
+  const v4i czero = {0, 0, 0, 0};
+  constexpr uint32_t LOGNT = NT == 8 ? 3 : 2, RPI = 64 / NT;  // read-back: lane -> (row lane >> LOGNT (+ RPI per pass), unit lane & (NT - 1))
+  uint8_t* const owr = ot + (lane & 15) * PO + 4u * (lane >> 4);      // lane (y, g') writes bytes 4 g' .. 4 g' + 3 of every tile of row y
+  const uint8_t* const ord = ot + (lane >> LOGNT) * PO + 16u * (lane & (NT - 1));
+  const uint32_t ob = ob0 + 16u * (lane & (NT - 1));                   // first destination byte of the unit this lane stores
+  const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
+  uint8_t* const obase = dst + (size_t)(lane >> LOGNT) * dp + ob;
+  auto emit = [&](uint32_t t, uint32_t y0) {
+    const v4i b2h = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16);
+    const v4i b2l = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const v4i hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringH[j], b2h, czero, 0, 0, 0);
+      v4i mid = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringH[j], b2l, czero, 0, 0, 0);
+      mid = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringL[j], b2h, mid, 0, 0, 0);
+      const v4i ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringL[j], b2l, cll, 0, 0, 0);
+      int32_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r] = (int32_t)(((uint32_t)hh[r] << 16) + opaque(((uint32_t)mid[r] << 8) + (uint32_t)ll[r])) >> 20;
+      const uint32_t q01 = sat_pk_u8_i16(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[0], o[1])));
+      const uint32_t q23 = sat_pk_u8_i16(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[2], o[3])));
+      *reinterpret_cast<uint32_t*>(owr + 16u * j) = __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+    }
+    wave_lds_sync();
+    uint8_t* const orow = obase + (size_t)y0 * dp;
+#pragma unroll
+    for (int it = 0; it < NT / 4; it++) {
+      const uint32_t y = y0 + (lane >> LOGNT) + RPI * it;
+      if (y <= yb) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ord + RPI * it * PO);
+        uint8_t* const out = orow + (size_t)(RPI * it) * dp;
+        if (ofull) {
+          stg<true, u32x4>(out, v);
+        } else if (opart) {  // the row's last, partial unit
+          const uint32_t nb = dwb - ob;
+          for (uint32_t i = 0; i < nb; i++) out[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
+        }
+      }
+    }
+    wave_lds_sync();
+  };
+
+  // row weights of the 64 destination rows from yg on (lane = row; rows past the band repeat its last row and are never stored):
+  // scattered into the operand image of four destination tiles; every lane keeps the last source tile its row needs
+  int32_t tmax_l = 0;
+  auto load_group = [&](uint32_t yg) {
+    const uint32_t yrow = yg + lane < yb ? yg + lane : yb;
+    const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
+    u32x4* z = reinterpret_cast<u32x4*>(wm);
+#pragma unroll
+    for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+    uint8_t* const cell = wm + ((lane >> 4) * 2 * 64 + (lane & 15)) * 16;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      if (m.pos[k] < 0) continue;
+      const uint32_t pos = (uint32_t)m.pos[k];
+      int32_t hi, lo;
+      split_i8(m.q[k], hi, lo);
+      // K slot (g, 4 p + r) <-> source row 16 T + 4 g + r of the tile in ring slot p = (T - t_first) & 3
+      uint8_t* const a = cell + ((pos >> 2) & 3) * 256 + 4 * (((pos >> 4) - (uint32_t)t_first) & 3) + (pos & 3);
+      a[0] = (uint8_t)hi;
+      a[64 * 16] = (uint8_t)lo;
+    }
+    tmax_l = m.pos[5] >> 4;
+    wave_lds_sync();
+  };
+
+  uint32_t yg = ya, y_next = ya;  // first row of the weight group in LDS / of the next destination tile to emit
+  int32_t T = t_first;
+  fetch(T);
+  load_group(yg);
+  // one step: the next source tile, then every destination tile whose last source tile it was
+#define VPF_LZM_STEP(S)                                                                                              \
+  pass1(T, std::integral_constant<int, S>{});                                                                       \
+  T++;                                                                                                              \
+  for (;;) {                                                                                                        \
+    const uint32_t tl = (y_next - yg) >> 4;                                                                         \
+    if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + 15) >= T) break;                                                \
+    emit(tl, y_next);                                                                                               \
+    y_next += 16;                                                                                                   \
+    if (y_next > yb) return;                                                                                        \
+    if (y_next - yg == 64) { yg += 64; load_group(yg); }                                                            \
+  }
+  for (;;) {
+    VPF_LZM_STEP(0) VPF_LZM_STEP(1) VPF_LZM_STEP(2) VPF_LZM_STEP(3)
+  }
+#undef VPF_LZM_STEP
+}
+
+template <int CH> struct LzMfma8 : LanczosMfmaTask<CH, 8, 4> {};
+template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
+
+// all planes of up to 32 frames in one dispatch (the k_planes_mp scheme of k_resize_common.h, with this family's register budget:
+// two workgroups per CU)
+template <template <int> class TaskCH>
+__global__ __launch_bounds__(256, 2) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  const uint32_t by = blockIdx.y;
+  const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
+  const uint32_t k = T.k[pi], lby = by - T.by0[pi];
+  switch (T.ch[pi]) {  // workgroup-uniform
+    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+  }
+}
+
+// Does a plane shape fit the kernel's windows (vpf_plan_bounds.h: the tiles are walked with the kernel's own coordinate arithmetic)?
+// A per-frame caller asks the same question every call: a small per-thread cache answers it.
+struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8; bool rows_ok; };
+static LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
+  thread_local LzmShape cache[8] = {};
+  thread_local uint32_t next = 0;
+  for (const LzmShape& c : cache)
+    if (c.ch == ch && c.sw == sw && c.sh == sh && c.dw == dw && c.dh == dh) return c;
+  const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
+  LzmShape s{ch, sw, sh, dw, dh, 0, 0, false};
+  s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) != 0;
+  if (s.rows_ok) { s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8); }
+  cache[next++ & 7] = s;
+  return s;
+}
+
+// Launch shape.  Every wave of a plane does the same work per row, the kernel keeps two 4-wave workgroups per CU resident (512 slots),
+// and a wave's fixed work (column weights) is paid once per band: as few bands as fill the chip.
+// `bands` = bands per plane: the smallest count that gives >= 512 workgroups (>= 1 full round), rounded so that bands are whole tiles.
+bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
+  const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
+  if (tune == 9 || tune == 40 || tuning(VPF_TUNE_RESIZE_MFMA) == 1) return false;
+  if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return false;
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    if (j.sw >= (1u << 22) || j.sh >= (1u << 22) || j.dw >= (1u << 22) || j.dh >= (1u << 22)) return false;
+    for (uint32_t i = 0; i < n; i++)
+      if ((((uintptr_t)a.f[i].s[j.k] | a.f[i].sp[j.k] | (uintptr_t)a.f[i].d[j.k] | a.f[i].dp[j.k]) & 15)) return false;
+    if (!lzm_shape(j.ch, j.sw, j.sh, j.dw, j.dh).rows_ok) return false;
+  }
+  // strip width: 8 tiles (128 B of a destination row) unless that leaves the chip short of work or the strip does not fit: a staged row is
+  // at most 4 (PF) x 4 lanes x 16 B, and the workgroup's four wave-private LDS regions must fit the 64 KB a launch gets without opt-in
+  const int forced = tuning(VPF_TUNE_RESIZE_MFMA);  // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
+  int nt = 8;
+  {
+    uint64_t wg8 = 0;
+    for (int p = 0; p < njobs; p++) wg8 += (uint64_t)(((jobs[p].dw * jobs[p].ch + 127) / 128 + 3) / 4) * ((jobs[p].dh + 63) / 64) * n;
+    if (wg8 < 512) nt = 4;
+  }
+  if (forced > 1 && (forced >> 8) != 0) nt = forced >> 8;
+  uint32_t pitch = 0, span = 0, wave_lds = 0;
+  auto fits = [&]() {
+    span = 0;
+    for (int p = 0; p < njobs; p++) {
+      const LzmShape s = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh);
+      const uint32_t sp = nt == 8 ? s.span8 : s.span4;
+      if (!sp) return false;  // some tile's taps do not fit the 64-B window
+      span = std::max(span, sp);
+    }
+    pitch = vpf_bound_lzm_pitch(span);
+    wave_lds = lzm_wave_lds(nt, pitch);
+    return span <= 4u * 64u && 4 * wave_lds <= 64u * 1024u;  // PF = 4 staging loads of 4 lanes x 16 B per row
+  };
+  if (!fits()) {
+    if (nt != 8) return false;
+    nt = 4;
+    if (!fits()) return false;
+  }
+  PlaneTable t{};
+  t.np = (uint32_t)njobs;
+  uint32_t gx = 0, gy = 0;
+  uint64_t cols = 0;  // workgroups per band row, all planes
+  for (int p = 0; p < njobs; p++) cols += ((jobs[p].dw * jobs[p].ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
+    const uint32_t tiles = (j.dh + 15) / 16;
+    uint32_t bands = (uint32_t)((512 + cols * n - 1) / (cols * n));  // >= 512 workgroups in the launch
+    bands = bands < 1 ? 1 : (bands > tiles ? tiles : bands);
+    uint32_t rows = ((tiles + bands - 1) / bands) * 16;
+    if (forced > 1 && (forced & 0xff)) rows = (uint32_t)(forced & 0xff) * 16;
+    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, 0};
+    t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
+    const uint32_t bxs = ((j.dw * j.ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
+    gx = bxs > gx ? bxs : gx;
+    gy += (j.dh + rows - 1) / rows;
+  }
+  const dim3 grid(gx, gy, n);
+  const uint32_t lds = 4 * wave_lds;
+  if (log_level() >= 2 || trace_on()) note_kernel(nt == 8 ? "k_lanczos_mfma<LzMfma8>" : "k_lanczos_mfma<LzMfma4>");
+  (void)hipGetLastError();
+  if (nt == 8) hipLaunchKernelGGL((k_lanczos_mfma<LzMfma8>), grid, dim3(256), lds, st, a, t);
+  else hipLaunchKernelGGL((k_lanczos_mfma<LzMfma4>), grid, dim3(256), lds, st, a, t);
+  return true;
+}
+
+}  // namespace vpf

@@ -20,50 +20,9 @@
 #include <algorithm>
 #include <cstring>
 
-#include "k_bilinear_blend.h"
+#include "k_resize_common.h"
 
 namespace vpf {
-
-// Geometry of one plane of a resize launch, in the form every kernel family takes it.  a0..a3 are family-specific:
-//   tiled kernels     a0 = destination rows per tile, a1 = source rows the LDS layout is sized for, a2 = 16-B units per staged source row,
-//                     a3 = log2(lanes per row while staging)
-//   row-pair kernels  a0 = strip size in 16-B units
-//   half3_r16         a0 = 1024-px chunks per row, a1 = tasks
-struct PlaneGeom {
-  uint32_t sw, sh, dw, dh;
-  float scx, scy;
-  int vec_ok;
-  uint32_t a0, a1, a2, a3;
-};
-// A resize "Task" is a struct with `static constexpr int kThreads` and
-//   static VPF_DEV void run(const uint8_t* src, uint32_t sp, uint8_t* dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by)
-// The single-frame kernels below keep their scalar-argument entries (kernarg preload, see VPF_ONE_SRC_PARAMS in vpf_internal.h);
-// vpf_resize_batch reaches the same task bodies through these two generic entries:
-//   k_plane_batch   ONE plane (index k in FrameDesc) of up to 32 frames: blockIdx.z = frame
-//   k_planes_mp     EVERY plane of up to 32 frames in one dispatch: blockIdx.z = frame, blockIdx.y runs through the planes' block rows
-//                   one plane after the other (by0[p] = first blockIdx.y of plane p), blockIdx.x covers the widest plane (a task returns
-//                   at once when its block lies outside its plane)
-template <class Task>
-__global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BatchArgs args, const int k, const PlaneGeom G) {
-  const FrameDesc& f = args.f[blockIdx.z];
-  Task::run(f.s[k], f.sp[k], f.d[k], f.dp[k], G, blockIdx.x, blockIdx.y);
-}
-struct PlaneTable {
-  PlaneGeom g[3];
-  uint32_t by0[3], k[3], ch[3], np;
-};
-template <template <int> class TaskCH>
-__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchArgs args, const PlaneTable T) {
-  const FrameDesc& f = args.f[blockIdx.z];
-  const uint32_t by = blockIdx.y;
-  const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
-  const uint32_t k = T.k[pi], lby = by - T.by0[pi];
-  switch (T.ch[pi]) {  // workgroup-uniform
-    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-  }
-}
 
 // CH interleaved channels per pixel (1, 2 or 3); 4 destination pixels per lane
 template <int CH, int INTERP>
@@ -121,88 +80,6 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 // polynomials and the six taps from angle-addition identities so the host oracle reproduces the weights bit for bit
 // (the test oracle restates the same sequence).  Gather kernel: lane = one destination pixel.
 // ------------------------------------------------------------------------------------------
-VPF_DEV float lz_sinpi_poly(float g) {  // sin(pi g), g in [0, 0.5]
-  const float x = 3.14159274f * g, x2 = x * x;
-  float p = __builtin_fmaf(x2, -2.50521084e-8f, 2.75573192e-6f);
-  p = __builtin_fmaf(x2, p, -1.98412698e-4f);
-  p = __builtin_fmaf(x2, p, 8.33333333e-3f);
-  p = __builtin_fmaf(x2, p, -1.66666667e-1f);
-  p = __builtin_fmaf(x2, p, 1.0f);
-  return x * p;
-}
-VPF_DEV float lz_cos_poly(float x) {  // cos(x), x in [0, pi/3]
-  const float x2 = x * x;
-  float p = __builtin_fmaf(x2, -2.75573192e-7f, 2.48015873e-5f);
-  p = __builtin_fmaf(x2, p, -1.38888889e-3f);
-  p = __builtin_fmaf(x2, p, 4.16666667e-2f);
-  p = __builtin_fmaf(x2, p, -0.5f);
-  return __builtin_fmaf(x2, p, 1.0f);
-}
-struct LTap {
-  int32_t i0;
-  float w[6];
-};
-VPF_DEV LTap make_ltap(uint32_t d, float scale) {
-  LTap t;
-  const float s = __builtin_fmaf((float)d + 0.5f, scale, -0.5f);
-  const float fl = __builtin_floorf(s);
-  t.i0 = (int32_t)fl;
-  const float f = s - fl;
-  if (f == 0.f) {
-    t.w[0] = t.w[1] = t.w[3] = t.w[4] = t.w[5] = 0.f; t.w[2] = 1.f;
-    return t;
-  }
-  const float s1 = lz_sinpi_poly(f <= 0.5f ? f : 1.0f - f);
-  const float s3 = lz_sinpi_poly(f * 0.333333343f);
-  const float c3 = lz_cos_poly(1.04719758f * f);
-  constexpr float cm[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};
-  constexpr float sm[6] = {-0.866025388f, -0.866025388f, 0.0f, 0.866025388f, 0.866025388f, 0.0f};
-  constexpr float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
-  // w_k = L(t_k) / sum_j L(t_j) with L(t) = 3 sin(pi t) sin(pi t / 3) / (pi t)^2, t_k = f - (k - 2): multiplying numerator and
-  // denominator by prod_j t_j^2 leaves n_k D_k / sum_j n_j D_j with n_k = sin(pi t_k) sin(pi t_k / 3) and D_k = prod_{j != k} t_j^2
-  // — ONE division per weight set instead of seven (the weights are ~1/4 of the tiled kernel's instructions at small tiles)
-  float n[6], u[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float tt = f - (float)(k - 2);
-    u[k] = tt * tt;
-    n[k] = (sg[k] * s1) * __builtin_fmaf(s3, cm[k], -(c3 * sm[k]));
-  }
-  float pre[6], suf[6];  // pre[k] = u_0 .. u_{k-1}, suf[k] = u_{k+1} .. u_5
-  pre[0] = 1.0f; suf[5] = 1.0f;
-#pragma unroll
-  for (int k = 1; k < 6; k++) pre[k] = pre[k - 1] * u[k - 1];
-#pragma unroll
-  for (int k = 4; k >= 0; k--) suf[k] = suf[k + 1] * u[k + 1];
-  float sum = 0.f;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    t.w[k] = n[k] * (pre[k] * suf[k]);
-    sum += t.w[k];
-  }
-  const float inv = 1.0f / sum;
-#pragma unroll
-  for (int k = 0; k < 6; k++) t.w[k] *= inv;
-  return t;
-}
-
-// The horizontal pass on 8-bit surfaces runs in integers: the six normalised weights become Q14 fixed point (ties to even), tap 2
-// absorbs the rounding residue so that they sum to exactly 16384 (a flat picture stays flat), and H = sum q_k p_k is exact in 32
-// bits whatever the order — which is what lets the tiled kernel take two taps per v_dot2_i32_i16 and still match the gather form
-// and the oracle bit for bit.  Every |q_k| <= 16384 fits an int16.
-struct QTap {
-  int32_t i0;
-  int32_t q[6];
-};
-VPF_DEV QTap quantize_ltap(const LTap& t) {
-  QTap o;
-  o.i0 = t.i0;
-  int32_t sum = 0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) { o.q[k] = (int32_t)__builtin_rintf(t.w[k] * 16384.0f); sum += o.q[k]; }
-  o.q[2] += 16384 - sum;
-  return o;
-}
 VPF_DEV uint32_t pack_i16(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 VPF_DEV int32_t dot2(uint32_t a, uint32_t b, int32_t c) {  // a.lo * b.lo + a.hi * b.hi + c on int16 halves
@@ -235,17 +112,16 @@ VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_
   const float scx = G.scx, scy = G.scy;
   const uint32_t x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
-  const QTap tx = quantize_ltap(make_ltap(x, scx));
-  const LTap ty = make_ltap(y, scy);
+  const QTap tx = quantize_ltap(make_ltap(x, scx)), ty = quantize_ltap(make_ltap(y, scy));
   uint32_t xi[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const int32_t i = tx.i0 + k - 2;
     xi[k] = (uint32_t)(i < 0 ? 0 : (i > (int32_t)sw - 1 ? (int32_t)sw - 1 : i)) * CH;
   }
-  float acc[CH];
+  int32_t acc[CH];
 #pragma unroll
-  for (int c = 0; c < CH; c++) acc[c] = 0.f;
+  for (int c = 0; c < CH; c++) acc[c] = 1 << 19;
 #pragma unroll
   for (int ky = 0; ky < 6; ky++) {
     const int32_t j = ty.i0 + ky - 2;
@@ -261,12 +137,15 @@ VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_
       int32_t h = 0;  // exact: |h| <= 255 * sum |q| < 2^24
 #pragma unroll
       for (int kx = 0; kx < 6; kx++) h += tx.q[kx] * (int32_t)v[kx][c];
-      acc[c] = __builtin_fmaf(ty.w[ky], (float)h, acc[c]);
+      acc[c] += ty.q[ky] * ((h + 128) >> 8);  // the row sum rounded half up to Q6 (fits 16 bits); exact: |acc| < 2^30
     }
   }
   uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
 #pragma unroll
-  for (int c = 0; c < CH; c++) o[c] = (uint8_t)sat_rne(acc[c] * kQ14Inv);  // the scaling is exact (power of two); one rounding, ties to even
+  for (int c = 0; c < CH; c++) {
+    const int32_t v = acc[c] >> 20;  // (V + 2^19) >> 20: round half up
+    o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -399,41 +278,32 @@ VPF_DEV void RowBandTask<CH, R, IT, P1>::run(const uint8_t* __restrict__ src, ui
 }
 
 // ------------------------------------------------------------------------------------------
-// Tiled, separable resize: Lanczos-3 (always) and bilinear up-scaling (k_resize_lanczos / k_resize remain the any-input gather forms).
-// The gather kernel evaluates, per destination pixel, six horizontal 6-tap dots (one per source row) and then the vertical 6-tap
-// dot.  The horizontal dot of (source row r, destination column x) does not depend on the destination row, so a workgroup that
-// owns a tile of 64 columns x TY rows computes each of them ONCE:
-//   phase 1  wave w takes source rows w, w + WPB, ...: stages the row's byte span in a wave-private LDS strip with dense 16-B loads
-//            (the next row's load is already in flight); every lane (= one destination column) takes its 6 x CH taps out of the
-//            strip as aligned dwords, spreads tap PAIRS into int16 halves with v_perm_b32 and multiplies them with the column's Q14
-//            weight pairs, two taps per v_dot2_i32_i16 (exact integer sums: see quantize_ltap); the sum goes to LDS as a float,
-//            H[row][channel][column];
-//   phase 2  every lane combines six H rows per destination pixel with the vertical fp32 weights (computed once per destination
-//            row by one lane and broadcast from LDS) and scales the result back by 2^-14 in the rounding fma.
-// Bilinear (LZ = false): 2 taps; H = the horizontal lerp fma(fx, p1 - p0, p0) of k_resize's bilerp, which for an up-scale is shared
-// by every destination row between two source rows.  Same arithmetic as the gather forms -> bit-identical to them and to the oracle.
-// 1.5x down-scale: 1.9 horizontal dots per destination pixel instead of 6; 2x up-scale: 0.7 instead of 6.
+// Tiled, separable BILINEAR resize for up-scales (8-bit Lanczos-3 lives in k_lanczos_mfma.hip; k_resize_lanczos / k_resize remain the
+// any-input gather forms).  The horizontal lerp of (source row r, destination column x) does not depend on the destination row, and
+// in an up-scale several destination rows sit between the same two source rows, so a workgroup that owns a tile of 64 columns x TY
+// rows computes each of them ONCE:
+//   phase 0  the tile's whole source window goes to LDS in one sweep of dense 16-B loads;
+//   phase 1  wave w takes source rows w, w + WPB, ...: H[row][channel][column] = fma(fx, p1 - p0, p0) (k_resize's bilerp) as floats in LDS;
+//   phase 2  every lane blends two H rows per destination pixel: fma(fy, bottom - top, top) + 0.5, truncating pack.
+// Same arithmetic as the gather forms -> bit-identical to them and to the oracle.  2x up-scale: 0.7 horizontal lerps per
+// destination pixel instead of 2.
 // WPB = waves per workgroup (4 or 8): 8 halves the number of source rows a wave walks through one after the other, which is what
 // the duration of a single-frame launch (one round of workgroups, each a chain of dependent steps) is made of.
+// TileTaskF32 below is the same tiling for float surfaces (bilinear and Lanczos-3).
 // ------------------------------------------------------------------------------------------
-VPF_DEV int32_t ltap_i0(uint32_t d, float scale) {  // make_ltap's first expression sequence
-  return (int32_t)__builtin_floorf(__builtin_fmaf((float)d + 0.5f, scale, -0.5f));
-}
 constexpr uint32_t kLzStripQ = 128;  // at most 2 KiB of source bytes per row of a tile
 
 constexpr int kTileStagePasses = 6;  // staging loads a thread may have in flight (the launcher sizes tiles accordingly)
 
-template <int CH, bool LZ, int WPB>
+template <int CH, int WPB>
 struct TileTask {
   static constexpr int kThreads = 64 * WPB;
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P, uint32_t bx, uint32_t by);
 };
-template <int CH, bool LZ, int WPB>
-VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P,
-                                        uint32_t bx, uint32_t by) {
-  // dynamic LDS: RAW[nr_cap][rowq x 16 B] source bytes | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats | WX[4][64] dwords (Lanczos)
-  // (WY — Lanczos: 6 weights + first H row; bilinear: fy, -, ..., top H row, bottom H row)
-  constexpr int NT = LZ ? 6 : 2;
+template <int CH, int WPB>
+VPF_DEV void TileTask<CH, WPB>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P,
+                                    uint32_t bx, uint32_t by) {
+  // dynamic LDS: RAW[nr_cap][rowq x 16 B] source bytes | H[nr_cap][CH][64] floats | WY[tile_rows][8] floats (fy, -, ..., top H row, bottom H row)
   constexpr uint32_t T = 64 * WPB;
   const uint32_t sw = P.sw, sh = P.sh, dw = P.dw, dh = P.dh, tile_rows = P.a0, nr_cap = P.a1, rowq = P.a2, lshift = P.a3;
   const float scx = P.scx, scy = P.scy;
@@ -446,24 +316,13 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
   const uint32_t x = xf + lane, xc = x < dw ? x : dw - 1;  // lanes past the right edge compute a duplicate, never stored
   const uint32_t y0 = by * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
   auto clampi = [](int32_t i, int32_t hi) { return (uint32_t)(i < 0 ? 0 : (i > hi ? hi : i)); };
-  int32_t R0, R1;
-  uint32_t first, last, xo[NT];
-  float wx = 0.f;  // bilinear: fx
-  int32_t fv = 0, lv = 0;  // Lanczos: the tile's VIRTUAL source columns [fv, lv]; columns before 0 / after sw - 1 are copies of the edge pixel
-  if constexpr (LZ) {
-    R0 = ltap_i0(y0, scy) - 2; R1 = ltap_i0(yl, scy) + 3;
-    fv = ltap_i0(xf, scx) - 2; lv = ltap_i0(xl, scx) + 3;
-    first = clampi(fv, (int32_t)sw - 1); last = clampi(lv, (int32_t)sw - 1);
-  } else {
-    R0 = (int32_t)make_tap<VPF_INTERP_LINEAR>(y0, scy, sh).i0; R1 = (int32_t)make_tap<VPF_INTERP_LINEAR>(yl, scy, sh).i1;
-    first = make_tap<VPF_INTERP_LINEAR>(xf, scx, sw).i0; last = make_tap<VPF_INTERP_LINEAR>(xl, scx, sw).i1;
-  }
+  const int32_t R0 = (int32_t)make_tap<VPF_INTERP_LINEAR>(y0, scy, sh).i0, R1 = (int32_t)make_tap<VPF_INTERP_LINEAR>(yl, scy, sh).i1;
+  const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xf, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xl, scx, sw).i1;
   const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
   // Phase 0: the tile's whole source window goes to LDS in ONE sweep — every 16-B unit of every source row is requested before the
-  // first one is waited for, so the workgroup pays one memory latency, not one per source row (a per-row prefetch chain spent
-  // 3 of the kernel's 9 us at 1080p -> 720p waiting: the compiler's conservative vmcnt(0) around the predicated loads serialised
-  // it).  The weights are computed while the loads are in flight.
+  // first one is waited for, so the workgroup pays one memory latency, not one per source row.  The weights are computed while the
+  // loads are in flight.
   const uint32_t scol = threadIdx.x & ((1u << lshift) - 1u), srow0 = threadIdx.x >> lshift, srows = T >> lshift;
   u32x4 stage[kTileStagePasses];
 #pragma unroll
@@ -471,120 +330,35 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
     const uint32_t r = srow0 + k * srows;
     if (r < nrows && scol < nq) stage[k] = ldg<false, u32x4>(src + (size_t)clampi(R0 + (int32_t)r, (int32_t)sh - 1) * sp + base + 16 * scol);
   }
-  // A Lanczos weight set is ~100 VALU instructions (two polynomials, one division): the horizontal sets of the tile's 64 columns are
-  // computed ONCE, by wave 0, and handed to the other waves through LDS; wave 1 computes the vertical sets meanwhile.
-  const uint32_t vt = LZ ? threadIdx.x - 64 : threadIdx.x;  // lane that owns destination row y0 + vt
-  if (vt < tile_rows) {  // vertical weights: one lane per destination row
-    const uint32_t y = y0 + vt, yc = y < dh ? y : dh - 1;
-    if constexpr (LZ) {
-      const LTap t = make_ltap(yc, scy);
-#pragma unroll
-      for (int k = 0; k < 6; k++) WY[vt * 8 + k] = t.w[k];
-      WY[vt * 8 + 6] = __int_as_float(t.i0 - 2 - R0);
-    } else {
-      const Tap t = make_tap<VPF_INTERP_LINEAR>(yc, scy, sh);
-      WY[vt * 8] = t.f;
-      WY[vt * 8 + 6] = __int_as_float((int32_t)t.i0 - R0);
-      WY[vt * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
-    }
+  if (threadIdx.x < tile_rows) {  // vertical weights: one lane per destination row
+    const uint32_t y = y0 + threadIdx.x, yc = y < dh ? y : dh - 1;
+    const Tap t = make_tap<VPF_INTERP_LINEAR>(yc, scy, sh);
+    WY[threadIdx.x * 8] = t.f;
+    WY[threadIdx.x * 8 + 6] = __int_as_float((int32_t)t.i0 - R0);
+    WY[threadIdx.x * 8 + 7] = __int_as_float((int32_t)t.i1 - R0);
   }
-  uint32_t* const WX = reinterpret_cast<uint32_t*>(WY + (size_t)tile_rows * 8);  // Lanczos, [4][64]: three weight pairs and the first tap index of every column
-  if constexpr (LZ) {
-    if (wv == 0) {
-      const QTap tx = quantize_ltap(make_ltap(xc, scx));
-#pragma unroll
-      for (int k = 0; k < 3; k++) WX[k * 64 + lane] = pack_i16(tx.q[2 * k], tx.q[2 * k + 1]);
-      WX[3 * 64 + lane] = (uint32_t)tx.i0;
-    }
-  }
-  constexpr uint32_t PADQ = LZ ? 1 : 0;  // Lanczos rows start one 16-B unit into their LDS row: room for up to 3 replicated pixels on the left
 #pragma unroll
   for (int k = 0; k < kTileStagePasses; k++) {
     const uint32_t r = srow0 + k * srows;
-    if (r < nrows && scol < nq) RAW[r * rowq + scol + PADQ] = stage[k];
-  }
-  if constexpr (LZ) {
-    // Tiles on the left / right image edge: the pixels clamped taps fall on are REPLICATED into the margins of every staged row, so that
-    // every lane's six taps are contiguous bytes in every tile (the byte-by-byte walk these tiles used to take made them the slowest
-    // workgroups of a single-frame launch, which lasts as long as its slowest workgroup)
-    if (fv < 0 || lv > (int32_t)sw - 1) {  // workgroup-uniform
-      __syncthreads();
-      const int32_t nl = fv < 0 ? -fv * CH : 0, nr = lv > (int32_t)sw - 1 ? (lv - ((int32_t)sw - 1)) * CH : 0;  // bytes to add on each side (<= 3 px)
-      for (uint32_t t = threadIdx.x; t < nrows * 16; t += T) {
-        uint8_t* b = reinterpret_cast<uint8_t*>(RAW + (size_t)(t >> 4) * rowq) + 16;
-        const int32_t i = (int32_t)(t & 15);
-        if (i < nl) b[CH * fv + i] = b[i % CH];                                                    // base == 0 on the left edge
-        if (i < nr) b[CH * sw - base + (uint32_t)i] = b[CH * (sw - 1) - base + (uint32_t)i % CH];
-      }
-    }
+    if (r < nrows && scol < nq) RAW[r * rowq + scol] = stage[k];
   }
   __syncthreads();
-  uint32_t qx[3] = {0, 0, 0};  // Lanczos: the column's six Q14 weights as three int16 pairs (taps 0|1, 2|3, 4|5)
-  if constexpr (LZ) {
-    const int32_t i0 = (int32_t)WX[3 * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 6; k++) xo[k] = (uint32_t)((i0 + k - 2) * CH - (int32_t)base + 16);  // contiguous by construction
-#pragma unroll
-    for (int k = 0; k < 3; k++) qx[k] = WX[k * 64 + lane];
-  } else {
-    const Tap tx = make_tap<VPF_INTERP_LINEAR>(xc, scx, sw);
-    xo[0] = tx.i0 * CH - base; xo[1] = tx.i1 * CH - base; wx = tx.f;
-  }
+  const Tap tx = make_tap<VPF_INTERP_LINEAR>(xc, scx, sw);
+  const uint32_t xo0 = tx.i0 * CH - base, xo1 = tx.i1 * CH - base;
+  const float wx = tx.f;
   // Phase 1, horizontal: wave w takes source rows w, w + WPB, ...; rows are independent of one another (no barrier inside the loop)
-  if constexpr (LZ) {
-    // In integers, two taps per v_dot2_i32_i16.  A lane's 6 x CH taps are contiguous bytes (edge tiles: replicated margins, above)
-    // -> aligned dword reads, v_alignbyte_b32 to drop the lead, one v_perm_b32
-    // per tap pair to spread two bytes into int16 halves, then the dots; same exact sums as the byte-by-byte form below and as the
-    // gather kernel.  Two source rows per iteration: both rows' LDS reads are in flight before the first is used.
-    constexpr int NE = (6 * CH + 3) / 4;  // dwords of the lead-free run
-    const uint32_t lead = xo[0] & 3u, qoff = xo[0] & ~3u;
-    auto fetch = [&](uint32_t r, uint32_t* d) {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq) + qoff);
+  for (uint32_t r = wv; r < nrows; r += WPB) {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq);
+    if constexpr (CH == 3) {
+      float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
+      strip_window_taps(b, xo0, t0, t1);
 #pragma unroll
-      for (int i = 0; i <= NE; i++) d[i] = q[i];
-    };
-    auto hdots = [&](uint32_t r, const uint32_t* d) {
-      uint32_t e[NE];
-#pragma unroll
-      for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead);
+      for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx, t1[c] - t0[c], t0[c]);
+    } else {
 #pragma unroll
       for (int c = 0; c < CH; c++) {
-        uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c
-        if constexpr (CH == 3) {  // bytes c, 3 + c | 6 + c, 9 + c | 12 + c, 15 + c of the run
-          p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
-          p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
-          p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
-        } else if constexpr (CH == 2) {  // bytes c, 2 + c of dwords 0, 1, 2
-          const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
-          p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
-        } else {  // bytes 0, 1 | 2, 3 | 4, 5
-          p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
-        }
-        H[(r * CH + c) * 64 + lane] = (float)dot2(p2, qx[2], dot2(p1, qx[1], dot2z(p0, qx[0])));  // exact: |h| < 2^24
-      }
-    };
-    for (uint32_t r = wv; r < nrows; r += 2 * WPB) {
-      uint32_t da[NE + 1], db[NE + 1];
-      const bool two = r + WPB < nrows;  // wave-uniform
-      fetch(r, da);
-      if (two) fetch(r + WPB, db);
-      hdots(r, da);
-      if (two) hdots(r + WPB, db);
-    }
-  } else {
-    for (uint32_t r = wv; r < nrows; r += WPB) {
-      const uint8_t* b = reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq);
-      if constexpr (CH == 3) {
-        float t0[3], t1[3];  // at the right image edge i1 == i0 and the window's second tap is junk with weight exactly 0
-        strip_window_taps(b, xo[0], t0, t1);
-#pragma unroll
-        for (int c = 0; c < 3; c++) H[(r * 3 + c) * 64 + lane] = __builtin_fmaf(wx, t1[c] - t0[c], t0[c]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-          const float p0 = (float)b[xo[0] + c], p1 = (float)b[xo[1] + c];
-          H[(r * CH + c) * 64 + lane] = __builtin_fmaf(wx, p1 - p0, p0);
-        }
+        const float p0 = (float)b[xo0 + c], p1 = (float)b[xo1 + c];
+        H[(r * CH + c) * 64 + lane] = __builtin_fmaf(wx, p1 - p0, p0);
       }
     }
   }
@@ -596,257 +370,44 @@ VPF_DEV void TileTask<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint32_
   for (uint32_t yb = 0; yb < tile_rows; yb += 4 * WPB) {
     const uint32_t yy = yb + wv * 4 + rsub, y = y0 + yy;
     if (yy >= tile_rows || y >= dh || x0 >= dw) continue;
-    const uint32_t r0 = (uint32_t)__float_as_int(WY[yy * 8 + 6]);
+    const uint32_t r0 = (uint32_t)__float_as_int(WY[yy * 8 + 6]), r1 = (uint32_t)__float_as_int(WY[yy * 8 + 7]);
     // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two independent IEEE operations per instruction at the issue cost of one —
-    // tools/probe_valu_rate.hip, profiles/r02_probe_valu_rate.txt: 4.4 cycles per wave-instruction, the same as a scalar v_fma_f32);
-    // every component goes through exactly the scalar form's operations, so results are bit-identical to it
+    // tools/probe_valu_rate.hip, profiles/r02_probe_valu_rate.txt); every component goes through exactly the scalar form's
+    // operations, so results are bit-identical to it
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 acc[CH][2];
-    if constexpr (LZ) {
+    const float fy = WY[yy * 8];
+    const f32x2 fy2 = {fy, fy};
 #pragma unroll
-      for (int c = 0; c < CH; c++) acc[c][0] = acc[c][1] = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int ky = 0; ky < 6; ky++) {
-        const float wy = WY[yy * 8 + ky];
-        const f32x2 wy2 = {wy, wy};
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(&H[((r0 + ky) * CH + c) * 64 + 4 * cg]);
-          acc[c][0] = __builtin_elementwise_fma(wy2, f32x2{hv[0], hv[1]}, acc[c][0]);
-          acc[c][1] = __builtin_elementwise_fma(wy2, f32x2{hv[2], hv[3]}, acc[c][1]);
-        }
-      }
-    } else {
-      const uint32_t r1 = (uint32_t)__float_as_int(WY[yy * 8 + 7]);
-      const float fy = WY[yy * 8];
-      const f32x2 fy2 = {fy, fy};
-#pragma unroll
-      for (int c = 0; c < CH; c++) {
-        const f32x4 top = *reinterpret_cast<const f32x4*>(&H[(r0 * CH + c) * 64 + 4 * cg]);
-        const f32x4 bot = *reinterpret_cast<const f32x4*>(&H[(r1 * CH + c) * 64 + 4 * cg]);
-        const f32x2 t0 = {top[0], top[1]}, t1 = {top[2], top[3]}, b0 = {bot[0], bot[1]}, b1 = {bot[2], bot[3]};
-        acc[c][0] = __builtin_elementwise_fma(fy2, b0 - t0, t0);
-        acc[c][1] = __builtin_elementwise_fma(fy2, b1 - t1, t1);
-      }
+    for (int c = 0; c < CH; c++) {
+      const f32x4 top = *reinterpret_cast<const f32x4*>(&H[(r0 * CH + c) * 64 + 4 * cg]);
+      const f32x4 bot = *reinterpret_cast<const f32x4*>(&H[(r1 * CH + c) * 64 + 4 * cg]);
+      const f32x2 t0 = {top[0], top[1]}, t1 = {top[2], top[3]}, b0 = {bot[0], bot[1]}, b1 = {bot[2], bot[3]};
+      acc[c][0] = __builtin_elementwise_fma(fy2, b0 - t0, t0);
+      acc[c][1] = __builtin_elementwise_fma(fy2, b1 - t1, t1);
     }
-    // pixel-major.  Bilinear: + 0.5, then the truncating pack of every bilinear kernel.  Lanczos: the Q14 sums are scaled back (exact:
-    // a power of two) and rounded + saturated + byte-packed by v_cvt_pk_u8_f32 (ties to even, one instruction per byte instead of
-    // clamp + convert + shift / or: the pack was a tenth of the kernel's instructions)
-    float o[4 * CH];
+    float o[4 * CH];  // pixel-major; + 0.5, then the truncating pack of every bilinear kernel
 #pragma unroll
     for (int c = 0; c < CH; c++)
 #pragma unroll
       for (int hlf = 0; hlf < 2; hlf++) {
-        const f32x2 v = LZ ? acc[c][hlf] * f32x2{kQ14Inv, kQ14Inv} : acc[c][hlf] + f32x2{0.5f, 0.5f};
+        const f32x2 v = acc[c][hlf] + f32x2{0.5f, 0.5f};
         o[(2 * hlf) * CH + c] = v[0]; o[(2 * hlf + 1) * CH + c] = v[1];
       }
-    auto pk4 = [](float a, float b, float c, float d) { return LZ ? pack4<1>(a, b, c, d) : pack4_trunc(a, b, c, d); };
     uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
     if (P.vec_ok && x0 + 4 <= dw) {
       if constexpr (CH == 3) {
-        stg3<true>(out, pk4(o[0], o[1], o[2], o[3]), pk4(o[4], o[5], o[6], o[7]), pk4(o[8], o[9], o[10], o[11]));
+        stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
       } else if constexpr (CH == 2) {
-        stg<true, u32x2>(out, u32x2{pk4(o[0], o[1], o[2], o[3]), pk4(o[4], o[5], o[6], o[7])});
+        stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
       } else {
-        stg<true, uint32_t>(out, pk4(o[0], o[1], o[2], o[3]));
+        stg<true, uint32_t>(out, pack4_trunc(o[0], o[1], o[2], o[3]));
       }
     } else {
       const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
-      for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(LZ ? sat_rne(o[i]) : sat_trunc(o[i]));
+      for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_trunc(o[i]);
     }
   }
-}
-// ------------------------------------------------------------------------------------------
-// Lanczos-3 "march" (batches): a WAVE owns 256 destination columns (512 of a 1-channel plane) and walks down a band of G.a1 destination rows on its own — no
-// workgroup barrier, no H plane in LDS.  The horizontal Q14 sums of the six source rows under the current destination row live in
-// REGISTERS (a ring of six rows x 4 pixels x CH values per lane — 8 pixels when CH = 1; the walk is unrolled six source rows deep so that every slot number
-// is a compile-time constant and the ring never moves), so a source row's horizontal pass is evaluated once per band — (R - 1) scy + 6
-// evaluations for R destination rows, 1.7 per row at a 1.5x down-scale with R = 24 — and the vertical pass reads nothing but
-// registers and six broadcast weights.  Source rows reach the wave through a private LDS strip, kMarchGroup rows per memory round
-// trip; the pixels an image edge clamps to are REPLICATED into the strip's margins while staging, so every lane's taps are contiguous
-// bytes everywhere (the tiled kernel walks edge tiles byte by byte).  Column weight sets are computed once per WORKGROUP (its four waves
-// own the same columns: each computes a quarter and shares it through LDS — the only barrier of the kernel, before the walk starts),
-// the band's vertical weight sets by the first R lanes in one go (v_readlane_b32 hands row y's set to the wave).
-// Same exact integer sums and the same vertical fma chain (tap 0 first, accumulator from 0, x 2^-14, v_cvt_pk_u8_f32) as TileTask /
-// LanczosGatherTask / the oracle -> same bytes.  VALU instructions per destination pixel at 1080p -> 720p: 2.31 (TileLz8) -> see
-// profiles/r02_pmc_resize_batch.txt.
-// ------------------------------------------------------------------------------------------
-constexpr int kMarchGroup = 4;       // source rows staged per round trip
-constexpr uint32_t kMarchPad = VPF_MARCH_PAD;  // bytes in front of a strip's first real byte: room for up to 3 replicated pixels (and 16-B aligned stores)
-constexpr int march_px(int ch) { return ch == 1 ? 8 : 4; }  // destination pixels per lane: a 1-channel plane takes 512 columns per wave (the per-band and per-row fixed work of a wave is the same whatever the channel count)
-template <int CH>
-struct LanczosMarchTask {
-  static constexpr int kThreads = 256;
-  static constexpr int kPx = march_px(CH);
-  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
-};
-template <int CH>
-VPF_DEV void LanczosMarchTask<CH>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
-                                       uint32_t bx, uint32_t by) {
-  constexpr int PX = kPx, NV = PX * CH;
-  constexpr uint32_t W = 64 * PX;  // destination columns per wave
-  constexpr int NE = (6 * CH + 3) / 4;  // dwords of a pixel's lead-free run of 6 x CH tap bytes
-  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, R = G.a1;
-  const float scx = G.scx, scy = G.scy;
-  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t ya = (by * 4 + wv) * R, xs = bx * W;
-  if (xs >= dw) return;  // workgroup-uniform (the barrier below is reached by all four waves or by none)
-  const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
-  // columns: virtual source pixels [first_v, last_v] (taps before pixel 0 / after pixel sw - 1 exist in the strip as copies of the edge pixel)
-  const int32_t first_v = __builtin_amdgcn_readfirstlane(ltap_i0(xs, scx) - 2), last_v = __builtin_amdgcn_readfirstlane(ltap_i0(xe, scx) + 3);
-  const uint32_t first_r = first_v < 0 ? 0u : (uint32_t)first_v, last_r = last_v > (int32_t)sw - 1 ? sw - 1 : (uint32_t)last_v;
-  const uint32_t base = (CH * first_r) & ~15u, nq = (CH * (last_r + 1) - base + 15) / 16;
-  u32x4* const strips = dyn_strip + (size_t)wv * kMarchGroup * rowq;
-  const uint32_t x0 = xs + lane * PX;
-  // Column weight sets (~130 VALU instructions each, PX per lane): the four waves of a workgroup own the SAME columns (consecutive bands
-  // of one chunk), so each computes PX / 4 of the sets and hands them to the others through LDS
-  u32x4* const wsets = dyn_strip + (size_t)4 * kMarchGroup * rowq;  // [PX][64] x {q0|q1, q2|q3, q4|q5, byte offset of tap 0 in a strip}
-#pragma unroll
-  for (int j = 0; j < PX / 4; j++) {
-    const uint32_t k = wv * (PX / 4) + j;
-    const uint32_t xc = x0 + k < dw ? x0 + k : dw - 1;  // lanes / pixels past the right edge compute a duplicate, never stored
-    const QTap t = quantize_ltap(make_ltap(xc, scx));
-    const uint32_t off = (uint32_t)((int32_t)CH * (t.i0 - 2) - (int32_t)base + (int32_t)kMarchPad);  // >= 7: i0 - 2 >= -3 where base == 0
-    wsets[k * 64 + lane] = u32x4{pack_i16(t.q[0], t.q[1]), pack_i16(t.q[2], t.q[3]), pack_i16(t.q[4], t.q[5]), off};
-  }
-  __syncthreads();
-  if (ya >= dh) return;
-  uint32_t qx[PX][3], qoff[PX], lead[PX];
-#pragma unroll
-  for (int k = 0; k < PX; k++) {
-    const u32x4 w = wsets[k * 64 + lane];
-    qx[k][0] = w[0]; qx[k][1] = w[1]; qx[k][2] = w[2];
-    qoff[k] = w[3] & ~3u; lead[k] = w[3] & 3u;
-  }
-  // rows: lane l holds the vertical tap set of destination row ya + l (R <= 64)
-  const LTap tyl = make_ltap(ya + lane < dh ? ya + lane : dh - 1, scy);
-  const int32_t jlast = __builtin_amdgcn_readlane(tyl.i0, yb - ya) + 3;  // last virtual source row of the band
-  int32_t hnext = __builtin_amdgcn_readlane(tyl.i0, 0) - 2;             // next virtual source row to evaluate
-  int32_t staged_lo = hnext, staged_hi = hnext - 1;                     // virtual rows in the strips: slot = row - staged_lo
-  float ring[6][NV];                                                     // horizontal sums of virtual rows hnext - 6 .. hnext - 1
-
-  // Source rows travel global memory -> registers -> LDS in groups of kMarchGroup, one group AHEAD of the arithmetic: fetch() requests
-  // a group, commit() (called when the horizontal pass runs out of staged rows) moves it to the strips and requests the next one,
-  // which then has the horizontal passes of kMarchGroup rows and the vertical passes in between to arrive.
-  Span<2> pf[kMarchGroup];
-  int32_t pf_lo = 0, pf_hi = -1;
-  auto fetch = [&](int32_t lo) {
-    pf_lo = lo;
-    pf_hi = lo + kMarchGroup - 1 < jlast ? lo + kMarchGroup - 1 : jlast;
-#pragma unroll
-    for (int g = 0; g < kMarchGroup; g++)
-      if (lo + g <= pf_hi) {
-        const int32_t r = lo + g;
-        pf[g].load(src + (size_t)(r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r)) * sp, base, nq, lane);
-      }
-  };
-  auto commit = [&]() {
-    staged_lo = pf_lo; staged_hi = pf_hi;
-#pragma unroll
-    for (int g = 0; g < kMarchGroup; g++)
-      if (staged_lo + g <= staged_hi) pf[g].store(strips + (size_t)g * rowq + kMarchPad / 16, nq, lane);
-    if (staged_hi < jlast) fetch(staged_hi + 1);
-    if (first_v < 0 || last_v > (int32_t)sw - 1) {  // wave-uniform: this chunk touches an image edge
-      wave_lds_sync();
-#pragma unroll
-      for (int g = 0; g < kMarchGroup; g++)
-        if (staged_lo + g <= staged_hi) {
-          uint8_t* b = reinterpret_cast<uint8_t*>(strips + (size_t)g * rowq);
-          if (first_v < 0 && lane < (uint32_t)(-first_v) * CH) b[kMarchPad + CH * first_v + (int32_t)lane] = b[kMarchPad + lane % CH];  // base == 0 here
-          const int32_t nr = last_v - ((int32_t)sw - 1);
-          if (nr > 0 && lane < (uint32_t)nr * CH) b[kMarchPad + CH * sw - base + lane] = b[kMarchPad + CH * (sw - 1) - base + lane % CH];
-        }
-    }
-    wave_lds_sync();
-  };
-  fetch(hnext);
-  // one source row's horizontal pass: PX pixels x CH exact Q14 sums -> h[]  (requesting the LDS reads of several pixels together
-  // changes nothing measurable: the compiler already keeps 6 - 8 reads in flight and waits with descending lgkmcnt)
-  auto hrow = [&](uint32_t slot, float* h) {
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(strips + (size_t)slot * rowq);
-#pragma unroll
-    for (int k = 0; k < PX; k++) {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(b + qoff[k]);
-      uint32_t d[NE + 1], e[NE];
-#pragma unroll
-      for (int i = 0; i <= NE; i++) d[i] = q[i];
-#pragma unroll
-      for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead[k]);
-#pragma unroll
-      for (int c = 0; c < CH; c++) {
-        uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c (see TileTask)
-        if constexpr (CH == 3) {
-          p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
-          p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
-          p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
-        } else if constexpr (CH == 2) {
-          const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
-          p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
-        } else {
-          p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
-        }
-        h[k * CH + c] = (float)dot2(p2, qx[k][2], dot2(p1, qx[k][1], dot2z(p0, qx[k][0])));  // exact: |h| < 2^24
-      }
-    }
-  };
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const bool vec4 = G.vec_ok && x0 + PX <= dw;
-  // The walk runs over SOURCE rows, six per trip of the loop, so that the ring slot a row's sums go to — and with it the slots of the
-  // six taps of every destination row that ends on this source row (taps hnext - 5 .. hnext = slots S + 1 .. S + 6 mod 6) — are
-  // compile-time constants: the ring stays where it is in the register file (a run-time slot number made the compiler rotate 72
-  // registers per source row).  A destination row is emitted as soon as its last source row has been evaluated.
-  uint32_t y = ya;
-  int32_t jy = __builtin_amdgcn_readlane(tyl.i0, 0) + 3;  // last virtual source row under destination row y
-  auto emit = [&](const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5) {
-    const uint32_t li = y - ya;
-    float wy[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) wy[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tyl.w[k]), li));
-    const float* tap[6] = {t0, t1, t2, t3, t4, t5};
-    f32x2 acc[NV / 2];
-#pragma unroll
-    for (int q = 0; q < NV / 2; q++) acc[q] = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int ky = 0; ky < 6; ky++) {
-      const f32x2 w2 = {wy[ky], wy[ky]};
-#pragma unroll
-      for (int q = 0; q < NV / 2; q++) acc[q] = __builtin_elementwise_fma(w2, f32x2{tap[ky][2 * q], tap[ky][2 * q + 1]}, acc[q]);
-    }
-    if (x0 < dw) {
-      float o[NV];  // pixel-major
-#pragma unroll
-      for (int q = 0; q < NV / 2; q++) {
-        const f32x2 v = acc[q] * f32x2{kQ14Inv, kQ14Inv};
-        o[2 * q] = v[0]; o[2 * q + 1] = v[1];
-      }
-      uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
-      if (vec4) {
-        if constexpr (CH == 3) {
-          stg3<true>(out, pack4<1>(o[0], o[1], o[2], o[3]), pack4<1>(o[4], o[5], o[6], o[7]), pack4<1>(o[8], o[9], o[10], o[11]));
-        } else if constexpr (CH == 2) {
-          stg<true, u32x2>(out, u32x2{pack4<1>(o[0], o[1], o[2], o[3]), pack4<1>(o[4], o[5], o[6], o[7])});
-        } else {
-#pragma unroll
-          for (int q = 0; q < PX / 4; q++) stg<true, uint32_t>(out + 4 * q, pack4<1>(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]));
-        }
-      } else {
-        const uint32_t nv = (dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX) * CH;
-        for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)sat_rne(o[i]);
-      }
-    }
-    y++;
-    if (y <= yb) jy = __builtin_amdgcn_readlane(tyl.i0, y - ya) + 3;
-  };
-#define VPF_MARCH_STEP(S)                                                                                                                   \
-  if (hnext > jlast) break;                                                                                                                \
-  if (hnext > staged_hi) commit();                                                                                                         \
-  hrow((uint32_t)(hnext - staged_lo), ring[S]);                                                                                            \
-  while (y <= yb && jy == hnext) emit(ring[((S) + 1) % 6], ring[((S) + 2) % 6], ring[((S) + 3) % 6], ring[((S) + 4) % 6], ring[((S) + 5) % 6], ring[S]); \
-  hnext++;
-  for (;;) {
-    VPF_MARCH_STEP(0) VPF_MARCH_STEP(1) VPF_MARCH_STEP(2) VPF_MARCH_STEP(3) VPF_MARCH_STEP(4) VPF_MARCH_STEP(5)
-  }
-#undef VPF_MARCH_STEP
 }
 
 // The same tiling for 32-bit float surfaces (RGB_32F: CH = 3 interleaved, RGB_32F_PLANAR: CH = 1 per plane; reference
@@ -1006,18 +567,16 @@ VPF_DEV void TileTaskF32<CH, LZ, WPB>::run(const uint8_t* __restrict__ src, uint
   }
 }
 // single plane, single frame: scalar arguments, source side first (kernarg preload: see VPF_ONE_SRC_PARAMS in vpf_internal.h)
-template <int CH, bool LZ, int WPB>
+template <int CH, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_resize_tile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
                                                           uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
                                                           float scx, float scy, uint32_t tile_rows, uint32_t nr_cap, uint32_t rowq, uint32_t lshift,
                                                           int vec_ok) {
-  TileTask<CH, LZ, WPB>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, tile_rows, nr_cap, rowq, lshift}, blockIdx.x, blockIdx.y);
+  TileTask<CH, WPB>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, tile_rows, nr_cap, rowq, lshift}, blockIdx.x, blockIdx.y);
 }
 // the template-template forms k_planes_mp wants
-template <int CH> struct TileLz4 : TileTask<CH, true, 4> {};
-template <int CH> struct TileLz8 : TileTask<CH, true, 8> {};
-template <int CH> struct TileBl4 : TileTask<CH, false, 4> {};
-template <int CH> struct TileBl8 : TileTask<CH, false, 8> {};
+template <int CH> struct TileBl4 : TileTask<CH, 4> {};
+template <int CH> struct TileBl8 : TileTask<CH, 8> {};
 template <int CH> struct RowPair1 : RowPairTask<CH, 1> {};
 template <int CH> struct RowPair2 : RowPairTask<CH, 2> {};
 template <int CH> struct RowPair3 : RowPairTask<CH, 3> {};
@@ -1029,7 +588,6 @@ template <int CH> struct RowBand8n : RowBandTask<CH, 8, 1> {};    // narrow stri
 template <int CH> struct RowBand16n : RowBandTask<CH, 16, 1> {};
 template <int CH> struct RowBand8w : RowBandTask<CH, 8, 1, 8> {};   // ... and 8 pixels per lane on 1-channel planes
 template <int CH> struct RowBand16w : RowBandTask<CH, 16, 1, 8> {};
-template <int CH> struct LzMarch : LanczosMarchTask<CH> {};
 
 // ------------------------------------------------------------------------------------------
 // Exact 2x bilinear down-scale (4K -> 1080p ...): s = 2 d + 0.5 exactly, so every destination pixel is the fx = fy = 0.5
@@ -1192,20 +750,18 @@ static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, c
   return best;
 }
 
-// tiled separable launch of ONE plane of ONE frame (Lanczos always; bilinear when up-scaling, where the horizontal lerp is shared by
-// several destination rows): needs 16-B aligned source rows and a 64-column span that fits the 2-KiB strip.  Returns false when it
-// does not apply.
-static bool launch_resize_tile(hipStream_t st, bool lz, int ch, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp,
+// tiled separable launch of ONE plane of ONE frame (bilinear up-scales, where the horizontal lerp is shared by several destination
+// rows): needs 16-B aligned source rows and a 64-column span that fits the 2-KiB strip.  Returns false when it does not apply.
+static bool launch_resize_tile(hipStream_t st, int ch, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t sp,
                                uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp, float scx, float scy) {
   if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9 || (((uintptr_t)src | sp) & 15)) return false;
-  const TileShape t = plan_tile(lz, 1, &ch, &dw, &dh, &scx, &scy, 1);
+  const TileShape t = plan_tile(false, 1, &ch, &dw, &dh, &scx, &scy, 1);
   if (!t.ok) return false;
   dim3 tgrid((dw + 63) / 64, (dh + t.ty - 1) / t.ty);
   const int vec_ok = ((((uintptr_t)dst | dp) & 3) == 0) && (ch != 2 || (((uintptr_t)dst | dp) & 7) == 0);
-#define VPF_TILE3(C, L, W) VPF_LAUNCH((k_resize_tile<C, L, W>), tgrid, dim3(64 * W), t.lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, t.ty, t.nr, t.rowq, t.lshift, vec_ok)
-#define VPF_TILE(C, L) do { if (t.wpb == 8) VPF_TILE3(C, L, 8); else VPF_TILE3(C, L, 4); } while (0)
-  if (lz) { if (ch == 1) VPF_TILE(1, true); else if (ch == 2) VPF_TILE(2, true); else VPF_TILE(3, true); }
-  else { if (ch == 1) VPF_TILE(1, false); else if (ch == 2) VPF_TILE(2, false); else VPF_TILE(3, false); }
+#define VPF_TILE3(C, W) VPF_LAUNCH((k_resize_tile<C, W>), tgrid, dim3(64 * W), t.lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, t.ty, t.nr, t.rowq, t.lshift, vec_ok)
+#define VPF_TILE(C) do { if (t.wpb == 8) VPF_TILE3(C, 8); else VPF_TILE3(C, 4); } while (0)
+  if (ch == 1) VPF_TILE(1); else if (ch == 2) VPF_TILE(2); else VPF_TILE(3);
 #undef VPF_TILE
 #undef VPF_TILE3
   return true;
@@ -1239,7 +795,13 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
     return hipGetLastError();
   }
   if (interp == VPF_INTERP_LANCZOS3) {
-    if (launch_resize_tile(st, true, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy)) return hipGetLastError();
+    {  // the matrix-core kernel (k_lanczos_mfma.hip) wherever its windows fit; else the gather form
+      BatchArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.f[0].s[0] = src; a.f[0].sp[0] = sp; a.f[0].d[0] = dst; a.f[0].dp[0] = dp;
+      const ResizeJob j{ch, 0, sw, sh, dw, dh};
+      if (launch_lanczos_mfma(st, 1, &j, 1, a)) return hipGetLastError();
+    }
     dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
     if (ch == 1) VPF_LAUNCH((k_resize_lanczos<1>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
     else if (ch == 2) VPF_LAUNCH((k_resize_lanczos<2>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
@@ -1252,7 +814,7 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
   // for mild down-scales the row-pair kernel is as fast or faster (1080p->720p 5.9 vs 5.8, 4K->1440p 16.2 vs 12.4,
   // 4K->3000x1688 21.2 vs 14.9), so the tiled kernel is used below 1.0 only
   if (interp == VPF_INTERP_LINEAR && (scy < 1.0f || tuning(VPF_TUNE_NV12_RGB_VARIANT) == 43) && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 &&
-      launch_resize_tile(st, false, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy))
+      launch_resize_tile(st, ch, sw, sh, src, sp, dw, dh, dst, dp, scx, scy))
     return hipGetLastError();
   const uint32_t rowb = (interp == VPF_INTERP_LINEAR) ? lds_strip_bytes(ch, sw, dw, src, sp, kResizeRowBytes) : 0;
   if (rowb) {
@@ -1500,60 +1062,8 @@ static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const Ba
   return {bs.rows, bs.slots, bs.narrow, 4, rb};
 }
 
-// Lanczos march (LanczosMarchTask): destination rows per wave (R) and strip size, or rows == 0 when the tiled kernel keeps the launch.
-// Every plane's 256-column source span must fit a 2-KiB strip and the vertical factor must stay below 6 (no skipped source rows).
-// The kernel is VALU-bound with three waves per SIMD resident (167 VGPRs), i.e. three 4-wave workgroups per CU, and every wave of a
-// plane does the same work, so a launch lasts about ceil(workgroups / 768) rounds of one wave's time, and a wave's time grows with R as
-// a fixed part (column and row weight sets) + ((R - 1) scy + 6) horizontal passes + R vertical passes (measured: 166 and 80 VALU
-// instructions per 256 columns of packed RGB).  R is the value that minimises rounds x wave time — 32 frames 1080p -> 720p: R = 20
-// (1440 workgroups, two rounds filled to 94 %) where R = 16 spends a third round on half the chip and R = 19 (38 bands = 9.5
-// workgroups per column of chunks) a third round on a twelfth of it (3.52 us / frame against 3.10, profiles/r02_lanczos_march.txt).
-// The tiled kernel keeps what the march does not win (A/B over batch sizes 2 .. 32, profiles/r02_lanczos_march.txt and
-// r02_lanczos_march_planes.txt): launches under ~600 workgroups (its 64-column tiles spread a small job wider; ~1000 when every plane
-// has one channel, where a wave's fixed work weighs three times as much per byte), three-plane formats (YUV420: 2.5 - 2.8 us / frame
-// either way), and up-scales whose best R is below 20 (the six extra source rows of a short band cost more than the tiled kernel's barriers).
-constexpr uint32_t kMarchGroupSlots = 768;  // 256 CUs x 3 workgroups (counting 4 % fewer made the 16-frame launches slower: 4K -> 1080p 7.7 -> 8.5 us / frame)
-struct MarchShape { uint32_t rows, rowq; };
-static MarchShape plan_march(int njobs, const ResizeJob* jobs, uint32_t n) {
-  const int forced = tuning(VPF_TUNE_RESIZE_MARCH);
-  if (forced == 1) return {0, 0};
-  uint32_t rowq = 0;
-  for (int p = 0; p < njobs; p++) {
-    const ResizeJob& j = jobs[p];
-    const double sy = (double)j.sh / (double)j.dh;
-    const uint32_t q = vpf_bound_march_rowq(j.ch, j.sw, j.dw, 64u * march_px(j.ch));  // (vpf_plan_bounds.h: checked on the CPU against the tap arithmetic)
-    if (!q || sy > 5.9) return {0, 0};
-    rowq = q > rowq ? q : rowq;
-  }
-  if (forced) return {(uint32_t)forced, rowq};
-  uint32_t best = 0;
-  double best_cost = 0.0;
-  uint64_t best_groups = 0;
-  for (uint32_t r = 6; r <= 64; r++) {
-    uint64_t groups = 0;
-    double work = 0.0;
-    for (int p = 0; p < njobs; p++) {
-      const ResizeJob& j = jobs[p];
-      const uint32_t wcols = 64u * march_px(j.ch);
-      const uint64_t g = (uint64_t)((j.dw + wcols - 1) / wcols) * (((j.dh + r - 1) / r + 3) / 4) * n;
-      const double sy = (double)j.sh / (double)j.dh;
-      groups += g;
-      const double vals = j.ch * march_px(j.ch) / 4.0;  // values per lane and row, in units of a 4-pixel 1-channel row
-      work += (double)g * (700.0 + ((double)(r - 1) * sy + 6.0) * (40.0 + 42.0 * vals) + (double)r * (20.0 + 20.0 * vals));
-    }
-    const double cost = (double)((groups + kMarchGroupSlots - 1) / kMarchGroupSlots) * work / (double)groups;
-    if (!best || cost < best_cost) { best = r; best_cost = cost; best_groups = groups; }
-  }
-  double scy_min = 1e9;
-  for (int p = 0; p < njobs; p++) scy_min = std::min(scy_min, (double)jobs[p].sh / (double)jobs[p].dh);
-  bool wide = false;  // some plane has 2 or 3 channels
-  for (int p = 0; p < njobs; p++) wide = wide || jobs[p].ch >= 2;
-  if (best_groups < (wide ? 600u : 1000u) || njobs == 3 || (scy_min < 1.0 && best < 20)) return {0, 0};
-  return {best, rowq};
-}
-
 hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
-  enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
+  enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_LZ_MFMA, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
   if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return hipErrorInvalidValue;
   Fam fam[3];
@@ -1590,7 +1100,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
         fam[p] = FAM_HALF;
       }
     } else if (eff[p] == VPF_INTERP_LANCZOS3) {
-      fam[p] = src16 ? FAM_TILE : FAM_LZ_GATHER;
+      fam[p] = src16 ? FAM_LZ_MFMA : FAM_LZ_GATHER;
     } else if (eff[p] == VPF_INTERP_LINEAR && (scy < 1.0f || tune == 43) && tune != 40 && src16 && !band_up) {
       fam[p] = FAM_TILE;
     } else if (eff[p] == VPF_INTERP_LINEAR && src16 && (rowb[p] = lds_strip_bytes(j.ch, j.sw, j.dw, a.f[0].s[j.k], a.f[0].sp[j.k], kResizeRowBytes)) != 0) {
@@ -1605,38 +1115,28 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     all_tile = all_tile && fam[p] == FAM_TILE && eff[p] == eff[0];
     all_rowpair = all_rowpair && fam[p] == FAM_ROWPAIR;
   }
-  if (all_tile && eff[0] == VPF_INTERP_LANCZOS3 && tune != 40) {  // a batch of Lanczos planes: the barrier-free march kernel when the launch is large enough
-    const MarchShape ms = plan_march(njobs, jobs, n);
-    if (ms.rows) {
-      PlaneTable t{};
-      t.np = (uint32_t)njobs;
-      uint32_t gx = 0, gy = 0;
-      for (int p = 0; p < njobs; p++) {
-        t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
-        t.g[p].a0 = ms.rowq; t.g[p].a1 = ms.rows;
-        const uint32_t wcols = 64u * march_px(jobs[p].ch), bx = (jobs[p].dw + wcols - 1) / wcols;
-        gx = bx > gx ? bx : gx;
-        gy += (jobs[p].dh + 4 * ms.rows - 1) / (4 * ms.rows);
-      }
-      launch_planes_mp<LzMarch>(st, dim3(gx, gy, n), 4u * kMarchGroup * ms.rowq * 16u + 8u * 64u * 16u /* column weight sets */, a, t);
-      return hipGetLastError();
-    }
+  {  // every plane Lanczos: one matrix-core launch for the whole format (k_lanczos_mfma.hip); planes it cannot take fall back to the gather form
+    bool all_mfma = !f32;
+    for (int p = 0; p < njobs; p++) all_mfma = all_mfma && fam[p] == FAM_LZ_MFMA;
+    if (all_mfma && launch_lanczos_mfma(st, njobs, jobs, n, a)) return hipGetLastError();
+    for (int p = 0; p < njobs; p++)
+      if (fam[p] == FAM_LZ_MFMA && !launch_lanczos_mfma(st, 1, &jobs[p], n, a)) fam[p] = FAM_LZ_GATHER;
   }
   TileShape ts{false, 0, 0, 0, 0, 0, 4};
   if (all_tile) {
     int ch[3]; uint32_t dw[3], dh[3]; float sx[3], sy[3];
     for (int p = 0; p < njobs; p++) { ch[p] = jobs[p].ch; dw[p] = jobs[p].dw; dh[p] = jobs[p].dh; sx[p] = g[p].scx; sy[p] = g[p].scy; }
-    ts = plan_tile(eff[0] == VPF_INTERP_LANCZOS3, njobs, ch, dw, dh, sx, sy, n);
+    ts = plan_tile(false, njobs, ch, dw, dh, sx, sy, n);
     if (!ts.ok) {  // the span does not fit a strip: every plane falls back to its gather form
       all_tile = false;
-      for (int p = 0; p < njobs; p++) fam[p] = eff[p] == VPF_INTERP_LANCZOS3 ? FAM_LZ_GATHER : FAM_GATHER;
+      for (int p = 0; p < njobs; p++) fam[p] = FAM_GATHER;
     }
   } else {
     for (int p = 0; p < njobs; p++)
       if (fam[p] == FAM_TILE) {  // mixed families: this plane is tiled on its own
         const float sx = g[p].scx, sy = g[p].scy;
-        const TileShape t1 = plan_tile(eff[p] == VPF_INTERP_LANCZOS3, 1, &jobs[p].ch, &jobs[p].dw, &jobs[p].dh, &sx, &sy, n);
-        if (!t1.ok) { fam[p] = eff[p] == VPF_INTERP_LANCZOS3 ? FAM_LZ_GATHER : FAM_GATHER; continue; }
+        const TileShape t1 = plan_tile(false, 1, &jobs[p].ch, &jobs[p].dw, &jobs[p].dh, &sx, &sy, n);
+        if (!t1.ok) { fam[p] = FAM_GATHER; continue; }
         g[p].a0 = t1.ty; g[p].a1 = t1.nr; g[p].a2 = t1.rowq; g[p].a3 = t1.lshift;
         rowb[p] = t1.lds | ((uint32_t)t1.wpb << 24);  // carried to the launch below
       }
@@ -1664,10 +1164,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     }
     const dim3 grid(gx, gy, n);
     if (all_tile) {
-      const bool lz = eff[0] == VPF_INTERP_LANCZOS3;
-      if (lz && ts.wpb == 8) launch_planes_mp<TileLz8>(st, grid, ts.lds, a, t);
-      else if (lz) launch_planes_mp<TileLz4>(st, grid, ts.lds, a, t);
-      else if (ts.wpb == 8) launch_planes_mp<TileBl8>(st, grid, ts.lds, a, t);
+      if (ts.wpb == 8) launch_planes_mp<TileBl8>(st, grid, ts.lds, a, t);
       else launch_planes_mp<TileBl4>(st, grid, ts.lds, a, t);
     } else {
       for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; }  // one strip size for the launch (the widest plane's)
@@ -1690,6 +1187,11 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
   // ---- otherwise: one launch per plane over all frames
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
+    if (fam[p] == FAM_LZ_MFMA) {  // launched above
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      continue;
+    }
     const dim3 grid1((j.dw + 63) / 64, (j.dh + 3) / 4, n), grid4(((j.dw + 3) / 4 + 63) / 64, (j.dh + 3) / 4, n);
     if (f32 && (eff[p] == VPF_INTERP_LANCZOS3 || (eff[p] == VPF_INTERP_LINEAR && g[p].scy < 1.0f && tune == 43)) && tune != 9 && tune != 40 && planes_aligned(a, n, j.k, 15, 0)) {
       const bool lz = eff[p] == VPF_INTERP_LANCZOS3;
@@ -1723,11 +1225,8 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     } else if (fam[p] == FAM_TILE) {
       const uint32_t lds = rowb[p] & 0xffffffu, wpb = rowb[p] >> 24;
       const dim3 tgrid((j.dw + 63) / 64, (j.dh + g[p].a0 - 1) / g[p].a0, n);
-      const bool lz = eff[p] == VPF_INTERP_LANCZOS3;
-#define VPF_TILEB(C) do { if (lz && wpb == 8) launch_plane_batch<TileTask<C, true, 8>>(st, tgrid, lds, a, j.k, g[p]); \
-                          else if (lz) launch_plane_batch<TileTask<C, true, 4>>(st, tgrid, lds, a, j.k, g[p]); \
-                          else if (wpb == 8) launch_plane_batch<TileTask<C, false, 8>>(st, tgrid, lds, a, j.k, g[p]); \
-                          else launch_plane_batch<TileTask<C, false, 4>>(st, tgrid, lds, a, j.k, g[p]); } while (0)
+#define VPF_TILEB(C) do { if (wpb == 8) launch_plane_batch<TileTask<C, 8>>(st, tgrid, lds, a, j.k, g[p]); \
+                          else launch_plane_batch<TileTask<C, 4>>(st, tgrid, lds, a, j.k, g[p]); } while (0)
       if (j.ch == 1) VPF_TILEB(1); else if (j.ch == 2) VPF_TILEB(2); else VPF_TILEB(3);
 #undef VPF_TILEB
     } else if (fam[p] == FAM_ROWPAIR) {

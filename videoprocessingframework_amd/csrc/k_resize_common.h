@@ -1,0 +1,139 @@
+// k_resize_common.h — what the resize translation units share (k_resize.hip, k_lanczos_mfma.hip): the plane geometry record and the two
+// generic batch entries, and the Lanczos-3 tap arithmetic (fp32 weights from fixed fma polynomials, Q14 quantisation) that the oracle
+// restates bit for bit (its lanczos_weights_fp32 / lanczos_weights_q14).
+#pragma once
+#include "k_bilinear_blend.h"
+
+namespace vpf {
+
+// Geometry of one plane of a resize launch, in the form every kernel family takes it.  a0..a3 are family-specific:
+//   tiled kernels     a0 = destination rows per tile, a1 = source rows the LDS layout is sized for, a2 = 16-B units per staged source row,
+//                     a3 = log2(lanes per row while staging)
+//   row-pair kernels  a0 = strip size in 16-B units
+//   half3_r16         a0 = 1024-px chunks per row, a1 = tasks
+struct PlaneGeom {
+  uint32_t sw, sh, dw, dh;
+  float scx, scy;
+  int vec_ok;
+  uint32_t a0, a1, a2, a3;
+};
+// A resize "Task" is a struct with `static constexpr int kThreads` and
+//   static VPF_DEV void run(const uint8_t* src, uint32_t sp, uint8_t* dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by)
+// The single-frame kernels below keep their scalar-argument entries (kernarg preload, see VPF_ONE_SRC_PARAMS in vpf_internal.h);
+// vpf_resize_batch reaches the same task bodies through these two generic entries:
+//   k_plane_batch   ONE plane (index k in FrameDesc) of up to 32 frames: blockIdx.z = frame
+//   k_planes_mp     EVERY plane of up to 32 frames in one dispatch: blockIdx.z = frame, blockIdx.y runs through the planes' block rows
+//                   one plane after the other (by0[p] = first blockIdx.y of plane p), blockIdx.x covers the widest plane (a task returns
+//                   at once when its block lies outside its plane)
+template <class Task>
+__global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BatchArgs args, const int k, const PlaneGeom G) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  Task::run(f.s[k], f.sp[k], f.d[k], f.dp[k], G, blockIdx.x, blockIdx.y);
+}
+struct PlaneTable {
+  PlaneGeom g[3];
+  uint32_t by0[3], k[3], ch[3], np;
+};
+template <template <int> class TaskCH>
+__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchArgs args, const PlaneTable T) {
+  const FrameDesc& f = args.f[blockIdx.z];
+  const uint32_t by = blockIdx.y;
+  const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
+  const uint32_t k = T.k[pi], lby = by - T.by0[pi];
+  switch (T.ch[pi]) {  // workgroup-uniform
+    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lanczos-3 taps (see the comment above LanczosGatherTask in k_resize.hip)
+// ------------------------------------------------------------------------------------------
+VPF_DEV float lz_sinpi_poly(float g) {  // sin(pi g), g in [0, 0.5]
+  const float x = 3.14159274f * g, x2 = x * x;
+  float p = __builtin_fmaf(x2, -2.50521084e-8f, 2.75573192e-6f);
+  p = __builtin_fmaf(x2, p, -1.98412698e-4f);
+  p = __builtin_fmaf(x2, p, 8.33333333e-3f);
+  p = __builtin_fmaf(x2, p, -1.66666667e-1f);
+  p = __builtin_fmaf(x2, p, 1.0f);
+  return x * p;
+}
+VPF_DEV float lz_cos_poly(float x) {  // cos(x), x in [0, pi/3]
+  const float x2 = x * x;
+  float p = __builtin_fmaf(x2, -2.75573192e-7f, 2.48015873e-5f);
+  p = __builtin_fmaf(x2, p, -1.38888889e-3f);
+  p = __builtin_fmaf(x2, p, 4.16666667e-2f);
+  p = __builtin_fmaf(x2, p, -0.5f);
+  return __builtin_fmaf(x2, p, 1.0f);
+}
+struct LTap {
+  int32_t i0;
+  float w[6];
+};
+VPF_DEV LTap make_ltap(uint32_t d, float scale) {
+  LTap t;
+  const float s = __builtin_fmaf((float)d + 0.5f, scale, -0.5f);
+  const float fl = __builtin_floorf(s);
+  t.i0 = (int32_t)fl;
+  const float f = s - fl;
+  if (f == 0.f) {
+    t.w[0] = t.w[1] = t.w[3] = t.w[4] = t.w[5] = 0.f; t.w[2] = 1.f;
+    return t;
+  }
+  const float s1 = lz_sinpi_poly(f <= 0.5f ? f : 1.0f - f);
+  const float s3 = lz_sinpi_poly(f * 0.333333343f);
+  const float c3 = lz_cos_poly(1.04719758f * f);
+  constexpr float cm[6] = {-0.5f, 0.5f, 1.0f, 0.5f, -0.5f, -1.0f};
+  constexpr float sm[6] = {-0.866025388f, -0.866025388f, 0.0f, 0.866025388f, 0.866025388f, 0.0f};
+  constexpr float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
+  // w_k = L(t_k) / sum_j L(t_j) with L(t) = 3 sin(pi t) sin(pi t / 3) / (pi t)^2, t_k = f - (k - 2): multiplying numerator and
+  // denominator by prod_j t_j^2 leaves n_k D_k / sum_j n_j D_j with n_k = sin(pi t_k) sin(pi t_k / 3) and D_k = prod_{j != k} t_j^2
+  // — ONE division per weight set instead of seven (the weights are ~1/4 of the tiled kernel's instructions at small tiles)
+  float n[6], u[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float tt = f - (float)(k - 2);
+    u[k] = tt * tt;
+    n[k] = (sg[k] * s1) * __builtin_fmaf(s3, cm[k], -(c3 * sm[k]));
+  }
+  float pre[6], suf[6];  // pre[k] = u_0 .. u_{k-1}, suf[k] = u_{k+1} .. u_5
+  pre[0] = 1.0f; suf[5] = 1.0f;
+#pragma unroll
+  for (int k = 1; k < 6; k++) pre[k] = pre[k - 1] * u[k - 1];
+#pragma unroll
+  for (int k = 4; k >= 0; k--) suf[k] = suf[k + 1] * u[k + 1];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    t.w[k] = n[k] * (pre[k] * suf[k]);
+    sum += t.w[k];
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int k = 0; k < 6; k++) t.w[k] *= inv;
+  return t;
+}
+
+// The horizontal pass on 8-bit surfaces runs in integers: the six normalised weights become Q14 fixed point (ties to even), tap 2
+// absorbs the rounding residue so that they sum to exactly 16384 (a flat picture stays flat), and H = sum q_k p_k is exact in 32
+// bits whatever the order — which is what lets the tiled kernel take two taps per v_dot2_i32_i16 and still match the gather form
+// and the oracle bit for bit.  Every |q_k| <= 16384 fits an int16.
+struct QTap {
+  int32_t i0;
+  int32_t q[6];
+};
+VPF_DEV QTap quantize_ltap(const LTap& t) {
+  QTap o;
+  o.i0 = t.i0;
+  int32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { o.q[k] = (int32_t)__builtin_rintf(t.w[k] * 16384.0f); sum += o.q[k]; }
+  o.q[2] += 16384 - sum;
+  return o;
+}
+VPF_DEV int32_t ltap_i0(uint32_t d, float scale) {  // make_ltap's first expression sequence
+  return (int32_t)__builtin_floorf(__builtin_fmaf((float)d + 0.5f, scale, -0.5f));
+}
+
+}  // namespace vpf

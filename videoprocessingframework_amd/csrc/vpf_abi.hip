@@ -82,9 +82,9 @@ void note_kernel(const char* k) {
   if (trace_on() && g_roctx_mark) g_roctx_mark(k);
 }
 
-static std::atomic<int> g_tune_variant{0}, g_tune_tile{0}, g_tune_band{0}, g_tune_march{0};
+static std::atomic<int> g_tune_variant{0}, g_tune_tile{0}, g_tune_band{0}, g_tune_mfma{0};
 int tuning(int key) {
-  return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : key == VPF_TUNE_RESIZE_BAND ? g_tune_band.load() : key == VPF_TUNE_RESIZE_MARCH ? g_tune_march.load() : 0;
+  return key == VPF_TUNE_NV12_RGB_VARIANT ? g_tune_variant.load() : key == VPF_TUNE_RESIZE_TILE ? g_tune_tile.load() : key == VPF_TUNE_RESIZE_BAND ? g_tune_band.load() : key == VPF_TUNE_RESIZE_MFMA ? g_tune_mfma.load() : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -288,7 +288,7 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
   if (guard.err != hipSuccess) return status_of(guard.err);
   hipStream_t st = static_cast<hipStream_t>(exec->stream);
   const int np = num_planes(fmt);
-  const bool forced_family = tuning(VPF_TUNE_RESIZE_MARCH) >= 2 || tuning(VPF_TUNE_RESIZE_BAND) >= 2;  // measurement runs: the batch kernels on one frame
+  const bool forced_family = tuning(VPF_TUNE_RESIZE_MFMA) >= 2 || tuning(VPF_TUNE_RESIZE_BAND) >= 2;  // measurement runs: the batch kernels on one frame
   if (n == 1 && nj == 1 && !forced_family) {  // one plane of one frame: the scalar-argument kernel entries (kernarg preload)
     const vpf_plane &s0 = frames[0].src[0], &d0 = frames[0].dst[0];
     const hipError_t e = f32 ? launch_resize_f32(st, jobs[0].ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(s0.ptr), s0.pitch, ds.width, ds.height,
@@ -423,7 +423,11 @@ int vpf_set_tuning(int key, int value) {
     if (value != 0 && (ty < 4 || ty > 64 || (ty & 3) || (wpb != 4 && wpb != 8))) return -1;
     return g_tune_tile.exchange(value);
   }
-  if (key == VPF_TUNE_RESIZE_MARCH) return (value >= 0 && value <= 64) ? g_tune_march.exchange(value) : -1;
+  if (key == VPF_TUNE_RESIZE_MFMA) {
+    const int nt = value >> 8, tiles = value & 0xff;
+    if (value != 0 && value != 1 && (value < 0 || (nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
+    return g_tune_mfma.exchange(value);
+  }
   if (key == VPF_TUNE_RESIZE_BAND) return (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? g_tune_band.exchange(value) : -1;
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)

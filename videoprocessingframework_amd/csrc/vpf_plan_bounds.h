@@ -7,6 +7,7 @@
  * (source size, destination size, position) combinations. */
 #ifndef VPF_PLAN_BOUNDS_H_
 #define VPF_PLAN_BOUNDS_H_
+#include <math.h>
 #include <stdint.h>
 
 /* strip bytes for the source span of `cols` destination columns of a `ch`-channel plane (bilinear taps): <= (cols - 1) * scale + 3
@@ -49,6 +50,41 @@ static inline uint32_t vpf_bound_tile_rows(uint32_t ty, float scy, int taps) {
 }
 static inline uint32_t vpf_bound_tile_rowq(float scx, int taps, int ch, int elem) {
   return (uint32_t)((((double)scx * 63.0 + (double)taps + 3.0) * ch * elem + 32.0) / 16.0) + 1 + ((taps == 6 && elem == 1) ? 2 : 0);
+}
+
+/* MFMA Lanczos kernel (k_lanczos_mfma.hip; a CPU model of its bookkeeping: tests/lanczos_mfma_model.py).  A wave owns `nt` N-tiles of 16
+ * destination BYTES each; every tap of a tile's bytes must lie in the 64-B window that starts at the 16-B aligned source byte below the
+ * first tap of the tile's first pixel (K = 64 of v_mfma_i32_16x16x64_i8), and a 16-row destination tile must find all its source rows in
+ * four consecutive 16-row source tiles (the ring).  Closed-form bounds on floor differences are one too pessimistic exactly at the ratios
+ * that matter (2.0 with three channels), so the launcher WALKS the tiles with the kernel's own fp32 coordinate arithmetic — a few hundred
+ * fma + floor per plane shape, cached per thread — instead of estimating. */
+static inline int32_t vpf_lz_i0(uint32_t d, float scale) { return (int32_t)floorf(fmaf((float)d + 0.5f, scale, -0.5f)); }  /* ltap_i0 of the kernels */
+static inline uint32_t vpf_lz_clamp(int32_t i, uint32_t size) { return i < 0 ? 0u : (i > (int32_t)size - 1 ? size - 1u : (uint32_t)i); }
+/* 0 when some tile's taps do not fit its window; else the bytes a wave stages per source row: the largest (window of a strip's last tile
+ * - window of its first tile) + 64 over all strips of `nt` tiles */
+static inline uint32_t vpf_bound_lzm_span(int ch, uint32_t sw, uint32_t dw, float scx, int nt) {
+  const uint32_t dwb = dw * (uint32_t)ch, ntile = (dwb + 15u) / 16u;
+  uint32_t span = 0, ws0 = 0;
+  for (uint32_t t = 0; t < ntile; t++) {
+    const uint32_t b0 = 16u * t, b1 = b0 + 15u < dwb - 1u ? b0 + 15u : dwb - 1u;
+    const uint32_t ws = ((uint32_t)ch * vpf_lz_clamp(vpf_lz_i0(b0 / (uint32_t)ch, scx) - 2, sw)) & ~15u;
+    /* highest source byte of the tile: the last tap of its last pixel, any channel (the taps of earlier pixels lie below: i0 is monotone) */
+    const uint32_t hi = (uint32_t)ch * vpf_lz_clamp(vpf_lz_i0(b1 / (uint32_t)ch, scx) + 3, sw) + (uint32_t)ch - 1u;
+    if (hi - ws >= 64u) return 0;
+    if (t % (uint32_t)nt == 0) ws0 = ws;
+    if (ws - ws0 + 64u > span) span = ws - ws0 + 64u;
+  }
+  return span;
+}
+static inline uint32_t vpf_bound_lzm_pitch(uint32_t span) { return ((span + 223u) & ~255u) + 32u; }  /* smallest 256 m + 32 >= span: the pitch that
+                                                               makes the A-operand ds_read_b128 of 16 rows x 4 lane groups conflict-free */
+/* every 16-row destination tile (tiles start at multiples of 16: bands are whole tiles) spans at most four 16-row source tiles */
+static inline int vpf_bound_lzm_rows_ok(uint32_t sh, uint32_t dh, float scy) {
+  for (uint32_t y0 = 0; y0 < dh; y0 += 16) {
+    const uint32_t y1 = y0 + 15u < dh - 1u ? y0 + 15u : dh - 1u;
+    if ((vpf_lz_clamp(vpf_lz_i0(y1, scy) + 3, sh) >> 4) - (vpf_lz_clamp(vpf_lz_i0(y0, scy) - 2, sh) >> 4) > 3u) return 0;
+  }
+  return 1;
 }
 
 #endif /* VPF_PLAN_BOUNDS_H_ */
