@@ -35,6 +35,7 @@
 //     rows (four tiles) the same way every fourth tile.
 // VGPRs: 2 x 4 x NT column weights + 2 x 4 x NT ring + staging prefetch: NT = 8 -> two waves per SIMD.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "k_resize_common.h"
@@ -87,12 +88,14 @@ struct LanczosMfmaTask {
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
 
-constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles
+constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles (one "group" of 64 rows)
+constexpr uint32_t kLzmB1Chunk = 4;                                              // N-tiles whose column-weight operands are built per pass through LDS
 constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
-constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of LDS per wave
-  const uint32_t run = 16u * pitch + kLzmWmBytes + 16u * lzm_out_pitch(nt), setup = 2u * (uint32_t)nt * 1024u;
+constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of wave-private LDS: staged tile | out tile, or the setup scratch
+  const uint32_t run = 16u * pitch + 16u * lzm_out_pitch(nt), setup = 2u * kLzmB1Chunk * 1024u;
   return run > setup ? run : setup;
 }
+constexpr uint32_t lzm_group_lds(int nt, uint32_t pitch) { return 4u * lzm_wave_lds(nt, pitch) + 2u * kLzmWmBytes; }  // + the workgroup's two row-weight buffers
 
 template <int CH, int NT, int PF>
 VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
@@ -101,13 +104,57 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t dwb = dw * CH, ob0 = (bx * 4 + wv) * (16u * NT), ya = by * R;
-  if (ob0 >= dwb || ya >= dh) return;  // wave-uniform; the kernel has no workgroup barrier
+  if (bx * 4 * (16u * NT) >= dwb || ya >= dh) return;  // workgroup-uniform: this plane is narrower / shorter than the launch grid
   const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
   uint8_t* const lds = reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)wv * G.a2;
   uint8_t* const stage = lds;                         // [16 rows][P]
-  uint8_t* const wm = lds + 16u * P;                  // [4 tiles][2 planes][64 lanes][16 B]
-  uint8_t* const ot = wm + kLzmWmBytes;               // [16 rows][lzm_out_pitch]
+  uint8_t* const ot = lds + 16u * P;                  // [16 rows][lzm_out_pitch]
+  uint8_t* const wmb = reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)4 * G.a2;  // workgroup-shared: two groups x [4 tiles][2 planes][64 lanes][16 B]
   constexpr uint32_t PO = lzm_out_pitch(NT);
+
+  // ---- row weights, shared by the workgroup.  Its four waves own four neighbouring strips of the SAME band, and a weight set is ~300
+  // instructions per 64 rows whoever evaluates it: wave (G & 3) produces group G (the 64 destination rows from ya + 64 G) for all four,
+  // into buffer G & 1, one group ahead of its use; the waves meet at one barrier per group.  Lane = row (rows past the band repeat its
+  // last row and are never stored); the bytes are SCATTERED into the operand image: K slot (g, 4 p + r) <-> source row 16 T + 4 g + r of
+  // the tile in ring slot p = (T - t_first) & 3.
+  int32_t t_first;                                    // first source tile of the band
+  {
+    int32_t r = ltap_i0(ya, scy) - 2;
+    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+    t_first = __builtin_amdgcn_readfirstlane(r >> 4);
+  }
+  const uint32_t ngroups = (yb - ya) / 64u + 1u;
+  auto produce = [&](uint32_t g) {
+    uint8_t* const wm = wmb + (g & 1u) * kLzmWmBytes;
+    const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
+    const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
+    u32x4* z = reinterpret_cast<u32x4*>(wm);
+#pragma unroll
+    for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+    uint8_t* const cell = wm + ((lane >> 4) * 2 * 64 + (lane & 15)) * 16;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      if (m.pos[k] < 0) continue;
+      const uint32_t pos = (uint32_t)m.pos[k];
+      int32_t hi, lo;
+      split_i8(m.q[k], hi, lo);
+      uint8_t* const a = cell + ((pos >> 2) & 3) * 256 + 4 * (((pos >> 4) - (uint32_t)t_first) & 3) + (pos & 3);
+      a[0] = (uint8_t)hi;
+      a[64 * 16] = (uint8_t)lo;
+    }
+  };
+  // the step from group g to g + 1: everybody is done with g's buffer, g + 1 is complete; g + 2 goes where g was
+  auto next_group = [&](uint32_t g) {
+    __syncthreads();
+    if (g + 2 < ngroups && wv == ((g + 2) & 3u)) produce(g + 2);
+  };
+  if (wv == 0) produce(0);
+  if (wv == 1 && ngroups > 1) produce(1);
+  if (ob0 >= dwb) {  // a wave without columns (the row's last workgroup): it still produces its groups and meets the others
+    __syncthreads();
+    for (uint32_t g = 0; g + 1 < ngroups; g++) next_group(g);
+    return;
+  }
 
   // ---- windows: ws_j = 16-B aligned source byte below the first tap of tile j's first pixel (tiles past the row end copy the last window)
   auto window = [&](uint32_t b) -> uint32_t {
@@ -121,75 +168,92 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #pragma unroll
   for (int j = 0; j < NT; j++) wrel[j] = __builtin_amdgcn_readfirstlane(window(ob0 + 16u * j)) - S0;
 
-  // ---- column weights -> pass-1 B operands.  Operand image in LDS: [plane][tile j][lane 16 g + n][16 bytes]; zero it, scatter the bytes
+  // ---- column weights -> pass-1 B operands, kLzmB1Chunk tiles at a time.  Operand image in LDS: [plane][tile][lane 16 g + n][16 bytes];
+  // zero it, evaluate the sets of the chunk's pixels (one per lane), scatter their bytes, read the operands back
+  v4i b1h[NT], b1l[NT];
   {
-    u32x4* z = reinterpret_cast<u32x4*>(lds);
+    const uint32_t ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb;
 #pragma unroll
-    for (int i = 0; i < 2 * NT; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
-    const uint32_t px_first = ob0 / CH, ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb, px_last = (ob1 - 1) / CH;
-    for (uint32_t px = px_first + lane; px <= px_last; px += 64) {
-      const MTap m = merge_taps(quantize_ltap(make_ltap(px, scx)), sw);
+    for (int ck = 0; ck < NT / (int)kLzmB1Chunk; ck++) {
+      const uint32_t cb0 = ob0 + 64u * ck, cb1 = cb0 + 64u < ob1 ? cb0 + 64u : ob1;  // destination bytes of the chunk
+      u32x4* z = reinterpret_cast<u32x4*>(lds);
 #pragma unroll
-      for (int c = 0; c < CH; c++) {
-        const uint32_t b = px * CH + c;
-        if (b < ob0 || b >= ob1) continue;
-        const uint32_t j = (b - ob0) >> 4, n = (b - ob0) & 15;
-        const uint32_t wsj = window(ob0 + 16u * j);
-        uint8_t* const cell = lds + (j * 64 + n) * 16;
+      for (int i = 0; i < 2 * (int)kLzmB1Chunk; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+      if (cb0 < cb1) {
+        const uint32_t px_first = cb0 / CH, px_last = (cb1 - 1) / CH;
+        for (uint32_t px = px_first + lane; px <= px_last; px += 64) {
+          const MTap m = merge_taps(quantize_ltap(make_ltap(px, scx)), sw);
+          int32_t whi[6], wlo[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-          if (m.pos[k] < 0) continue;
-          const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 (vpf_bound_lzm_cols_ok)
-          int32_t hi, lo;
-          split_i8(m.q[k], hi, lo);
-          uint8_t* const a = cell + (kk >> 4) * 256 + (kk & 15);
-          a[0] = (uint8_t)hi;
-          a[NT * 1024] = (uint8_t)lo;
+          for (int k = 0; k < 6; k++) split_i8(m.q[k], whi[k], wlo[k]);
+#pragma unroll
+          for (int c = 0; c < CH; c++) {
+            const uint32_t b = px * CH + c;
+            if (b < cb0 || b >= cb1) continue;
+            const uint32_t j = (b - cb0) >> 4, n = (b - cb0) & 15;
+            const uint32_t wsj = window(cb0 + 16u * j);
+            uint8_t* const cell = lds + (j * 64 + n) * 16;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+              if (m.pos[k] < 0) continue;
+              const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 (vpf_bound_lzm_span)
+              uint8_t* const a = cell + (kk >> 4) * 256 + (kk & 15);
+              a[0] = (uint8_t)whi[k];
+              a[kLzmB1Chunk * 1024] = (uint8_t)wlo[k];
+            }
+          }
         }
       }
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < (int)kLzmB1Chunk; j++) {
+        b1h[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + (j * 64 + lane) * 16);
+        b1l[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + kLzmB1Chunk * 1024 + (j * 64 + lane) * 16);
+      }
+      wave_lds_sync();
     }
   }
-  wave_lds_sync();
-  v4i b1h[NT], b1l[NT];
-#pragma unroll
-  for (int j = 0; j < NT; j++) {
-    b1h[j] = *reinterpret_cast<const v4i*>(lds + (j * 64 + lane) * 16);
-    b1l[j] = *reinterpret_cast<const v4i*>(lds + NT * 1024 + (j * 64 + lane) * 16);
-  }
-  wave_lds_sync();
 
   // ---- the march
   // 16-B units of a staged row (<= 4 PF, <= P / 16: host), cut at the row's last unit: the last window of a strip at the right image
   // edge reaches past the row (those bytes carry no weight and are never loaded: the LDS keeps whatever it held)
   const uint32_t nq_win = (wrel[NT - 1] + 64u) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
   const uint32_t nq = nq_win < nq_row ? nq_win : nq_row;
-  const uint32_t npf = __builtin_amdgcn_readfirstlane((nq + 3u) / 4u);  // staging loads per lane and tile (wave-uniform, <= PF)
   const uint32_t srow = lane >> 2, sq = lane & 3;  // staging: lane -> (row of the tile, unit (lane & 3) + 4 k)
-  int32_t t_first;                                 // first source tile of the band: ring slot of tile T = (T - t_first) & 3
-  {
-    int32_t r = ltap_i0(ya, scy) - 2;
-    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
-    t_first = __builtin_amdgcn_readfirstlane(r >> 4);
-  }
   // the units a lane stages: (lane & 3) + 4 k, clamped to the last one instead of predicated (all loads issue back to back; the clamped
   // duplicates land in LDS units >= nq, which carry no weight — 4 PF units always fit the pitch)
   uint32_t soff[PF];
 #pragma unroll
   for (int k = 0; k < PF; k++) soff[k] = 16u * (sq + 4u * k < nq ? sq + 4u * k : nq - 1u);
-  u32x4 pf[PF];
-  auto fetch = [&](int32_t T) {
-    int32_t r = 16 * T + (int32_t)srow;
+  // Source tiles travel global memory -> registers -> LDS, TWO tiles ahead of the arithmetic (two register sets: the march is unrolled
+  // four deep, so "which set" is a compile-time constant).  One tile ahead left the waves waiting for HBM: with two waves per SIMD a
+  // tile's arithmetic lasts ~1 us, less than a loaded chip's memory latency (SQ_WAIT_ANY was 42 % of the wave cycles).
+  int32_t t_last;                                  // last source tile of the band (nothing past it is fetched)
+  {
+    int32_t r = ltap_i0(yb, scy) + 3;
+    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+    t_last = __builtin_amdgcn_readfirstlane(r >> 4);
+  }
+  // (every fetch issues exactly PF loads, predicated on nothing — units past the strip are clamped duplicates, tiles past the band's last
+  // re-read the last — so that the compiler can count: the wait in front of a commit is vmcnt(PF), not vmcnt(0))
+  u32x4 pf[2][PF];
+  auto fetch = [&](int32_t T, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    int32_t r = 16 * (T < t_last ? T : t_last) + (int32_t)srow;
     r = r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r;
     const uint8_t* row = src + (size_t)r * sp + S0;
 #pragma unroll
-    for (int k = 0; k < PF; k++)
-      if ((uint32_t)k < npf) pf[k] = ldg<false, u32x4>(row + soff[k]);
+    for (int k = 0; k < PF; k++) pf[SET][k] = ldg<false, u32x4>(row + soff[k]);
   };
   v4i ringH[NT], ringL[NT];
 #pragma unroll
   for (int j = 0; j < NT; j++) { ringH[j] = v4i{0, 0, 0, 0}; ringL[j] = v4i{0, 0, 0, 0}; }
   const v4i c128 = {128, 128, 128, 128};
-  const uint32_t arow = (lane & 15) * P + 16u * (lane >> 4);  // A operand of pass 1: lane (i, g) -> row i, bytes 16 g ..
+  // A operand of pass 1: lane (i, g) -> row i, bytes 16 g .. of tile j's window (one address register per tile: the kernel is issue-bound,
+  // an add per read is 7 % of pass 1)
+  const uint8_t* aptr[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
   uint8_t* const sdst = stage + srow * P + 16u * sq;
 
   // pass 1 of source tile T into ring slot SLOT = (T - t_first) & 3 (a compile-time constant: the march below is unrolled four deep so
@@ -198,13 +262,19 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int k = 0; k < PF; k++)
-      if ((uint32_t)k < npf)
-        *reinterpret_cast<u32x4*>(sdst + 64u * k) = pf[k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-    fetch(T + 1);  // one tile ahead (the tile past the band's last is a harmless clamped re-read)
+      *reinterpret_cast<u32x4*>(sdst + 64u * k) = pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
     wave_lds_sync();
+    // every A operand of the tile is requested before the first is used: one LDS latency per source tile, not one per pair of reads
+    // (left alone the compiler keeps two reads in flight and the wave waits four times per tile)
+    v4i av[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
+    if constexpr (NT == 8) asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+    else asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      const v4i a = *reinterpret_cast<const v4i*>(stage + arow + wrel[j]);
+      const v4i a = av[j];
       const v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1h[j], c128, 0, 0, 0);
       const v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1l[j], c128, 0, 0, 0);
       uint32_t h[4];
@@ -226,7 +296,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint32_t ob = ob0 + 16u * (lane & (NT - 1));                   // first destination byte of the unit this lane stores
   const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
   uint8_t* const obase = dst + (size_t)(lane >> LOGNT) * dp + ob;
-  auto emit = [&](uint32_t t, uint32_t y0) {
+  auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
     const v4i b2h = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16);
     const v4i b2l = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
 #pragma unroll
@@ -261,46 +331,30 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     wave_lds_sync();
   };
 
-  // row weights of the 64 destination rows from yg on (lane = row; rows past the band repeat its last row and are never stored):
-  // scattered into the operand image of four destination tiles; every lane keeps the last source tile its row needs
-  int32_t tmax_l = 0;
-  auto load_group = [&](uint32_t yg) {
-    const uint32_t yrow = yg + lane < yb ? yg + lane : yb;
-    const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
-    u32x4* z = reinterpret_cast<u32x4*>(wm);
-#pragma unroll
-    for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
-    uint8_t* const cell = wm + ((lane >> 4) * 2 * 64 + (lane & 15)) * 16;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      if (m.pos[k] < 0) continue;
-      const uint32_t pos = (uint32_t)m.pos[k];
-      int32_t hi, lo;
-      split_i8(m.q[k], hi, lo);
-      // K slot (g, 4 p + r) <-> source row 16 T + 4 g + r of the tile in ring slot p = (T - t_first) & 3
-      uint8_t* const a = cell + ((pos >> 2) & 3) * 256 + 4 * (((pos >> 4) - (uint32_t)t_first) & 3) + (pos & 3);
-      a[0] = (uint8_t)hi;
-      a[64 * 16] = (uint8_t)lo;
-    }
-    tmax_l = m.pos[5] >> 4;
-    wave_lds_sync();
+  // the last source tile each row of the current group needs (lane = row), for the emit test below
+  auto group_tmax = [&](uint32_t g) -> int32_t {
+    const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
+    int32_t r = ltap_i0(yrow, scy) + 3;
+    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+    return r >> 4;
   };
-
-  uint32_t yg = ya, y_next = ya;  // first row of the weight group in LDS / of the next destination tile to emit
+  uint32_t grp = 0, y_next = ya;  // current weight group / first row of the next destination tile to emit
+  int32_t tmax_l = group_tmax(0);
   int32_t T = t_first;
-  fetch(T);
-  load_group(yg);
+  fetch(T, std::integral_constant<int, 0>{});
+  fetch(T + 1, std::integral_constant<int, 1>{});
+  __syncthreads();  // groups 0 and 1 are in LDS
   // one step: the next source tile, then every destination tile whose last source tile it was
 #define VPF_LZM_STEP(S)                                                                                              \
   pass1(T, std::integral_constant<int, S>{});                                                                       \
   T++;                                                                                                              \
   for (;;) {                                                                                                        \
-    const uint32_t tl = (y_next - yg) >> 4;                                                                         \
+    const uint32_t tl = ((y_next - ya) >> 4) & 3u;                                                                  \
     if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + 15) >= T) break;                                                \
-    emit(tl, y_next);                                                                                               \
+    emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next);                                                               \
     y_next += 16;                                                                                                   \
     if (y_next > yb) return;                                                                                        \
-    if (y_next - yg == 64) { yg += 64; load_group(yg); }                                                            \
+    if (tl == 3) { next_group(grp); grp++; tmax_l = group_tmax(grp); }                                              \
   }
   for (;;) {
     VPF_LZM_STEP(0) VPF_LZM_STEP(1) VPF_LZM_STEP(2) VPF_LZM_STEP(3)
@@ -308,8 +362,10 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #undef VPF_LZM_STEP
 }
 
-template <int CH> struct LzMfma8 : LanczosMfmaTask<CH, 8, 4> {};
+template <int CH> struct LzMfma8 : LanczosMfmaTask<CH, 8, 4> {};   // strips of 8 tiles, staged rows of up to 256 B
+template <int CH> struct LzMfma8n : LanczosMfmaTask<CH, 8, 2> {};  // ... of up to 128 B (up-scales)
 template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
+template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 
 // all planes of up to 32 frames in one dispatch (the k_planes_mp scheme of k_resize_common.h, with this family's register budget:
 // two workgroups per CU)
@@ -324,6 +380,23 @@ __global__ __launch_bounds__(256, 2) void k_lanczos_mfma(const BatchArgs args, c
     case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
     default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
   }
+}
+
+// Two workgroups per CU share its 160 KB of LDS: up to 80 KB per workgroup, which is above the 64 KB a kernel gets without asking
+// (a 2x down-scale with 8-tile strips stages 544-B rows: 76 KB).  hipFuncSetAttribute is per device and not a stream operation: done
+// once per device and kernel, outside any capture-sensitive path (it neither allocates nor synchronises).
+constexpr uint32_t kLzmMaxLds = 80u * 1024u;
+template <template <int> class TaskCH>
+static bool lzm_big_lds_ok() {
+  static std::atomic<uint64_t> done{0}, failed{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+  const uint64_t bit = 1ull << dev;
+  if (done.load(std::memory_order_acquire) & bit) return !(failed.load(std::memory_order_acquire) & bit);
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_mfma<TaskCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLzmMaxLds);
+  if (e != hipSuccess) { (void)hipGetLastError(); failed.fetch_or(bit, std::memory_order_release); }
+  done.fetch_or(bit, std::memory_order_release);
+  return e == hipSuccess;
 }
 
 // Does a plane shape fit the kernel's windows (vpf_plan_bounds.h: the tiles are walked with the kernel's own coordinate arithmetic)?
@@ -357,7 +430,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     if (!lzm_shape(j.ch, j.sw, j.sh, j.dw, j.dh).rows_ok) return false;
   }
   // strip width: 8 tiles (128 B of a destination row) unless that leaves the chip short of work or the strip does not fit: a staged row is
-  // at most 4 (PF) x 4 lanes x 16 B, and the workgroup's four wave-private LDS regions must fit the 64 KB a launch gets without opt-in
+  // at most 4 (PF) x 4 lanes x 16 B, and the workgroup's four wave-private LDS regions must fit half a CU's LDS (two workgroups per CU)
   const int forced = tuning(VPF_TUNE_RESIZE_MFMA);  // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
   int nt = 8;
   {
@@ -377,7 +450,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     }
     pitch = vpf_bound_lzm_pitch(span);
     wave_lds = lzm_wave_lds(nt, pitch);
-    return span <= 4u * 64u && 4 * wave_lds <= 64u * 1024u;  // PF = 4 staging loads of 4 lanes x 16 B per row
+    return span <= 4u * 64u && lzm_group_lds(nt, pitch) <= kLzmMaxLds;  // PF = 4 staging loads of 4 lanes x 16 B per row
   };
   if (!fits()) {
     if (nt != 8) return false;
@@ -404,11 +477,16 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     gy += (j.dh + rows - 1) / rows;
   }
   const dim3 grid(gx, gy, n);
-  const uint32_t lds = 4 * wave_lds;
-  if (log_level() >= 2 || trace_on()) note_kernel(nt == 8 ? "k_lanczos_mfma<LzMfma8>" : "k_lanczos_mfma<LzMfma4>");
-  (void)hipGetLastError();
-  if (nt == 8) hipLaunchKernelGGL((k_lanczos_mfma<LzMfma8>), grid, dim3(256), lds, st, a, t);
-  else hipLaunchKernelGGL((k_lanczos_mfma<LzMfma4>), grid, dim3(256), lds, st, a, t);
+  const uint32_t lds = lzm_group_lds(nt, pitch);
+  const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
+  if (lds > 64u * 1024u && !(nt == 8 ? lzm_big_lds_ok<LzMfma8>() : lzm_big_lds_ok<LzMfma4>())) return false;  // (only wide strips get there)
+#define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
+                           hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t); } while (0)
+  if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);
+  else if (nt == 8) VPF_LZM_GO(LzMfma8);
+  else if (narrow) VPF_LZM_GO(LzMfma4n);
+  else VPF_LZM_GO(LzMfma4);
+#undef VPF_LZM_GO
   return true;
 }
 
