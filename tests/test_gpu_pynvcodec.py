@@ -97,7 +97,7 @@ def test_chain_resnet_sample(oracle):
     pln = nvc.PySurfaceConverter(tw, th, PF.RGB, PF.RGB_PLANAR, GPU).Execute(rgb, cc)
     assert (small.Width(), small.Height()) == (tw, th) and not pln.Empty()
     _, a = oracle.convert(oracle.NV12, oracle.YUV420, 0, 0, w, h, src)
-    _, b = oracle.resize(oracle.YUV420, oracle.LINEAR, w, h, a, tw, th)
+    _, b = oracle.resize(oracle.YUV420, oracle.LANCZOS3, w, h, a, tw, th)  # the resizer's default is the reference's filter
     _, c = oracle.convert(oracle.YUV420, oracle.RGB, 0, 0, tw, th, b)
     _, d = oracle.convert(oracle.RGB, oracle.RGB_PLANAR, 0, 0, tw, th, c)
     assert np.array_equal(download(pln), host_frame(d))
@@ -126,6 +126,7 @@ def test_fused_convert_resizer_equals_the_two_step_chain(oracle):
         out = fused.Execute(nv12, cc)
         assert not out.Empty() and (out.Width(), out.Height(), out.Format()) == (tw, th, fmt) and fused.Format() == fmt
         conv, rs = nvc.PySurfaceConverter(w, h, PF.NV12, fmt, GPU), nvc.PySurfaceResizer(tw, th, fmt, GPU)
+        rs.SetInterpolation(1)  # the fused task is the bilinear chain (the resizer alone defaults to Lanczos like the reference)
         two_step = rs.Execute(conv.Execute(nv12, cc))
         assert np.array_equal(download(out), download(two_step))
         _, want = oracle.convert_resize(oracle.NV12, ofmt, 1, 0, w, h, src, tw, th)
@@ -157,9 +158,9 @@ def test_resizer_accepts_float_surfaces_like_the_reference(oracle):
     small_pln = nvc.PySurfaceResizer(tw // 2, th // 2, PF.RGB_32F_PLANAR, GPU).Execute(pln)
     assert (small.Width(), small.Height(), small.Format()) == (tw, th, PF.RGB_32F) and not small_pln.Empty()
     _, a = oracle.convert(oracle.RGB, oracle.RGB_32F, 0, 0, w, h, src)
-    _, b = oracle.resize(oracle.RGB_32F, oracle.LINEAR, w, h, a, tw, th)
+    _, b = oracle.resize(oracle.RGB_32F, oracle.LANCZOS3, w, h, a, tw, th)
     _, c = oracle.convert(oracle.RGB_32F, oracle.RGB_32F_PLANAR, 0, 0, tw, th, b)
-    _, d = oracle.resize(oracle.RGB_32F_PLANAR, oracle.LINEAR, tw, th, c, tw // 2, th // 2)
+    _, d = oracle.resize(oracle.RGB_32F_PLANAR, oracle.LANCZOS3, tw, th, c, tw // 2, th // 2)
     assert np.array_equal(download(small, np.float32), host_frame(b).view(np.float32))
     assert np.array_equal(download(small_pln, np.float32), host_frame(d).view(np.float32))
 
@@ -226,7 +227,7 @@ def test_chain_multithread_sample(oracle):
     assert not errors, errors
     for i, (src, out) in results.items():
         _, rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
-        _, want = oracle.resize(oracle.RGB, oracle.LINEAR, w, h, rgb, w // 2, h // 2)
+        _, want = oracle.resize(oracle.RGB, oracle.LANCZOS3, w, h, rgb, w // 2, h // 2)
         assert np.array_equal(out, want[0].reshape(-1)), i
 
 
@@ -445,7 +446,7 @@ def test_concurrent_threads_mixed_operations(oracle):
     _, rgb = oracle.convert(oracle.NV12, oracle.RGB, 1, 0, w, h, src)
     _, pln = oracle.convert(oracle.NV12, oracle.RGB_PLANAR, 1, 0, w, h, src)
     _, yuv = oracle.convert(oracle.NV12, oracle.YUV420, 1, 0, w, h, src)
-    _, small = oracle.resize(oracle.RGB, oracle.LINEAR, w, h, rgb, tw, th)
+    _, small = oracle.resize(oracle.RGB, oracle.LANCZOS3, w, h, rgb, tw, th)
     _, fused = oracle.convert_resize(oracle.NV12, oracle.RGB_PLANAR, 1, 0, w, h, src, tw, th)
     xm, ym = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
     xm, ym = (xm + 2.5 * np.sin(ym / 11)).astype(np.float32), (ym + 1.5 * np.cos(xm / 13)).astype(np.float32)
@@ -569,7 +570,7 @@ def test_resizer_and_remaper_async_opt_out(oracle):
     assert rs.GetAsync() is True
     out = rs.Execute(src)
     torch.cuda.synchronize()
-    assert np.array_equal(download(out), host_frame(oracle.resize(oracle.RGB, 1, w, h, planes, dw, dh, oracle.FP32)[1]))
+    assert np.array_equal(download(out), host_frame(oracle.resize(oracle.RGB, 2, w, h, planes, dw, dh, oracle.FP32)[1]))
     yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
     rm = nvc.PySurfaceRemaper((xx * 2).astype(np.float32), (yy * 1.5).astype(np.float32), PF.RGB, GPU)
     rm.SetAsync(True)

@@ -188,10 +188,10 @@ def test_resizer_and_remaper_argument_errors():
     assert rs.Format() == PF.RGB
     assert rs.Execute(nvc.Surface.Make(PF.BGR, 128, 64, context=0)).Empty()  # format mismatch -> TASK_EXEC_FAIL (:1166-1168)
     assert rs.Execute(None).Empty()
-    # additive knobs: defaults are the reference's behaviour (blocking Run, bilinear per north_star); ExecuteBatch validates before it launches
-    assert rs.GetAsync() is False and rs.GetInterpolation() == 1
-    rs.SetAsync(True); rs.SetInterpolation(2)
-    assert rs.GetAsync() is True and rs.GetInterpolation() == 2
+    # additive knobs: defaults are the reference's behaviour (blocking Run, the Lanczos filter it asks NPP for); ExecuteBatch validates before it launches
+    assert rs.GetAsync() is False and rs.GetInterpolation() == 2
+    rs.SetAsync(True); rs.SetInterpolation(1)
+    assert rs.GetAsync() is True and rs.GetInterpolation() == 1
     a = [nvc.Surface.Make(PF.RGB, 128, 64, context=0) for _ in range(2)]
     assert not rs.ExecuteBatch(a, [nvc.Surface.Make(PF.RGB, 64, 32, context=0)])                       # length mismatch
     assert not rs.ExecuteBatch(a, [nvc.Surface.Make(PF.RGB, 66, 32, context=0) for _ in range(2)])    # wrong destination size

@@ -222,7 +222,7 @@ def test_hip_matches_reference_resizer(path):
     for key in (k for k in z.files if k.startswith("out_")):
         dw, dh = (int(v) for v in key[4:].split("x"))
         rs = nvc.PySurfaceResizer(dw, dh, getattr(nvc.PixelFormat, fmt), 0)
-        rs.SetInterpolation(2)  # Lanczos: what the reference's resizer asks NPP for (Tasks.cpp:1190); bilinear is this repo's default
+        rs.SetInterpolation(2)  # Lanczos: what the reference's resizer asks NPP for (Tasks.cpp:1190) — also this repo's default since round 3
         mx, frac = lsb_report(down(fmt, dw, dh, rs.Execute(up(fmt, w, h, z["src"]))), z[key])
         assert mx <= 1, f"{os.path.basename(path)} -> {dw}x{dh}: max |diff| {mx}, {frac:.2%} off by more than 1 LSB"
 

@@ -533,7 +533,7 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PySurfaceResizer::GetFormat)
       .def("SetInterpolation", &PySurfaceResizer::SetInterpolation, py::arg("interp"),
-           "additive: 0 nearest, 1 bilinear (default), 2 Lanczos-3 (the filter the reference requests from NPP)")
+           "additive: 0 nearest, 1 bilinear, 2 Lanczos-3 (default: the filter the reference requests from NPP)")
       .def("GetInterpolation", &PySurfaceResizer::GetInterpolation)
       .def("SetAsync", &PySurfaceResizer::SetAsync, py::arg("on"),
            "additive: Execute() no longer waits for the stream (like PySurfaceConverter); default False = the reference's blocking behaviour")

@@ -360,7 +360,7 @@ struct ResizeSurface::Impl {
   uint32_t w, h;
   StreamRef sref;
   std::unique_ptr<Surface> out;
-  int interp = VPF_INTERP_LINEAR;
+  int interp = VPF_INTERP_LANCZOS3;  // what the reference's resizer asks NPP for (NPPI_INTER_LANCZOS, Tasks.cpp:1190,1248,1373,1431)
   bool async = false;
 };
 void ResizeSurface::SetAsync(bool on) { pImpl->async = on; }
@@ -383,9 +383,12 @@ ResizeSurface::ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext 
     ss << "pixel format not supported";
     throw std::runtime_error(ss.str());
   }
-  pImpl.reset(new Impl{f, w, h, StreamRef{ctx, str}, nullptr, VPF_INTERP_LINEAR});
-  if (const char* e = std::getenv("VPF_HIP_RESIZE_INTERP")) {  // "lanczos" restores the reference resizer's filter
+  // Default = the reference's filter (round 3; rounds 1-2 defaulted to bilinear, which SetInterpolation(1) / VPF_HIP_RESIZE_INTERP=bilinear
+  // still select per instance / per process: it is the cheaper filter, and the one the fused PySurfaceConvertResizer implements)
+  pImpl.reset(new Impl{f, w, h, StreamRef{ctx, str}, nullptr, VPF_INTERP_LANCZOS3});
+  if (const char* e = std::getenv("VPF_HIP_RESIZE_INTERP")) {
     if (!std::strcmp(e, "lanczos") || !std::strcmp(e, "2")) pImpl->interp = VPF_INTERP_LANCZOS3;
+    else if (!std::strcmp(e, "bilinear") || !std::strcmp(e, "linear") || !std::strcmp(e, "1")) pImpl->interp = VPF_INTERP_LINEAR;
     else if (!std::strcmp(e, "nearest") || !std::strcmp(e, "0")) pImpl->interp = VPF_INTERP_NEAREST;
   }
   pImpl->out.reset(Surface::Make(f, w, h, ctx));
