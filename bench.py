@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from videoprocessingframework_amd import capi, sharding  # noqa: E402  (capi raises if libvpfhip.so is missing: no fallback)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
 
 
 def _pitched(rows, row_bytes, dev, gen=None, align=256):
@@ -177,13 +177,13 @@ class RehearsalWorkload:
         time.sleep(self.sleep)
 
 
-def timed(wl, steps: int, warmup: int, dist_on: bool):
+def timed_block(wl, steps: int):
+    """EXACTLY `steps` steps bracketed by barrier + torch.cuda.synchronize on both sides -> (wall seconds incl. the closing barrier,
+    this rank's own device seconds from HIP events on the launch stream)"""
     gpu = wl.dev is not None
-    for _ in range(warmup):
-        wl.step()
     if gpu:
         torch.cuda.synchronize()
-    sharding.barrier(wl.dev)  # barrier + torch.cuda.synchronize on both sides of the timed region
+    sharding.barrier(wl.dev)
     if gpu:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # on the launch stream
     t0 = time.perf_counter()
@@ -198,6 +198,27 @@ def timed(wl, steps: int, warmup: int, dist_on: bool):
     sharding.barrier(wl.dev)
     wall = time.perf_counter() - t0
     return wall, (e0.elapsed_time(e1) * 1e-3 if gpu else t_own)
+
+
+def preheat(wl, ms: float):
+    """Untimed and DECLARED (`preheat_ms` in the JSON line): the same dispatch repeated for ~ms milliseconds before the warm-up steps, so that
+    clocks, the power state and the caches' steady state are those of a long run.  `--warmup 5` of this workload is 1 ms of work — a chip
+    that idled during the build of the ring has not left its idle clocks by then, which showed as a 4 % spread between driver runs."""
+    if ms <= 0 or wl.dev is None:
+        return 0.0
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            wl.step()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def timed(wl, steps: int, warmup: int, dist_on: bool):
+    """one warm-up + one timed block (the sweeps' form)"""
+    for _ in range(warmup):
+        wl.step()
+    return timed_block(wl, steps)
 
 
 def effective_cpus() -> int:
@@ -293,9 +314,12 @@ def other_configs(dev, main_wl):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE under torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps steps is run this many times; the MEDIAN block is reported "
+                    "(ms_per_step, value, roofline), all of them in per_repeat_ms (SURVEY 8d: median of 5)")
+    ap.add_argument("--preheat-ms", type=float, default=300.0, help="untimed, declared pre-heat of the same dispatch before --warmup (0 = none)")
     ap.add_argument("--ring", type=int, default=32, help="distinct frame pairs in the ring (32 x 37.3 MB = 1.19 GB)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--mode", choices=["batch", "single"], default="batch")
@@ -311,14 +335,13 @@ def main():
 
     rank, world, local = sharding.env_rank()
     dist_on = world > 1
+    if a.gpus is None:
+        a.gpus = world  # a torchrun line that does not repeat --gpus: the launcher's WORLD_SIZE is the answer
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` typed by hand: become the launch line the driver uses (one rank per GPU)
-        import socket
-        with socket.socket() as s_:
-            s_.bind(("127.0.0.1", 0))
-            port = s_.getsockname()[1]
-        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+        # `python bench.py --gpus N` typed by hand: become the launch line the driver uses (one rank per GPU); --standalone lets the c10d
+        # rendezvous pick its own free port (binding one here and handing the number over would race with other processes)
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+                                  f"--nproc-per-node={a.gpus}", os.path.abspath(__file__)] + sys.argv[1:])
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}")
     if a.rehearse_host:
@@ -385,9 +408,16 @@ def main():
             torch.cuda.empty_cache()
 
     wl = RehearsalWorkload(rank) if a.rehearse_host else Workload(a.workload, dev, a.ring, a.variant, a.mode)
-    wall, ev = timed(wl, a.steps, a.warmup, dist_on)
-    total_px, wall_max = sharding.aggregate(wl.px_per_step * a.steps, wall, red_dev)  # sum of pixels, MAX time over ranks
-    per_rank_ms = [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)]  # each rank's own device time per step
+    heated_ms = preheat(wl, 0.0 if a.rehearse_host else a.preheat_ms)
+    for _ in range(a.warmup):
+        wl.step()
+    blocks = []  # per repeat: (whole-job pixels, MAX wall over ranks, this rank's device seconds, every rank's device ms per step)
+    for _ in range(max(1, a.repeats)):
+        wall, ev = timed_block(wl, a.steps)
+        px, wmax = sharding.aggregate(wl.px_per_step * a.steps, wall, red_dev)  # sum of pixels, MAX time over ranks
+        blocks.append((px, wmax, ev, [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)]))
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][1])
+    total_px, wall_max, ev, per_rank_ms = blocks[order[len(order) // 2]]  # the median block (same index on every rank: wmax is all-reduced)
 
     if rank == 0:
         n_launch = wl.launches_per_step * a.steps
@@ -417,6 +447,8 @@ def main():
             "dtype": "f32",  # u8 pixels in/out, fp32 FMA arithmetic, round-to-nearest-even saturating pack
             "data": "synthetic",
             "per_rank_ms_per_step": per_rank_ms,
+            "repeats": len(blocks), "per_repeat_ms": [round(b[1] / a.steps * 1e3, 4) for b in blocks],  # ms_per_step is their median
+            "preheat_ms": round(heated_ms, 1),
             "config": {"workload": f"{a.workload}: {wl.w}x{wl.h} NV12 -> {'RGB' if a.workload != 'nv12_planar_1080p' else 'RGB_PLANAR'}, BT.709 limited range, "
                                    f"ring of {a.ring} device-resident frames per GPU, {wl.launches_per_step} dispatch(es) per step",
                        "mode": a.mode, "frames_per_step_per_gpu": a.ring, "variant": a.variant,

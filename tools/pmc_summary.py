@@ -14,7 +14,7 @@ def mean(path, kern, ctr):
 GiB_KiB = 1048576.0
 cal = {}
 for k, kr, kw in (("copy16(", GiB_KiB, GiB_KiB), ("copy16_nt(", GiB_KiB, GiB_KiB), ("copy4_12(", (2**30 // 12) * 12 / 1024, (2**30 // 12) * 12 / 1024),
-                  ("mix_1r2w(", GiB_KiB, 2 * GiB_KiB)):
+                  ("mix_1r2w(", GiB_KiB, 2 * GiB_KiB), ("mix_1r2w_strided(", GiB_KiB, 2 * GiB_KiB)):
     f, _ = mean(P + "calib_FETCH_SIZE/c_counter_collection.csv", k, "FETCH_SIZE")
     w, _ = mean(P + "calib_WRITE_SIZE/c_counter_collection.csv", k, "WRITE_SIZE")
     cal[k.rstrip("(")] = {"known_read_KiB": kr, "FETCH_SIZE_KiB": f, "fetch_ratio": round(f / kr, 5), "known_write_KiB": kw, "WRITE_SIZE_KiB": w,
