@@ -50,7 +50,7 @@ def build(force: bool = False) -> str:
         if os.path.exists(vpflib):
             so = os.path.join(ref, "libtc_ref_hip.so")
             dep_m = max([os.path.getmtime(vpflib), os.path.getmtime(os.path.join(_HERE, "ref_tc_hip_shim.cpp")), os.path.getmtime(os.path.join(_HERE, "Makefile")),
-                         os.path.getmtime(os.path.join(_HERE, "ref_shim_hip", "npp_over_vpf.h"))])
+                         os.path.getmtime(os.path.join(_HERE, "ref_shim_hip", "npp_over_vpf.h")), os.path.getmtime(os.path.join(_HERE, "ref_tasks_stubs.py"))])
             if force or not os.path.exists(so) or os.path.getmtime(so) < dep_m:
                 subprocess.check_call(["make", "-C", _HERE, "ref_tc_hip"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -43,6 +43,7 @@ CUresult cuMemAllocPitch(CUdeviceptr*, size_t* pitch, size_t width_bytes, size_t
 CUresult cuMemFree(CUdeviceptr);
 CUresult cuMemcpyDtoD(CUdeviceptr, CUdeviceptr, size_t);
 CUresult cuMemcpyHtoDAsync(CUdeviceptr, const void*, size_t, CUstream);
+CUresult cuMemcpyDtoHAsync(void*, CUdeviceptr, size_t, CUstream);
 CUresult cuMemcpy2DAsync(const CUDA_MEMCPY2D*, CUstream);
 CUresult cuStreamSynchronize(CUstream);
 CUresult cuCtxPushCurrent(CUcontext);

@@ -169,5 +169,47 @@ inline NppStatus nppiCopy_8u_C1R_Ctx(const Npp8u* pSrc, int nSrcStep, Npp8u* pDs
 inline NppStatus nppiDivC_16u_C1RSfs_Ctx(const Npp16u*, int, Npp16u, Npp16u*, int, NppiSize, int, NppStreamContext) { ref_hip_note(__func__, -1); return NPP_ERROR; }
 inline NppStatus nppiConvert_16u8u_C1R_Ctx(const Npp16u*, int, Npp8u*, int, NppiSize, NppStreamContext) { ref_hip_note(__func__, -1); return NPP_ERROR; }
 
+/* ---- resize / remap (round 3): the reference's ResizeSurface / RemapSurface (src/TC/src/Tasks.cpp:1162-1203 packed 3C, :1217-1261
+ * one C1R call per plane, :1285-1324 the NV12 chain C3 -> R2 -> C4, :1555-1602 remap) call these with NPPI_INTER_LANCZOS / NPPI_INTER_LINEAR.
+ * NPP's argument lists (nppi_geometry_transforms.h); the ROIs the reference passes are always the whole image (checked). */
+namespace npp_over_vpf {
+inline int interp_of(int e) { return e == NPPI_INTER_LANCZOS ? VPF_INTERP_LANCZOS3 : e == NPPI_INTER_LINEAR ? VPF_INTERP_LINEAR : e == NPPI_INTER_NN ? VPF_INTERP_NEAREST : -1; }
+inline bool whole(NppiSize s, NppiRect r) { return r.x == 0 && r.y == 0 && r.width == s.width && r.height == s.height; }
+inline NppStatus resize(const char* name, int fmt, const void* pSrc, int nSrcStep, NppiSize ss, NppiRect sr, void* pDst, int nDstStep, NppiSize ds, NppiRect dr,
+                        int eInterpolation, const NppStreamContext& ctx) {
+  const int interp = interp_of(eInterpolation);
+  if (interp < 0 || !whole(ss, sr) || !whole(ds, dr)) { ref_hip_note(name, -1); return NPP_ERROR; }
+  const vpf_exec ex = {-1, 0, (void*)ctx.hStream};
+  const P3 s = planes(pSrc, nSrcStep), d = planes(pDst, nDstStep);
+  const vpf_status st = vpf_resize(&ex, fmt, interp, vpf_size{(uint32_t)ss.width, (uint32_t)ss.height}, s.p, vpf_size{(uint32_t)ds.width, (uint32_t)ds.height}, d.p);
+  ref_hip_note(name, (int)st);
+  return st == VPF_OK ? NPP_NO_ERROR : NPP_ERROR;
+}
+}  // namespace npp_over_vpf
+inline NppStatus nppiResize_8u_C3R_Ctx(const Npp8u* pSrc, int nSrcStep, NppiSize oSrcSize, NppiRect oSrcRectROI, Npp8u* pDst, int nDstStep, NppiSize oDstSize,
+                                       NppiRect oDstRectROI, int eInterpolation, NppStreamContext ctx) {
+  return npp_over_vpf::resize(__func__, VPF_FMT_RGB, pSrc, nSrcStep, oSrcSize, oSrcRectROI, pDst, nDstStep, oDstSize, oDstRectROI, eInterpolation, ctx);
+}
+inline NppStatus nppiResize_8u_C1R_Ctx(const Npp8u* pSrc, int nSrcStep, NppiSize oSrcSize, NppiRect oSrcRectROI, Npp8u* pDst, int nDstStep, NppiSize oDstSize,
+                                       NppiRect oDstRectROI, int eInterpolation, NppStreamContext ctx) {
+  return npp_over_vpf::resize(__func__, VPF_FMT_Y, pSrc, nSrcStep, oSrcSize, oSrcRectROI, pDst, nDstStep, oDstSize, oDstRectROI, eInterpolation, ctx);
+}
+inline NppStatus nppiResize_32f_C3R_Ctx(const Npp32f* pSrc, int nSrcStep, NppiSize oSrcSize, NppiRect oSrcRectROI, Npp32f* pDst, int nDstStep, NppiSize oDstSize,
+                                        NppiRect oDstRectROI, int eInterpolation, NppStreamContext ctx) {
+  return npp_over_vpf::resize(__func__, VPF_FMT_RGB_32F, pSrc, nSrcStep, oSrcSize, oSrcRectROI, pDst, nDstStep, oDstSize, oDstRectROI, eInterpolation, ctx);
+}
+/* one float plane at a time: vpf_resize takes a whole RGB_32F_PLANAR surface (three planes) — not forwarded */
+inline NppStatus nppiResize_32f_C1R_Ctx(const Npp32f*, int, NppiSize, NppiRect, Npp32f*, int, NppiSize, NppiRect, int, NppStreamContext) { ref_hip_note(__func__, -1); return NPP_ERROR; }
+inline NppStatus nppiRemap_8u_C3R_Ctx(const Npp8u* pSrc, NppiSize oSrcSize, int nSrcStep, NppiRect oSrcROI, const Npp32f* pXMap, int nXMapStep, const Npp32f* pYMap,
+                                      int nYMapStep, Npp8u* pDst, int nDstStep, NppiSize oDstSizeROI, int eInterpolation, NppStreamContext ctx) {
+  if (eInterpolation != NPPI_INTER_LINEAR || !npp_over_vpf::whole(oSrcSize, oSrcROI)) { ref_hip_note(__func__, -1); return NPP_ERROR; }
+  const vpf_exec ex = {-1, 0, (void*)ctx.hStream};
+  const vpf_plane s = {const_cast<Npp8u*>(pSrc), (uint32_t)nSrcStep, 0}, d = {pDst, (uint32_t)nDstStep, 0};
+  const vpf_status st = vpf_remap(&ex, VPF_FMT_RGB, vpf_size{(uint32_t)oSrcSize.width, (uint32_t)oSrcSize.height}, &s, pXMap, (uint32_t)nXMapStep, pYMap, (uint32_t)nYMapStep,
+                                  vpf_size{(uint32_t)oDstSizeROI.width, (uint32_t)oDstSizeROI.height}, &d);
+  ref_hip_note(__func__, (int)st);
+  return st == VPF_OK ? NPP_NO_ERROR : NPP_ERROR;
+}
+
 #undef NOV_FWD
 #undef NOV

@@ -7,6 +7,10 @@
 //   * ref_shim_hip/npp_over_vpf.h, where every nppi*_Ctx the reference calls forwards to libvpfhip's C ABI (vpf_convert).
 // ref_hip_convert() below then drives the reference's ConvertSurface exactly as PySurfaceConverter::Execute does
 // (src/PyNvCodec/src/PySurfaceConverter.cpp:50-74).  tests/test_gpu_reference_caller.py compares its pixels with the oracle.
+// Round 3: the recipe also compiles the reference's Tasks.cpp, and ref_hip_resize() / ref_hip_remap() drive its ResizeSurface (packed 3C,
+// planar, and the NV12 chain NV12 -> YUV420 -> resize -> NV12) and RemapSurface the way PySurfaceResizer / PySurfaceRemaper::Execute do
+// (src/PyNvCodec/src/PySurfaceResizer.cpp:45-62, PySurfaceRemaper.cpp:51-68): nppiResize_* / nppiRemap_* land in vpf_resize / vpf_remap.
+// The NVENC / NVDEC / demux tasks of that file link against abort stubs (ref_tasks_stubs.py) and are never constructed.
 // Nothing in the product links or loads this file.
 #include <hip/hip_runtime_api.h>
 
@@ -48,6 +52,9 @@ CUresult cuMemcpyDtoD(CUdeviceptr d, CUdeviceptr s, size_t n) {
 }
 CUresult cuMemcpyHtoDAsync(CUdeviceptr d, const void* s, size_t n, CUstream st) {
   return hipMemcpyAsync((void*)(uintptr_t)d, s, n, hipMemcpyHostToDevice, (hipStream_t)st) == hipSuccess ? CUDA_SUCCESS : CUDA_ERROR_INVALID_VALUE;
+}
+CUresult cuMemcpyDtoHAsync(void* d, CUdeviceptr s, size_t n, CUstream st) {
+  return hipMemcpyAsync(d, (const void*)(uintptr_t)s, n, hipMemcpyDeviceToHost, (hipStream_t)st) == hipSuccess ? CUDA_SUCCESS : CUDA_ERROR_INVALID_VALUE;
 }
 CUresult cuMemcpy2DAsync(const CUDA_MEMCPY2D* m, CUstream st) {
   const bool sh = m->srcMemoryType == CU_MEMORYTYPE_HOST, dh = m->dstMemoryType == CU_MEMORYTYPE_HOST;
@@ -139,5 +146,90 @@ int ref_hip_convert(int in_fmt, int out_fmt, uint32_t w, uint32_t h, int cs, int
   if (log && cap) std::snprintf(log, cap, "%s", g_log.c_str());
   if (vpf_calls) *vpf_calls = g_vpf_calls;
   return rc;
+}
+}
+
+// a call into a part of the reference that this recipe does not compile (NvEncoder / NvDecoder / FFmpegDemuxer ...): see ref_tasks_stubs.py
+extern "C" void vpf_ref_uncompiled_part() {
+  std::fprintf(stderr, "libtc_ref_hip: call into a reference source that oracle/Makefile ref_tc_hip does not compile\n");
+  std::abort();
+}
+
+namespace {
+// tight host frame <-> the planes of a reference Surface (the layout of CudaUploadFrame / CudaDownloadSurface, Tasks.cpp:643-658,815-854)
+int upload_planes(Surface* s, const uint8_t* src, size_t src_bytes, hipStream_t st) {
+  if (s->HostMemSize() > src_bytes) return -3;
+  size_t off = 0;
+  for (uint32_t p = 0; p < s->NumPlanes(); p++) {
+    const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
+    if (hipMemcpy2DAsync((void*)(uintptr_t)s->PlanePtr(p), s->Pitch(p), src + off, wb, wb, rows, hipMemcpyHostToDevice, st) != hipSuccess) return -4;
+    off += wb * rows;
+  }
+  return 0;
+}
+int download_planes(Surface* s, uint8_t* dst, size_t cap, size_t* bytes, hipStream_t st) {
+  if (s->HostMemSize() > cap) return -3;
+  size_t off = 0;
+  for (uint32_t p = 0; p < s->NumPlanes(); p++) {
+    const size_t wb = s->WidthInBytes(p), rows = s->Height(p);
+    if (hipMemcpy2DAsync(dst + off, wb, (const void*)(uintptr_t)s->PlanePtr(p), s->Pitch(p), wb, rows, hipMemcpyDeviceToHost, st) != hipSuccess) return -4;
+    off += wb * rows;
+  }
+  if (bytes) *bytes = off;
+  return 0;
+}
+template <class MakeTask>
+int run_task(MakeTask make, int fmt, uint32_t sw, uint32_t sh, const uint8_t* src, size_t src_bytes, uint8_t* dst, size_t dst_cap, size_t* dst_bytes,
+             uint32_t* ow, uint32_t* oh, char* log, int cap, int* vpf_calls) {
+  g_log.clear();
+  g_vpf_calls = 0;
+  if (log && cap) log[0] = 0;
+  int rc = 0;
+  try {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -4;
+    {
+      std::unique_ptr<Task> task(make((CUstream)st));
+      std::unique_ptr<Surface> in(Surface::Make((Pixel_Format)fmt, sw, sh, nullptr));
+      if (!task || !in) { (void)hipStreamDestroy(st); return -1; }
+      rc = upload_planes(in.get(), src, src_bytes, st);
+      task->SetInput(in.get(), 0U);
+      const auto status = rc == 0 ? task->Execute() : TaskExecStatus::TASK_EXEC_FAIL;  // (Execute ends with the task's cuda_stream_sync callback)
+      auto* out = (Surface*)task->GetOutput(0U);
+      if (rc == 0 && status == TaskExecStatus::TASK_EXEC_SUCCESS && out) {
+        if (ow) *ow = out->Width();
+        if (oh) *oh = out->Height();
+        rc = download_planes(out, dst, dst_cap, dst_bytes, st);
+        if (rc == 0) rc = 1;
+      }
+      if (hipStreamSynchronize(st) != hipSuccess) rc = -4;
+    }
+    (void)hipStreamDestroy(st);
+  } catch (std::exception& e) {
+    if (log && cap) std::snprintf(log, cap, "EXC:%s", e.what());
+    return -1;
+  }
+  if (log && cap) std::snprintf(log, cap, "%s", g_log.c_str());
+  if (vpf_calls) *vpf_calls = g_vpf_calls;
+  return rc;
+}
+}  // namespace
+
+extern "C" {
+// One resize through the REFERENCE'S ResizeSurface on the GPU (it asks its "NPP" for NPPI_INTER_LANCZOS).  Return codes as ref_hip_convert.
+int ref_hip_resize(int fmt, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const uint8_t* src, size_t src_bytes, uint8_t* dst, size_t dst_cap,
+                   size_t* dst_bytes, char* log, int cap, int* vpf_calls) {
+  uint32_t ow = 0, oh = 0;
+  const int rc = run_task([&](CUstream st) -> Task* { return ResizeSurface::Make(dw, dh, (Pixel_Format)fmt, nullptr, st); }, fmt, sw, sh, src, src_bytes, dst,
+                          dst_cap, dst_bytes, &ow, &oh, log, cap, vpf_calls);
+  return rc == 1 && (ow != dw || oh != dh) ? -5 : rc;
+}
+// One remap through the REFERENCE'S RemapSurface (host maps of map_w x map_h floats, uploaded by its CudaBuffer::Make).
+int ref_hip_remap(int fmt, uint32_t sw, uint32_t sh, const float* xmap, const float* ymap, uint32_t map_w, uint32_t map_h, const uint8_t* src, size_t src_bytes,
+                  uint8_t* dst, size_t dst_cap, size_t* dst_bytes, char* log, int cap, int* vpf_calls) {
+  uint32_t ow = 0, oh = 0;
+  const int rc = run_task([&](CUstream st) -> Task* { return RemapSurface::Make(xmap, ymap, map_w, map_h, (Pixel_Format)fmt, nullptr, st); }, fmt, sw, sh, src,
+                          src_bytes, dst, dst_cap, dst_bytes, &ow, &oh, log, cap, vpf_calls);
+  return rc == 1 && (ow != map_w || oh != map_h) ? -5 : rc;
 }
 }

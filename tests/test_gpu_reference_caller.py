@@ -3,7 +3,10 @@ MemoryInterfaces.cpp compiled unmodified from /root/reference into oracle/_ref/l
 runs on the MI355X with its CUDA driver calls served by the HIP runtime and every `nppi*_Ctx` it calls forwarded to libvpfhip's C
 ABI (oracle/ref_shim_hip/npp_over_vpf.h).  Its ConvertSurface::Execute, driven the way PySurfaceConverter::Execute drives it
 (src/PyNvCodec/src/PySurfaceConverter.cpp:50-74), must produce oracle-equal pixels for every converter and every context it
-accepts.  The library is built in the build container (the GPU box has no /root/reference) and travels with the snapshot."""
+accepts.  Round 3: the recipe also compiles the reference's Tasks.cpp, so its ResizeSurface::Execute (packed RGB, planar YUV420, and the
+NV12 chain NV12 -> YUV420 -> resize -> NV12, Tasks.cpp:1152-1332) and RemapSurface::Execute (:1544-1603) drive vpf_resize (Lanczos, what the
+reference asks NPP for) and vpf_remap the same way: all three families of the C ABI behind the reference's own caller.
+The library is built in the build container (the GPU box has no /root/reference) and travels with the snapshot."""
 import ctypes as C
 import os
 import sys
@@ -28,6 +31,9 @@ def ref(capi):
     L = C.CDLL(SO)
     L.ref_hip_convert.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                   C.POINTER(C.c_size_t), C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ref_hip_resize.argtypes = [C.c_int] + [C.c_uint32] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ref_hip_remap.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                C.POINTER(C.c_size_t), C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     return L
 
 
@@ -76,3 +82,66 @@ def test_reference_convertsurface_runs_on_mi355x_with_oracle_equal_pixels(ref, o
         n_ok += 1
     capfd.readouterr()  # the reference prints a diagnostic for every refused combination
     assert n_ok >= 1
+
+
+def _flat(planes):
+    return np.concatenate([p.reshape(-1).view(np.uint8) for p in planes])
+
+
+@pytest.mark.parametrize("fmt", [2, 6, 4, 7, 3, 1], ids=lambda f: NAMES[f])
+def test_reference_resizesurface_runs_on_mi355x_with_oracle_equal_pixels(ref, oracle, fmt):
+    """ResizeSurface::Make(dw, dh, fmt) -> SetInput -> Execute, as PySurfaceResizer::Execute does (PySurfaceResizer.cpp:45-62): the
+    reference passes NPPI_INTER_LANCZOS (Tasks.cpp:1190,1248), the adapter hands that to vpf_resize as VPF_INTERP_LANCZOS3.  RGB / BGR: one
+    nppiResize_8u_C3R; YUV420 / YCBCR: one nppiResize_8u_C1R per plane; NV12: the reference's chain nv12_yuv420 -> resize -> yuv420_nv12
+    (:1285-1324), i.e. two re-layout conversions around three plane resizes — compared with the oracle's resize of the NV12 frame (its
+    chroma plane resized as interleaved pairs = the same samples); Y: refused by the reference's constructor (:1458-1476)."""
+    o = oracle
+    for (sw, sh, dw, dh) in ((640, 360, 426, 240), (320, 180, 640, 360), (96, 64, 96, 64)):
+        src = o.synth(fmt, sw, sh, 5200 + fmt)
+        flat = _flat(src)
+        out = np.zeros(sum(r * rb for r, rb, _ in o.plane_shapes(fmt, dw, dh)), np.uint8)
+        nbytes, calls, log = C.c_size_t(0), C.c_int(0), C.create_string_buffer(1024)
+        rc = ref.ref_hip_resize(fmt, sw, sh, dw, dh, flat.ctypes.data, flat.size, out.ctypes.data, out.size, C.byref(nbytes), log, 1024, C.byref(calls))
+        what = f"reference ResizeSurface {NAMES[fmt]} {sw}x{sh}->{dw}x{dh}: rc {rc}, adapters [{log.value.decode()}]"
+        if fmt == 1:
+            assert rc == -1 and b"EXC" in log.value, what   # "pixel format not supported"
+            continue
+        assert rc == 1 and nbytes.value == out.size, what
+        st, want = o.resize(fmt, o.LANCZOS3, sw, sh, src, dw, dh, o.FP32)
+        assert st == 0
+        want = _flat(want)
+        if not np.array_equal(out, want):
+            d = np.flatnonzero(out != want)
+            raise AssertionError(f"{what}: {d.size} of {out.size} bytes differ from the oracle, first at {d[0]}: {out[d[0]]} vs {want[d[0]]}")
+        names = log.value.decode().split(",")
+        if fmt in (2, 6):
+            assert names == ["nppiResize_8u_C3R_Ctx:ok"], what
+        elif fmt in (4, 7):
+            assert names == ["nppiResize_8u_C1R_Ctx:ok"] * 3, what
+        else:  # NV12: re-layout, three plane resizes, re-layout
+            assert names.count("nppiResize_8u_C1R_Ctx:ok") == 3 and len(names) == 5 and all(n.endswith(":ok") for n in names), what
+
+
+def test_reference_remapsurface_runs_on_mi355x_with_oracle_equal_pixels(ref, oracle):
+    """RemapSurface::Make(x_map, y_map, w, h, RGB) -> SetInput -> Execute (PySurfaceRemaper.cpp:51-68; the maps are uploaded by the
+    reference's own CudaBuffer::Make): nppiRemap_8u_C3R + NPPI_INTER_LINEAR lands in vpf_remap.  Destination pixels whose source lies
+    outside the picture stay untouched (the reference's fresh surface: whatever the allocation held), so only mapped pixels are compared."""
+    o = oracle
+    sw, sh, dw, dh = 320, 200, 256, 144
+    src = o.synth(o.RGB, sw, sh, 5300)
+    yy, xx = np.meshgrid(np.arange(dh, dtype=np.float32), np.arange(dw, dtype=np.float32), indexing="ij")
+    for name, xm, ym in (("identity-ish", xx * 1.0, yy * 1.0), ("shift", xx + 0.5, yy + 0.25), ("scale", xx * 1.21 + 3.3, yy * 1.37 + 1.7),
+                         ("partly outside", xx * 1.5 - 20.0, yy * 1.5 - 10.0)):
+        xm, ym = np.ascontiguousarray(xm, np.float32), np.ascontiguousarray(ym, np.float32)
+        flat = _flat(src)
+        out = np.zeros(dh * dw * 3, np.uint8)
+        nbytes, calls, log = C.c_size_t(0), C.c_int(0), C.create_string_buffer(512)
+        rc = ref.ref_hip_remap(o.RGB, sw, sh, xm.ctypes.data, ym.ctypes.data, dw, dh, flat.ctypes.data, flat.size, out.ctypes.data, out.size, C.byref(nbytes), log, 512,
+                               C.byref(calls))
+        what = f"reference RemapSurface {name}: rc {rc}, adapters [{log.value.decode()}]"
+        assert rc == 1 and nbytes.value == out.size and log.value == b"nppiRemap_8u_C3R_Ctx:ok", what
+        inside = (xm >= 0) & (xm <= sw - 1) & (ym >= 0) & (ym <= sh - 1)
+        st, want = o.remap(o.RGB, sw, sh, src, xm, ym)
+        assert st == 0
+        got, want = out.reshape(dh, dw, 3), want[0].reshape(dh, dw, 3)
+        assert inside.any() and np.array_equal(got[inside], want[inside]), what
