@@ -83,7 +83,7 @@ def test_yuv420p_clips_come_out_as_real_nv12(feeder, oracle, w, h, fmt):
     nbytes = w * h + 2 * cw * ch
     info = c.info()
     assert info[:2] == [w, h] and info[4] == 3 and info[6] == 29970            # NV12 = Pixel_Format 3; 30000/1001 fps
-    assert info[5] == w * h * 3 // 2                                            # FrameBytes() of the announced size
+    assert info[5] == nbytes   # FrameBytes() of the announced size: the buffer DecodeNextFrame asks for, odd sizes included (33 x 17: 867, not 841)
     for i in range(n):
         rc, got = c.decode(nbytes)
         assert rc == 1, (i, c.err.value)

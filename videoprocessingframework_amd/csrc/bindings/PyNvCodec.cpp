@@ -311,7 +311,9 @@ public:
   ColorRange GetColorRange() const { return dec_->GetColorRange(); }
   Pixel_Format GetPixelFormat() const { return dec_->GetPixelFormat(); }
   uint32_t up_w_ = 0, up_h_ = 0;
-  std::vector<std::unique_ptr<PyFrameUploader>> retired_;  // uploaders of earlier resolutions: surfaces already handed out alias their memory
+  // uploaders of earlier resolutions, keyed by size: surfaces already handed out alias their memory, and a stream that alternates between
+  // resolutions gets its old uploader back instead of a new pair of pinned + device buffers per switch
+  std::map<std::pair<uint32_t, uint32_t>, std::unique_ptr<PyFrameUploader>> parked_;
 
   bool DecodeSingleFrame(py::array_t<uint8_t>& frame) {
     if (!dec_->NextFrame()) return false;
@@ -325,8 +327,10 @@ public:
     host_.resize(dec_->PendingFrameBytes());
     if (!dec_->CopyFrameNV12(host_.data(), host_.size())) return empty_surface(NV12);
     if (!up_ || w != up_w_ || h != up_h_) {
-      if (up_) retired_.push_back(std::move(up_));
-      up_.reset(new PyFrameUploader(w, h, NV12, ctx_of(gpu_), str_of(gpu_)));
+      if (up_) parked_[{up_w_, up_h_}] = std::move(up_);
+      auto it = parked_.find({w, h});
+      if (it != parked_.end()) { up_ = std::move(it->second); parked_.erase(it); }
+      else up_.reset(new PyFrameUploader(w, h, NV12, ctx_of(gpu_), str_of(gpu_)));
       up_w_ = w; up_h_ = h;
     }
     return up_->Upload(host_.data(), host_.size());

@@ -35,7 +35,9 @@ public:
   ColorSpace GetColorSpace() const;   // from the stream's colorspace tag (BT.709 / BT.601 / UNSPEC)
   ColorRange GetColorRange() const;   // MPEG (limited) / JPEG (full) / UDEF
   Pixel_Format GetPixelFormat() const { return NV12; }
-  size_t FrameBytes() const { return (size_t)Width() * Height() * 3 / 2; }
+  // tight NV12 bytes of a Width() x Height() picture: luma + interleaved chroma of ceil(W/2) x ceil(H/2) samples (odd sizes round chroma up,
+  // the same formula DecodeNextFrame checks its capacity against)
+  size_t FrameBytes() const { return (size_t)Width() * Height() + 2 * (size_t)((Width() + 1) / 2) * ((Height() + 1) / 2); }
 
   // Decode the next frame into `nv12` (tight W x 1.5H bytes: Y plane then interleaved UV).  false at end of stream.  Throws when
   // the decoded frame does not fit `capacity` (sizes are taken from the frame itself, not from the container's announcement).

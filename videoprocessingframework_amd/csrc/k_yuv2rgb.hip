@@ -235,6 +235,8 @@ static hipError_t launch_420(hipStream_t st, const Yuv2RgbCoef& c, uint32_t w, u
   const bool p4_ok = aligned_all(a, n, nsrc, ndst, 4, 4, SRC == FC_NV12 ? 4 : 2);
   const bool big_single = n < 4 && (size_t)w * h >= (size_t)3 << 20;
   const bool p16x_ok = p16_ok && DST != FC_PLANAR && w >= 1024 && (uint64_t)(w / 16) * (h / 2) < (1u << 30);
+  // values of the shared tuning key that name no NV12 / YUV420 -> RGB kernel (43 = a resize-only hint, anything unknown) mean the default policy
+  if (variant != 4 && variant != 8 && variant != 9 && variant != 12 && variant != 30 && variant != 37 && variant != 40 && variant != 44 && variant != 45 && variant != 46) variant = 0;
   if (variant == 0) variant = p16_ok ? (DST == FC_PLANAR ? (big_single ? 8 : 37) : (n >= 4 ? (p16x_ok ? 46 : 30) : 8)) : 4;  // (single frames: p16x measured level with p16, 0.710 vs 0.717)
   if ((variant == 45 || variant == 46) && !p16x_ok) variant = variant == 46 ? 30 : 8;  // narrow frames / planar outputs: the chunk-per-row form
   const bool is_p16 = variant == 8 || variant == 12 || variant == 30, is_r16 = variant == 37 || variant == 44;
