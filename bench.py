@@ -281,11 +281,30 @@ def cpu_baseline(wl: Workload, budget_s=10.0):
     o.set_threads(1)
     matches = bool(np.array_equal(gpu_out[:, :3 * w], dst[0]))
     return {"value": round(n * w * h / el / 1e9, 4), "unit": "Gpix/s", "cores": best, "kind": "port", "matches_gpu": matches,
-            "decode_leg": "not measurable here: the reference's only software component is libav decode, and this image has no libav; "
-                          "this is the conversion half only (the reference itself has no CPU converter)",
+            "decode_leg": decode_leg(),
             "sample": f"{n} frames of 3840x2160 NV12->RGB BT.709 limited in {el:.1f} s; oracle FP32 mode (AVX2+FMA rows, OpenMP), "
                       f"{best} threads; {avail} usable CPUs (affinity {len(os.sched_getaffinity(0))}, cgroup quota applied) (calibration Gpix/s: " +
                       ", ".join(f"{t}t={v / 1e9:.2f}" for t, v in calib.items()) + ")"}
+
+
+def decode_leg():
+    """The reference's only software component is libav decode (src/TC/src/FfmpegSwDecoder.cpp).  Where the bindings were built against libav
+    (PyNvCodec.HAVE_LIBAV) and VPF_BENCH_CLIP names a clip, tools/clip_pipeline.py's decode-only leg is timed on it; this image has no libav."""
+    clip = os.environ.get("VPF_BENCH_CLIP")
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "videoprocessingframework_amd"))
+        import PyNvCodec as nvc
+        have = bool(getattr(nvc, "HAVE_LIBAV", False))
+    except Exception:  # noqa: BLE001
+        have = False
+    if have and clip and os.path.exists(clip):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import clip_pipeline
+        n, dt, _, (cw, ch) = clip_pipeline.decode_only(nvc, clip, 2000)
+        return {"clip": os.path.basename(clip), "size": f"{cw}x{ch}", "frames": n, "frames_per_s": round(n / dt, 1), "Gpix_per_s": round(n * cw * ch / dt / 1e9, 4),
+                "threads": 1, "what": "libav demux + software decode + NV12 repack through PyFfmpegDecoder (host only)"}
+    return ("not measurable here: the reference's only software component is libav decode, and this image has no libav" if not have
+            else "no clip given (VPF_BENCH_CLIP)") + "; this is the conversion half only (the reference itself has no CPU converter)"
 
 
 def other_configs(dev, main_wl):

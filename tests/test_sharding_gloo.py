@@ -98,3 +98,38 @@ def test_bench_refuses_mismatched_world_size():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rehearse-host"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_numa_helpers_read_sysfs_and_bind(tmp_path, monkeypatch):
+    """sharding.gpu_numa_cpus / bind_to_gpu_numa against a fake sysfs tree: cpulist parsing, node -1 = no locality, the affinity actually set
+    is the intersection with what the process already may use, and a missing tree is a no-op, not an error."""
+    import os
+    import types
+
+    from videoprocessingframework_amd import sharding as sh
+
+    assert sh.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and sh.parse_cpulist("") == []
+    assert sh.pci_address(0, 0xc1, 0) == "0000:c1:00.0"
+    dev = tmp_path / "0000:c1:00.0"
+    dev.mkdir()
+    (dev / "numa_node").write_text("1\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    local = allowed[: max(1, len(allowed) // 2)]
+    (dev / "local_cpulist").write_text(",".join(map(str, local + [4093])) + "\n")   # a CPU this process does not have is ignored
+    assert sh.gpu_numa_cpus("0000:c1:00.0", str(tmp_path)) == (1, sorted(local + [4093]))
+    assert sh.gpu_numa_cpus("0000:ff:00.0", str(tmp_path)) == (None, [])
+    (tmp_path / "0000:c2:00.0").mkdir()
+    (tmp_path / "0000:c2:00.0" / "numa_node").write_text("-1\n")
+    assert sh.gpu_numa_cpus("0000:c2:00.0", str(tmp_path))[0] is None
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xc1, pci_device_id=0)
+    monkeypatch.setattr(sh.torch.cuda, "get_device_properties", lambda i: props)
+    try:
+        info = sh.bind_to_gpu_numa(0, str(tmp_path))
+        if len(allowed) > 1:
+            assert info["bound"] and info["numa_node"] == 1 and sorted(os.sched_getaffinity(0)) == local
+        again = sh.bind_to_gpu_numa(0, str(tmp_path))
+        assert not again["bound"]                                  # already there
+    finally:
+        os.sched_setaffinity(0, allowed)
+    props.pci_bus_id = 0xee
+    assert sh.bind_to_gpu_numa(0, str(tmp_path))["bound"] is False and sorted(os.sched_getaffinity(0)) == allowed

@@ -37,13 +37,15 @@ import PyNvCodec as nvc  # noqa: E402
 
 
 class SyntheticClip:
-    """Stand-in for demux + software decode of one clip: `distinct` NV12 frames in page-locked host memory, seeded per clip."""
+    """Stand-in for demux + software decode of one clip: `distinct` NV12 frames in host memory, seeded per clip — page-locked (what a decoder
+    writing into AllocPinned() buffers produces: DMA'd in place) or ordinary pageable numpy arrays (what an unmodified decoder produces: the
+    uploader stages them through its own pinned slots, one host copy per frame, and returns as soon as the DMA is queued)."""
 
-    def __init__(self, clip_id, w, h, distinct=4):
+    def __init__(self, clip_id, w, h, distinct=4, pinned=True):
         rng = np.random.default_rng(7000 + clip_id)
         self.frames = []
         for _ in range(distinct):
-            buf = nvc.AllocPinned(w * h * 3 // 2)
+            buf = nvc.AllocPinned(w * h * 3 // 2) if pinned else np.empty(w * h * 3 // 2, np.uint8)
             buf[:] = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
             self.frames.append(buf)
 
@@ -59,6 +61,10 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--source", choices=["pinned", "pageable"], default="pinned", help="where the stand-in decoder leaves its frames")
+    ap.add_argument("--threads", action="store_true", help="one worker thread per clip (the reference sample's shape: the GIL is released inside "
+                    "upload / convert, so the staging copies of different clips run in parallel) instead of one thread round-robin")
+    ap.add_argument("--no-numa", action="store_true", help="do not confine the rank to the CPUs of its GPU's NUMA node")
     a = ap.parse_args()
     rank, world, local = sharding.env_rank()
     if a.gpus != world:
@@ -68,6 +74,7 @@ def main():
     gpu = local % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
+    numa = {"bound": False, "why": "--no-numa"} if a.no_numa else sharding.bind_to_gpu_numa(gpu)  # BEFORE pinned buffers and threads exist
     sharding.init(a.backend, dev)
     red_dev = dev if a.backend == "nccl" else None
     w, h, pf = a.width, a.height, nvc.PixelFormat
@@ -77,21 +84,34 @@ def main():
     for c in mine:  # one stream + task chain per clip, like one worker thread per stream in the reference sample
         stream = torch.cuda.Stream(device=dev)
         ctx = nvc.GetContext(gpu)
-        chains.append({"clip": c, "src": SyntheticClip(c, w, h), "stream": stream,
+        chains.append({"clip": c, "src": SyntheticClip(c, w, h, pinned=a.source == "pinned"), "stream": stream,
                        "up": nvc.PyFrameUploader(w, h, pf.NV12, ctx, stream.cuda_stream),
                        "conv": nvc.PySurfaceConverter(w, h, pf.NV12, pf.RGB, ctx, stream.cuda_stream),
                        "down": nvc.PySurfaceDownloader(w, h, pf.RGB, ctx, stream.cuda_stream)})
 
+    def one(ch, i, end_to_end, last):
+        if end_to_end or "nv12" not in ch:
+            ch["nv12"] = ch["up"].UploadSingleFrame(ch["src"].decode(i))
+        rgb = ch["conv"].Execute(ch["nv12"], cc)
+        if rgb.Empty():
+            raise SystemExit(f"rank {rank}: conversion failed on clip {ch['clip']}")
+        last[ch["clip"]] = (i, rgb)
+
     def run(end_to_end, frames):
         last = {}
-        for i in range(frames):
-            for ch in chains:  # round-robin over this rank's clips: their uploads and kernels overlap across streams
-                if end_to_end or "nv12" not in ch:
-                    ch["nv12"] = ch["up"].UploadSingleFrame(ch["src"].decode(i))
-                rgb = ch["conv"].Execute(ch["nv12"], cc)
-                if rgb.Empty():
-                    raise SystemExit(f"rank {rank}: conversion failed on clip {ch['clip']}")
-                last[ch["clip"]] = (i, rgb)
+        if a.threads and len(chains) > 1:
+            import threading
+
+            def worker(ch):
+                for i in range(frames):
+                    one(ch, i, end_to_end, last)
+            ts = [threading.Thread(target=worker, args=(ch,)) for ch in chains]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+        else:
+            for i in range(frames):
+                for ch in chains:  # round-robin over this rank's clips: their uploads and kernels overlap across streams
+                    one(ch, i, end_to_end, last)
         torch.cuda.synchronize(dev)
         return last
 
@@ -124,7 +144,10 @@ def main():
     if rank == 0:
         print(json.dumps({"runner": "shard_pipeline", "n_gpus": world, "clips": a.clips, "clips_per_rank": clips_per_rank,
                           "frames_total": a.clips * a.frames, "size": f"{w}x{h}", "verified_clips": int(verified_all),
-                          "decode": "stand-in: frames pre-decoded into AllocPinned() host buffers (no libav in this image)",
+                          "decode": f"stand-in: frames pre-decoded into {'AllocPinned()' if a.source == 'pinned' else 'pageable numpy'} host buffers "
+                                    "(no libav in this image; tools/clip_pipeline.py runs a real decoder where libav exists)",
+                          "threads": "one per clip" if a.threads else "one, round-robin", "numa": numa,
+                          "bytes_per_s_end_to_end": round(rates["end_to_end"]["frames_per_s"] * w * h * 1.5 / 1e9, 2),
                           "end_to_end": rates["end_to_end"], "device_resident": rates["device_resident"],
                           "sharding": "clip s -> rank s mod N; no data-path collective"}), flush=True)
     if world > 1:

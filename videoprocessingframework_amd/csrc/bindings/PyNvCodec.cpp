@@ -224,6 +224,8 @@ public:
     up_.reset(CudaUploadFrame::Make(str, ctx, w, h, f));
   }
   Pixel_Format GetFormat() const { return fmt_; }
+  void SetAsync(bool on) { up_->SetAsync(on); }
+  bool GetAsync() const { return up_->GetAsync(); }
   std::shared_ptr<Surface> Upload(void* data, size_t bytes) {
     py::gil_scoped_release nogil;  // the reference releases the GIL around uploads too (PyFrameUploader.cpp:118-160)
     std::unique_ptr<Buffer> raw(Buffer::Make(bytes, data));
@@ -565,6 +567,10 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PyFrameUploader(w, h, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PyFrameUploader::GetFormat)
+      .def("SetAsync", &PyFrameUploader::SetAsync, py::arg("on"),
+           "additive: frames in page-locked memory (AllocPinned) are DMA'd in place; True = do not wait for that copy (the caller will not reuse the "
+           "buffer before synchronising).  Pageable frames are staged and never wait.  VPF_HIP_UPLOAD_SYNC=1 restores the reference's blocking upload")
+      .def("GetAsync", &PyFrameUploader::GetAsync)
       .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size()); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
       .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },

@@ -527,12 +527,14 @@ TaskExecStatus RemapSurface::RunBatch(Surface* const* ins, Surface* const* outs,
 // frame i+1 overlap the kernels still converting frame i.  The reference copies straight from the (pageable)
 // numpy buffer on the task stream and blocks (src/TC/src/Tasks.cpp:625-662).
 struct CudaUploadFrame::Impl {
-  static constexpr int kSlots = 2;
+  static constexpr int kSlots = 4;  // staging buffers / device surfaces in rotation: the host copy of frame i + 1 overlaps the DMA of frame i
   StreamRef sref;
+  bool async_pinned = false;  // SetAsync(true): do not wait for the DMA out of caller-owned page-locked memory either
+  bool force_sync = false;    // VPF_HIP_UPLOAD_SYNC=1: block on every copy like the reference (Tasks.cpp:617-618)
   Pixel_Format fmt;
   hipStream_t copy_stream = nullptr;
-  hipEvent_t done[kSlots] = {nullptr, nullptr};
-  hipEvent_t consumed[kSlots] = {nullptr, nullptr};  // task-stream work submitted before the slot's surface is rewritten
+  hipEvent_t done[kSlots] = {};
+  hipEvent_t consumed[kSlots] = {};  // task-stream work submitted before the slot's surface is rewritten
   std::unique_ptr<Buffer> staging[kSlots];
   std::unique_ptr<Surface> surf[kSlots];
   uint64_t n = 0;
@@ -549,6 +551,7 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
     : Task("HipUploadFrame", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl) {
   pImpl->sref = StreamRef{ctx, str};
   pImpl->fmt = f;
+  if (const char* e = std::getenv("VPF_HIP_UPLOAD_SYNC")) pImpl->force_sync = e[0] && e[0] != '0';
   DeviceScope scope(ctx);
   for (int i = 0; i < Impl::kSlots; i++) {
     pImpl->surf[i].reset(Surface::Make(f, w, h, ctx));
@@ -560,6 +563,8 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
   if (hipStreamCreateWithFlags(&pImpl->copy_stream, hipStreamNonBlocking) != hipSuccess) pImpl->copy_stream = nullptr;
 }
 CudaUploadFrame::~CudaUploadFrame() {}
+void CudaUploadFrame::SetAsync(bool on) { pImpl->async_pinned = on; }
+bool CudaUploadFrame::GetAsync() const { return pImpl->async_pinned; }
 CudaUploadFrame* CudaUploadFrame::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
   return new CudaUploadFrame(str, ctx, w, h, f);
 }
@@ -600,11 +605,17 @@ TaskExecStatus CudaUploadFrame::Run() {
     src += wb * rows;
   }
   if (pImpl->done[slot] && cs != (hipStream_t)pImpl->sref.str) {
-    // order the task stream behind the copy, then block the HOST on the copy alone (the reference task is blocking,
-    // Tasks.cpp:617-618) — kernels still running on the task stream keep running underneath the next upload
+    // order the task stream behind the copy.  A frame that was STAGED (pageable source) has left the caller's memory already: return
+    // without waiting — the returned surface is valid in stream order on the task's stream, where its consumers run, and the host goes
+    // on to decode / stage the next frame while this one crosses PCIe (round 3; rounds 1-2 blocked here like the reference's task,
+    // Tasks.cpp:617-618, which capped one uploader at 0.72 of the link).  A frame DMA'd straight out of caller-owned page-locked memory
+    // is still in use by the engine: block on the copy alone (kernels on the task stream keep running underneath) unless the caller
+    // promised not to touch the buffer before its next synchronisation (SetAsync(true)).
     if (!hip_ok(hipEventRecord(pImpl->done[slot], cs), "CudaUploadFrame: hipEventRecord")) return TASK_EXEC_FAIL;
     if (!hip_ok(hipStreamWaitEvent((hipStream_t)pImpl->sref.str, pImpl->done[slot], 0), "CudaUploadFrame: hipStreamWaitEvent")) return TASK_EXEC_FAIL;
-    if (!hip_ok(hipEventSynchronize(pImpl->done[slot]), "CudaUploadFrame: hipEventSynchronize")) return TASK_EXEC_FAIL;
+    if (pImpl->force_sync || (pinned_src && !pImpl->async_pinned)) {
+      if (!hip_ok(hipEventSynchronize(pImpl->done[slot]), "CudaUploadFrame: hipEventSynchronize")) return TASK_EXEC_FAIL;
+    }
   } else {
     hip_stream_sync(&pImpl->sref);
   }

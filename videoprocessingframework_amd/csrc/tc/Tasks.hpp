@@ -103,6 +103,11 @@ public:
   static CudaUploadFrame* Make(HipStream str, HipContext ctx, uint32_t width, uint32_t height, Pixel_Format format);
   ~CudaUploadFrame() override;
   TaskExecStatus Run() final;
+  // Additive.  Pageable frames are staged and return as soon as the DMA is queued (the surface is valid in stream order); frames in
+  // page-locked memory are DMA'd in place and Run() waits for that copy unless SetAsync(true) says the caller will not reuse the buffer
+  // before it synchronises the stream.  VPF_HIP_UPLOAD_SYNC=1 makes every Run() block like the reference's.
+  void SetAsync(bool on);
+  bool GetAsync() const;
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;

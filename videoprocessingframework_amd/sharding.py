@@ -6,7 +6,7 @@ here ranks meet only to agree on timing.  Works on the gloo backend (CPU tensors
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -71,3 +71,64 @@ def gather(value_local: float, device: torch.device | None = None) -> List[float
 def throughput(units_local: float, seconds_local: float, device: torch.device | None = None) -> float:
     u, t = aggregate(units_local, seconds_local, device)
     return u / t
+
+
+# ------------------------------------------------------------------------------------------------
+# NUMA placement.  The end-to-end leg of a sharded pipeline is host-memory traffic: software decode writes frames, the uploader
+# copies them into page-locked staging buffers, the DMA engine reads those.  On a two-socket 8-GPU node a rank whose threads and
+# pinned buffers sit on the other socket pushes every byte across the inter-socket link twice.  One process per GPU makes the
+# fix simple: before allocating anything, confine the rank to the CPUs of its GPU's NUMA node (first-touch then places the
+# pinned buffers there as well).  The reference has no counterpart (it is one process with a thread per GPU,
+# samples/SampleDecodeMultiThread.py:50-115).
+# ------------------------------------------------------------------------------------------------
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of sysfs local_cpulist)."""
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(cpus))
+
+
+def pci_address(domain: int, bus: int, device: int, function: int = 0) -> str:
+    return f"{domain:04x}:{bus:02x}:{device:02x}.{function:x}"
+
+
+def gpu_numa_cpus(pci_addr: str, sysfs_pci: str = "/sys/bus/pci/devices") -> Tuple[Optional[int], List[int]]:
+    """(NUMA node, CPUs local to it) of the PCI device, from sysfs; (None, []) when the platform does not say (single-node
+    machines report node -1, containers may hide sysfs)."""
+    base = os.path.join(sysfs_pci, pci_addr)
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None, []
+    try:
+        cpus = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except (OSError, ValueError):
+        cpus = []
+    return (node if node >= 0 else None), cpus
+
+
+def bind_to_gpu_numa(device_index: int, sysfs_pci: str = "/sys/bus/pci/devices") -> Dict[str, object]:
+    """Confine this process to the CPUs local to GPU `device_index` (intersection with the affinity it already has).  Call it BEFORE
+    allocating pinned buffers or starting worker threads.  Returns what was found and done; never raises for a missing sysfs."""
+    info: Dict[str, object] = {"device": device_index, "numa_node": None, "bound": False}
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        addr = pci_address(int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(p.pci_device_id))
+    except Exception as e:  # noqa: BLE001  (no GPU, or a torch build without the PCI fields)
+        info["why"] = f"no PCI address: {e}"
+        return info
+    info["pci"] = addr
+    node, cpus = gpu_numa_cpus(addr, sysfs_pci)
+    info["numa_node"] = node
+    allowed = os.sched_getaffinity(0)
+    want = sorted(set(cpus) & allowed)
+    if node is None or not want or set(want) == set(allowed):
+        info["why"] = "platform reports no NUMA locality for this device" if node is None or not cpus else "already confined to the local CPUs"
+        return info
+    os.sched_setaffinity(0, want)
+    info.update(bound=True, cpus=len(want))
+    return info
