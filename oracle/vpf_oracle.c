@@ -707,8 +707,9 @@ static int resize_plane(int mode, int interp, int ch, uint32_t sw, uint32_t sh, 
  *   w_k = L(f - (k - 2)),  L(t) = sinc(t) sinc(t/3),  weights normalised to sum 1, no widening when minifying.
  * EXACT: double + libm.  FP32: the kernels' arithmetic — sin(pi f), sin(pi f/3), cos(pi f/3) from fixed fma polynomials (so host
  * and device agree bit for bit), the six taps from angle-addition identities; on 8-bit surfaces BOTH passes then run in integers on
- * Q14 weights (lanczos_weights_q14) with the row sums rounded to Q6 in between (see resize_plane_lanczos; round 3 — the vertical pass
- * was an fp32 fma chain before, which an integer matrix unit cannot reproduce); float surfaces stay fp32 throughout.
+ * Q14 weights (lanczos_weights_q14) with the row sums rounded to Q6 in between and the vertical products formed from byte-wide partial
+ * products (see resize_plane_lanczos; round 3 — the vertical pass was an fp32 fma chain before, which an integer matrix unit cannot
+ * reproduce); float surfaces stay fp32 throughout.
  * ------------------------------------------------------------------------------------------ */
 static inline float lz_sinpi_poly(float g) { /* sin(pi g), g in [0, 0.5]; odd Taylor polynomial in x = pi g, degree 11 */
   const float x = 3.14159274f * g, x2 = x * x;
@@ -832,18 +833,29 @@ static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, cons
           }
           const double v = floor(acc + 0.5);
           o[ch * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-        } else { /* kernel arithmetic, all integers and therefore order-free (the MFMA kernel sums 64 terms per instruction, the gather
-                    kernel six): H = sum q_x p exact (Q14); Hr = (H + 128) >> 8 = H rounded half up to Q6, which fits 16 bits (Lanczos
-                    overshoot included: -4.5k .. 20.8k); V = sum q_y Hr exact in 32 bits (Q20); out = clamp((V + 2^19) >> 20).  The two
-                    roundings move the result by < 0.02 LSB + the Q14 weight quantisation: within 1 LSB of EXACT (test_oracle_kat.py). */
-          int32_t v = 0;
+        } else { /* kernel arithmetic, all integers and therefore order-free (the MFMA kernel sums 64 or 128 terms per instruction, the gather
+                    kernel six).  H = sum q_x p exact (Q14); Hr = (H + 128) >> 8 = H rounded half up to Q6, which fits 16 bits (Lanczos
+                    overshoot included: -4.5k .. 20.8k).  The vertical pass multiplies 16-bit Hr by 15-bit q_y the way a byte-wide matrix unit
+                    does: both factors as two signed bytes about a centre, z = Hr - 8192 = 256 zh + zl and q_y = 256 qh + ql with zl, ql in
+                    [-128, 127], and the product as its three upper partial products — qh zh 2^16 + (qh zl + ql zh) 2^8; the lowest one, ql zl
+                    (|.| <= 2^14 per tap, < 0.1 LSB of the result over six taps, 0.013 LSB rms), is NOT formed (round 3: it costs a fourth
+                    matrix instruction and a shift-add per output byte in a kernel that is issue-bound).  V = sum (q_y z - ql zl) + 8192 * 16384
+                    is a multiple of 256; out = clamp((V / 256 + 2^11) >> 12).  Identity (q = 0 0 16384 0 0 0: ql = 0) stays exact, a flat
+                    picture stays flat, and the result is within 1 LSB of EXACT (test_oracle_kat.py). */
+          int32_t v = 1 << 19; /* 8192 * 16384 / 256 */
           for (int ky = 0; ky < 6; ky++) {
+            /* taps that the edge clamp puts on the same source row act as ONE tap with the summed weight (it is the weight of the row
+               that is split into bytes, whoever contributes to it): the run's last tap carries the sum */
+            int32_t q = ty[yy].q[ky];
+            while (ky < 5 && ty[yy].idx[ky + 1] == ty[yy].idx[ky]) q += ty[yy].q[++ky];
             const uint8_t* r = prow(s, (uint32_t)ty[yy].idx[ky]);
             int32_t h = 0;
             for (int kx = 0; kx < 6; kx++) h += tx[x].q[kx] * (int32_t)r[ch * tx[x].idx[kx] + c];
-            v += ty[yy].q[ky] * asr32(h + 128, 8);
+            const int32_t z = asr32(h + 128, 8) - 8192;
+            const int32_t zl = ((z + 128) & 0xff) - 128, ql = ((q + 128) & 0xff) - 128;
+            v += asr32(q * z - ql * zl, 8); /* exact: the difference is a multiple of 256 */
           }
-          v = asr32(v + (1 << 19), 20);
+          v = asr32(v + (1 << 11), 12);
           o[ch * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         }
       }

@@ -14,9 +14,12 @@ Layout facts modelled (kernel comments carry the same names):
                         lie in [ws_j, ws_j + 64)  (host bound, vpf_plan_bounds.h)
   pass 1                D[row i][n] = sum_k A[i][k] B[k][n],  A = source bytes - 128 (16 rows x 64 window bytes),
                         B = Q14 weight split into two signed bytes (w = 256 wh + wl): two MFMAs -> HI, LO;  h'' = ((HI + 128) << 8) + LO + 128
-                        byte 2 of h'' = hb (signed), byte 1 of h'' ^ 0x80 = lb (signed):  Hr - 8192 = 256 hb + lb
-  ring                  the packed hb / lb bytes of the last four 16-row tiles: slot T & 3, K slot (g, 4 p + r) <-> source row 16 T + 4 g + r
-  pass 2                D[n][y] = sum over the ring's 64 rows: HH, MID = HL + LH, LL;  V = 65536 HH + 256 MID + LL + 2^27;  out = clamp((V + 2^19) >> 20)
+                        bits 8..23 of h'' = z + 128 with z = Hr - 8192 = 256 zh + zl: byte 2 = zh (signed), byte 1 ^ 0x80 = zl (signed)
+  ring                  the (zl, zh) byte PAIRS of the last four 16-row tiles, two K chunks of two tiles: tile in slot p = (T - t_first) & 3 ->
+                        chunk p >> 1, K slot (g, 8 (p & 1) + 2 r + s) <-> source row 16 T + 4 g + r, s = 0: zl, s = 1: zh
+  pass 2                D[n][y] = sum over the ring's 64 rows x 2 bytes: X = sum qh zh, Y = sum (ql zh + qh zl) (the weight operands carry
+                        qh at the zh slots for X; ql at the zh slots and qh at the zl slots for Y; ql zl is not formed);
+                        out = clamp((256 X + Y + 2^19 + 2^11) >> 12)
 """
 import numpy as np
 
@@ -97,23 +100,29 @@ class Model:
         P = self.P if self.P else ((ws[-1] - S0 + 64 + 255) & ~255) + 32
         assert ws[-1] - S0 + 64 <= P
         # ---- the march
-        ring = np.zeros((2, nt, 4, 16, 16), np.int8)   # [plane][j][slot p][row i of the tile][n]; garbage before first use is fine, zero here
-        ring[:] = self.rng.integers(-128, 128, ring.shape, dtype=np.int8)  # ... but the kernel must not depend on it: poison
+        ring = np.zeros((2, nt, 4, 16, 16), np.int8)   # [byte s: zl, zh][j][slot p][row i of the tile][n]
+        ring[:] = self.rng.integers(-128, 128, ring.shape, dtype=np.int8)  # whatever it held before first use must not matter: poison
+        t_first = None
         t_done = None
         ngroups = (yb - ya + 64) // 64
         for G in range(ngroups):
             rows = [min(ya + 64 * G + l, yb) for l in range(64)]
             taps = [merged_taps(int(self.i0y[y]), self.qy[6 * y:6 * y + 6], sh) for y in rows]
             ntile = min(4, (yb - (ya + 64 * G)) // 16 + 1)
-            # vertical weight operands of the group's four destination tiles: Wm[t][plane][k slot = 16 g + 4 p + r][y]
-            Wm = np.zeros((4, 2, 64, 16), np.int8)
+            if t_first is None:
+                t_first = taps[0][0][0] >> 4          # first source tile of the band: ring slots are numbered from it
+            # vertical weight operands of the group's four destination tiles: Wm[t][X | Y][chunk c][k slot = 16 g + 8 (p & 1) + 2 r + s][y]
+            Wm = np.zeros((4, 2, 2, 64, 16), np.int8)
             for l in range(64):
                 t, y = l >> 4, l & 15
                 for pos, w in taps[l]:
                     T, g, r = pos >> 4, (pos >> 2) & 3, pos & 3
-                    slot = 16 * g + 4 * (T & 3) + r
-                    assert Wm[t, 0, slot, y] == 0 and Wm[t, 1, slot, y] == 0
-                    Wm[t, 0, slot, y], Wm[t, 1, slot, y] = split_i8(w)
+                    p = (T - t_first) & 3
+                    slot = 16 * g + 8 * (p & 1) + 2 * r
+                    qh, ql = split_i8(w)
+                    assert not Wm[t, :, p >> 1, slot:slot + 2, y].any()
+                    Wm[t, 0, p >> 1, slot + 1, y] = qh                                  # X: qh against zh
+                    Wm[t, 1, p >> 1, slot, y], Wm[t, 1, p >> 1, slot + 1, y] = qh, ql   # Y: qh against zl, ql against zh
             for t in range(ntile):
                 tmin = taps[16 * t][0][0] >> 4
                 tmax = taps[16 * t + 15][-1][0] >> 4
@@ -123,12 +132,12 @@ class Model:
                     t_done = tmin - 1
                 while t_done < tmax:
                     t_done += 1
-                    self.pass1(src, ring, B1, ws, S0, P, t_done)
+                    self.pass1(src, ring, B1, ws, S0, P, t_done, t_first)
                 # every source tile this destination tile needs is one of the last four produced
                 assert tmin >= t_done - 3
                 self.emit(dst, ring, Wm[t], ob0, ya + 64 * G + 16 * t, yb)
 
-    def pass1(self, src, ring, B1, ws, S0, P, T):
+    def pass1(self, src, ring, B1, ws, S0, P, T, t_first):
         ch, nt, sw, sh = self.ch, self.nt, self.sw, self.sh
         # staging: rows 16 T .. 16 T + 15 (clamped), bytes [S0, S0 + P): real bytes where the row has them, garbage elsewhere
         stage = self.rng.integers(0, 256, (16, P), dtype=np.uint8)
@@ -143,26 +152,29 @@ class Model:
             HI = mfma_i8(A, B1[0, j], 128)
             LO = mfma_i8(A, B1[1, j], 128)
             h2 = ((HI.astype(np.int64) << 8) + LO).astype(np.int64) & 0xffffffff
-            hb = ((h2 >> 16) & 0xff).astype(np.uint8).view(np.int8)
-            lb = (((h2 >> 8) & 0xff) ^ 0x80).astype(np.uint8).view(np.int8)
-            ring[0, j, T & 3], ring[1, j, T & 3] = hb, lb
+            zh = ((h2 >> 16) & 0xff).astype(np.uint8).view(np.int8)
+            zl = (((h2 >> 8) & 0xff) ^ 0x80).astype(np.uint8).view(np.int8)
+            ring[0, j, (T - t_first) & 3], ring[1, j, (T - t_first) & 3] = zl, zh
 
     def emit(self, dst, ring, W, ob0, y0, yb):
         ch, nt = self.ch, self.nt
         dwb = self.dw * ch
         for j in range(nt):
-            # A2[n][k slot = 16 g + 4 p + r] = ring[.., j, p, row 4 g + r, n]
-            A2 = np.zeros((2, 16, 64), np.int8)
-            for g in range(4):
-                for p in range(4):
-                    for r in range(4):
-                        A2[:, :, 16 * g + 4 * p + r] = ring[:, j, p, 4 * g + r, :]
-            HH = mfma_i8(A2[0], W[0], 0)
-            MID = mfma_i8(A2[0], W[1], 0) + mfma_i8(A2[1], W[0], 0)
-            LL = mfma_i8(A2[1], W[1], (1 << 27) + (1 << 19))
-            V = (HH.astype(np.int64) << 16) + (MID.astype(np.int64) << 8) + LL
+            # chunk c: A2[n][k slot = 16 g + 8 (p & 1) + 2 r + s] = ring[s, j, p, row 4 g + r, n] for the two tiles p = 2 c, 2 c + 1
+            X = np.zeros((16, 16), np.int32)
+            Y = np.full((16, 16), (1 << 19) + (1 << 11), np.int32)
+            for c in range(2):
+                A2 = np.zeros((16, 64), np.int8)
+                for g in range(4):
+                    for pp in range(2):
+                        for r in range(4):
+                            for sb in range(2):
+                                A2[:, 16 * g + 8 * pp + 2 * r + sb] = ring[sb, j, 2 * c + pp, 4 * g + r, :]
+                X = X + mfma_i8(A2, W[0, c], 0)
+                Y = Y + mfma_i8(A2, W[1, c], 0)
+            V = (X.astype(np.int64) << 8) + Y
             assert np.all(np.abs(V) < 2 ** 31)
-            out = np.clip(V >> 20, 0, 255).astype(np.uint8)   # [n][y]
+            out = np.clip(V >> 12, 0, 255).astype(np.uint8)   # [n][y]
             for y in range(16):
                 if y0 + y > yb:
                     break

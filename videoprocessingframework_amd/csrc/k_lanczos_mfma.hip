@@ -88,7 +88,8 @@ struct LanczosMfmaTask {
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
 
-constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles (one "group" of 64 rows)
+constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles (one "group" of 64 rows):
+                                                                                 // per tile the Y operand of the ring's two K chunks (X is derived from it)
 constexpr uint32_t kLzmB1Chunk = 4;                                              // N-tiles whose column-weight operands are built per pass through LDS
 constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
 constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of wave-private LDS: staged tile | out tile, or the setup scratch
@@ -131,16 +132,18 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     u32x4* z = reinterpret_cast<u32x4*>(wm);
 #pragma unroll
     for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+    // operand image of destination tile t = lane >> 4: [chunk c][lane 16 g + y][16 B] of the Y operand; the tile in ring slot
+    // p = (T - t_first) & 3 sits in chunk p >> 1, and source row 16 T + 4 g + r owns the byte pair 8 (p & 1) + 2 r (zl) / + 1 (zh): Y carries qh
+    // against zl and ql against zh (the X operand — qh against zh, nothing against zl — is (Y << 8) & 0xff00ff00: pass 2 derives it)
     uint8_t* const cell = wm + ((lane >> 4) * 2 * 64 + (lane & 15)) * 16;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       if (m.pos[k] < 0) continue;
-      const uint32_t pos = (uint32_t)m.pos[k];
+      const uint32_t pos = (uint32_t)m.pos[k], p = ((pos >> 4) - (uint32_t)t_first) & 3;
       int32_t hi, lo;
       split_i8(m.q[k], hi, lo);
-      uint8_t* const a = cell + ((pos >> 2) & 3) * 256 + 4 * (((pos >> 4) - (uint32_t)t_first) & 3) + (pos & 3);
-      a[0] = (uint8_t)hi;
-      a[64 * 16] = (uint8_t)lo;
+      uint8_t* const a = cell + (p >> 1) * 1024 + ((pos >> 2) & 3) * 256 + 8 * (p & 1) + 2 * (pos & 3);
+      *reinterpret_cast<uint16_t*>(a) = (uint16_t)(((uint32_t)hi & 0xffu) | (((uint32_t)lo & 0xffu) << 8));
     }
   };
   // the step from group g to g + 1: everybody is done with g's buffer, g + 1 is complete; g + 2 goes where g was
@@ -245,9 +248,9 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #pragma unroll
     for (int k = 0; k < PF; k++) pf[SET][k] = ldg<false, u32x4>(row + soff[k]);
   };
-  v4i ringH[NT], ringL[NT];
+  v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs)
 #pragma unroll
-  for (int j = 0; j < NT; j++) { ringH[j] = v4i{0, 0, 0, 0}; ringL[j] = v4i{0, 0, 0, 0}; }
+  for (int j = 0; j < NT; j++) { ring[j][0] = v4i{0, 0, 0, 0}; ring[j][1] = v4i{0, 0, 0, 0}; }
   const v4i c128 = {128, 128, 128, 128};
   // A operand of pass 1: lane (i, g) -> row i, bytes 16 g .. of tile j's window (one address register per tile: the kernel is issue-bound,
   // an add per read is 7 % of pass 1)
@@ -280,15 +283,16 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
       uint32_t h[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[r] << 8) + (uint32_t)lo[r];
-      const uint32_t p01 = __builtin_amdgcn_perm(h[1], h[0], 0x06050201u), p23 = __builtin_amdgcn_perm(h[3], h[2], 0x06050201u);
-      ringH[j][SLOT] = (int32_t)__builtin_amdgcn_perm(p23, p01, 0x07050301u);
-      ringL[j][SLOT] = (int32_t)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+      // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
+      // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
+      ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
+      ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
     }
     wave_lds_sync();  // the next tile's staging stores must not pass these reads
   };
 
   // pass 2 + store of one destination tile: rows y0 .. y0 + 15, weight operands of tile t of the current group
-  const v4i cll = {(1 << 27) + (1 << 19), (1 << 27) + (1 << 19), (1 << 27) + (1 << 19), (1 << 27) + (1 << 19)};
+  const v4i cy = {(1 << 19) + (1 << 11), (1 << 19) + (1 << 11), (1 << 19) + (1 << 11), (1 << 19) + (1 << 11)};  // 8192 * 16384 / 256 + the rounding half
   const v4i czero = {0, 0, 0, 0};
   constexpr uint32_t LOGNT = NT == 8 ? 3 : 2, RPI = 64 / NT;  // read-back: lane -> (row lane >> LOGNT (+ RPI per pass), unit lane & (NT - 1))
   uint8_t* const owr = ot + (lane & 15) * PO + 4u * (lane >> 4);      // lane (y, g') writes bytes 4 g' .. 4 g' + 3 of every tile of row y
@@ -297,17 +301,18 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
   uint8_t* const obase = dst + (size_t)(lane >> LOGNT) * dp + ob;
   auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
-    const v4i b2h = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16);
-    const v4i b2l = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
+    const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16), by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
+    const v4i hmask = {(int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u};
+    const v4i bx0 = (by0 << 8) & hmask, bx1 = (by1 << 8) & hmask;  // qh moves from the zl slot to the zh slot, the zl slots become 0
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      const v4i hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringH[j], b2h, czero, 0, 0, 0);
-      v4i mid = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringH[j], b2l, czero, 0, 0, 0);
-      mid = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringL[j], b2h, mid, 0, 0, 0);
-      const v4i ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(ringL[j], b2l, cll, 0, 0, 0);
+      v4i x = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], bx0, czero, 0, 0, 0);
+      x = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], bx1, x, 0, 0, 0);
+      v4i y = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], by0, cy, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], by1, y, 0, 0, 0);
       int32_t o[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) o[r] = (int32_t)(((uint32_t)hh[r] << 16) + opaque(((uint32_t)mid[r] << 8) + (uint32_t)ll[r])) >> 20;
+      for (int r = 0; r < 4; r++) o[r] = (int32_t)(((uint32_t)x[r] << 8) + (uint32_t)y[r]) >> 12;  // (V / 256 + 2^11) >> 12
       const uint32_t q01 = sat_pk_u8_i16(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[0], o[1])));
       const uint32_t q23 = sat_pk_u8_i16(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[2], o[3])));
       *reinterpret_cast<uint32_t*>(owr + 16u * j) = __builtin_amdgcn_perm(q23, q01, 0x05040100u);

@@ -119,31 +119,41 @@ VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_
     const int32_t i = tx.i0 + k - 2;
     xi[k] = (uint32_t)(i < 0 ? 0 : (i > (int32_t)sw - 1 ? (int32_t)sw - 1 : i)) * CH;
   }
+  // vertical pass on byte-wide partial products (the arithmetic of the matrix-core kernel, restated by the oracle): z = Hr - 8192 and the
+  // row's weight q as two signed bytes each, q z without its lowest partial product ql zl; taps the edge clamp puts on the same source row
+  // act as one tap with the summed weight
   int32_t acc[CH];
 #pragma unroll
-  for (int c = 0; c < CH; c++) acc[c] = 1 << 19;
+  for (int c = 0; c < CH; c++) acc[c] = (1 << 19) + (1 << 11);
+  int32_t qrun = 0;
 #pragma unroll
   for (int ky = 0; ky < 6; ky++) {
-    const int32_t j = ty.i0 + ky - 2;
-    const uint8_t* r = src + (size_t)(j < 0 ? 0 : (j > (int32_t)sh - 1 ? (int32_t)sh - 1 : j)) * sp;
+    const int32_t j = ty.i0 + ky - 2, hi = (int32_t)sh - 1;
+    const int32_t row = j < 0 ? 0 : (j > hi ? hi : j), nxt = j + 1 < 0 ? 0 : (j + 1 > hi ? hi : j + 1);
+    qrun += ty.q[ky];
+    if (ky < 5 && nxt == row) continue;  // the run goes on: its last tap carries the sum
+    const uint8_t* r = src + (size_t)row * sp;
     uint8_t v[6][CH];  // all taps of the row requested before the first is used (see k_resize_f32)
 #pragma unroll
     for (int kx = 0; kx < 6; kx++)
 #pragma unroll
       for (int c = 0; c < CH; c++) v[kx][c] = r[xi[kx] + c];
     __builtin_amdgcn_sched_barrier(0);
+    const int32_t ql = ((qrun + 128) & 0xff) - 128;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       int32_t h = 0;  // exact: |h| <= 255 * sum |q| < 2^24
 #pragma unroll
       for (int kx = 0; kx < 6; kx++) h += tx.q[kx] * (int32_t)v[kx][c];
-      acc[c] += ty.q[ky] * ((h + 128) >> 8);  // the row sum rounded half up to Q6 (fits 16 bits); exact: |acc| < 2^30
+      const int32_t z = ((h + 128) >> 8) - 8192, zl = ((z + 128) & 0xff) - 128;
+      acc[c] += (qrun * z - ql * zl) >> 8;  // a multiple of 256: exact
     }
+    qrun = 0;
   }
   uint8_t* o = dst + (size_t)y * dp + (size_t)CH * x;
 #pragma unroll
   for (int c = 0; c < CH; c++) {
-    const int32_t v = acc[c] >> 20;  // (V + 2^19) >> 20: round half up
+    const int32_t v = acc[c] >> 12;  // (V / 256 + 2^19 + 2^11) >> 12: round half up
     o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
   }
 }
