@@ -223,8 +223,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint32_t nq_win = (wrel[NT - 1] + 64u) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
   const uint32_t nq = nq_win < nq_row ? nq_win : nq_row;
   const uint32_t srow = lane >> 2, sq = lane & 3;  // staging: lane -> (row of the tile, unit (lane & 3) + 4 k)
-  // the units a lane stages: (lane & 3) + 4 k, clamped to the last one instead of predicated (all loads issue back to back; the clamped
-  // duplicates land in LDS units >= nq, which carry no weight — 4 PF units always fit the pitch)
+  // the units a lane stages: (lane & 3) + 4 k, clamped to the last one instead of predicated (all loads issue back to back; a clamped
+  // duplicate is loaded from AND stored to the last unit's place — the pitch need not hold 4 PF units)
   uint32_t soff[PF];
 #pragma unroll
   for (int k = 0; k < PF; k++) soff[k] = 16u * (sq + 4u * k < nq ? sq + 4u * k : nq - 1u);
@@ -257,7 +257,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint8_t* aptr[NT];
 #pragma unroll
   for (int j = 0; j < NT; j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
-  uint8_t* const sdst = stage + srow * P + 16u * sq;
+  uint8_t* const sdst = stage + srow * P;
 
   // pass 1 of source tile T into ring slot SLOT = (T - t_first) & 3 (a compile-time constant: the march below is unrolled four deep so
   // that the ring never moves in the register file)
@@ -265,7 +265,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int k = 0; k < PF; k++)
-      *reinterpret_cast<u32x4*>(sdst + 64u * k) = pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+      *reinterpret_cast<u32x4*>(sdst + soff[k]) = pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
     fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
     wave_lds_sync();
     // every A operand of the tile is requested before the first is used: one LDS latency per source tile, not one per pair of reads
@@ -369,6 +369,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 
 template <int CH> struct LzMfma8 : LanczosMfmaTask<CH, 8, 4> {};   // strips of 8 tiles, staged rows of up to 256 B
 template <int CH> struct LzMfma8n : LanczosMfmaTask<CH, 8, 2> {};  // ... of up to 128 B (up-scales)
+template <int CH> struct LzMfma8w : LanczosMfmaTask<CH, 8, 5> {};  // ... of up to 320 B (2x down-scales)
 template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
 template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 
@@ -455,7 +456,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     }
     pitch = vpf_bound_lzm_pitch(span);
     wave_lds = lzm_wave_lds(nt, pitch);
-    return span <= 4u * 64u && lzm_group_lds(nt, pitch) <= kLzmMaxLds;  // PF = 4 staging loads of 4 lanes x 16 B per row
+    return span <= (nt == 8 ? 5u : 4u) * 64u && lzm_group_lds(nt, pitch) <= kLzmMaxLds;  // PF staging loads of 4 lanes x 16 B per row
   };
   if (!fits()) {
     if (nt != 8) return false;
@@ -484,10 +485,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const dim3 grid(gx, gy, n);
   const uint32_t lds = lzm_group_lds(nt, pitch);
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
-  if (lds > 64u * 1024u && !(nt == 8 ? lzm_big_lds_ok<LzMfma8>() : lzm_big_lds_ok<LzMfma4>())) return false;  // (only wide strips get there)
+  if (lds > 64u * 1024u && !(nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
                            hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t); } while (0)
   if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);
+  else if (nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzMfma8w);
   else if (nt == 8) VPF_LZM_GO(LzMfma8);
   else if (narrow) VPF_LZM_GO(LzMfma4n);
   else VPF_LZM_GO(LzMfma4);
