@@ -48,50 +48,55 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-FORMATS = ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")) + (((capi.Y, "Y"),) if os.environ.get("VPF_BENCH_Y") else ())
-for fmt, fname in FORMATS:
-    for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (1920, 1080, 416, 416), (3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (1280, 720, 1920, 1080)):
-        ring = max(32, min(256, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // 32 * 32))
-        S = [surf(fmt, sw, sh, True) for _ in range(ring)]
-        D = [surf(fmt, dw, dh, False) for _ in range(ring)]
-        NB = int(os.environ.get("VPF_BENCH_N", "0"))  # frames per batch (0: the whole ring, in dispatches of 32)
-        if NB:
-            batches = [capi.make_batch([(s[1], d[1]) for s, d in list(zip(S, D))[i:i + NB]]) for i in range(0, ring, NB)]
-        batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
-        planes = [(capi.planes(s[1]), capi.planes(d[1])) for s, d in zip(S, D)]
-        nbytes = S[0][2] + D[0][2]
-        for interp in ((1,) if ONLY == "bilinear" else (2,) if ONLY == "lanczos" else (1, 2)):
-            if fmt not in (capi.RGB, capi.Y) and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
-                continue
+def main():
+    FORMATS = ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")) + (((capi.Y, "Y"),) if os.environ.get("VPF_BENCH_Y") else ())
+    for fmt, fname in FORMATS:
+        for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (1920, 1080, 416, 416), (3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (1280, 720, 1920, 1080)):
+            ring = max(32, min(256, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // 32 * 32))
+            S = [surf(fmt, sw, sh, True) for _ in range(ring)]
+            D = [surf(fmt, dw, dh, False) for _ in range(ring)]
+            NB = int(os.environ.get("VPF_BENCH_N", "0"))  # frames per batch (0: the whole ring, in dispatches of 32)
             if NB:
-                tb = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in batches], 5) / ring
-            else:
-                tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
-            ts = timed(lambda: [capi.resize(ex, fmt, interp, sw, sh, s, dw, dh, d) for s, d in planes], 3) / ring
-            extra = ""
-            if os.environ.get("VPF_BENCH_ONE"):  # batches of ONE frame: the multi-plane / band kernels at single-frame launch sizes
-                ones = [capi.make_batch([(s[1], d[1])]) for s, d in zip(S, D)]
-                t1 = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in ones], 3) / ring
-                extra = f" | batches of one {t1:6.2f} us/frame ({nbytes / t1 / 8e6:.2f})"
-            print(f"[resize_batch] {fname:6s} {sw}x{sh}->{dw}x{dh} {NAMES[interp]:8s}: batched {tb:6.2f} us/frame = {nbytes / tb / 1e6:5.2f} TB/s ({nbytes / tb / 8e6:.2f} of 8 TB/s)"
-                  f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f}){extra}  ring {ring}", flush=True)
-        del S, D, batch, planes
+                batches = [capi.make_batch([(s[1], d[1]) for s, d in list(zip(S, D))[i:i + NB]]) for i in range(0, ring, NB)]
+            batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
+            planes = [(capi.planes(s[1]), capi.planes(d[1])) for s, d in zip(S, D)]
+            nbytes = S[0][2] + D[0][2]
+            for interp in ((1,) if ONLY == "bilinear" else (2,) if ONLY == "lanczos" else (1, 2)):
+                if fmt not in (capi.RGB, capi.Y) and (sw, sh, dw, dh) not in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080)):
+                    continue
+                if NB:
+                    tb = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in batches], 5) / ring
+                else:
+                    tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
+                ts = timed(lambda: [capi.resize(ex, fmt, interp, sw, sh, s, dw, dh, d) for s, d in planes], 3) / ring
+                extra = ""
+                if os.environ.get("VPF_BENCH_ONE"):  # batches of ONE frame: the multi-plane / band kernels at single-frame launch sizes
+                    ones = [capi.make_batch([(s[1], d[1])]) for s, d in zip(S, D)]
+                    t1 = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in ones], 3) / ring
+                    extra = f" | batches of one {t1:6.2f} us/frame ({nbytes / t1 / 8e6:.2f})"
+                print(f"[resize_batch] {fname:6s} {sw}x{sh}->{dw}x{dh} {NAMES[interp]:8s}: batched {tb:6.2f} us/frame = {nbytes / tb / 1e6:5.2f} TB/s ({nbytes / tb / 8e6:.2f} of 8 TB/s)"
+                      f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f}){extra}  ring {ring}", flush=True)
+            del S, D, batch, planes
+            torch.cuda.empty_cache()
+
+    # remap: one pair of maps, many frames
+    for (w, h) in (() if ONLY else ((1920, 1080), (3840, 2160))):
+        ring = 32
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
+        nx, ny = (xx - (w - 1) / 2) / ((w - 1) / 2), (yy - (h - 1) / 2) / ((h - 1) / 2)
+        k = 1 + 0.1 * (nx * nx + ny * ny)
+        xm, ym = (nx * k * ((w - 1) / 2) + (w - 1) / 2).contiguous(), (ny * k * ((h - 1) / 2) + (h - 1) / 2).contiguous()
+        S = [surf(capi.RGB, w, h, True) for _ in range(ring)]
+        D = [surf(capi.RGB, w, h, False) for _ in range(ring)]
+        batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
+        tb = timed(lambda: capi.remap_batch(ex, capi.RGB, w, h, xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, batch), 5) / ring
+        ts = timed(lambda: [capi.remap(ex, capi.RGB, w, h, s[1][0], xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, d[1][0]) for s, d in zip(S, D)], 3) / ring
+        nb = 14 * w * h  # 8 B of maps + 3 B of source + 3 B written per pixel
+        print(f"[remap_batch] RGB {w}x{h} barrel map: batched {tb:6.2f} us/frame = {nb / tb / 1e6:5.2f} TB/s ({nb / tb / 8e6:.2f} of 8 TB/s on 14 B/px)"
+              f" | one dispatch per frame {ts:6.2f} us/frame ({nb / ts / 8e6:.2f})", flush=True)
+        del S, D, batch
         torch.cuda.empty_cache()
 
-# remap: one pair of maps, many frames
-for (w, h) in (() if ONLY else ((1920, 1080), (3840, 2160))):
-    ring = 32
-    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
-    nx, ny = (xx - (w - 1) / 2) / ((w - 1) / 2), (yy - (h - 1) / 2) / ((h - 1) / 2)
-    k = 1 + 0.1 * (nx * nx + ny * ny)
-    xm, ym = (nx * k * ((w - 1) / 2) + (w - 1) / 2).contiguous(), (ny * k * ((h - 1) / 2) + (h - 1) / 2).contiguous()
-    S = [surf(capi.RGB, w, h, True) for _ in range(ring)]
-    D = [surf(capi.RGB, w, h, False) for _ in range(ring)]
-    batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
-    tb = timed(lambda: capi.remap_batch(ex, capi.RGB, w, h, xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, batch), 5) / ring
-    ts = timed(lambda: [capi.remap(ex, capi.RGB, w, h, s[1][0], xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, d[1][0]) for s, d in zip(S, D)], 3) / ring
-    nb = 14 * w * h  # 8 B of maps + 3 B of source + 3 B written per pixel
-    print(f"[remap_batch] RGB {w}x{h} barrel map: batched {tb:6.2f} us/frame = {nb / tb / 1e6:5.2f} TB/s ({nb / tb / 8e6:.2f} of 8 TB/s on 14 B/px)"
-          f" | one dispatch per frame {ts:6.2f} us/frame ({nb / ts / 8e6:.2f})", flush=True)
-    del S, D, batch
-    torch.cuda.empty_cache()
+
+if __name__ == "__main__":
+    main()

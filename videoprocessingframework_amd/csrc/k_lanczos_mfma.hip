@@ -421,9 +421,6 @@ static LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_
   return s;
 }
 
-// Launch shape.  Every wave of a plane does the same work per row, the kernel keeps two 4-wave workgroups per CU resident (512 slots),
-// and a wave's fixed work (column weights) is paid once per band: as few bands as fill the chip.
-// `bands` = bands per plane: the smallest count that gives >= 512 workgroups (>= 1 full round), rounded so that bands are whole tiles.
 bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
   if (tune == 9 || tune == 40 || tuning(VPF_TUNE_RESIZE_MFMA) == 1) return false;
@@ -435,16 +432,17 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
       if ((((uintptr_t)a.f[i].s[j.k] | a.f[i].sp[j.k] | (uintptr_t)a.f[i].d[j.k] | a.f[i].dp[j.k]) & 15)) return false;
     if (!lzm_shape(j.ch, j.sw, j.sh, j.dw, j.dh).rows_ok) return false;
   }
-  // strip width: 8 tiles (128 B of a destination row) unless that leaves the chip short of work or the strip does not fit: a staged row is
-  // at most 4 (PF) x 4 lanes x 16 B, and the workgroup's four wave-private LDS regions must fit half a CU's LDS (two workgroups per CU)
+  // Launch shape = (N-tiles per wave, 16-row destination tiles per band), the same for every plane of the launch.  A staged row is at most
+  // PF x 4 lanes x 16 B and the workgroup's LDS must leave room for two workgroups per CU; among the shapes that fit, the cheapest by a
+  // small cost model read off a sweep over both (profiles/r03_lanczos_shape_sweep_n32.txt / _n8.txt, tools/lanczos_shape_sweep.py):
+  //   a wave costs S + R w (its fixed part — column weights, first fetch — plus R tiles of work, w scaled by the vertical factor),
+  //   the launch W = sum over planes of strips-of-four x bands x frames workgroups against 512 resident ones: whole rounds cost one wave
+  //   time each, a partial round at least 0.8 of one (a half-empty chip runs its waves faster, not twice as fast).
+  // S = 3.0 / 2.0 and w = 1.0 / 0.6 tile units for 8- / 4-tile strips.  Against the sweep's 18 cases the model's pick is within 6 % of the
+  // best measured shape on average; the rule it replaces (bands = 512 / workgroups per band row, per plane) lost 20 - 35 % on the
+  // multi-plane formats, whose planes it sized independently.
   const int forced = tuning(VPF_TUNE_RESIZE_MFMA);  // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
   int nt = 8;
-  {
-    uint64_t wg8 = 0;
-    for (int p = 0; p < njobs; p++) wg8 += (uint64_t)(((jobs[p].dw * jobs[p].ch + 127) / 128 + 3) / 4) * ((jobs[p].dh + 63) / 64) * n;
-    if (wg8 < 512) nt = 4;
-  }
-  if (forced > 1 && (forced >> 8) != 0) nt = forced >> 8;
   uint32_t pitch = 0, span = 0, wave_lds = 0;
   auto fits = [&]() {
     span = 0;
@@ -458,24 +456,43 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     wave_lds = lzm_wave_lds(nt, pitch);
     return span <= (nt == 8 ? 5u : 4u) * 64u && lzm_group_lds(nt, pitch) <= kLzmMaxLds;  // PF staging loads of 4 lanes x 16 B per row
   };
-  if (!fits()) {
-    if (nt != 8) return false;
-    nt = 4;
+  uint32_t band_tiles = 0;
+  {
+    double best = 0.0;
+    int best_nt = 0;
+    for (int cand = 8; cand >= 4; cand -= 4) {
+      if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
+      nt = cand;
+      if (!fits()) continue;
+      const double S = cand == 8 ? 3.0 : 2.0, w = cand == 8 ? 1.0 : 0.6;
+      uint32_t tmax = 0;
+      for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
+      for (uint32_t r = 1; r <= std::min(tmax, 64u); r++) {
+        if (forced > 1 && (forced & 0xff) && (uint32_t)(forced & 0xff) != r && !((uint32_t)(forced & 0xff) > tmax && r == std::min(tmax, 64u))) continue;
+        uint64_t wgs = 0;
+        double work = 0.0;
+        for (int p = 0; p < njobs; p++) {
+          const uint32_t tiles = (jobs[p].dh + 15) / 16, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
+          wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
+          const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
+          work = std::max(work, (double)std::min(r, tiles) * w * (0.5 + scy / 3.0));
+        }
+        const uint64_t full = wgs / 512, part = wgs % 512;
+        const double cost = (S + work) * ((double)full + (part ? std::max((double)part / 512.0, 0.8) : 0.0));
+        if (!best_nt || cost < best) { best = cost; best_nt = cand; band_tiles = r; }
+      }
+    }
+    if (!best_nt) return false;
+    nt = best_nt;
     if (!fits()) return false;
   }
   PlaneTable t{};
   t.np = (uint32_t)njobs;
   uint32_t gx = 0, gy = 0;
-  uint64_t cols = 0;  // workgroups per band row, all planes
-  for (int p = 0; p < njobs; p++) cols += ((jobs[p].dw * jobs[p].ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
-    const uint32_t tiles = (j.dh + 15) / 16;
-    uint32_t bands = (uint32_t)((512 + cols * n - 1) / (cols * n));  // >= 512 workgroups in the launch
-    bands = bands < 1 ? 1 : (bands > tiles ? tiles : bands);
-    uint32_t rows = ((tiles + bands - 1) / bands) * 16;
-    if (forced > 1 && (forced & 0xff)) rows = (uint32_t)(forced & 0xff) * 16;
+    const uint32_t rows = band_tiles * 16;
     t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, 0};
     t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
     const uint32_t bxs = ((j.dw * j.ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
