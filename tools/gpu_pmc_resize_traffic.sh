@@ -17,7 +17,7 @@ acc = collections.defaultdict(list)
 name = None
 for f in sorted(glob.glob(f"{out}/t_*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "resize" in r["Kernel_Name"] or "plane" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("resize", "plane", "lanczos")):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"])); name = r["Kernel_Name"]
 rd = 2.0 * 1024 * sum(acc["FETCH_SIZE"]) / max(1, len(acc["FETCH_SIZE"]))
 wr = 1024.0 * sum(acc["WRITE_SIZE"]) / max(1, len(acc["WRITE_SIZE"]))

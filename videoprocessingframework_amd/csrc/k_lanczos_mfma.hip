@@ -42,6 +42,9 @@
 #include "vpf_plan_bounds.h"
 
 namespace vpf {
+#ifndef VPF_LZM_X
+#define VPF_LZM_X 0
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -75,9 +78,22 @@ VPF_DEV uint32_t opaque(uint32_t v) {
   asm("" : "+v"(v));
   return v;
 }
-VPF_DEV uint32_t sat_pk_u8_i16(uint32_t two_i16) {  // {sat_u8(hi half), sat_u8(lo half)} in the low 16 bits
-  uint32_t r;
-  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(two_i16));
+// four Q12 values (|w| < 2^27) -> four bytes: clamp(w >> 12, 0, 255), value k in byte k.  Six instructions instead of nine (four shifts, two
+// v_cvt_pk_i16_i32, two v_sat_pk_u8_i16, one v_perm_b32): the SDWA forms write a 16-bit result into the upper half of a register whose
+// lower half already holds its neighbour, so nothing has to be packed afterwards (w >> 12 fits 16 bits as it is).  The inputs are results
+// of ordinary VALU instructions of the compiler's, not of an MFMA: nothing in here needs wait states the compiler cannot see, except the
+// gfx940+ rule that a VALU reading a register right after an SDWA wrote part of it waits one state (the s_nop / the instruction order).
+VPF_DEV uint32_t shift12_sat_pack4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  uint32_t a, b, r;
+  asm("v_ashrrev_i32_e32 %0, 12, %3\n\t"
+      "v_ashrrev_i32_e32 %1, 12, %5\n\t"
+      "v_ashrrev_i32_sdwa %0, 12, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_ashrrev_i32_sdwa %1, 12, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_e32 %2, %0\n\t"
+      "v_sat_pk_u8_i16_sdwa %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(a), "=&v"(b), "=&v"(r)
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
   return r;
 }
 
@@ -148,7 +164,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   };
   // the step from group g to g + 1: everybody is done with g's buffer, g + 1 is complete; g + 2 goes where g was
   auto next_group = [&](uint32_t g) {
-    __syncthreads();
+    if (!(VPF_LZM_X & 1)) __syncthreads();
     if (g + 2 < ngroups && wv == ((g + 2) & 3u)) produce(g + 2);
   };
   if (wv == 0) produce(0);
@@ -244,9 +260,9 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     constexpr int SET = decltype(set_tag)::value;
     int32_t r = 16 * (T < t_last ? T : t_last) + (int32_t)srow;
     r = r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r;
-    const uint8_t* row = src + (size_t)r * sp + S0;
+    const uint32_t row = mad24((uint32_t)r, sp, S0);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
 #pragma unroll
-    for (int k = 0; k < PF; k++) pf[SET][k] = ldg<false, u32x4>(row + soff[k]);
+    for (int k = 0; k < PF; k++) pf[SET][k] = ldg<false, u32x4>(src + (row + soff[k]));
   };
   v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs)
 #pragma unroll
@@ -263,30 +279,46 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   // that the ring never moves in the register file)
   auto pass1 = [&](int32_t T, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
+    if (!(VPF_LZM_X & 8)) {
 #pragma unroll
     for (int k = 0; k < PF; k++)
       *reinterpret_cast<u32x4*>(sdst + soff[k]) = pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
     fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
     wave_lds_sync();
-    // every A operand of the tile is requested before the first is used: one LDS latency per source tile, not one per pair of reads
-    // (left alone the compiler keeps two reads in flight and the wave waits four times per tile)
-    v4i av[NT];
+    }
+    if (VPF_LZM_X & 16) return;  // X16: no pass 1 arithmetic
+    // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
+    // flight and the wave waits four times per tile); the other four are requested one by one into the registers the MFMAs free
+    v4i av[4];
 #pragma unroll
-    for (int j = 0; j < NT; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
-    if constexpr (NT == 8) asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
-    else asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
+    for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
+    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
+    // software pipeline over the N-tiles: the two MFMAs of tile j + 1 are issued BEFORE the eight VALU instructions that unpack tile j, so
+    // the unpacking runs while the matrix pipe works (left alone the compiler gives every tile the same result registers: MFMA, MFMA, wait
+    // for the pipe, unpack, next MFMA — the wave idles through every MFMA latency)
+    v4i hi[2], lo[2];
+    hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1h[0], c128, 0, 0, 0);
+    lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1l[0], c128, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      const v4i a = av[j];
-      const v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1h[j], c128, 0, 0, 0);
-      const v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1l[j], c128, 0, 0, 0);
+      if (j + 1 < NT) {
+        hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
+        lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+      if (j + 4 < NT) {
+        av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
       uint32_t h[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[r] << 8) + (uint32_t)lo[r];
+      for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
       // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
       // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
       ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
       ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
     }
     wave_lds_sync();  // the next tile's staging stores must not pass these reads
   };
@@ -299,32 +331,42 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint8_t* const ord = ot + (lane >> LOGNT) * PO + 16u * (lane & (NT - 1));
   const uint32_t ob = ob0 + 16u * (lane & (NT - 1));                   // first destination byte of the unit this lane stores
   const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
-  uint8_t* const obase = dst + (size_t)(lane >> LOGNT) * dp + ob;
+  const uint32_t obase = mad24(lane >> LOGNT, dp, ob);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
   auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
+    if (VPF_LZM_X & 4) return;
     const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16), by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
     const v4i hmask = {(int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u};
     const v4i bx0 = (by0 << 8) & hmask, bx1 = (by1 << 8) & hmask;  // qh moves from the zl slot to the zh slot, the zl slots become 0
+    // software pipeline like pass 1: the four MFMAs of tile j + 1 go out before tile j is shifted, clamped and packed
+    v4i x[2], y[2];
+    auto mm = [&](int j) {
+      v4i t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], bx0, czero, 0, 0, 0);
+      x[j & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], bx1, t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], by0, cy, 0, 0, 0);
+      y[j & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], by1, t, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    };
+    mm(0);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      v4i x = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], bx0, czero, 0, 0, 0);
-      x = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], bx1, x, 0, 0, 0);
-      v4i y = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], by0, cy, 0, 0, 0);
-      y = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], by1, y, 0, 0, 0);
-      int32_t o[4];
+      if (j + 1 < NT) mm(j + 1);
+      uint32_t w[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) o[r] = (int32_t)(((uint32_t)x[r] << 8) + (uint32_t)y[r]) >> 12;  // (V / 256 + 2^11) >> 12
-      const uint32_t q01 = sat_pk_u8_i16(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[0], o[1])));
-      const uint32_t q23 = sat_pk_u8_i16(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[2], o[3])));
-      *reinterpret_cast<uint32_t*>(owr + 16u * j) = __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+      for (int r = 0; r < 4; r++) w[r] = ((uint32_t)x[j & 1][r] << 8) + (uint32_t)y[j & 1][r];  // V / 256 + 2^11 (Q12): the byte is w >> 12, clamped
+      if (!(VPF_LZM_X & 2)) *reinterpret_cast<uint32_t*>(owr + 16u * j) = shift12_sat_pack4(w[0], w[1], w[2], w[3]);
+      else asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
+    if (VPF_LZM_X & 2) return;
     wave_lds_sync();
-    uint8_t* const orow = obase + (size_t)y0 * dp;
+    const uint32_t orow = mad24(y0, dp, obase);
 #pragma unroll
     for (int it = 0; it < NT / 4; it++) {
       const uint32_t y = y0 + (lane >> LOGNT) + RPI * it;
       if (y <= yb) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(ord + RPI * it * PO);
-        uint8_t* const out = orow + (size_t)(RPI * it) * dp;
+        uint8_t* const out = dst + (orow + (uint32_t)(RPI * it) * dp);
         if (ofull) {
           stg<true, u32x4>(out, v);
         } else if (opart) {  // the row's last, partial unit
@@ -349,6 +391,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   fetch(T, std::integral_constant<int, 0>{});
   fetch(T + 1, std::integral_constant<int, 1>{});
   __syncthreads();  // groups 0 and 1 are in LDS
+  if (VPF_LZM_X & 32) { if (b1h[0][0] == 0x12345678 && b1l[NT - 1][3] == 0x1234567) dst[0] = 1; return; }
   // one step: the next source tile, then every destination tile whose last source tile it was
 #define VPF_LZM_STEP(S)                                                                                              \
   pass1(T, std::integral_constant<int, S>{});                                                                       \
@@ -377,14 +420,22 @@ template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 // two workgroups per CU)
 template <template <int> class TaskCH>
 __global__ __launch_bounds__(256, 2) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T) {
-  const FrameDesc& f = args.f[blockIdx.z];
-  const uint32_t by = blockIdx.y;
+  // Workgroups are handed to the eight XCDs round robin in launch order, and each XCD has an L2 of its own: with the plain numbering the
+  // four-strip groups next to each other in a row — which share the 128-B lines their staged rows straddle — and the bands above each
+  // other — which share up to 21 source rows — sit on eight different L2s and every shared line comes from HBM once per sharer (measured:
+  // 1.30-1.33 x the source bytes; the kernel moves 5.1-5.6 TB/s at that, i.e. it is at the HBM ceiling with a third of the reads wasted).
+  // Renumber: XCD x takes the x-th eighth of the picture-ordered task list, so neighbours in the picture are neighbours in time on ONE L2.
+  const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), xcd = lin & 7u, idx = lin >> 3, per = total >> 3, rem = total & 7u;
+  const uint32_t m = xcd < rem ? xcd * (per + 1u) + idx : rem * (per + 1u) + (xcd - rem) * per + idx;
+  const uint32_t bx = m % gx, byz = m / gx, by = byz % gy, bz = byz / gy;
+  const FrameDesc& f = args.f[bz];
   const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
   const uint32_t k = T.k[pi], lby = by - T.by0[pi];
   switch (T.ch[pi]) {  // workgroup-uniform
-    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby); break;
+    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby); break;
+    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby); break;
   }
 }
 
@@ -428,8 +479,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     if (j.sw >= (1u << 22) || j.sh >= (1u << 22) || j.dw >= (1u << 22) || j.dh >= (1u << 22)) return false;
-    for (uint32_t i = 0; i < n; i++)
+    for (uint32_t i = 0; i < n; i++) {
       if ((((uintptr_t)a.f[i].s[j.k] | a.f[i].sp[j.k] | (uintptr_t)a.f[i].d[j.k] | a.f[i].dp[j.k]) & 15)) return false;
+      // the kernel addresses a plane with 32-bit offsets built by 24-bit multiplies
+      if (a.f[i].sp[j.k] >= (1u << 24) || a.f[i].dp[j.k] >= (1u << 24) || (uint64_t)j.sh * a.f[i].sp[j.k] >= (1ull << 32) || (uint64_t)j.dh * a.f[i].dp[j.k] >= (1ull << 32)) return false;
+    }
     if (!lzm_shape(j.ch, j.sw, j.sh, j.dw, j.dh).rows_ok) return false;
   }
   // Launch shape = (N-tiles per wave, 16-row destination tiles per band), the same for every plane of the launch.  A staged row is at most
