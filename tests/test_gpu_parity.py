@@ -969,10 +969,12 @@ def test_batched_resize_at_full_size_with_the_kernels_the_policy_picks(capi, ora
         assert_planes_equal(got, wants[i % 2], f"policy batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} frame {i}")
 
 
-@pytest.mark.parametrize("shape", [1, (4 << 8) | 1, (4 << 8) | 3, (8 << 8) | 1, (8 << 8) | 2, (8 << 8) | 64, 5])
+@pytest.mark.parametrize("shape", [1, (4 << 8) | 1, (4 << 8) | 3, (8 << 8) | 1, (8 << 8) | 2, (8 << 8) | 64, 5,
+                                   0x10000, 0x10000 | (4 << 8) | 1, 0x10000 | (8 << 8) | 2, 0x10000 | 5])
 def test_lanczos_mfma_kernel_shapes_write_the_oracle_pixels(capi, oracle, shape):
     """VPF_TUNE_RESIZE_MFMA = N-tiles per wave << 8 | 16-row destination tiles per band of the matrix-core Lanczos kernel (1 = never: the
-    gather form).  Every value writes the oracle's pixels: down- and up-scales, strips on the left / right image edge (clamped taps merged
+    gather form), | 0x10000 = filter weights evaluated inside the kernel instead of loaded from the per-shape tables (the path a full table
+    arena takes).  Every value writes the oracle's pixels: down- and up-scales, strips on the left / right image edge (clamped taps merged
     on the edge sample) and pictures narrower than one strip or one N-tile, bands cut by the bottom edge, factors the kernel's 64-B
     window / four-tile ring cannot hold (-> gather form), multi-plane formats (chroma planes with their own factors and channel counts),
     heights below one tile, a 33-frame batch"""
@@ -999,6 +1001,34 @@ def test_lanczos_mfma_kernel_shapes_write_the_oracle_pixels(capi, oracle, shape)
     finally:
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
     assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, (3 << 8) | 2) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, -1) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, (8 << 8) | 65) == -1
+
+
+def test_lanczos_weight_tables_across_streams(capi, oracle):
+    """The matrix-core Lanczos kernel loads its filter weights from per-shape tables that the first launch of a shape builds on ITS stream.
+    A second stream using the same shape right away — before the first stream's build need have run — queues its own build instead of
+    reading a table that may not exist yet; a shape first met under one band height and then another gets a second row table.  Several
+    shapes on several streams, issued back to back with no synchronisation in between: every frame equals the oracle."""
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    shapes = [("RGB", 1283, 211, 857, 140), ("NV12", 1920, 240, 1280, 160), ("RGB", 1283, 211, 857, 140), ("Y", 811, 97, 1622, 194), ("RGB", 1283, 211, 640, 97)]
+    jobs = []
+    for rnd, knob in enumerate((0, (8 << 8) | 2, (4 << 8) | 3)):
+        capi.set_tuning(capi.TUNE_RESIZE_MFMA, knob)
+        try:
+            for si, st in enumerate(streams):
+                for ci, (fmt, sw, sh, dw, dh) in enumerate(shapes):
+                    f, of = getattr(capi, fmt), getattr(oracle, fmt)
+                    src = oracle.synth(of, sw, sh, 9100 + 10 * rnd + ci)
+                    with torch.cuda.stream(st):
+                        S, D = DevPlanes(src), DevPlanes(oracle.alloc(of, dw, dh))
+                        capi.resize_batch(capi.make_exec(st.cuda_stream), f, 2, sw, sh, dw, dh, capi.make_batch([(S.desc(), D.desc())]))
+                    jobs.append((fmt, of, sw, sh, dw, dh, src, S, D, si, knob))
+        finally:
+            capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
+    torch.cuda.synchronize()
+    for fmt, of, sw, sh, dw, dh, src, S, D, si, knob in jobs:
+        got, intact = D.download()
+        assert intact
+        assert_planes_equal(got, oracle.resize(of, 2, sw, sh, src, dw, dh, oracle.FP32)[1], f"tables across streams: {fmt} {sw}x{sh}->{dw}x{dh} stream {si} knob {knob:#x}")
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
@@ -1034,6 +1064,8 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
         march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64]))  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
+        if march != 1 and rng.integers(3) == 0:
+            march |= 0x10000                                                                # ... with its weights evaluated in the kernel, not loaded from the shape's tables
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, march)
         try:
             capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))

@@ -36,15 +36,14 @@
 // VGPRs: 2 x 4 x NT column weights + 2 x 4 x NT ring + staging prefetch: NT = 8 -> two waves per SIMD.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <type_traits>
 
 #include "k_resize_common.h"
 #include "vpf_plan_bounds.h"
 
 namespace vpf {
-#ifndef VPF_LZM_X
-#define VPF_LZM_X 0
-#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -101,6 +100,7 @@ VPF_DEV uint32_t shift12_sat_pack4(uint32_t w0, uint32_t w1, uint32_t w2, uint32
 template <int CH, int NT, int PF>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
+  static constexpr int kGroupsPerCu = NT == 4 ? 3 : 2;  // register budget: 168 / 256 VGPRs
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
 
@@ -114,6 +114,139 @@ constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                       
 }
 constexpr uint32_t lzm_group_lds(int nt, uint32_t pitch) { return 4u * lzm_wave_lds(nt, pitch) + 2u * kLzmWmBytes; }  // + the workgroup's two row-weight buffers
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Weight operands.  They depend on the plane SHAPE only — not on the frame, and the column operands not on the band either — yet a
+// 32-frame launch of 1080p -> 720p evaluated each column set 64 times and each row set 256 times: 22 % of the kernel
+// (profiles/r03_lanczos_ablation.txt, "setup only").  They are built ONCE per shape by two small kernels into a table that lives in static
+// device memory (no allocation at run time: the C ABI still owns and allocates nothing), and the main kernel loads them — 16 B per lane
+// and operand — instead of evaluating ~130 instructions per set.  Entries are never evicted or rewritten with other bytes (a full arena
+// falls back to evaluating the weights in the kernel, as does VPF_TUNE_RESIZE_MFMA | 0x10000: same pixels), so a table in use by a
+// kernel on another stream can never change under it; a stream that has not built a shape itself queues its own (identical) build
+// in front of its first use instead of synchronising with the stream that did, and a capturing stream always does (a captured build
+// has not run).  Builds compose an image in LDS and copy it out whole: concurrent builds of a shape only ever write the final bytes.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kLzmArenaBytes = 48u << 20;
+__device__ u32x4 g_lzm_arena[kLzmArenaBytes / 16];
+
+// window of the N-tile that starts at destination byte b: the 16-B aligned source byte below the first tap of its first pixel (tiles
+// past the row end copy the last window)
+template <int CH>
+VPF_DEV uint32_t lzm_window(uint32_t b, uint32_t dwb, uint32_t sw, float scx) {
+  const uint32_t bb = b < dwb - 1 ? b : dwb - 1;
+  int32_t p0 = ltap_i0(bb / CH, scx) - 2;
+  p0 = p0 < 0 ? 0 : (p0 > (int32_t)sw - 1 ? (int32_t)sw - 1 : p0);
+  return ((uint32_t)CH * (uint32_t)p0) & ~15u;
+}
+
+// column weights of the strip that starts at destination byte ob0 -> pass-1 B operands, kLzmB1Chunk tiles at a time through an 8-KiB LDS
+// scratch.  Operand image in LDS: [plane][tile][lane 16 g + n][16 bytes]; zero it, evaluate the sets of the chunk's pixels (one per lane),
+// scatter their bytes, read the operands back.  Clamped taps add their weights on the edge pixel's slot: image edges cost nothing.
+template <int CH, int NT>
+VPF_DEV void lzm_col_operands(uint8_t* lds, uint32_t lane, uint32_t ob0, uint32_t dwb, uint32_t sw, float scx, v4i (&b1h)[NT], v4i (&b1l)[NT]) {
+  const uint32_t ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb;
+#pragma unroll
+  for (int ck = 0; ck < NT / (int)kLzmB1Chunk; ck++) {
+    const uint32_t cb0 = ob0 + 64u * ck, cb1 = cb0 + 64u < ob1 ? cb0 + 64u : ob1;  // destination bytes of the chunk
+    u32x4* z = reinterpret_cast<u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 2 * (int)kLzmB1Chunk; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+    if (cb0 < cb1) {
+      const uint32_t px_first = cb0 / CH, px_last = (cb1 - 1) / CH;
+      for (uint32_t px = px_first + lane; px <= px_last; px += 64) {
+        const MTap m = merge_taps(quantize_ltap(make_ltap(px, scx)), sw);
+        int32_t whi[6], wlo[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) split_i8(m.q[k], whi[k], wlo[k]);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          const uint32_t b = px * CH + c;
+          if (b < cb0 || b >= cb1) continue;
+          const uint32_t j = (b - cb0) >> 4, n = (b - cb0) & 15;
+          const uint32_t wsj = lzm_window<CH>(cb0 + 16u * j, dwb, sw, scx);
+          uint8_t* const cell = lds + (j * 64 + n) * 16;
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            if (m.pos[k] < 0) continue;
+            const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 (vpf_bound_lzm_span)
+            uint8_t* const a = cell + (kk >> 4) * 256 + (kk & 15);
+            a[0] = (uint8_t)whi[k];
+            a[kLzmB1Chunk * 1024] = (uint8_t)wlo[k];
+          }
+        }
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < (int)kLzmB1Chunk; j++) {
+      b1h[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + (j * 64 + lane) * 16);
+      b1l[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + kLzmB1Chunk * 1024 + (j * 64 + lane) * 16);
+    }
+    wave_lds_sync();
+  }
+}
+
+VPF_DEV int32_t lzm_band_first_tile(uint32_t ya, float scy, uint32_t sh) {  // first source tile of the band that starts at destination row ya
+  int32_t r = ltap_i0(ya, scy) - 2;
+  r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+  return r >> 4;
+}
+
+// row weights of group g (the 64 destination rows from ya + 64 g; rows past the band repeat its last row and are never stored) of the
+// band [ya, yb] -> the pass-2 operand image wm (kLzmWmBytes).  Lane = row; the bytes are SCATTERED into the image: destination tile
+// t = lane >> 4 owns [chunk c][lane 16 g' + y][16 B] of the Y operand; the source tile in ring slot p = (T - t_first) & 3 sits in chunk p >> 1,
+// and source row 16 T + 4 g' + r owns the byte pair 8 (p & 1) + 2 r (zl) / + 1 (zh): Y carries qh against zl and ql against zh (the X operand —
+// qh against zh, nothing against zl — is (Y << 8) & 0xff00ff00: pass 2 derives it)
+VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb, uint32_t g, float scy, uint32_t sh, int32_t t_first) {
+  const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
+  const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
+  u32x4* z = reinterpret_cast<u32x4*>(wm);
+#pragma unroll
+  for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+  uint8_t* const cell = wm + ((lane >> 4) * 2 * 64 + (lane & 15)) * 16;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (m.pos[k] < 0) continue;
+    const uint32_t pos = (uint32_t)m.pos[k], p = ((pos >> 4) - (uint32_t)t_first) & 3;
+    int32_t hi, lo;
+    split_i8(m.q[k], hi, lo);
+    uint8_t* const a = cell + (p >> 1) * 1024 + ((pos >> 2) & 3) * 256 + 8 * (p & 1) + 2 * (pos & 3);
+    *reinterpret_cast<uint16_t*>(a) = (uint16_t)(((uint32_t)hi & 0xffu) | (((uint32_t)lo & 0xffu) << 8));
+  }
+}
+
+// table builders: one wave per strip / per (group, band).  Column table of a plane row: [strip][plane hi | lo][tile][lane][16 B];
+// row table of a (plane height, band height): [band][group][kLzmWmBytes]
+template <int NT>
+__global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw, uint32_t dw, float scx, uint32_t off16) {
+  __shared__ u32x4 scratch[2 * kLzmB1Chunk * 64];
+  const uint32_t lane = threadIdx.x, dwb = dw * ch, ob0 = blockIdx.x * (16u * NT);
+  v4i b1h[NT], b1l[NT];
+  uint8_t* const lds = reinterpret_cast<uint8_t*>(scratch);
+  switch (ch) {
+    case 1: lzm_col_operands<1, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
+    case 2: lzm_col_operands<2, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
+    default: lzm_col_operands<3, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
+  }
+  u32x4* const out = g_lzm_arena + off16 + (size_t)blockIdx.x * (NT * 128u);
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    out[j * 64 + lane] = __builtin_bit_cast(u32x4, b1h[j]);
+    out[(NT + j) * 64 + lane] = __builtin_bit_cast(u32x4, b1l[j]);
+  }
+}
+__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, uint32_t off16) {
+  __shared__ u32x4 wm[kLzmWmBytes / 16];
+  const uint32_t lane = threadIdx.x, g = blockIdx.x, ya = blockIdx.y * R;
+  if (ya >= dh) return;
+  const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
+  if (g > (yb - ya) / 64u) return;
+  lzm_row_group(reinterpret_cast<uint8_t*>(wm), lane, ya, yb, g, scy, sh, lzm_band_first_tile(ya, scy, sh));
+  wave_lds_sync();
+  u32x4* const out = g_lzm_arena + off16 + (size_t)(blockIdx.y * gridDim.x + g) * (kLzmWmBytes / 16);
+#pragma unroll
+  for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) out[i * 64 + lane] = wm[i * 64 + lane];
+}
+
 template <int CH, int NT, int PF>
 VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                               const PlaneGeom& G, uint32_t bx, uint32_t by) {
@@ -123,114 +256,77 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint32_t dwb = dw * CH, ob0 = (bx * 4 + wv) * (16u * NT), ya = by * R;
   if (bx * 4 * (16u * NT) >= dwb || ya >= dh) return;  // workgroup-uniform: this plane is narrower / shorter than the launch grid
   const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
-  uint8_t* const lds = reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)wv * G.a2;
+  uint8_t* const wmb = reinterpret_cast<uint8_t*>(dyn_strip);  // workgroup-shared: two groups x [4 tiles][2 planes][64 lanes][16 B] (first: an LDS-DMA target's address travels in M0)
+  uint8_t* const lds = wmb + 2u * kLzmWmBytes + (size_t)wv * G.a2;
   uint8_t* const stage = lds;                         // [16 rows][P]
   uint8_t* const ot = lds + 16u * P;                  // [16 rows][lzm_out_pitch]
-  uint8_t* const wmb = reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)4 * G.a2;  // workgroup-shared: two groups x [4 tiles][2 planes][64 lanes][16 B]
   constexpr uint32_t PO = lzm_out_pitch(NT);
 
-  // ---- row weights, shared by the workgroup.  Its four waves own four neighbouring strips of the SAME band, and a weight set is ~300
-  // instructions per 64 rows whoever evaluates it: wave (G & 3) produces group G (the 64 destination rows from ya + 64 G) for all four,
-  // into buffer G & 1, one group ahead of its use; the waves meet at one barrier per group.  Lane = row (rows past the band repeat its
-  // last row and are never stored); the bytes are SCATTERED into the operand image: K slot (g, 4 p + r) <-> source row 16 T + 4 g + r of
-  // the tile in ring slot p = (T - t_first) & 3.
-  int32_t t_first;                                    // first source tile of the band
-  {
-    int32_t r = ltap_i0(ya, scy) - 2;
-    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
-    t_first = __builtin_amdgcn_readfirstlane(r >> 4);
-  }
+  // ---- row weights, shared by the workgroup.  Its four waves own four neighbouring strips of the SAME band: wave (G & 3) brings in group G
+  // (the 64 destination rows from ya + 64 G) for all four — a copy of the shape's row table (G.vec_ok: its offset in the arena), or, without
+  // a table, evaluated here — into buffer G & 1, one group ahead of its use; the waves meet at one barrier per group.
+  const int32_t t_first = __builtin_amdgcn_readfirstlane(lzm_band_first_tile(ya, scy, sh));  // first source tile of the band
   const uint32_t ngroups = (yb - ya) / 64u + 1u;
+  const uint32_t rtab = (uint32_t)G.vec_ok;
   auto produce = [&](uint32_t g) {
     uint8_t* const wm = wmb + (g & 1u) * kLzmWmBytes;
-    const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
-    const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
-    u32x4* z = reinterpret_cast<u32x4*>(wm);
+    if (rtab) {
+      // a straight 8-KiB copy, global memory -> LDS: eight LDS-DMA instructions (lane l's 16 bytes land at M0 + offset + 16 l), no register
+      // and no ds_write involved.  The compiler does not see these loads: the wave that issued them waits for them by hand (group_ready)
+      // before the barrier that hands the group to the others.  M0 is the compiler's: saved, set and restored inside each statement.
+      const u32x4* const t = g_lzm_arena + rtab + (size_t)(by * ((R + 63u) / 64u) + g) * (kLzmWmBytes / 16);
+      const uint32_t voff = 16u * lane, ldst = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(wm));
+      static_assert(kLzmWmBytes == 8192, "two statements of four 1-KiB pieces");
 #pragma unroll
-    for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
-    // operand image of destination tile t = lane >> 4: [chunk c][lane 16 g + y][16 B] of the Y operand; the tile in ring slot
-    // p = (T - t_first) & 3 sits in chunk p >> 1, and source row 16 T + 4 g + r owns the byte pair 8 (p & 1) + 2 r (zl) / + 1 (zh): Y carries qh
-    // against zl and ql against zh (the X operand — qh against zh, nothing against zl — is (Y << 8) & 0xff00ff00: pass 2 derives it)
-    uint8_t* const cell = wm + ((lane >> 4) * 2 * 64 + (lane & 15)) * 16;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      if (m.pos[k] < 0) continue;
-      const uint32_t pos = (uint32_t)m.pos[k], p = ((pos >> 4) - (uint32_t)t_first) & 3;
-      int32_t hi, lo;
-      split_i8(m.q[k], hi, lo);
-      uint8_t* const a = cell + (p >> 1) * 1024 + ((pos >> 2) & 3) * 256 + 8 * (p & 1) + 2 * (pos & 3);
-      *reinterpret_cast<uint16_t*>(a) = (uint16_t)(((uint32_t)hi & 0xffu) | (((uint32_t)lo & 0xffu) << 8));
+      for (int h = 0; h < 2; h++) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %1\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:2048\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(reinterpret_cast<const uint8_t*>(t) + 4096 * h), "v"(voff), "s"(ldst + 4096u * h) : "memory");
+      }
+    } else {
+      lzm_row_group(wm, lane, ya, yb, g, scy, sh, t_first);
     }
+  };
+  // the wave that brought group g in by DMA: everything it has in flight must have landed before it enters the barrier in front of g's use
+  auto group_ready = [&](uint32_t g) {
+    if (rtab && wv == (g & 3u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   // the step from group g to g + 1: everybody is done with g's buffer, g + 1 is complete; g + 2 goes where g was
   auto next_group = [&](uint32_t g) {
-    if (!(VPF_LZM_X & 1)) __syncthreads();
+    group_ready(g + 1);
+    __syncthreads();
     if (g + 2 < ngroups && wv == ((g + 2) & 3u)) produce(g + 2);
   };
   if (wv == 0) produce(0);
   if (wv == 1 && ngroups > 1) produce(1);
   if (ob0 >= dwb) {  // a wave without columns (the row's last workgroup): it still produces its groups and meets the others
+    group_ready(0); group_ready(1);
     __syncthreads();
     for (uint32_t g = 0; g + 1 < ngroups; g++) next_group(g);
     return;
   }
 
   // ---- windows: ws_j = 16-B aligned source byte below the first tap of tile j's first pixel (tiles past the row end copy the last window)
-  auto window = [&](uint32_t b) -> uint32_t {
-    const uint32_t bb = b < dwb - 1 ? b : dwb - 1;
-    int32_t p0 = ltap_i0(bb / CH, scx) - 2;
-    p0 = p0 < 0 ? 0 : (p0 > (int32_t)sw - 1 ? (int32_t)sw - 1 : p0);
-    return ((uint32_t)CH * (uint32_t)p0) & ~15u;
-  };
-  const uint32_t S0 = __builtin_amdgcn_readfirstlane(window(ob0));
+  const uint32_t S0 = __builtin_amdgcn_readfirstlane(lzm_window<CH>(ob0, dwb, sw, scx));
   uint32_t wrel[NT];
 #pragma unroll
-  for (int j = 0; j < NT; j++) wrel[j] = __builtin_amdgcn_readfirstlane(window(ob0 + 16u * j)) - S0;
+  for (int j = 0; j < NT; j++) wrel[j] = __builtin_amdgcn_readfirstlane(lzm_window<CH>(ob0 + 16u * j, dwb, sw, scx)) - S0;
 
-  // ---- column weights -> pass-1 B operands, kLzmB1Chunk tiles at a time.  Operand image in LDS: [plane][tile][lane 16 g + n][16 bytes];
-  // zero it, evaluate the sets of the chunk's pixels (one per lane), scatter their bytes, read the operands back
+  // ---- column weights -> pass-1 B operands: the strip's 2 NT operands from the shape's column table (G.a3: its offset in the arena), or
+  // evaluated here
   v4i b1h[NT], b1l[NT];
-  {
-    const uint32_t ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb;
+  if (G.a3) {
+    const u32x4* const t = g_lzm_arena + G.a3 + (size_t)(bx * 4 + wv) * (NT * 128u);
 #pragma unroll
-    for (int ck = 0; ck < NT / (int)kLzmB1Chunk; ck++) {
-      const uint32_t cb0 = ob0 + 64u * ck, cb1 = cb0 + 64u < ob1 ? cb0 + 64u : ob1;  // destination bytes of the chunk
-      u32x4* z = reinterpret_cast<u32x4*>(lds);
-#pragma unroll
-      for (int i = 0; i < 2 * (int)kLzmB1Chunk; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
-      if (cb0 < cb1) {
-        const uint32_t px_first = cb0 / CH, px_last = (cb1 - 1) / CH;
-        for (uint32_t px = px_first + lane; px <= px_last; px += 64) {
-          const MTap m = merge_taps(quantize_ltap(make_ltap(px, scx)), sw);
-          int32_t whi[6], wlo[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) split_i8(m.q[k], whi[k], wlo[k]);
-#pragma unroll
-          for (int c = 0; c < CH; c++) {
-            const uint32_t b = px * CH + c;
-            if (b < cb0 || b >= cb1) continue;
-            const uint32_t j = (b - cb0) >> 4, n = (b - cb0) & 15;
-            const uint32_t wsj = window(cb0 + 16u * j);
-            uint8_t* const cell = lds + (j * 64 + n) * 16;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-              if (m.pos[k] < 0) continue;
-              const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 (vpf_bound_lzm_span)
-              uint8_t* const a = cell + (kk >> 4) * 256 + (kk & 15);
-              a[0] = (uint8_t)whi[k];
-              a[kLzmB1Chunk * 1024] = (uint8_t)wlo[k];
-            }
-          }
-        }
-      }
-      wave_lds_sync();
-#pragma unroll
-      for (int j = 0; j < (int)kLzmB1Chunk; j++) {
-        b1h[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + (j * 64 + lane) * 16);
-        b1l[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + kLzmB1Chunk * 1024 + (j * 64 + lane) * 16);
-      }
-      wave_lds_sync();
+    for (int j = 0; j < NT; j++) {
+      b1h[j] = __builtin_bit_cast(v4i, t[j * 64 + lane]);
+      b1l[j] = __builtin_bit_cast(v4i, t[(NT + j) * 64 + lane]);
     }
+  } else {
+    lzm_col_operands<CH, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l);
   }
 
   // ---- the march
@@ -279,14 +375,11 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   // that the ring never moves in the register file)
   auto pass1 = [&](int32_t T, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
-    if (!(VPF_LZM_X & 8)) {
 #pragma unroll
     for (int k = 0; k < PF; k++)
       *reinterpret_cast<u32x4*>(sdst + soff[k]) = pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
     fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
     wave_lds_sync();
-    }
-    if (VPF_LZM_X & 16) return;  // X16: no pass 1 arithmetic
     // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
     // flight and the wave waits four times per tile); the other four are requested one by one into the registers the MFMAs free
     v4i av[4];
@@ -333,7 +426,6 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
   const uint32_t obase = mad24(lane >> LOGNT, dp, ob);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
   auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
-    if (VPF_LZM_X & 4) return;
     const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16), by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
     const v4i hmask = {(int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u};
     const v4i bx0 = (by0 << 8) & hmask, bx1 = (by1 << 8) & hmask;  // qh moves from the zl slot to the zh slot, the zl slots become 0
@@ -353,12 +445,10 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
       uint32_t w[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) w[r] = ((uint32_t)x[j & 1][r] << 8) + (uint32_t)y[j & 1][r];  // V / 256 + 2^11 (Q12): the byte is w >> 12, clamped
-      if (!(VPF_LZM_X & 2)) *reinterpret_cast<uint32_t*>(owr + 16u * j) = shift12_sat_pack4(w[0], w[1], w[2], w[3]);
-      else asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+      *reinterpret_cast<uint32_t*>(owr + 16u * j) = shift12_sat_pack4(w[0], w[1], w[2], w[3]);
       __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
-    if (VPF_LZM_X & 2) return;
     wave_lds_sync();
     const uint32_t orow = mad24(y0, dp, obase);
 #pragma unroll
@@ -390,8 +480,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   int32_t T = t_first;
   fetch(T, std::integral_constant<int, 0>{});
   fetch(T + 1, std::integral_constant<int, 1>{});
+  group_ready(0); group_ready(1);
   __syncthreads();  // groups 0 and 1 are in LDS
-  if (VPF_LZM_X & 32) { if (b1h[0][0] == 0x12345678 && b1l[NT - 1][3] == 0x1234567) dst[0] = 1; return; }
   // one step: the next source tile, then every destination tile whose last source tile it was
 #define VPF_LZM_STEP(S)                                                                                              \
   pass1(T, std::integral_constant<int, S>{});                                                                       \
@@ -419,7 +509,7 @@ template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 // all planes of up to 32 frames in one dispatch (the k_planes_mp scheme of k_resize_common.h, with this family's register budget:
 // two workgroups per CU)
 template <template <int> class TaskCH>
-__global__ __launch_bounds__(256, 2) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T) {
+__global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T) {
   // Workgroups are handed to the eight XCDs round robin in launch order, and each XCD has an L2 of its own: with the plain numbering the
   // four-strip groups next to each other in a row — which share the 128-B lines their staged rows straddle — and the bands above each
   // other — which share up to 21 source rows — sit on eight different L2s and every shared line comes from HBM once per sharer (measured:
@@ -472,9 +562,52 @@ static LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_
   return s;
 }
 
+// ---- weight-table bookkeeping (host).  One arena per device, bump-allocated, never freed.  An entry remembers the (up to four) streams
+// that have queued its build: a launch on one of them is ordered behind the build by the stream itself; any other stream — and any stream
+// that is being captured into a graph, whose build has not run — queues the build again (idempotent: same bytes).
+struct LzmTab {
+  int dev;
+  uint32_t kind, k0, k1, k2, k3;  // kind 0: columns (ch, sw, dw, nt) | 1: rows (sh, dh, band rows, 0)
+  uint32_t off16;
+  hipStream_t streams[4];
+  int nstreams;
+};
+static std::mutex g_lzm_mu;
+static std::vector<LzmTab> g_lzm_tabs;
+static uint32_t g_lzm_used16[64];  // per device, in 16-B units (0 = "no table": the first 256 B stay unused)
+
+// -> offset of the table in the arena (16-B units), 0 when there is no room; `build(off16)` queues the build kernel on st
+template <class Build>
+static uint32_t lzm_table(hipStream_t st, int dev, bool capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes, Build build) {
+  std::lock_guard<std::mutex> lock(g_lzm_mu);
+  LzmTab* e = nullptr;
+  for (LzmTab& t : g_lzm_tabs)
+    if (t.dev == dev && t.kind == kind && t.k0 == k0 && t.k1 == k1 && t.k2 == k2 && t.k3 == k3) { e = &t; break; }
+  if (!e) {
+    uint32_t& used = g_lzm_used16[dev];
+    if (!used) used = 16;
+    const uint64_t need16 = (bytes + 255) / 256 * 16;
+    if ((uint64_t)used + need16 > kLzmArenaBytes / 16) return 0;
+    g_lzm_tabs.push_back(LzmTab{dev, kind, k0, k1, k2, k3, used, {}, 0});
+    used += (uint32_t)need16;
+    e = &g_lzm_tabs.back();
+  }
+  bool known = false;
+  for (int i = 0; i < e->nstreams; i++) known = known || e->streams[i] == st;
+  if (known && !capturing) return e->off16;
+  build(e->off16);
+  if (!capturing) {
+    if (e->nstreams < 4) e->streams[e->nstreams++] = st;
+    else { e->streams[0] = e->streams[1]; e->streams[1] = e->streams[2]; e->streams[2] = e->streams[3]; e->streams[3] = st; }
+  }
+  return e->off16;
+}
+
 bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
-  const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
-  if (tune == 9 || tune == 40 || tuning(VPF_TUNE_RESIZE_MFMA) == 1) return false;
+  const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT), knob = tuning(VPF_TUNE_RESIZE_MFMA);
+  const int forced = knob & 0xffff;           // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
+  const bool tables = !(knob & 0x10000);      // | 0x10000: evaluate the weights in the kernel (the path a full arena takes)
+  if (tune == 9 || tune == 40 || forced == 1) return false;
   if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return false;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
@@ -495,7 +628,6 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   // S = 3.0 / 2.0 and w = 1.0 / 0.6 tile units for 8- / 4-tile strips.  Against the sweep's 18 cases the model's pick is within 6 % of the
   // best measured shape on average; the rule it replaces (bands = 512 / workgroups per band row, per plane) lost 20 - 35 % on the
   // multi-plane formats, whose planes it sized independently.
-  const int forced = tuning(VPF_TUNE_RESIZE_MFMA);  // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
   int nt = 8;
   uint32_t pitch = 0, span = 0, wave_lds = 0;
   auto fits = [&]() {
@@ -518,7 +650,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
       if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
       nt = cand;
       if (!fits()) continue;
-      const double S = cand == 8 ? 3.0 : 2.0, w = cand == 8 ? 1.0 : 0.6;
+      const double S = (cand == 8 ? 3.0 : 2.0) * (tables ? 0.35 : 1.0), w = cand == 8 ? 1.0 : 0.6;  // with weight tables a wave's fixed part is its first fetch
       uint32_t tmax = 0;
       for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
       for (uint32_t r = 1; r <= std::min(tmax, 64u); r++) {
@@ -543,11 +675,32 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   PlaneTable t{};
   t.np = (uint32_t)njobs;
   uint32_t gx = 0, gy = 0;
+  int dev = 0;
+  bool capturing = false;
+  if (tables) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+    capturing = cs != hipStreamCaptureStatusNone;
+  }
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
     const uint32_t rows = band_tiles * 16;
-    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, 0};
+    uint32_t ctab = 0, rtab = 0;
+    if (tables) {
+      const uint32_t strips = (j.dw * (uint32_t)j.ch + 16u * nt - 1) / (16u * nt), bands = (j.dh + rows - 1) / rows, gpb = (rows + 63) / 64;
+      ctab = lzm_table(st, dev, capturing, 0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt, (uint64_t)strips * nt * 2048u, [&](uint32_t off16) {
+        (void)hipGetLastError();
+        if (nt == 8) hipLaunchKernelGGL(k_lzm_build_cols<8>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, off16);
+        else hipLaunchKernelGGL(k_lzm_build_cols<4>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, off16);
+      });
+      rtab = lzm_table(st, dev, capturing, 1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes, [&](uint32_t off16) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, off16);
+      });
+    }
+    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, (int)rtab, pitch, rows, wave_lds, ctab};
     t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
     const uint32_t bxs = ((j.dw * j.ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
     gx = bxs > gx ? bxs : gx;

@@ -424,8 +424,9 @@ int vpf_set_tuning(int key, int value) {
     return g_tune_tile.exchange(value);
   }
   if (key == VPF_TUNE_RESIZE_MFMA) {
-    const int nt = value >> 8, tiles = value & 0xff;
-    if (value != 0 && value != 1 && (value < 0 || (nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
+    const int shape = value & 0xffff, nt = shape >> 8, tiles = shape & 0xff;  // | 0x10000: no weight tables
+    if (value < 0 || (value & ~0x1ffff)) return -1;
+    if (shape != 0 && shape != 1 && ((nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
     return g_tune_mfma.exchange(value);
   }
   if (key == VPF_TUNE_RESIZE_BAND) return (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? g_tune_band.exchange(value) : -1;
