@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "k_bilinear_blend.h"
+#include "k_resize_common.h"
 
 namespace vpf {
 
@@ -88,13 +89,13 @@ constexpr uint32_t kFusedRowBytes = 2048;  // cap; the launch sizes the strips f
 
 template <int SRC, int DST, int IT>
 VPF_DEV void convert_resize_lds_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx,
-                                     float scy, int vec_ok, uint32_t rowq) {
+                                     float scy, int vec_ok, uint32_t rowq, uint32_t bx, uint32_t by) {
   // per wave, NS strips of rowq x 16 B in dynamic LDS: 0,1 luma rows; 2,3 chroma rows (NV12: UV interleaved | YUV420: U);
   // 4,5 V rows (YUV420 only)
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t y = blockIdx.y * 4 + wv;
+  const uint32_t y = by * 4 + wv;
   if (y >= dh) return;
-  const uint32_t xs = blockIdx.x * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  const uint32_t xs = bx * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
   const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t ybase = first & ~15u, ynq = (last + 1 - ybase + 15) / 16;
@@ -271,14 +272,15 @@ VPF_DEV void convert_resize_lds_task(const FrameDesc& f, const Yuv2RgbCoef& c, u
 template <int SRC, int DST, int IT>
 __global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
                                                             uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok, uint32_t rowq) {
-  convert_resize_lds_task<SRC, DST, IT>(args.f[blockIdx.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq);
+  const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h)
+  convert_resize_lds_task<SRC, DST, IT>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
 }
 // single-frame entry: scalar arguments, what the first loads need in front (see VPF_ONE_SRC_PARAMS in vpf_internal.h)
 template <int SRC, int DST, int IT>
 __global__ __launch_bounds__(256) void k_convert_resize_lds_one(const uint8_t* s0, const uint8_t* s1, uint32_t sp0, uint32_t sp1, uint32_t sw,
                                                                 uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy, uint32_t rowq,
                                                                 int vec_ok, const uint8_t* s2, uint32_t sp2, VPF_ONE_DST_PARAMS, const Yuv2RgbCoef c) {
-  convert_resize_lds_task<SRC, DST, IT>(VPF_ONE_FRAME, c, sw, sh, dw, dh, scx, scy, vec_ok, rowq);
+  convert_resize_lds_task<SRC, DST, IT>(VPF_ONE_FRAME, c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, blockIdx.x, blockIdx.y);
 }
 
 
@@ -379,10 +381,10 @@ __global__ __launch_bounds__(256) void k_convert_half_one(VPF_ONE_SRC_PARAMS, ui
 constexpr int kStripRows = 8;  // source rows a wave's strip can hold
 template <int SRC, int DST, int R>
 VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy,
-                                int vec_ok, uint32_t rowq) {
+                                int vec_ok, uint32_t rowq, uint32_t bx, uint32_t by) {
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t ya = (blockIdx.y * 4 + wv) * R;
-  const uint32_t xs = blockIdx.x * 256;
+  const uint32_t ya = (by * 4 + wv) * R;
+  const uint32_t xs = bx * 256;
   if (ya >= dh || xs >= dw) return;
   const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
@@ -485,7 +487,8 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
 template <int SRC, int DST, int R>
 __global__ __launch_bounds__(256) void k_convert_strip(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
                                                        float scx, float scy, int vec_ok, uint32_t rowq) {
-  convert_strip_task<SRC, DST, R>(args.f[blockIdx.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq);
+  const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): bands above each other and chunks next to each other share one L2
+  convert_strip_task<SRC, DST, R>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
 }
 
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh,

@@ -510,15 +510,8 @@ template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 // two workgroups per CU)
 template <template <int> class TaskCH>
 __global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T) {
-  // Workgroups are handed to the eight XCDs round robin in launch order, and each XCD has an L2 of its own: with the plain numbering the
-  // four-strip groups next to each other in a row — which share the 128-B lines their staged rows straddle — and the bands above each
-  // other — which share up to 21 source rows — sit on eight different L2s and every shared line comes from HBM once per sharer (measured:
-  // 1.30-1.33 x the source bytes; the kernel moves 5.1-5.6 TB/s at that, i.e. it is at the HBM ceiling with a third of the reads wasted).
-  // Renumber: XCD x takes the x-th eighth of the picture-ordered task list, so neighbours in the picture are neighbours in time on ONE L2.
-  const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
-  const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), xcd = lin & 7u, idx = lin >> 3, per = total >> 3, rem = total & 7u;
-  const uint32_t m = xcd < rem ? xcd * (per + 1u) + idx : rem * (per + 1u) + (xcd - rem) * per + idx;
-  const uint32_t bx = m % gx, byz = m / gx, by = byz % gy, bz = byz / gy;
+  const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): neighbouring strips and bands share one L2
+  const uint32_t bx = b.x, by = b.y, bz = b.z;
   const FrameDesc& f = args.f[bz];
   const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
   const uint32_t k = T.k[pi], lby = by - T.by0[pi];

@@ -25,10 +25,27 @@ struct PlaneGeom {
 //   k_planes_mp     EVERY plane of up to 32 frames in one dispatch: blockIdx.z = frame, blockIdx.y runs through the planes' block rows
 //                   one plane after the other (by0[p] = first blockIdx.y of plane p), blockIdx.x covers the widest plane (a task returns
 //                   at once when its block lies outside its plane)
+// Workgroups are handed to the chip's eight XCDs round robin in launch order, and every XCD has an L2 of its own.  With the plain numbering
+// the blocks next to each other in a picture — which share the 128-B lines their strips straddle, and, above each other, the source rows
+// their bands / taps overlap on — sit on eight different L2s, and every shared line comes from HBM once per sharer (measured on the
+// matrix-core Lanczos kernel: HBM reads 1.30-1.33 x the source -> 1.02-1.09 x with the renumbering; profiles/r03_pmc_lanczos_traffic_*).
+// picture_order() renumbers: XCD x takes the x-th eighth of the picture-ordered block list (x fastest, then y, then the frame), so neighbours
+// in the picture are neighbours in time on ONE L2.  A bijection of the launch grid onto itself for any grid size.
+struct BlockId {
+  uint32_t x, y, z;
+};
+VPF_DEV BlockId picture_order() {
+  const uint32_t gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), xcd = lin & 7u, idx = lin >> 3, per = total >> 3, rem = total & 7u;
+  const uint32_t m = xcd < rem ? xcd * (per + 1u) + idx : rem * (per + 1u) + (xcd - rem) * per + idx;
+  const uint32_t yz = m / gx;
+  return BlockId{m - yz * gx, yz % gy, yz / gy};
+}
 template <class Task>
 __global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BatchArgs args, const int k, const PlaneGeom G) {
-  const FrameDesc& f = args.f[blockIdx.z];
-  Task::run(f.s[k], f.sp[k], f.d[k], f.dp[k], G, blockIdx.x, blockIdx.y);
+  const BlockId b = picture_order();
+  const FrameDesc& f = args.f[b.z];
+  Task::run(f.s[k], f.sp[k], f.d[k], f.dp[k], G, b.x, b.y);
 }
 struct PlaneTable {
   PlaneGeom g[3];
@@ -36,14 +53,15 @@ struct PlaneTable {
 };
 template <template <int> class TaskCH>
 __global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchArgs args, const PlaneTable T) {
-  const FrameDesc& f = args.f[blockIdx.z];
-  const uint32_t by = blockIdx.y;
+  const BlockId b = picture_order();
+  const FrameDesc& f = args.f[b.z];
+  const uint32_t by = b.y;
   const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
   const uint32_t k = T.k[pi], lby = by - T.by0[pi];
   switch (T.ch[pi]) {  // workgroup-uniform
-    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
-    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], blockIdx.x, lby); break;
+    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], b.x, lby); break;
+    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], b.x, lby); break;
+    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], b.x, lby); break;
   }
 }
 
