@@ -23,8 +23,30 @@ What is recorded (inputs travel inside the fixture, so nothing has to be regener
   remap     PySurfaceRemaper (nppiRemap_8u_C3R linear, Tasks.cpp:1590-1595) on 848x464 RGB: identity, half-pixel shift, barrel
             distortion r' = r (1 + 0.1 r^2), and a map with out-of-range entries over a pre-filled destination
 
+  quirks    the reference behaviours this repo knowingly does NOT reproduce are recorded as cases of their own, each with a "quirk" tag
+            the loader understands, so that a first run against real NPP output classifies them instead of reporting a generic mismatch:
+              R2   PySurfaceResizer on RGB_PLANAR / YUV444: GetSurfacePlane(i) returns the same stacked W x 3H plane for i = 0, 1, 2
+                   (src/TC/src/MemoryInterfaces.cpp:1617-1621), so the reference resizes the whole stack as ONE W x 3H image, three times
+                   (src/TC/src/Tasks.cpp:1227-1253): rows near the two seams blend pixels of neighbouring planes.  This repo resizes
+                   each plane on its own.  The loader checks both readings and says which one the fixture follows.
+              C13  RGB -> YUV444 under an MPEG-range context calls the PACKED nppiRGBToYCbCr_8u_C3R on plane 0 of the planar surface
+                   (src/TC/src/TasksColorCvt.cpp:758): interleaved Y Cb Cr triples where the Y plane should be.  This repo writes
+                   planar YCbCr.  The loader checks whether plane 0's first row starts with packed triples.
+              BGR  Surface::Make(BGR) (no-size overload) has no BGR case (src/TC/src/MemoryInterfaces.cpp:596-630): a refused
+                   conversion into BGR returns Python None where other formats return an Empty() surface.  Recorded per refused
+                   context as refusedkind_<ctx> = 1 (None) / 0 (Empty()).
+              R5   PySurfaceResizer on RGB_32F_PLANAR dereferences a null plane for i >= 1 (src/TC/src/Tasks.cpp:1390-1445,
+                   MemoryInterfaces.cpp:1815-1818).  Probed in a CHILD process; its exit status is the fixture.
+              default context  cc_ctx = None is recorded for every converter (out_none / refused_none): each *_Impl picks its own default.
+
 The same script runs against this repo's drop-in PyNvCodec (same API); fixtures produced that way are marked
 "producer": "vpf-hip" in the manifest and are NOT a pin — tests treat them as a rehearsal of the kit only.
+
+    python tests/golden/make_npp_fixtures.py --verify-only [--out DIR]
+reads the fixtures back (no GPU, no PyNvCodec: it needs this repository's CPU oracle and tests/test_reference_fixtures.py) and prints,
+per fixture and recorded output, which combinations of the oracle's assumption switches A2 / A6 / A8 (oracle/vpf_oracle.h) land within
+1 LSB — "the default" when (0, 0, 0) is among them — and how each quirk case classifies.  First contact with NPP output is then a
+table to read, not a debugging session.
 """
 import argparse
 import json
@@ -67,12 +89,69 @@ def synth(fmt, w, h, seed, dist="A"):
     return ((i % max(w, 1)) + 3 * (i // max(w, 1))).astype(np.uint8)
 
 
+def verify_only(out_dir):
+    """Per fixture: the A2 / A6 / A8 combinations (oracle EXACT mode) within 1 LSB of every recorded output, and the quirk classification."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import oracle as o
+    import test_reference_fixtures as T
+
+    man = json.load(open(os.path.join(out_dir, "manifest.json")))
+    print(f"{len(man['cases'])} fixtures, producer '{man['producer']}'" + ("  (self-produced: a rehearsal, not a pin)" if man["producer"] != "nvidia-vpf" else ""))
+    default, bad = {"A2": 0, "A6": 0, "A8": 0}, 0
+    for name in man["cases"]:
+        z = np.load(os.path.join(out_dir, name + ".npz"))
+        kind, quirk = str(z["kind"]), (str(z["quirk"]) if "quirk" in z.files else "")
+        lines = []
+        if kind == "convert":
+            sf, df, w, h = str(z["src_fmt"]), str(z["dst_fmt"]), int(z["w"]), int(z["h"])
+            for key in (k for k in z.files if k.startswith("out_")):
+                res = T.resolve_like_the_reference(sf, df, T._ctx_of(key[4:]))
+                if res is None:
+                    lines.append(f"ctx {key[4:]}: the reference ACCEPTS it, this repo's dispatch refuses it")
+                    continue
+                run = lambda: o.convert(getattr(o, sf), getattr(o, df), res[0], res[1], w, h, T.split_planes(o, sf, w, h, z["src"]), o.EXACT)  # noqa: E731
+                lines.append(f"ctx {key[4:]}: {T.describe_hits(T.which_assumptions(o, run, z[key]), default)}")
+                if quirk == "C13" and key[4:] != "none" and key[5] == "0":   # MPEG range
+                    lines.append(f"ctx {key[4:]}: quirk C13 -> {T.classify_c13(o, w, h, z['src'], res, z[key])}")
+            for key in (k for k in z.files if k.startswith("refusedkind_")):
+                if quirk == "BGR":
+                    lines.append(f"ctx {key[12:]}: refused with {'None (quirk BGR: Surface::Make(BGR) is null)' if int(z[key]) else 'an Empty() surface'}")
+        elif kind == "resize":
+            fmt, w, h = str(z["fmt"]), int(z["w"]), int(z["h"])
+            src = T.split_planes(o, fmt, w, h, z["src"])
+            for key in (k for k in z.files if k.startswith("out_")):
+                dw, dh = (int(v) for v in key[4:].split("x"))
+                run = lambda: o.resize(getattr(o, fmt), o.LANCZOS3, w, h, src, dw, dh, o.EXACT)  # noqa: E731
+                lines.append(f"-> {dw}x{dh}: {T.describe_hits(T.which_assumptions(o, run, z[key]), default)}")
+                if quirk == "R2":
+                    lines.append(f"-> {dw}x{dh}: quirk R2 -> {T.classify_r2(o, w, h, src, dw, dh, z[key])}")
+        elif kind == "remap":
+            w, h = int(z["w"]), int(z["h"])
+            st, out = o.remap(o.RGB, w, h, T.split_planes(o, "RGB", w, h, z["src"]), z["xmap"], z["ymap"], o.EXACT)
+            inside = (z["xmap"] >= 0) & (z["xmap"] <= w - 1) & (z["ymap"] >= 0) & (z["ymap"] <= h - 1)
+            mx, frac = T.lsb_report(out[0].reshape(h, w, 3)[inside], z["out"].reshape(h, w, 3)[inside])
+            lines.append(f"max |diff| {mx:g} over the mapped pixels" + ("" if mx <= 1 else f"  ({frac:.2%} off by more than 1 LSB)  MISMATCH"))
+        elif kind == "quirk":
+            lines.append(f"quirk {quirk}: child exit status {int(z['returncode'])} ({'crashed: the reference quirk' if int(z['returncode']) not in (0,) else 'ran'}): {str(z['said']).strip()[-120:]}")
+        bad += sum("MISMATCH" in l for l in lines)
+        print(name)
+        for l in lines:
+            print("   ", l)
+    print(f"{bad} recorded outputs match no assumption combination" if bad else "every recorded output matches at least one assumption combination")
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--module-dir", default=None, help="directory that contains the PyNvCodec package to import")
     ap.add_argument("--out", default=os.path.join(HERE, "npp"))
     ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--verify-only", action="store_true", help="read the fixtures in --out back and print which A2 / A6 / A8 combination matches each (needs this repo's oracle, no GPU)")
     a = ap.parse_args()
+    if a.verify_only:
+        return verify_only(a.out)
     if a.module_dir:
         sys.path.insert(0, a.module_dir)
     import PyNvCodec as nvc
@@ -116,21 +195,23 @@ def main():
                     key = "none" if c is None else f"{c[0]}{c[1]}"
                     if dst is None or dst.Empty():
                         outs["refused_" + key] = np.zeros(0, np.uint8)
+                        outs["refusedkind_" + key] = np.array(1 if dst is None else 0, np.uint8)  # quirk BGR: None instead of an Empty() surface
                         continue
                     outs["out_" + key] = download(df, w, h, dst)
                     accepted.append(key)
-                save(f"convert_{sf}_{df}_{w}x{h}_{dist}", kind="convert", src_fmt=sf, dst_fmt=df, w=w, h=h, src=src, **outs)
+                quirk = "C13" if (sf, df) == ("RGB", "YUV444") else "BGR" if df == "BGR" else ""
+                save(f"convert_{sf}_{df}_{w}x{h}_{dist}", kind="convert", src_fmt=sf, dst_fmt=df, w=w, h=h, src=src, quirk=quirk, **outs)
                 print(f"convert {sf}->{df} {w}x{h} {dist}: accepted contexts {accepted}")
 
     # ---- resize (the reference's resizer = NPP Lanczos) ---------------------------------------------------------------
     def resizer(dw, dh, fmt):
         rs = nvc.PySurfaceResizer(dw, dh, getattr(PF, fmt), a.gpu)
-        if hasattr(rs, "SetInterpolation"):  # this repo's module defaults to bilinear (north_star); the reference always asks NPP for Lanczos
+        if hasattr(rs, "SetInterpolation"):  # additive in this repo's module (its default is Lanczos too since round 3); the reference always asks NPP for Lanczos
             rs.SetInterpolation(2)
         return rs
 
     w, h = 848, 464
-    for fmt in ("RGB", "RGB_PLANAR", "YUV420", "NV12"):
+    for fmt in ("RGB", "RGB_PLANAR", "YUV444", "YUV420", "NV12"):
         src = synth(fmt, w, h, 2000 + len(manifest["cases"]), "A")
         surf = upload(fmt, w, h, src)
         outs = {}
@@ -138,7 +219,7 @@ def main():
             dst = resizer(dw, dh, fmt).Execute(surf)
             if dst is not None and not dst.Empty():
                 outs[f"out_{dw}x{dh}"] = download(fmt, dw, dh, dst)
-        save(f"resize_{fmt}_{w}x{h}", kind="resize", fmt=fmt, w=w, h=h, src=src, **outs)
+        save(f"resize_{fmt}_{w}x{h}", kind="resize", fmt=fmt, w=w, h=h, src=src, quirk="R2" if fmt in ("RGB_PLANAR", "YUV444") else "", **outs)
         print(f"resize {fmt}: {sorted(outs)}")
     imp = np.zeros((16, 16, 3), np.uint8)
     imp[5, 7] = (255, 128, 64)       # one lit pixel: the output IS the filter's footprint
@@ -149,6 +230,23 @@ def main():
         if dst is not None and not dst.Empty():
             outs[f"out_{dw}x{dh}"] = download("RGB", dw, dh, dst)
     save("resize_RGB_impulse_16x16", kind="resize", fmt="RGB", w=16, h=16, src=imp.reshape(-1), **outs)
+
+    # ---- quirk R5: the float planar resizer, probed in a child process (the reference dereferences a null plane) --------------------
+    import subprocess
+
+    probe = ("import sys, numpy as np\n" + (f"sys.path.insert(0, {a.module_dir!r})\n" if a.module_dir else "") +
+             "import PyNvCodec as nvc\nPF = nvc.PixelFormat\n"
+             f"up = nvc.PyFrameUploader(64, 32, PF.RGB_32F_PLANAR, {a.gpu})\n"
+             "s = up.UploadSingleFrame(np.random.default_rng(5).random(3 * 64 * 32, dtype=np.float32))\n"
+             f"d = nvc.PySurfaceResizer(32, 16, PF.RGB_32F_PLANAR, {a.gpu}).Execute(s)\n"
+             "print('R5 probe:', 'refused' if d is None or d.Empty() else 'resized')\n")
+    try:
+        r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300)
+        rc, said = r.returncode, (r.stdout + r.stderr)[-300:]
+    except Exception as e:  # noqa: BLE001
+        rc, said = -999, str(e)
+    save("quirk_R5_resize_RGB_32F_PLANAR", kind="quirk", quirk="R5", returncode=np.array(rc, np.int32), said=np.array(said))
+    print(f"quirk R5 (RGB_32F_PLANAR resize in a child process): exit status {rc}")
 
     # ---- remap ---------------------------------------------------------------------------------------------------------
     src = synth("RGB", w, h, 3000, "A")
@@ -172,4 +270,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -75,6 +75,54 @@ def which_assumptions(o, run, want):
     return hits
 
 
+def describe_hits(hits, default):
+    if not hits:
+        return "NO assumption combination lands within 1 LSB  MISMATCH"
+    if default in hits:
+        return f"the default (A2 = A6 = A8 = 0) matches ({len(hits)} of 18 combinations do)"
+    return "the default does NOT match; these do: " + ", ".join(f"A2={h['A2']} A6={h['A6']} A8={h['A8']}" for h in hits)
+
+
+def resolve_like_the_reference(sf, df, ctx):
+    """(colour space, colour range) this repo's converter dispatch — pinned against the reference's own TasksColorCvt.cpp by
+    tests/test_reference_tc_pin.py — resolves for a context, None when refused.  Host logic only."""
+    nvc = _nvc()
+    nvc.SetExtendedColorspaces(False)
+    cc = None if ctx is None else nvc.ColorspaceConversionContext(nvc.ColorSpace(ctx[0]), nvc.ColorRange(ctx[1]))
+    return nvc.ConverterResolve(getattr(nvc.PixelFormat, sf), getattr(nvc.PixelFormat, df), cc)
+
+
+def classify_r2(o, w, h, src_planes, dw, dh, want_flat):
+    """Reference quirk R2 (Tasks.cpp:1227-1253 + MemoryInterfaces.cpp:1617-1621): RGB_PLANAR / YUV444 are resized as ONE stacked W x 3H
+    plane.  -> which reading the recorded output follows: 'per plane' (this repo), 'stacked' (the reference's quirk), both (no row near a
+    seam differs at this size) or neither."""
+    st, per = o.resize(o.RGB_PLANAR, o.LANCZOS3, w, h, src_planes, dw, dh, o.EXACT)
+    assert st == 0
+    stack = np.ascontiguousarray(np.concatenate([p.reshape(h, w) for p in src_planes], axis=0))
+    st, stk = o.resize(o.Y, o.LANCZOS3, w, 3 * h, [stack], dw, 3 * dh, o.EXACT)
+    assert st == 0
+    a = lsb_report(join_planes(per), want_flat)[0] <= 1
+    b = lsb_report(stk[0].reshape(-1), want_flat)[0] <= 1
+    return {(True, True): "matches both readings", (True, False): "per plane (this repo's reading; NOT the reference quirk)",
+            (False, True): "stacked W x 3H (the reference quirk R2: seam rows blend neighbouring planes; deliberately not replicated)",
+            (False, False): "neither reading  MISMATCH"}[(a, b)]
+
+
+def classify_c13(o, w, h, src_flat, res, want_flat):
+    """Reference quirk C13 (TasksColorCvt.cpp:758): RGB -> YUV444 under MPEG range runs the PACKED converter on plane 0.  Row 0 of plane 0
+    cannot be overwritten by a later row, so its first W bytes tell: planar Y samples (this repo) or interleaved Y Cb Cr triples (the quirk)."""
+    st, out = o.convert(o.RGB, o.YUV444, res[0], res[1], w, h, split_planes(o, "RGB", w, h, src_flat), o.EXACT)
+    assert st == 0
+    y, cb, cr = (p.reshape(h, w)[0] for p in out)
+    packed = np.stack([y, cb, cr], axis=1).reshape(-1)[:w]
+    row0 = np.asarray(want_flat[:w]).astype(np.int64)
+    a = np.abs(row0 - y.astype(np.int64)).max() <= 1
+    b = np.abs(row0 - packed.astype(np.int64)).max() <= 1
+    return {(True, True): "matches both readings", (True, False): "planar Y (this repo's reading; NOT the reference quirk)",
+            (False, True): "packed Y Cb Cr triples in plane 0 (the reference quirk C13; deliberately not replicated)",
+            (False, False): "neither reading  MISMATCH"}[(bool(a), bool(b))]
+
+
 def need_fixtures():
     d, m = fixture_dir()
     if d is None:
@@ -107,8 +155,15 @@ def check_convert(path, o, produce):
     for key in z.files:
         if key.startswith("refused_"):
             assert produce(sf, df, w, h, z["src"], _ctx_of(key[8:])) is None, f"{os.path.basename(path)}: the reference refuses ctx {key[8:]}, we accept it"
+        elif key.startswith("refusedkind_"):
+            continue  # quirk BGR bookkeeping (None vs Empty()): reported by make_npp_fixtures.py --verify-only
         elif key.startswith("out_"):
             want = z[key]
+            if "quirk" in z.files and str(z["quirk"]) == "C13" and key[4:] != "none" and key[5] == "0":
+                res = resolve_like_the_reference(sf, df, _ctx_of(key[4:]))
+                if res is not None and classify_c13(o, w, h, z["src"], res, want).startswith("packed"):
+                    n += 1  # the fixture shows the reference bug (packed triples in a planar surface): classified, deliberately not matched
+                    continue
             got = produce(sf, df, w, h, z["src"], _ctx_of(key[4:]))
             assert got is not None, f"{os.path.basename(path)}: the reference accepts ctx {key[4:]}, we refuse it"
             assert got.shape == want.shape and got.dtype == want.dtype
@@ -159,6 +214,10 @@ def test_oracle_exact_matches_reference_resizer(oracle, path):
         st, out = run()
         assert st == 0
         mx, frac = lsb_report(join_planes(out), z[key])
+        if mx > 1 and "quirk" in z.files and str(z["quirk"]) == "R2":
+            verdict = classify_r2(o, w, h, src, dw, dh, z[key])
+            assert verdict.startswith("stacked"), f"{os.path.basename(path)} -> {dw}x{dh}: {verdict}"
+            continue  # the fixture shows the reference's stacked-plane resize: classified, deliberately not matched
         assert mx <= 1, (f"{os.path.basename(path)} -> {dw}x{dh}: max |diff| {mx}, {frac:.2%} of bytes off by more than 1 LSB; switches that would match: "
                          f"{which_assumptions(o, run, z[key])}")
 
@@ -224,6 +283,10 @@ def test_hip_matches_reference_resizer(path):
         rs = nvc.PySurfaceResizer(dw, dh, getattr(nvc.PixelFormat, fmt), 0)
         rs.SetInterpolation(2)  # Lanczos: what the reference's resizer asks NPP for (Tasks.cpp:1190) — also this repo's default since round 3
         mx, frac = lsb_report(down(fmt, dw, dh, rs.Execute(up(fmt, w, h, z["src"]))), z[key])
+        if mx > 1 and "quirk" in z.files and str(z["quirk"]) == "R2":
+            import oracle as o
+            assert classify_r2(o, w, h, split_planes(o, fmt, w, h, z["src"]), dw, dh, z[key]).startswith("stacked")
+            continue
         assert mx <= 1, f"{os.path.basename(path)} -> {dw}x{dh}: max |diff| {mx}, {frac:.2%} off by more than 1 LSB"
 
 
@@ -241,6 +304,36 @@ def test_hip_matches_reference_remaper(path):
     assert mx <= 1, f"{os.path.basename(path)}: max |diff| {mx}, {frac:.2%} off by more than 1 LSB"
 
 
+def test_quirk_classifiers_tell_the_two_readings_apart(oracle):
+    """The classifiers the pin kit uses on first contact, exercised on synthetic 'reference' outputs built from the oracle itself: an R2
+    fixture made by resizing the stacked W x 3H plane is recognised as the reference quirk and one made per plane as this repo's reading
+    (they differ only on rows within three taps of the two seams); a C13 fixture with packed triples in plane 0 likewise."""
+    o = oracle
+    w, h, dw, dh = 64, 24, 40, 15
+    src = o.synth(o.RGB_PLANAR, w, h, 4242)
+    st, per = o.resize(o.RGB_PLANAR, o.LANCZOS3, w, h, src, dw, dh, o.EXACT)
+    stack = np.ascontiguousarray(np.concatenate([p.reshape(h, w) for p in src], axis=0))
+    st2, stk = o.resize(o.Y, o.LANCZOS3, w, 3 * h, [stack], dw, 3 * dh, o.EXACT)
+    assert st == 0 and st2 == 0
+    per_flat, stk_flat = join_planes(per), stk[0].reshape(-1)
+    diff_rows = np.unique(np.nonzero(np.abs(per_flat.astype(int) - stk_flat.astype(int)).reshape(3 * dh, dw) > 1)[0])
+    assert len(diff_rows) and all(min(abs(r - dh), abs(r - dh + 1), abs(r - 2 * dh), abs(r - 2 * dh + 1)) <= 3 for r in diff_rows), diff_rows
+    assert classify_r2(o, w, h, src, dw, dh, per_flat).startswith("per plane")
+    assert classify_r2(o, w, h, src, dw, dh, stk_flat).startswith("stacked")
+    assert "MISMATCH" in classify_r2(o, w, h, src, dw, dh, 255 - per_flat)
+    rgb = o.synth(o.RGB, w, h, 77)
+    flat = join_planes(rgb)
+    st, yuv = o.convert(o.RGB, o.YUV444, 0, 0, w, h, rgb, o.EXACT)
+    assert st == 0
+    planar = join_planes(yuv)
+    y, cb, cr = (p.reshape(h, w) for p in yuv)
+    quirk = planar.copy()
+    quirk[:w] = np.stack([y[0], cb[0], cr[0]], axis=1).reshape(-1)[:w]
+    assert classify_c13(o, w, h, flat, (0, 0), planar).startswith("planar")
+    assert classify_c13(o, w, h, flat, (0, 0), quirk).startswith("packed")
+    assert describe_hits([], {"A2": 0, "A6": 0, "A8": 0}).endswith("MISMATCH")
+
+
 @pytest.mark.gpu
 def test_pin_kit_rehearsal_on_this_gpu(tmp_path):
     """The kit itself, end to end, before it ever meets an NVIDIA box: make_npp_fixtures.py runs against this repo's drop-in
@@ -254,9 +347,18 @@ def test_pin_kit_rehearsal_on_this_gpu(tmp_path):
                         os.path.join(ROOT, "videoprocessingframework_amd"), "--out", out], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     man = json.load(open(os.path.join(out, "manifest.json")))
-    assert man["producer"] == "vpf-hip" and len(man["cases"]) >= 40
+    assert man["producer"] == "vpf-hip" and len(man["cases"]) >= 42
     env = dict(os.environ, VPF_NPP_FIXTURES=out)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu or not gpu", "-k", "not rehearsal",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+    # --verify-only: the table a maintainer reads on first contact.  Against this repo's own output every fixture matches the default
+    # assumptions, the R2 / C13 cases classify as this repo's reading, the refused BGR contexts return Empty() surfaces, R5 does not crash.
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_npp_fixtures.py"), "--verify-only", "--out", out],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "MISMATCH" not in r.stdout and "the default does NOT match" not in r.stdout, r.stdout[-4000:]
+    assert r.stdout.count("quirk R2 -> per plane") >= 4 and r.stdout.count("quirk R2 -> per plane") + r.stdout.count("quirk R2 -> matches both") == 8, r.stdout[-4000:]
+    assert "quirk R2 -> stacked" not in r.stdout and "quirk C13 -> planar Y" in r.stdout and "an Empty() surface" in r.stdout, r.stdout[-4000:]
+    assert "quirk R5: child exit status 0" in r.stdout, r.stdout[-2000:]

@@ -35,6 +35,7 @@
 //     rows (four tiles) the same way every fourth tile.
 // VGPRs: 2 x 4 x NT column weights + 2 x 4 x NT ring + staging prefetch: NT = 8 -> two waves per SIMD.
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -613,14 +614,15 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     if (!lzm_shape(j.ch, j.sw, j.sh, j.dw, j.dh).rows_ok) return false;
   }
   // Launch shape = (N-tiles per wave, 16-row destination tiles per band), the same for every plane of the launch.  A staged row is at most
-  // PF x 4 lanes x 16 B and the workgroup's LDS must leave room for two workgroups per CU; among the shapes that fit, the cheapest by a
-  // small cost model read off a sweep over both (profiles/r03_lanczos_shape_sweep_n32.txt / _n8.txt, tools/lanczos_shape_sweep.py):
-  //   a wave costs S + R w (its fixed part — column weights, first fetch — plus R tiles of work, w scaled by the vertical factor),
-  //   the launch W = sum over planes of strips-of-four x bands x frames workgroups against 512 resident ones: whole rounds cost one wave
-  //   time each, a partial round at least 0.8 of one (a half-empty chip runs its waves faster, not twice as fast).
-  // S = 3.0 / 2.0 and w = 1.0 / 0.6 tile units for 8- / 4-tile strips.  Against the sweep's 18 cases the model's pick is within 6 % of the
-  // best measured shape on average; the rule it replaces (bands = 512 / workgroups per band row, per plane) lost 20 - 35 % on the
-  // multi-plane formats, whose planes it sized independently.
+  // PF x 4 lanes x 16 B and the workgroup's LDS must leave room for two (8-tile strips) or three (4-tile strips) workgroups per CU; among the
+  // shapes that fit, the cheapest by a small cost model fitted to sweeps over both at 32 / 8 / 1 frames per dispatch
+  // (profiles/r03_lanczos_shape_sweep_n*.txt, tools/lanczos_shape_sweep.py):
+  //   a wave costs S + R w (its fixed part — operand loads, first fetch — plus R tiles of work, w scaled by the vertical factor),
+  //   the launch W = sum over planes of strips-of-four x bands x frames workgroups against the resident ones (512 / 768): whole rounds cost
+  //   one wave time each, a partial round at least 0.9 of one (a half-empty chip runs its waves faster, not twice as fast).
+  // S = 2.0 / 1.0, w = 1.0 / 0.5 tile units for 8- / 4-tile strips — except that a 4-tile strip of a 3-channel plane costs as much as an
+  // 8-tile one (w = 1.0: its 64 destination bytes are 21 pixels under the same 64-B windows).  Over the sweeps' 27 cases the model's pick is
+  // within 3 % of the best measured shape on average (worst 12 %).  Without weight tables S is three times that.
   int nt = 8;
   uint32_t pitch = 0, span = 0, wave_lds = 0;
   auto fits = [&]() {
@@ -643,7 +645,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
       if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
       nt = cand;
       if (!fits()) continue;
-      const double S = (cand == 8 ? 3.0 : 2.0) * (tables ? 0.35 : 1.0), w = cand == 8 ? 1.0 : 0.6;  // with weight tables a wave's fixed part is its first fetch
+      const double S = (cand == 8 ? 2.0 : 1.0) * (tables ? 1.0 : 3.0), slots = cand == 8 ? 512.0 : 768.0;
       uint32_t tmax = 0;
       for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
       for (uint32_t r = 1; r <= std::min(tmax, 64u); r++) {
@@ -654,10 +656,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
           const uint32_t tiles = (jobs[p].dh + 15) / 16, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
           wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
           const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-          work = std::max(work, (double)std::min(r, tiles) * w * (0.5 + scy / 3.0));
+          const double w = cand == 8 || jobs[p].ch == 3 ? 1.0 : 0.5;
+          work = std::max(work, (double)std::min(r, tiles) * w * (0.3 + 0.7 * scy / 1.5));
         }
-        const uint64_t full = wgs / 512, part = wgs % 512;
-        const double cost = (S + work) * ((double)full + (part ? std::max((double)part / 512.0, 0.8) : 0.0));
+        const double rounds = (double)wgs / slots, full = std::floor(rounds), part = rounds - full;
+        const double cost = (S + work) * (full + (part > 0.0 ? std::max(part, 0.9) : 0.0));
         if (!best_nt || cost < best) { best = cost; best_nt = cand; band_tiles = r; }
       }
     }
