@@ -126,7 +126,7 @@ class Workload:
             self.px_per_step = ring * self.w * self.h
             self.bytes_per_step = ring * 3 * (self.w * self.h + self.dw * self.dh)  # algorithmic: source read once, destination written once
             self.launches_per_step = (ring + 31) // 32
-            self.kernel = "RowBandTask (4 destination rows per wave)" if name.endswith("bilinear") else "LanczosMarchTask (register ring, no barriers)"
+            self.kernel = "RowBandTask (4 destination rows per wave)" if name.endswith("bilinear") else "k_lanczos_mfma (i8 matrix cores, per-shape weight tables)"
         else:
             raise SystemExit(f"unknown workload {name}")
 

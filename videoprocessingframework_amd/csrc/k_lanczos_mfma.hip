@@ -9,31 +9,36 @@
 // zero — an i8 MFMA retires 16 x 16 x 64 products in 16 cycles — and, decisive here, they take the SOURCE BYTES AS THEY LIE IN MEMORY as
 // an operand: no unpacking, no per-channel shuffles.  The whole filter is integer arithmetic (the test oracle restates it: resize_plane_lanczos,
 // FP32 mode), so the order in which an MFMA adds its 64 products does not matter and every kernel of the family writes the same bytes:
-//   H  = sum_k qx[k] s[k]          Q14 weights (sum 16384), exact
-//   Hr = (H + 128) >> 8            Q6, fits 16 bits with the Lanczos overshoot
-//   V  = sum_k qy[k] Hr[k]         exact in 32 bits (Q20)
-//   out = clamp((V + 2^19) >> 20, 0, 255)
+//   H  = sum_k qx[k] s[k]                          Q14 weights (sum 16384), exact
+//   Hr = (H + 128) >> 8                            Q6, fits 16 bits with the Lanczos overshoot
+//   z  = Hr - 8192 = 256 zh + zl,  q = 256 qh + ql    signed low bytes; vertical taps that clamp onto the same source row are merged first
+//   V  = 2^19 + sum_k (qy[k] z[k] - ql[k] zl[k]) >> 8      i.e. 256 sum qh zh + sum (ql zh + qh zl): the lowest partial product is not formed
+//   out = clamp((V + 2^11) >> 12, 0, 255)
 //
 // Work decomposition (tests/lanczos_mfma_model.py is an executable model of exactly this bookkeeping, checked against the oracle on the CPU):
 //   * a WAVE owns a strip of NT "N-tiles" of 16 destination BYTES (byte b = pixel b / CH, channel b % CH: packed RGB needs no special
-//     case) and a band of destination rows, and marches down the source in tiles of 16 rows.  No workgroup barrier anywhere.
+//     case) and a band of destination rows, and marches down the source in tiles of 16 rows.  The four waves of a workgroup own four
+//     neighbouring strips of the same band and share the row-weight operands (one barrier per 64 destination rows).
 //   * pass 1, per source tile T and N-tile j:  D[16 rows][16 bytes] = A B with A = the 64 source bytes of each row that start at the
 //     tile's window ws_j (one ds_read_b128 per lane: lane (i, g) reads row i, bytes 16 g .. 16 g + 15; bytes are staged with 0x80 xor-ed
 //     in = s - 128 as a signed byte) and B = the column weights, each Q14 weight as two signed bytes (w = 256 wh + wl -> two MFMAs HI, LO).
 //     Clamped taps simply add their weights on the edge pixel's slot, so image edges cost nothing.  Per lane:
-//     h'' = ((HI + 128) << 8) + LO + 128 (the 128s ride in as the MFMAs' C operand) holds Hr - 8192 = 256 hb + lb in bytes 2 / 1, and
-//     four v_perm_b32 + one xor pack the four rows a lane holds into one dword of hb and one of lb.
+//     h'' = ((HI + 128) << 8) + LO + 128 (the 128s ride in as the MFMAs' C operand) holds z + 128 in bits 8 .. 23, and one v_perm_b32 + one
+//     xor per ROW PAIR pack the four rows a lane holds into two dwords of (zl, zh) byte pairs.
 //   * the D layout of pass 1 (lane (n, g) holds rows 4 g .. 4 g + 3 of column n) IS the A layout of pass 2 (lane (n, g) holds K slots
-//     16 g .. 16 g + 15 of row n) once the K slots are numbered to match: K slot (g, 4 p + r) <-> source row 16 T + 4 g + r of the tile in
-//     ring slot p = T & 3.  The ring (the packed bytes of the last four source tiles, 2 x 4 VGPRs per N-tile) never moves: pass 1 is
-//     instantiated per ring slot and the vertical weight operand is built for the slot numbering.
-//   * pass 2, per destination tile of 16 rows and N-tile: D[16 bytes][16 rows] = A B with A = the ring, B = the row weights split like the
-//     column weights: HH, MID = HL + LH, LL -> V = 65536 HH + 256 MID + LL (+ 2^27 for the 8192s, + 2^19 to round; both in LL's C operand);
-//     a lane ends up with four horizontally adjacent output bytes -> one dword -> a wave-private LDS tile -> dense 16-B row stores.
-//   * weights: the column sets of a strip are evaluated once per wave (one pixel per lane), merged at the image edges, split into bytes
-//     and SCATTERED into the operand image in LDS with ds_write_b8 (6 x CH x 2 byte stores per pixel); the row sets of 64 destination
-//     rows (four tiles) the same way every fourth tile.
-// VGPRs: 2 x 4 x NT column weights + 2 x 4 x NT ring + staging prefetch: NT = 8 -> two waves per SIMD.
+//     16 g .. 16 g + 15 of row n) once the K slots are numbered to match: the tile in ring slot p = (T - t_first) & 3 sits in K chunk p >> 1,
+//     and its source row 4 g + r owns the byte pair 16 g + 8 (p & 1) + 2 r (zl) / + 1 (zh).  The ring (the byte pairs of the last four
+//     source tiles, 2 x 4 VGPRs per N-tile) never moves: the march is unrolled four deep and pass 1 is instantiated per ring slot.
+//   * pass 2, per destination tile of 16 rows and N-tile: D[16 bytes][16 rows] = A B with A = the ring (two K chunks) and B = the row
+//     weights: the Y operand carries qh against the zl slots and ql against the zh slots, the X operand — qh against zh — is derived from
+//     it ((Y << 8) & 0xff00ff00); out = ((X << 8) + Y) >> 12 with 2^19 + 2^11 riding in as Y's C operand.  A lane ends up with four
+//     horizontally adjacent output bytes -> one dword (shift12_sat_pack4: six instructions) -> a wave-private LDS tile -> dense 16-B row
+//     stores.  In both passes the MFMAs of N-tile j + 1 are issued ahead of the vector-ALU work on tile j.
+//   * weights: operand images depend on the plane shape only; two small kernels build them once per shape into a table in static device
+//     memory (see "Weight operands" below), the main kernel loads its strip's 2 NT column operands (16 B per lane each) and copies the row
+//     operands of 64 destination rows to LDS by LDS-DMA.  Without a table (arena full / tuning flag) the same code evaluates them in place.
+//   * blocks are numbered XCD-aware (picture_order, k_resize_common.h): neighbouring strips and bands run on one L2.
+// VGPRs: 2 x 4 x NT column operands + 2 x 4 x NT ring + two staging sets: NT = 8 -> two waves per SIMD, NT = 4 -> three.
 #include <algorithm>
 #include <cmath>
 #include <atomic>
