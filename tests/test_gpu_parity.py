@@ -7,6 +7,7 @@ Padding bytes of every pitched destination must come back untouched.
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -20,6 +21,7 @@ if not torch.cuda.is_available():  # -m gpu on a box without a GPU: fail loudly 
 from gpu_util import DevPlanes, assert_planes_equal, stream_handle  # noqa: E402
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MATS = [(0, 0), (0, 1), (1, 0), (1, 1)]
 
 
@@ -1029,6 +1031,43 @@ def test_lanczos_weight_tables_across_streams(capi, oracle):
         got, intact = D.download()
         assert intact
         assert_planes_equal(got, oracle.resize(of, 2, sw, sh, src, dw, dh, oracle.FP32)[1], f"tables across streams: {fmt} {sw}x{sh}->{dw}x{dh} stream {si} knob {knob:#x}")
+
+
+def test_lanczos_weight_table_arena_full(tmp_path):
+    """The per-shape weight tables live in a fixed arena of static device memory that is never recycled; when it is full, later shapes run
+    with their weights evaluated inside the kernel.  VPF_HIP_LANCZOS_TABLE_KB shrinks the arena so that this happens after a few shapes: in a
+    child process (the knob is read once) a dozen shapes, the first ones with tables and the rest without — some planes of one launch with a
+    table and others without —, all equal the oracle; with 0 KB nothing gets a table."""
+    import subprocess
+    import textwrap
+
+    code = textwrap.dedent("""
+        import os, sys
+        import numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import oracle
+        from videoprocessingframework_amd import capi
+        from gpu_util import DevPlanes
+        ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
+        n = 0
+        for rep in range(2):
+            for i, (fmt, sw, sh, dw, dh) in enumerate([("RGB", 640, 360, 427, 240), ("NV12", 1280, 720, 854, 480), ("YUV420", 642, 362, 300, 170), ("Y", 997, 61, 333, 47),
+                                                        ("RGB", 320, 180, 640, 360), ("RGB", 1919, 64, 1280, 43), ("NV12", 854, 480, 1280, 720), ("RGB", 500, 300, 333, 200),
+                                                        ("YUV444", 100, 60, 150, 90), ("RGB", 1280, 200, 640, 100), ("RGB", 700, 400, 467, 267), ("Y", 2000, 100, 1000, 50)]):
+                f, of = getattr(capi, fmt), getattr(oracle, fmt)
+                src = oracle.synth(of, sw, sh, 8800 + i)
+                S, D = DevPlanes(src), DevPlanes(oracle.alloc(of, dw, dh))
+                capi.resize_batch(ex, f, 2, sw, sh, dw, dh, capi.make_batch([(S.desc(), D.desc())]))
+                torch.cuda.synchronize()
+                got, intact = D.download()
+                want = oracle.resize(of, 2, sw, sh, src, dw, dh, oracle.FP32)[1]
+                assert intact and all(np.array_equal(g, w) for g, w in zip(got, want)), (fmt, sw, sh, dw, dh, rep)
+                n += 1
+        print("ARENA-OK", n)
+    """) % (ROOT, ROOT)
+    for kb in ("300", "0", "40"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VPF_HIP_LANCZOS_TABLE_KB=kb), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ARENA-OK 24" in r.stdout, (kb, r.stdout[-1500:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))

@@ -41,6 +41,7 @@
 // VGPRs: 2 x 4 x NT column operands + 2 x 4 x NT ring + two staging sets: NT = 8 -> two waves per SIMD, NT = 4 -> three.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -586,7 +587,14 @@ static uint32_t lzm_table(hipStream_t st, int dev, bool capturing, uint32_t kind
     uint32_t& used = g_lzm_used16[dev];
     if (!used) used = 16;
     const uint64_t need16 = (bytes + 255) / 256 * 16;
-    if ((uint64_t)used + need16 > kLzmArenaBytes / 16) return 0;
+    // VPF_HIP_LANCZOS_TABLE_KB shrinks the part of the arena that is handed out (0 = no tables at all): a test knob for the "arena
+    // full" path, read once
+    static const uint64_t cap16 = [] {
+      const char* e = std::getenv("VPF_HIP_LANCZOS_TABLE_KB");
+      const uint64_t kb = e ? std::strtoull(e, nullptr, 10) : kLzmArenaBytes / 1024;
+      return std::min<uint64_t>(kb * 64, kLzmArenaBytes / 16);
+    }();
+    if ((uint64_t)used + need16 > cap16) return 0;
     g_lzm_tabs.push_back(LzmTab{dev, kind, k0, k1, k2, k3, used, {}, 0});
     used += (uint32_t)need16;
     e = &g_lzm_tabs.back();
