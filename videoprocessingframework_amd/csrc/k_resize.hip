@@ -92,7 +92,6 @@ VPF_DEV int32_t dot2z(uint32_t a, uint32_t b) {
   asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-constexpr float kQ14Inv = 6.103515625e-05f;  // 2^-14
 
 template <int CH>
 struct LanczosGatherTask {
@@ -125,6 +124,50 @@ VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_
   int32_t acc[CH];
 #pragma unroll
   for (int c = 0; c < CH; c++) acc[c] = (1 << 19) + (1 << 11);
+  // Horizontal sums of one source row.  The six taps of a pixel are 6 CH CONTIGUOUS bytes (unless the edge clamp folds some of them onto
+  // the border pixel), so the fast path fetches them as ONE window of dwords from the 4-B aligned address below the first tap — 1 / 1 / 2
+  // load instructions per row for 1 / 2 / 3 channels instead of 6 / 12 / 18 byte loads: with byte loads the kernel was bound by the rate
+  // at which the memory pipeline takes instructions, nothing else —, shifts the window down to the first tap with v_alignbyte_b32, spreads
+  // two taps of a channel into int16 halves with one v_perm_b32 and takes them two at a time with v_dot2_i32_i16 against the packed Q14
+  // weights.  Same exact integer sums as the byte-wise path, which the lanes next to the left / right image edge (clamped taps), windows
+  // that would reach past the row's last dword, and rows that are not 4-B aligned keep.
+  constexpr int NW = (6 * CH + 3) / 4;        // dwords of tap bytes: 2 / 3 / 5
+  constexpr int ND = NW + 1;                  // dwords loaded: the window may start up to 3 bytes below the first tap
+  const uint32_t b0 = (uint32_t)CH * (uint32_t)(tx.i0 - 2), a0 = b0 & ~3u;
+  const bool lane_fast = (((uintptr_t)src | sp) & 3u) == 0 && tx.i0 - 2 >= 0 && tx.i0 + 3 <= (int32_t)sw - 1 && a0 + 4u * ND <= (((uint32_t)CH * sw + 3u) & ~3u);
+  const bool fast = __builtin_amdgcn_ballot_w64(!lane_fast) == 0;  // decided per WAVE: the two waves at a row's ends take the byte-wise path whole, none runs both
+  const uint32_t q01 = pack_i16(tx.q[0], tx.q[1]), q23 = pack_i16(tx.q[2], tx.q[3]), q45 = pack_i16(tx.q[4], tx.q[5]);
+  auto row_sums = [&](const uint8_t* r, int32_t (&h)[CH]) {
+    if (fast) {
+      uint32_t d[ND];
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(r + a0);
+#pragma unroll
+      for (int i = 0; i < ND; i++) d[i] = p[i];
+      uint32_t w[NW + 1];
+#pragma unroll
+      for (int i = 0; i < NW; i++) w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], b0 & 3u);
+      w[NW] = w[NW - 1];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        uint32_t pr[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int B0 = 2 * k * CH + c, B1 = (2 * k + 1) * CH + c, W0 = B0 >> 2;                 // tap 2 k in the low half, tap 2 k + 1 in the high half
+          const uint32_t sel = (uint32_t)(B0 & 3) | 0x0c00u | ((uint32_t)((B1 >> 2) == W0 ? (B1 & 3) : 4 + (B1 & 3)) << 16) | 0x0c000000u;
+          pr[k] = __builtin_amdgcn_perm(w[W0 + 1], w[W0], sel);
+        }
+        h[c] = dot2(pr[2], q45, dot2(pr[1], q23, dot2z(pr[0], q01)));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        int32_t t = 0;  // exact: |t| <= 255 * sum |q| < 2^24
+#pragma unroll
+        for (int kx = 0; kx < 6; kx++) t += __mul24(tx.q[kx], (int32_t)r[xi[kx] + c]);  // 16-bit x 8-bit: v_mad_i32_i24 (a 32-bit multiply is quarter rate)
+        h[c] = t;
+      }
+    }
+  };
   int32_t qrun = 0;
 #pragma unroll
   for (int ky = 0; ky < 6; ky++) {
@@ -132,21 +175,13 @@ VPF_DEV void LanczosGatherTask<CH>::run(const uint8_t* __restrict__ src, uint32_
     const int32_t row = j < 0 ? 0 : (j > hi ? hi : j), nxt = j + 1 < 0 ? 0 : (j + 1 > hi ? hi : j + 1);
     qrun += ty.q[ky];
     if (ky < 5 && nxt == row) continue;  // the run goes on: its last tap carries the sum
-    const uint8_t* r = src + (size_t)row * sp;
-    uint8_t v[6][CH];  // all taps of the row requested before the first is used (see k_resize_f32)
-#pragma unroll
-    for (int kx = 0; kx < 6; kx++)
-#pragma unroll
-      for (int c = 0; c < CH; c++) v[kx][c] = r[xi[kx] + c];
-    __builtin_amdgcn_sched_barrier(0);
+    int32_t h[CH];
+    row_sums(src + (size_t)row * sp, h);
     const int32_t ql = ((qrun + 128) & 0xff) - 128;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-      int32_t h = 0;  // exact: |h| <= 255 * sum |q| < 2^24
-#pragma unroll
-      for (int kx = 0; kx < 6; kx++) h += tx.q[kx] * (int32_t)v[kx][c];
-      const int32_t z = ((h + 128) >> 8) - 8192, zl = ((z + 128) & 0xff) - 128;
-      acc[c] += (qrun * z - ql * zl) >> 8;  // a multiple of 256: exact
+      const int32_t z = ((h[c] + 128) >> 8) - 8192, zl = ((z + 128) & 0xff) - 128;
+      acc[c] += (__mul24(qrun, z) - __mul24(ql, zl)) >> 8;  // a multiple of 256: exact (|qrun| < 2^15, |z| < 2^15)
     }
     qrun = 0;
   }
@@ -727,7 +762,6 @@ struct TileShape { bool ok; uint32_t ty, nr, lds, rowq, lshift; int wpb; };
 static TileShape plan_tile(bool lz, int np, const int* ch, const uint32_t* dw, const uint32_t* dh, const float* scxs, const float* scys, uint32_t frames,
                            int elem = 1 /* bytes per sample: 1, or 4 for float surfaces */) {
   TileShape best{false, 0, 0, 0, 0, 0, 4};
-  const double taps = lz ? 6.0 : 2.0;
   int ch_max = 0;
   uint32_t rowq = 0;  // 16-B units a tile row can span (+ alignment slack), the widest plane decides
   float scy = 0.f;
