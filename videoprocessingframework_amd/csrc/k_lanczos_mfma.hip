@@ -48,6 +48,7 @@
 #include <type_traits>
 
 #include "k_resize_common.h"
+#include "vpf_lzm_plan.h"
 #include "vpf_plan_bounds.h"
 
 namespace vpf {
@@ -110,16 +111,6 @@ struct LanczosMfmaTask {
   static constexpr int kGroupsPerCu = NT == 4 ? 3 : 2;  // register budget: 168 / 256 VGPRs
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
-
-constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles (one "group" of 64 rows):
-                                                                                 // per tile the Y operand of the ring's two K chunks (X is derived from it)
-constexpr uint32_t kLzmB1Chunk = 4;                                              // N-tiles whose column-weight operands are built per pass through LDS
-constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
-constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of wave-private LDS: staged tile | out tile, or the setup scratch
-  const uint32_t run = 16u * pitch + 16u * lzm_out_pitch(nt), setup = 2u * kLzmB1Chunk * 1024u;
-  return run > setup ? run : setup;
-}
-constexpr uint32_t lzm_group_lds(int nt, uint32_t pitch) { return 4u * lzm_wave_lds(nt, pitch) + 2u * kLzmWmBytes; }  // + the workgroup's two row-weight buffers
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Weight operands.  They depend on the plane SHAPE only — not on the frame, and the column operands not on the band either — yet a
@@ -532,7 +523,6 @@ __global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(c
 // Two workgroups per CU share its 160 KB of LDS: up to 80 KB per workgroup, which is above the 64 KB a kernel gets without asking
 // (a 2x down-scale with 8-tile strips stages 544-B rows: 76 KB).  hipFuncSetAttribute is per device and not a stream operation: done
 // once per device and kernel, outside any capture-sensitive path (it neither allocates nor synchronises).
-constexpr uint32_t kLzmMaxLds = 80u * 1024u;
 template <template <int> class TaskCH>
 static bool lzm_big_lds_ok() {
   static std::atomic<uint64_t> done{0}, failed{0};
@@ -546,68 +536,15 @@ static bool lzm_big_lds_ok() {
   return e == hipSuccess;
 }
 
-// Does a plane shape fit the kernel's windows (vpf_plan_bounds.h: the tiles are walked with the kernel's own coordinate arithmetic)?
-// A per-frame caller asks the same question every call: a small per-thread cache answers it.
-struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8; bool rows_ok; };
-static LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
-  thread_local LzmShape cache[8] = {};
-  thread_local uint32_t next = 0;
-  for (const LzmShape& c : cache)
-    if (c.ch == ch && c.sw == sw && c.sh == sh && c.dw == dw && c.dh == dh) return c;
-  const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
-  LzmShape s{ch, sw, sh, dw, dh, 0, 0, false};
-  s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) != 0;
-  if (s.rows_ok) { s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8); }
-  cache[next++ & 7] = s;
-  return s;
-}
-
-// ---- weight-table bookkeeping (host).  One arena per device, bump-allocated, never freed.  An entry remembers the (up to four) streams
-// that have queued its build: a launch on one of them is ordered behind the build by the stream itself; any other stream — and any stream
-// that is being captured into a graph, whose build has not run — queues the build again (idempotent: same bytes).
-struct LzmTab {
-  int dev;
-  uint32_t kind, k0, k1, k2, k3;  // kind 0: columns (ch, sw, dw, nt) | 1: rows (sh, dh, band rows, 0)
-  uint32_t off16;
-  hipStream_t streams[4];
-  int nstreams;
-};
-static std::mutex g_lzm_mu;
-static std::vector<LzmTab> g_lzm_tabs;
-static uint32_t g_lzm_used16[64];  // per device, in 16-B units (0 = "no table": the first 256 B stay unused)
-
-// -> offset of the table in the arena (16-B units), 0 when there is no room; `build(off16)` queues the build kernel on st
-template <class Build>
-static uint32_t lzm_table(hipStream_t st, int dev, bool capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes, Build build) {
-  std::lock_guard<std::mutex> lock(g_lzm_mu);
-  LzmTab* e = nullptr;
-  for (LzmTab& t : g_lzm_tabs)
-    if (t.dev == dev && t.kind == kind && t.k0 == k0 && t.k1 == k1 && t.k2 == k2 && t.k3 == k3) { e = &t; break; }
-  if (!e) {
-    uint32_t& used = g_lzm_used16[dev];
-    if (!used) used = 16;
-    const uint64_t need16 = (bytes + 255) / 256 * 16;
-    // VPF_HIP_LANCZOS_TABLE_KB shrinks the part of the arena that is handed out (0 = no tables at all): a test knob for the "arena
-    // full" path, read once
-    static const uint64_t cap16 = [] {
-      const char* e = std::getenv("VPF_HIP_LANCZOS_TABLE_KB");
-      const uint64_t kb = e ? std::strtoull(e, nullptr, 10) : kLzmArenaBytes / 1024;
-      return std::min<uint64_t>(kb * 64, kLzmArenaBytes / 16);
-    }();
-    if ((uint64_t)used + need16 > cap16) return 0;
-    g_lzm_tabs.push_back(LzmTab{dev, kind, k0, k1, k2, k3, used, {}, 0});
-    used += (uint32_t)need16;
-    e = &g_lzm_tabs.back();
-  }
-  bool known = false;
-  for (int i = 0; i < e->nstreams; i++) known = known || e->streams[i] == st;
-  if (known && !capturing) return e->off16;
-  build(e->off16);
-  if (!capturing) {
-    if (e->nstreams < 4) e->streams[e->nstreams++] = st;
-    else { e->streams[0] = e->streams[1]; e->streams[1] = e->streams[2]; e->streams[2] = e->streams[3]; e->streams[3] = st; }
-  }
-  return e->off16;
+// the per-shape weight tables' bookkeeping (vpf_lzm_plan.h); VPF_HIP_LANCZOS_TABLE_KB shrinks the part of the arena that is handed out
+// (0 = no tables at all): a test knob for the "arena full" path, read once
+static LzmTableCache& lzm_tables() {
+  static LzmTableCache cache([] {
+    const char* e = std::getenv("VPF_HIP_LANCZOS_TABLE_KB");
+    const uint64_t kb = e ? std::strtoull(e, nullptr, 10) : kLzmArenaBytes / 1024;
+    return std::min<uint64_t>(kb * 1024, kLzmArenaBytes);
+  }());
+  return cache;
 }
 
 bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
@@ -626,61 +563,12 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     }
     if (!lzm_shape(j.ch, j.sw, j.sh, j.dw, j.dh).rows_ok) return false;
   }
-  // Launch shape = (N-tiles per wave, 16-row destination tiles per band), the same for every plane of the launch.  A staged row is at most
-  // PF x 4 lanes x 16 B and the workgroup's LDS must leave room for two (8-tile strips) or three (4-tile strips) workgroups per CU; among the
-  // shapes that fit, the cheapest by a small cost model fitted to sweeps over both at 32 / 8 / 1 frames per dispatch
-  // (profiles/r03_lanczos_shape_sweep_n*.txt, tools/lanczos_shape_sweep.py):
-  //   a wave costs S + R w (its fixed part — operand loads, first fetch — plus R tiles of work, w scaled by the vertical factor),
-  //   the launch W = sum over planes of strips-of-four x bands x frames workgroups against the resident ones (512 / 768): whole rounds cost
-  //   one wave time each, a partial round at least 0.9 of one (a half-empty chip runs its waves faster, not twice as fast).
-  // S = 2.0 / 1.0, w = 1.0 / 0.5 tile units for 8- / 4-tile strips — except that a 4-tile strip of a 3-channel plane costs as much as an
-  // 8-tile one (w = 1.0: its 64 destination bytes are 21 pixels under the same 64-B windows).  Over the sweeps' 27 cases the model's pick is
-  // within 3 % of the best measured shape on average (worst 12 %).  Without weight tables S is three times that.
-  int nt = 8;
-  uint32_t pitch = 0, span = 0, wave_lds = 0;
-  auto fits = [&]() {
-    span = 0;
-    for (int p = 0; p < njobs; p++) {
-      const LzmShape s = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh);
-      const uint32_t sp = nt == 8 ? s.span8 : s.span4;
-      if (!sp) return false;  // some tile's taps do not fit the 64-B window
-      span = std::max(span, sp);
-    }
-    pitch = vpf_bound_lzm_pitch(span);
-    wave_lds = lzm_wave_lds(nt, pitch);
-    return span <= (nt == 8 ? 5u : 4u) * 64u && lzm_group_lds(nt, pitch) <= kLzmMaxLds;  // PF staging loads of 4 lanes x 16 B per row
-  };
-  uint32_t band_tiles = 0;
-  {
-    double best = 0.0;
-    int best_nt = 0;
-    for (int cand = 8; cand >= 4; cand -= 4) {
-      if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
-      nt = cand;
-      if (!fits()) continue;
-      const double S = (cand == 8 ? 2.0 : 1.0) * (tables ? 1.0 : 3.0), slots = cand == 8 ? 512.0 : 768.0;
-      uint32_t tmax = 0;
-      for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
-      for (uint32_t r = 1; r <= std::min(tmax, 64u); r++) {
-        if (forced > 1 && (forced & 0xff) && (uint32_t)(forced & 0xff) != r && !((uint32_t)(forced & 0xff) > tmax && r == std::min(tmax, 64u))) continue;
-        uint64_t wgs = 0;
-        double work = 0.0;
-        for (int p = 0; p < njobs; p++) {
-          const uint32_t tiles = (jobs[p].dh + 15) / 16, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
-          wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
-          const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-          const double w = cand == 8 || jobs[p].ch == 3 ? 1.0 : 0.5;
-          work = std::max(work, (double)std::min(r, tiles) * w * (0.3 + 0.7 * scy / 1.5));
-        }
-        const double rounds = (double)wgs / slots, full = std::floor(rounds), part = rounds - full;
-        const double cost = (S + work) * (full + (part > 0.0 ? std::max(part, 0.9) : 0.0));
-        if (!best_nt || cost < best) { best = cost; best_nt = cand; band_tiles = r; }
-      }
-    }
-    if (!best_nt) return false;
-    nt = best_nt;
-    if (!fits()) return false;
-  }
+  LzmPlaneIn in[3];
+  for (int p = 0; p < njobs; p++) in[p] = LzmPlaneIn{jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh};
+  const LzmPlan plan = lzm_plan(njobs, in, n, forced, tables);  // launch shape by the cost model of vpf_lzm_plan.h
+  if (!plan.ok) return false;
+  const int nt = plan.nt;
+  const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
   PlaneTable t{};
   t.np = (uint32_t)njobs;
   uint32_t gx = 0, gy = 0;
@@ -699,15 +587,18 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     uint32_t ctab = 0, rtab = 0;
     if (tables) {
       const uint32_t strips = (j.dw * (uint32_t)j.ch + 16u * nt - 1) / (16u * nt), bands = (j.dh + rows - 1) / rows, gpb = (rows + 63) / 64;
-      ctab = lzm_table(st, dev, capturing, 0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt, (uint64_t)strips * nt * 2048u, [&](uint32_t off16) {
+      const LzmTableCache::Hit c = lzm_tables().get(st, dev, capturing, 0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt, (uint64_t)strips * nt * 2048u);
+      if (c.build) {
         (void)hipGetLastError();
-        if (nt == 8) hipLaunchKernelGGL(k_lzm_build_cols<8>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, off16);
-        else hipLaunchKernelGGL(k_lzm_build_cols<4>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, off16);
-      });
-      rtab = lzm_table(st, dev, capturing, 1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes, [&](uint32_t off16) {
+        if (nt == 8) hipLaunchKernelGGL(k_lzm_build_cols<8>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, c.off16);
+        else hipLaunchKernelGGL(k_lzm_build_cols<4>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, c.off16);
+      }
+      const LzmTableCache::Hit r = lzm_tables().get(st, dev, capturing, 1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes);
+      if (r.build) {
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, off16);
-      });
+        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, r.off16);
+      }
+      ctab = c.off16; rtab = r.off16;
     }
     t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, (int)rtab, pitch, rows, wave_lds, ctab};
     t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
@@ -716,7 +607,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     gy += (j.dh + rows - 1) / rows;
   }
   const dim3 grid(gx, gy, n);
-  const uint32_t lds = lzm_group_lds(nt, pitch);
+  const uint32_t lds = plan.group_lds;
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
   if (lds > 64u * 1024u && !(nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
