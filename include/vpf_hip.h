@@ -214,7 +214,7 @@ VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_NV12_RGB_VARIANT 1
 #define VPF_TUNE_RESIZE_TILE 2 /* shape of the tiled resize kernels for measurement sweeps: 0 = policy, else rows-per-tile | waves-per-workgroup << 8
                                   (rows 4..64 in steps of 4, waves 4 or 8); same pixels whatever the shape */
-#define VPF_TUNE_RESIZE_MFMA 5 /* 8-bit Lanczos-3 on the matrix cores (k_lanczos_mfma.hip): 0 = policy, 1 = never (gather kernel), else
+#define VPF_TUNE_RESIZE_MFMA 5 /* 8-bit Lanczos-3 on the matrix cores (k_lanczos_mfma.hip): 0 = policy, 1 = never (the tiled / gather kernels take Lanczos), else
                                   N-tiles per wave (0 = policy, 4 or 8) << 8 | destination 16-row tiles per band (0 = policy, 1..64); | 0x10000: the kernel
                                   evaluates its filter weights itself instead of loading the per-shape tables (the path taken when the table arena is full);
                                   same pixels whatever the value */

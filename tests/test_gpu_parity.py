@@ -914,6 +914,43 @@ def test_tiled_resize_shapes_write_identical_pixels(capi, oracle, shape):
     assert capi.set_tuning(capi.TUNE_RESIZE_TILE, 7) == -1 and capi.set_tuning(capi.TUNE_RESIZE_TILE, 16 | (5 << 8)) == -1
 
 
+@pytest.mark.parametrize("shape", [None, (8, 4), (8, 8), (16, 8), (32, 8), (12, 4)])
+def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
+    """The tiled separable Lanczos kernel (LanczosTileTask) takes what the matrix-core kernel cannot hold — scale factors above ~2.4: the
+    resizes in front of a network — and, with that kernel switched off (VPF_TUNE_RESIZE_MFMA = 1), everything else as well.  By policy and
+    with forced tile shapes (VPF_TUNE_RESIZE_TILE): strong and mild down-scales, up-scales, tiles on the left / right image edge (margins
+    replicated), clamped rows merged at the top / bottom, pictures smaller than the filter, multi-plane formats in one launch, planes of a
+    format that go different ways (NV12 chroma past the window limit), a 33-frame batch, single frames through vpf_resize."""
+    cases = [("RGB", 1920, 270, 416, 104, 2), ("RGB", 1280, 720, 224, 224, 3), ("YUV420", 1920, 136, 224, 28, 2), ("NV12", 1280, 72, 300, 20, 2),
+             ("RGB", 640, 360, 427, 240, 2), ("NV12", 320, 180, 640, 360, 2), ("Y", 997, 61, 333, 47, 2), ("RGB", 1000, 61, 211, 47, 33),
+             ("RGB", 20, 12, 45, 31, 2), ("RGB", 2, 3, 300, 5, 2), ("Y", 700, 2, 64, 1, 2), ("YUV444", 600, 90, 130, 31, 2), ("RGB", 3000, 40, 700, 9, 2)]
+    if shape is not None:
+        assert capi.set_tuning(capi.TUNE_RESIZE_TILE, shape[0] | (shape[1] << 8)) >= 0
+    try:
+        for mfma in (0, 1):
+            capi.set_tuning(capi.TUNE_RESIZE_MFMA, mfma)
+            for fmt, sw, sh, dw, dh, n in cases:
+                f, of = getattr(capi, fmt), getattr(oracle, fmt)
+                srcs = [oracle.synth(of, sw, sh, 7700 + i) for i in range(min(n, 3))]
+                wants = [oracle.resize(of, 2, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+                S = [DevPlanes(srcs[i % len(srcs)]) for i in range(n)]
+                D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+                capi.resize_batch(capi.make_exec(stream_handle()), f, 2, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+                one = DevPlanes(oracle.alloc(of, dw, dh))
+                capi.resize(capi.make_exec(stream_handle()), f, 2, sw, sh, S[0].desc(), dw, dh, one.desc())
+                torch.cuda.synchronize()
+                for i in range(n):
+                    got, intact = D[i].download()
+                    assert intact
+                    assert_planes_equal(got, wants[i % len(srcs)], f"lanczos tile shape {shape} mfma {mfma} {fmt} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+                got, intact = one.download()
+                assert intact
+                assert_planes_equal(got, wants[0], f"lanczos tile shape {shape} mfma {mfma} {fmt} {sw}x{sh}->{dw}x{dh} single frame")
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_TILE, 0)
+        capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
+
+
 @pytest.mark.parametrize("band", [1, 2, 4, 8, 16])
 def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 16 / 8 / 4 / 2 for launches with >= 2048

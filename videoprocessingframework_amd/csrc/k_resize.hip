@@ -619,6 +619,196 @@ __global__ __launch_bounds__(64 * WPB) void k_resize_tile(const uint8_t* __restr
                                                           int vec_ok) {
   TileTask<CH, WPB>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, tile_rows, nr_cap, rowq, lshift}, blockIdx.x, blockIdx.y);
 }
+// ------------------------------------------------------------------------------------------
+// Tiled, separable 8-bit LANCZOS-3 for the shapes the matrix-core kernel (k_lanczos_mfma.hip) cannot hold — scale factors above ~2.4,
+// i.e. the 1080p -> 416 x 416 / 608 x 608 / 224 x 224 resizes in front of a network, where its 64-B tap windows or its four-tile ring are
+// too small.  Same integer filter definition as that kernel, the gather kernel and the oracle: exact Q14 horizontal sums,
+// Hr = (H + 128) >> 8, vertical taps on byte-wide partial products with clamped taps merged per source row.  A workgroup of WPB waves owns
+// a tile of 64 columns x TY rows:
+//   phase 0  the tile's whole source window goes to LDS in one sweep of dense 16-B loads (edge tiles: the pixels clamped taps fall on are
+//            replicated into the rows' margins, so every lane's six taps are contiguous bytes in every tile); wave 0 evaluates the 64
+//            column weight sets meanwhile, wave 1 the row sets (merged where the clamp folds taps onto one row, split into signed bytes);
+//   phase 1  wave w takes source rows w, w + WPB, ...: aligned dword reads, v_alignbyte_b32, one v_perm_b32 per tap pair, two taps per
+//            v_dot2_i32_i16; z = Hr - 8192 goes to LDS as the int16 pair (z, zh) with z = 256 zh + zl;
+//   phase 2  a lane owns 4 consecutive columns of one destination row: per vertical tap and channel ONE v_dot2_i32_i16 of (z, zh)
+//            against (qh, ql) — qh z + ql zh = (q z - ql zl) >> 8 exactly —, then (acc + 2^19 + 2^11) >> 12, clamped.
+// (The gather kernel — a lane per destination pixel, six taps times six rows from global memory — remains for rows that are not 16-B
+// aligned and tiles that do not fit LDS.)
+// ------------------------------------------------------------------------------------------
+template <int CH, int WPB>
+struct LanczosTileTask {
+  static constexpr int kThreads = 64 * WPB;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P, uint32_t bx, uint32_t by);
+};
+template <int CH, int WPB>
+VPF_DEV void LanczosTileTask<CH, WPB>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& P,
+                                           uint32_t bx, uint32_t by) {
+  // dynamic LDS: RAW[nr_cap][rowq x 16 B] source bytes | H[nr_cap][CH][64] (z | zh << 16) | WY[tile_rows][8] (six (qh | ql << 16), first H row) | WX[4][64]
+  constexpr uint32_t T = 64 * WPB;
+  const uint32_t sw = P.sw, sh = P.sh, dw = P.dw, dh = P.dh, tile_rows = P.a0, nr_cap = P.a1, rowq = P.a2, lshift = P.a3;
+  const float scx = P.scx, scy = P.scy;
+  u32x4* const RAW = dyn_strip;
+  uint32_t* const H = reinterpret_cast<uint32_t*>(dyn_strip + (size_t)nr_cap * rowq);
+  uint32_t* const WY = H + (size_t)nr_cap * CH * 64;
+  uint32_t* const WX = WY + (size_t)tile_rows * 8;  // [4][64]: three Q14 weight pairs and the first tap index of every column
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t xf = bx * 64, xl = (xf + 63 < dw - 1) ? xf + 63 : dw - 1;
+  if (xf >= dw) return;  // a narrower plane of a multi-plane launch (workgroup-uniform)
+  const uint32_t x = xf + lane, xc = x < dw ? x : dw - 1;  // lanes past the right edge compute a duplicate, never stored
+  const uint32_t y0 = by * tile_rows, yl = (y0 + tile_rows - 1 < dh - 1) ? y0 + tile_rows - 1 : dh - 1;
+  auto clampi = [](int32_t i, int32_t hi) { return (uint32_t)(i < 0 ? 0 : (i > hi ? hi : i)); };
+  const int32_t R0 = ltap_i0(y0, scy) - 2, R1 = ltap_i0(yl, scy) + 3;
+  const int32_t fv = ltap_i0(xf, scx) - 2, lv = ltap_i0(xl, scx) + 3;  // the tile's VIRTUAL source columns: before 0 / after sw - 1 they are copies of the edge pixel
+  const uint32_t first = clampi(fv, (int32_t)sw - 1), last = clampi(lv, (int32_t)sw - 1);
+  const uint32_t nrows = (uint32_t)(R1 - R0 + 1);
+  const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
+  const uint32_t scol = threadIdx.x & ((1u << lshift) - 1u), srow0 = threadIdx.x >> lshift, srows = T >> lshift;
+  u32x4 stage[kTileStagePasses];
+#pragma unroll
+  for (int k = 0; k < kTileStagePasses; k++) {
+    const uint32_t r = srow0 + k * srows;
+    if (r < nrows && scol < nq) stage[k] = ldg<false, u32x4>(src + (size_t)clampi(R0 + (int32_t)r, (int32_t)sh - 1) * sp + base + 16 * scol);
+  }
+  const uint32_t vt = threadIdx.x - 64;  // lane of wave 1 (and later waves) that owns destination row y0 + vt
+  if (vt < tile_rows) {
+    const uint32_t y = y0 + vt, yc = y < dh ? y : dh - 1;
+    const QTap t = quantize_ltap(make_ltap(yc, scy));
+    int32_t q[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) q[k] = t.q[k];
+#pragma unroll
+    for (int k = 0; k < 5; k++)  // taps the clamp folds onto one source row act as ONE tap with the summed weight, carried by the last of them
+      if (clampi(t.i0 + k - 2, (int32_t)sh - 1) == clampi(t.i0 + k - 1, (int32_t)sh - 1)) { q[k + 1] += q[k]; q[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int32_t ql = ((q[k] + 128) & 0xff) - 128, qh = (q[k] - ql) >> 8;
+      WY[vt * 8 + k] = pack_i16(qh, ql);
+    }
+    WY[vt * 8 + 6] = (uint32_t)(t.i0 - 2 - R0);
+  }
+  if (wv == 0) {
+    const QTap tx = quantize_ltap(make_ltap(xc, scx));
+#pragma unroll
+    for (int k = 0; k < 3; k++) WX[k * 64 + lane] = pack_i16(tx.q[2 * k], tx.q[2 * k + 1]);
+    WX[3 * 64 + lane] = (uint32_t)tx.i0;
+  }
+#pragma unroll
+  for (int k = 0; k < kTileStagePasses; k++) {
+    const uint32_t r = srow0 + k * srows;
+    if (r < nrows && scol < nq) RAW[r * rowq + scol + 1] = stage[k];  // rows start one 16-B unit into their LDS row: room for up to 3 replicated pixels on the left
+  }
+  if (fv < 0 || lv > (int32_t)sw - 1) {  // workgroup-uniform: a tile on the left / right image edge
+    __syncthreads();
+    const int32_t nl = fv < 0 ? -fv * CH : 0, nr = lv > (int32_t)sw - 1 ? (lv - ((int32_t)sw - 1)) * CH : 0;  // bytes to add on each side (<= 3 px)
+    for (uint32_t t = threadIdx.x; t < nrows * 16; t += T) {
+      uint8_t* b = reinterpret_cast<uint8_t*>(RAW + (size_t)(t >> 4) * rowq) + 16;
+      const int32_t i = (int32_t)(t & 15);
+      if (i < nl) b[CH * fv + i] = b[i % CH];                                                    // base == 0 on the left edge
+      if (i < nr) b[CH * sw - base + (uint32_t)i] = b[CH * (sw - 1) - base + (uint32_t)i % CH];
+    }
+  }
+  __syncthreads();
+  uint32_t qx[3];
+  const int32_t i0 = (int32_t)WX[3 * 64 + lane];
+  const uint32_t xo0 = (uint32_t)((i0 - 2) * CH - (int32_t)base + 16);  // the six taps are contiguous bytes from here
+#pragma unroll
+  for (int k = 0; k < 3; k++) qx[k] = WX[k * 64 + lane];
+  // Phase 1, horizontal, two source rows per iteration (both rows' LDS reads are in flight before the first is used)
+  {
+    constexpr int NE = (6 * CH + 3) / 4;  // dwords of the lead-free run
+    const uint32_t lead = xo0 & 3u, qoff = xo0 & ~3u;
+    auto fetch = [&](uint32_t r, uint32_t* d) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(RAW + (size_t)r * rowq) + qoff);
+#pragma unroll
+      for (int i = 0; i <= NE; i++) d[i] = q[i];
+    };
+    auto hdots = [&](uint32_t r, const uint32_t* d) {
+      uint32_t e[NE];
+#pragma unroll
+      for (int i = 0; i < NE; i++) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], lead);
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        uint32_t p0, p1, p2;  // (tap 0 | tap 1 << 16), (tap 2 | tap 3 << 16), (tap 4 | tap 5 << 16) of channel c
+        if constexpr (CH == 3) {  // bytes c, 3 + c | 6 + c, 9 + c | 12 + c, 15 + c of the run
+          p0 = __builtin_amdgcn_perm(e[1], e[0], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+          p1 = __builtin_amdgcn_perm(e[2], e[1], 0x0c000c00u | ((5u + c) << 16) | (2u + c));
+          p2 = __builtin_amdgcn_perm(e[4], e[3], 0x0c000c00u | ((3u + c) << 16) | (uint32_t)c);
+        } else if constexpr (CH == 2) {  // bytes c, 2 + c of dwords 0, 1, 2
+          const uint32_t sel = 0x0c000c00u | ((2u + c) << 16) | (uint32_t)c;
+          p0 = __builtin_amdgcn_perm(e[0], e[0], sel); p1 = __builtin_amdgcn_perm(e[1], e[1], sel); p2 = __builtin_amdgcn_perm(e[2], e[2], sel);
+        } else {  // bytes 0, 1 | 2, 3 | 4, 5
+          p0 = __builtin_amdgcn_perm(e[0], e[0], 0x0c010c00u); p1 = __builtin_amdgcn_perm(e[0], e[0], 0x0c030c02u); p2 = __builtin_amdgcn_perm(e[1], e[1], 0x0c010c00u);
+        }
+        const int32_t h = dot2(p2, qx[2], dot2(p1, qx[1], dot2z(p0, qx[0])));  // exact: |h| < 2^24
+        const int32_t z = ((h + 128) >> 8) - 8192, zh = (z + 128) >> 8;
+        H[(r * CH + c) * 64 + lane] = pack_i16(z, zh);
+      }
+    };
+    for (uint32_t r = wv; r < nrows; r += 2 * WPB) {
+      uint32_t da[NE + 1], db[NE + 1];
+      const bool two = r + WPB < nrows;  // wave-uniform
+      fetch(r, da);
+      if (two) fetch(r + WPB, db);
+      hdots(r, da);
+      if (two) hdots(r + WPB, db);
+    }
+  }
+  __syncthreads();
+  // phase 2: a lane owns 4 consecutive columns of one destination row (a wave = 4 rows x 64 columns)
+  const uint32_t cg = lane & 15, rsub = lane >> 4, x0 = xf + 4 * cg;
+  for (uint32_t yb = 0; yb < tile_rows; yb += 4 * WPB) {
+    const uint32_t yy = yb + wv * 4 + rsub, y = y0 + yy;
+    if (yy >= tile_rows || y >= dh || x0 >= dw) continue;
+    const uint32_t r0 = WY[yy * 8 + 6];
+    int32_t acc[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[c][i] = (1 << 19) + (1 << 11);
+#pragma unroll
+    for (int ky = 0; ky < 6; ky++) {
+      const uint32_t wq = WY[yy * 8 + ky];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(&H[((r0 + ky) * CH + c) * 64 + 4 * cg]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[c][i] = dot2(hv[i], wq, acc[c][i]);  // qh z + ql zh
+      }
+    }
+    uint8_t o[4 * CH];  // pixel-major
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int32_t v = acc[c][i] >> 12;
+        o[i * CH + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+    auto pk4 = [&](int i) { return (uint32_t)o[i] | ((uint32_t)o[i + 1] << 8) | ((uint32_t)o[i + 2] << 16) | ((uint32_t)o[i + 3] << 24); };
+    uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
+    if (P.vec_ok && x0 + 4 <= dw) {
+      if constexpr (CH == 3) {
+        stg3<true>(out, pk4(0), pk4(4), pk4(8));
+      } else if constexpr (CH == 2) {
+        stg<true, u32x2>(out, u32x2{pk4(0), pk4(4)});
+      } else {
+        stg<true, uint32_t>(out, pk4(0));
+      }
+    } else {
+      const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
+      for (uint32_t i = 0; i < nv; i++) out[i] = o[i];
+    }
+  }
+}
+template <int CH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_resize_lztile(const uint8_t* __restrict__ src, uint32_t sp, uint32_t sw, uint32_t sh,
+                                                            uint8_t* __restrict__ dst, uint32_t dp, uint32_t dw, uint32_t dh,
+                                                            float scx, float scy, uint32_t tile_rows, uint32_t nr_cap, uint32_t rowq, uint32_t lshift,
+                                                            int vec_ok) {
+  LanczosTileTask<CH, WPB>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, tile_rows, nr_cap, rowq, lshift}, blockIdx.x, blockIdx.y);
+}
+template <int CH> struct TileLz4 : LanczosTileTask<CH, 4> {};
+template <int CH> struct TileLz8 : LanczosTileTask<CH, 8> {};
+
 // the template-template forms k_planes_mp wants
 template <int CH> struct TileBl4 : TileTask<CH, 4> {};
 template <int CH> struct TileBl8 : TileTask<CH, 8> {};
@@ -845,6 +1035,19 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
       a.f[0].s[0] = src; a.f[0].sp[0] = sp; a.f[0].d[0] = dst; a.f[0].dp[0] = dp;
       const ResizeJob j{ch, 0, sw, sh, dw, dh};
       if (launch_lanczos_mfma(st, 1, &j, 1, a)) return hipGetLastError();
+    }
+    // strong down-scales (beyond the matrix-core kernel's windows): the tiled separable form; the gather form for what is left
+    if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15)) {
+      const TileShape t = plan_tile(true, 1, &ch, &dw, &dh, &scx, &scy, 1);
+      if (t.ok) {
+        const dim3 tgrid((dw + 63) / 64, (dh + t.ty - 1) / t.ty);
+#define VPF_LZT3(C, W) VPF_LAUNCH((k_resize_lztile<C, W>), tgrid, dim3(64 * W), t.lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, t.ty, t.nr, t.rowq, t.lshift, vec_ok)
+#define VPF_LZT(C) do { if (t.wpb == 8) VPF_LZT3(C, 8); else VPF_LZT3(C, 4); } while (0)
+        if (ch == 1) VPF_LZT(1); else if (ch == 2) VPF_LZT(2); else VPF_LZT(3);
+#undef VPF_LZT
+#undef VPF_LZT3
+        return hipGetLastError();
+      }
     }
     dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
     if (ch == 1) VPF_LAUNCH((k_resize_lanczos<1>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
@@ -1107,7 +1310,8 @@ static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const Ba
 }
 
 hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
-  enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_LZ_MFMA, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
+  enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_LZ_MFMA, FAM_LZ_TILE, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
+  bool lz_tile_ok[3] = {false, false, false};  // a Lanczos plane the tiled kernel may take when the matrix-core kernel does not
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
   if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return hipErrorInvalidValue;
   Fam fam[3];
@@ -1145,6 +1349,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       }
     } else if (eff[p] == VPF_INTERP_LANCZOS3) {
       fam[p] = src16 ? FAM_LZ_MFMA : FAM_LZ_GATHER;
+      lz_tile_ok[p] = src16 && tune != 40;
     } else if (eff[p] == VPF_INTERP_LINEAR && (scy < 1.0f || tune == 43) && tune != 40 && src16 && !band_up) {
       fam[p] = FAM_TILE;
     } else if (eff[p] == VPF_INTERP_LINEAR && src16 && (rowb[p] = lds_strip_bytes(j.ch, j.sw, j.dw, a.f[0].s[j.k], a.f[0].sp[j.k], kResizeRowBytes)) != 0) {
@@ -1165,6 +1370,38 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     if (all_mfma && launch_lanczos_mfma(st, njobs, jobs, n, a)) return hipGetLastError();
     for (int p = 0; p < njobs; p++)
       if (fam[p] == FAM_LZ_MFMA && !launch_lanczos_mfma(st, 1, &jobs[p], n, a)) fam[p] = FAM_LZ_GATHER;
+    // what the matrix-core kernel does not take (strong down-scales): the tiled separable kernel — one launch for the whole format when
+    // every plane is in that position, else plane by plane — and the gather kernel for what is left
+    bool all_lzt = !f32;
+    for (int p = 0; p < njobs; p++) all_lzt = all_lzt && fam[p] == FAM_LZ_GATHER && lz_tile_ok[p];
+    if (all_lzt) {
+      int ch[3]; uint32_t dw[3], dh[3]; float sx[3], sy[3];
+      for (int p = 0; p < njobs; p++) { ch[p] = jobs[p].ch; dw[p] = jobs[p].dw; dh[p] = jobs[p].dh; sx[p] = g[p].scx; sy[p] = g[p].scy; }
+      const TileShape tl = plan_tile(true, njobs, ch, dw, dh, sx, sy, n);
+      if (tl.ok) {
+        PlaneTable t{};
+        t.np = (uint32_t)njobs;
+        uint32_t gx = 0, gy = 0;
+        for (int p = 0; p < njobs; p++) {
+          t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
+          t.g[p].a0 = tl.ty; t.g[p].a1 = tl.nr; t.g[p].a2 = tl.rowq; t.g[p].a3 = tl.lshift;
+          gx = std::max(gx, (jobs[p].dw + 63) / 64);
+          gy += (jobs[p].dh + tl.ty - 1) / tl.ty;
+        }
+        if (tl.wpb == 8) launch_planes_mp<TileLz8>(st, dim3(gx, gy, n), tl.lds, a, t);
+        else launch_planes_mp<TileLz4>(st, dim3(gx, gy, n), tl.lds, a, t);
+        return hipGetLastError();
+      }
+    }
+    for (int p = 0; p < njobs; p++)
+      if (fam[p] == FAM_LZ_GATHER && lz_tile_ok[p]) {
+        const float sx = g[p].scx, sy = g[p].scy;
+        const TileShape t1 = plan_tile(true, 1, &jobs[p].ch, &jobs[p].dw, &jobs[p].dh, &sx, &sy, n);
+        if (!t1.ok) continue;
+        fam[p] = FAM_LZ_TILE;
+        g[p].a0 = t1.ty; g[p].a1 = t1.nr; g[p].a2 = t1.rowq; g[p].a3 = t1.lshift;
+        rowb[p] = t1.lds | ((uint32_t)t1.wpb << 24);  // carried to the launch below
+      }
   }
   TileShape ts{false, 0, 0, 0, 0, 0, 4};
   if (all_tile) {
@@ -1273,6 +1510,13 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
                           else launch_plane_batch<TileTask<C, 4>>(st, tgrid, lds, a, j.k, g[p]); } while (0)
       if (j.ch == 1) VPF_TILEB(1); else if (j.ch == 2) VPF_TILEB(2); else VPF_TILEB(3);
 #undef VPF_TILEB
+    } else if (fam[p] == FAM_LZ_TILE) {
+      const uint32_t lds = rowb[p] & 0xffffffu, wpb = rowb[p] >> 24;
+      const dim3 tgrid((j.dw + 63) / 64, (j.dh + g[p].a0 - 1) / g[p].a0, n);
+#define VPF_LZTB(C) do { if (wpb == 8) launch_plane_batch<LanczosTileTask<C, 8>>(st, tgrid, lds, a, j.k, g[p]); \
+                         else launch_plane_batch<LanczosTileTask<C, 4>>(st, tgrid, lds, a, j.k, g[p]); } while (0)
+      if (j.ch == 1) VPF_LZTB(1); else if (j.ch == 2) VPF_LZTB(2); else VPF_LZTB(3);
+#undef VPF_LZTB
     } else if (fam[p] == FAM_ROWPAIR) {
       g[p].a0 = rowb[p] / 16;
       const BandPlan bs = plan_band(1, &j, n, a);
