@@ -1070,6 +1070,56 @@ def test_lanczos_weight_tables_across_streams(capi, oracle):
         assert_planes_equal(got, oracle.resize(of, 2, sw, sh, src, dw, dh, oracle.FP32)[1], f"tables across streams: {fmt} {sw}x{sh}->{dw}x{dh} stream {si} knob {knob:#x}")
 
 
+def test_lanczos_weight_tables_from_concurrent_threads(capi, oracle):
+    """Eight host threads, each with a stream of its own, resize the same few shapes (and some of their own) at the same time through
+    vpf_resize_batch: the table cache is shared by every caller of the library in the process, and every thread's first use of a shape
+    must queue that shape's build on ITS stream whoever allocated the entry.  Every frame equals the oracle (the ctypes calls release the
+    GIL, so the launches really interleave)."""
+    import threading
+
+    shapes = [("RGB", 1283, 211, 857, 140), ("NV12", 1280, 240, 854, 160), ("Y", 811, 97, 1622, 194), ("RGB", 640, 360, 427, 240)]
+    srcs = {i: oracle.synth(getattr(oracle, sh[0]), sh[1], sh[2], 9500 + i) for i, sh in enumerate(shapes)}
+    wants = {i: oracle.resize(getattr(oracle, sh[0]), 2, sh[1], sh[2], srcs[i], sh[3], sh[4], oracle.FP32)[1] for i, sh in enumerate(shapes)}
+    errors, results = [], []
+    start = threading.Barrier(8)
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream()
+            ex = capi.make_exec(st.cuda_stream)
+            mine = []
+            with torch.cuda.stream(st):
+                own = ("RGB", 500 + 16 * tid, 120, 333 + 8 * tid, 80)
+                osrc = oracle.synth(oracle.RGB, own[1], own[2], 9600 + tid)
+                staged = [(i, DevPlanes(srcs[i]), DevPlanes(oracle.alloc(getattr(oracle, sh[0]), sh[3], sh[4]))) for i, sh in enumerate(shapes)]
+                oS, oD = DevPlanes(osrc), DevPlanes(oracle.alloc(oracle.RGB, own[3], own[4]))
+                st.synchronize()
+                start.wait()
+                for rep in range(3):
+                    for i, S, D in (staged if tid % 2 == 0 else staged[::-1]):
+                        sh = shapes[i]
+                        capi.resize_batch(ex, getattr(capi, sh[0]), 2, sh[1], sh[2], sh[3], sh[4], capi.make_batch([(S.desc(), D.desc())]))
+                    capi.resize_batch(ex, capi.RGB, 2, own[1], own[2], own[3], own[4], capi.make_batch([(oS.desc(), oD.desc())]))
+                st.synchronize()
+            for i, S, D in staged:
+                mine.append((f"thread {tid} shape {shapes[i]}", D, wants[i]))
+            mine.append((f"thread {tid} own shape {own}", oD, oracle.resize(oracle.RGB, 2, own[1], own[2], osrc, own[3], own[4], oracle.FP32)[1]))
+            results.extend(mine)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    torch.cuda.synchronize()
+    assert len(results) == 8 * 5
+    for what, D, want in results:
+        got, intact = D.download()
+        assert intact
+        assert_planes_equal(got, want, what)
+
+
 def test_lanczos_weight_table_arena_full(tmp_path):
     """The per-shape weight tables live in a fixed arena of static device memory that is never recycled; when it is full, later shapes run
     with their weights evaluated inside the kernel.  VPF_HIP_LANCZOS_TABLE_KB shrinks the arena so that this happens after a few shapes: in a
