@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -34,13 +35,66 @@ constexpr auto TASK_EXEC_FAIL = TaskExecStatus::TASK_EXEC_FAIL;
 
 std::atomic<int> g_extended{-1};
 
+// The reference's resizer / remaper / down- and uploader tasks block until their stream has drained (their cuda_stream_sync callback:
+// Tasks.cpp:1630-1640).  What they wait for here is mostly a kernel of 2 - 20 us, and hipStreamSynchronize puts the thread to sleep on an
+// interrupt: ~15 - 20 us per call, several times the kernel (profiles/r03_sample_chain.txt: 36 us per frame as the reference's sample
+// chain is written, 16 with the wait dropped).  Polling hipStreamQuery is no better (measured: slower).  What is cheap is a completion FLAG in
+// page-locked host memory: the wait queues a 4-byte write of a sequence number behind the work (hipStreamWriteValue32) and spins on the
+// flag in its own cache — no runtime call in the loop.  After kSpinUs without the value (a long queue, a big copy) it falls back to
+// hipStreamSynchronize; a task whose flag could not be set up always takes that path.  VPF_HIP_SYNC_SPIN_US changes the budget (0: never spin).
 struct StreamRef {  // argument of the stream-sync callback (always non-null, also for the NULL stream)
   HipContext ctx;
   HipStream str;
+  volatile uint32_t* flag = nullptr;  // page-locked, mapped: written by the stream, read by the host
+  void* flag_dev = nullptr;
+  uint32_t seq = 0;
+  bool flag_failed = false;
+  StreamRef() = default;
+  StreamRef(HipContext c, HipStream s) : ctx(c), str(s) {}
+  StreamRef(const StreamRef& o) : ctx(o.ctx), str(o.str) {}  // the flag belongs to one owner: copies start without one
+  StreamRef& operator=(const StreamRef& o) {
+    if (this != &o) { release(); ctx = o.ctx; str = o.str; seq = 0; flag_failed = false; }
+    return *this;
+  }
+  ~StreamRef() { release(); }
+  void release() {
+    if (flag) { (void)hipHostFree(const_cast<uint32_t*>(flag)); flag = nullptr; flag_dev = nullptr; }
+  }
 };
 void hip_stream_sync(void* p) {
   auto* s = static_cast<StreamRef*>(p);
   DeviceScope scope(s->ctx);
+  static const int64_t spin_ns = [] {
+    const char* e = std::getenv("VPF_HIP_SYNC_SPIN_US");
+    return (int64_t)1000 * (e ? std::strtol(e, nullptr, 10) : 200);
+  }();
+  if (spin_ns > 0 && !s->flag_failed) {
+    if (!s->flag) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&s->flag_dev, h, 0) == hipSuccess) {
+        s->flag = static_cast<volatile uint32_t*>(h);
+        *s->flag = 0;
+      } else {
+        if (h) (void)hipHostFree(h);
+        (void)hipGetLastError();
+        s->flag_failed = true;
+      }
+    }
+    if (s->flag) {
+      const uint32_t want = ++s->seq;
+      if (hipStreamWriteValue32((hipStream_t)s->str, s->flag_dev, want, 0) == hipSuccess) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t i = 0;; i++) {
+          if (*s->flag == want) return;
+          __builtin_ia32_pause();
+          if ((i & 255u) == 255u && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns) break;
+        }
+      } else {
+        (void)hipGetLastError();
+        s->flag_failed = true;
+      }
+    }
+  }
   (void)hipStreamSynchronize((hipStream_t)s->str);
 }
 
