@@ -390,17 +390,16 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     v4i hi[2], lo[2];
     hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1h[0], c128, 0, 0, 0);
     lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1l[0], c128, 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       if (j + 1 < NT) {
         hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
         lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (j + 4 < NT) {
         av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       uint32_t h[4];
 #pragma unroll
@@ -409,7 +408,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
       // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
       ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
       ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
-      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_sync();  // the next tile's staging stores must not pass these reads
   };
@@ -434,7 +433,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
       x[j & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], bx1, t, 0, 0, 0);
       t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], by0, cy, 0, 0, 0);
       y[j & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], by1, t, 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
     };
     mm(0);
 #pragma unroll
@@ -444,8 +443,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #pragma unroll
       for (int r = 0; r < 4; r++) w[r] = ((uint32_t)x[j & 1][r] << 8) + (uint32_t)y[j & 1][r];  // V / 256 + 2^11 (Q12): the byte is w >> 12, clamped
       *reinterpret_cast<uint32_t*>(owr + 16u * j) = shift12_sat_pack4(w[0], w[1], w[2], w[3]);
-      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_sync();
     const uint32_t orow = mad24(y0, dp, obase);
