@@ -1,5 +1,5 @@
 """The reference's ResNet sample chain (samples/SampleTorchResnet.py:1073-1138) through the drop-in Python API, device-resident:
-NV12 1080p -> YUV420 -> PySurfaceResizer(224 x 224, the reference's Lanczos filter and our bilinear default) -> RGB -> RGB_PLANAR.
+NV12 1080p -> YUV420 -> PySurfaceResizer(224 x 224, the reference's Lanczos filter = the default, and bilinear) -> RGB -> RGB_PLANAR.
 (a) one Execute() per stage and frame, as the sample is written; (b) the additive ExecuteBatch of every stage over 32 frames;
 (c) the additive one-pass PySurfaceConvertResizer NV12 -> bilinear -> RGB_PLANAR (no Lanczos form of it exists).
 Frames per second of the whole chain; the ring (64 frames) is larger than what a stage leaves in the Infinity Cache."""
@@ -27,7 +27,7 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-for interp, name in ((2, "lanczos3 (reference)"), (1, "bilinear (default)")):
+for interp, name in ((2, "lanczos3 (the reference's filter, the default)"), (1, "bilinear (SetInterpolation(1))")):
     to_yuv = nvc.PySurfaceConverter(w, h, PF.NV12, PF.YUV420, GPU)
     rs = nvc.PySurfaceResizer(tw, th, PF.YUV420, GPU); rs.SetInterpolation(interp)
     to_rgb = nvc.PySurfaceConverter(tw, th, PF.YUV420, PF.RGB, GPU)
