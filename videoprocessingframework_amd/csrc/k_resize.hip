@@ -775,27 +775,23 @@ VPF_DEV void LanczosTileTask<CH, WPB>::run(const uint8_t* __restrict__ src, uint
         for (int i = 0; i < 4; i++) acc[c][i] = dot2(hv[i], wq, acc[c][i]);  // qh z + ql zh
       }
     }
-    uint8_t o[4 * CH];  // pixel-major
+    // pixel-major bytes, four per dword: shift, clamp and pack in six instructions per dword (shift12_sat_pack4, k_resize_common.h)
+    auto val = [&](int b) { return (uint32_t)acc[b % CH][b / CH]; };  // byte b of the lane's 4 CH output bytes
+    uint32_t ow[CH];
 #pragma unroll
-    for (int c = 0; c < CH; c++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int32_t v = acc[c][i] >> 12;
-        o[i * CH + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-      }
-    auto pk4 = [&](int i) { return (uint32_t)o[i] | ((uint32_t)o[i + 1] << 8) | ((uint32_t)o[i + 2] << 16) | ((uint32_t)o[i + 3] << 24); };
+    for (int q = 0; q < CH; q++) ow[q] = shift12_sat_pack4(val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
     uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
     if (P.vec_ok && x0 + 4 <= dw) {
       if constexpr (CH == 3) {
-        stg3<true>(out, pk4(0), pk4(4), pk4(8));
+        stg3<true>(out, ow[0], ow[1], ow[2]);
       } else if constexpr (CH == 2) {
-        stg<true, u32x2>(out, u32x2{pk4(0), pk4(4)});
+        stg<true, u32x2>(out, u32x2{ow[0], ow[1]});
       } else {
-        stg<true, uint32_t>(out, pk4(0));
+        stg<true, uint32_t>(out, ow[0]);
       }
     } else {
       const uint32_t nv = (dw - x0 < 4 ? dw - x0 : 4) * CH;
-      for (uint32_t i = 0; i < nv; i++) out[i] = o[i];
+      for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(ow[i >> 2] >> (8 * (i & 3)));
     }
   }
 }

@@ -65,6 +65,25 @@ __global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchAr
   }
 }
 
+// four Q12 values (|w| < 2^27) -> four bytes: clamp(w >> 12, 0, 255), value k in byte k.  Six instructions instead of nine (four shifts, two
+// v_cvt_pk_i16_i32, two v_sat_pk_u8_i16, one v_perm_b32): the SDWA forms write a 16-bit result into the upper half of a register whose
+// lower half already holds its neighbour, so nothing has to be packed afterwards (w >> 12 fits 16 bits as it is).  The inputs are results
+// of ordinary VALU instructions of the compiler's, not of an MFMA: nothing in here needs wait states the compiler cannot see, except the
+// gfx940+ rule that a VALU reading a register right after an SDWA wrote part of it waits one state (the s_nop / the instruction order).
+VPF_DEV uint32_t shift12_sat_pack4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  uint32_t a, b, r;
+  asm("v_ashrrev_i32_e32 %0, 12, %3\n\t"
+      "v_ashrrev_i32_e32 %1, 12, %5\n\t"
+      "v_ashrrev_i32_sdwa %0, 12, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_ashrrev_i32_sdwa %1, 12, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_e32 %2, %0\n\t"
+      "v_sat_pk_u8_i16_sdwa %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(a), "=&v"(b), "=&v"(r)
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // Lanczos-3 taps (see the comment above LanczosGatherTask in k_resize.hip)
 // ------------------------------------------------------------------------------------------
