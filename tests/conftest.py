@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test may hang a run: where pytest-timeout is installed (it is in the project image) every test without a timeout of its own
+    gets 20 minutes — far above the slowest (the pin-kit rehearsal, which builds and runs a second pytest), far below a stuck GPU call."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(1200))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (oracle/): test infrastructure only."""

@@ -1094,7 +1094,7 @@ def test_lanczos_weight_tables_from_concurrent_threads(capi, oracle):
                 staged = [(i, DevPlanes(srcs[i]), DevPlanes(oracle.alloc(getattr(oracle, sh[0]), sh[3], sh[4]))) for i, sh in enumerate(shapes)]
                 oS, oD = DevPlanes(osrc), DevPlanes(oracle.alloc(oracle.RGB, own[3], own[4]))
                 st.synchronize()
-                start.wait()
+                start.wait(timeout=120)  # (a thread that failed earlier aborts the barrier: nobody waits forever)
                 for rep in range(3):
                     for i, S, D in (staged if tid % 2 == 0 else staged[::-1]):
                         sh = shapes[i]
@@ -1107,10 +1107,12 @@ def test_lanczos_weight_tables_from_concurrent_threads(capi, oracle):
             results.extend(mine)
         except Exception as e:  # noqa: BLE001
             errors.append((tid, repr(e)))
+            start.abort()
 
-    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    ts = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(8)]
     [t.start() for t in ts]
-    [t.join() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a worker thread is stuck"
     assert not errors, errors
     torch.cuda.synchronize()
     assert len(results) == 8 * 5
