@@ -21,8 +21,8 @@ def pb(tmp_path_factory):
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"),
                            os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so, "-lm"])
     L = C.CDLL(so)
-    for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_march_rowq", [C.c_int] + [C.c_uint32] * 3),
-                       ("pb_march_pad", []), ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
+    for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]),
+                       ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
                        ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]),
                        ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32])):
         getattr(L, name).argtypes, getattr(L, name).restype = args, C.c_uint32
@@ -101,32 +101,6 @@ def test_bilinear_strips_hold_the_span_and_the_tap_window(pb, ch):
             a = ch * i0 - base[x // cols]
             reach = (a & ~3) + 12 if ch == 3 else a + 2 * ch                           # window of three dwords / two byte taps
             assert int(reach.max()) <= rb, (sw, dw, cols)
-
-
-@pytest.mark.parametrize("ch", [1, 2, 3])
-def test_march_strips_hold_margins_span_and_over_read(pb, ch):
-    """LanczosMarchTask: strip = pad | bytes [base, ch * (last_r + 1)) | replicated right margin; every lane reads (6 * ch + 3) / 4 + 1 dwords
-    from the dword below its first tap"""
-    rng = np.random.default_rng(3)
-    pad, ne = pb.pb_march_pad(), (6 * ch + 3) // 4
-    w = 512 if ch == 1 else 256
-    for sw, dw in size_pairs(rng, 1500, 0.05, 8.0):
-        rowq = pb.pb_march_rowq(ch, sw, dw, w)
-        if not rowq:
-            continue
-        xs = np.arange(0, dw, w)
-        xe = np.minimum(xs + w - 1, dw - 1)
-        first_v, last_v = lz_i0(xs, sw, dw) - 2, lz_i0(xe, sw, dw) + 3
-        assert first_v.min() >= -3 and (last_v - (sw - 1)).max() <= 3                 # at most three replicated pixels on either side
-        first_r, last_r = np.maximum(first_v, 0), np.minimum(last_v, sw - 1)
-        base = (ch * first_r) & ~15
-        nq = (ch * (last_r + 1) - base + 15) // 16
-        assert int(nq.max()) <= 128 and int((pad // 16 + nq).max()) <= rowq, (sw, dw)  # two 1-KiB staging passes; staged units fit behind the pad
-        assert int((pad + ch * first_v - base).min()) >= 0, (sw, dw)                  # left margin stays inside the pad
-        assert int((pad + ch * (last_v + 1) - base).max()) <= rowq * 16, (sw, dw)     # right margin
-        x = np.arange(dw)
-        off = pad + ch * (lz_i0(x, sw, dw) - 2) - base[x // w]
-        assert int(off.min()) >= 0 and int(((off & ~3) + 4 * (ne + 1)).max()) <= rowq * 16, (sw, dw)
 
 
 def test_fused_strip_rows_hold_the_converted_window(pb):

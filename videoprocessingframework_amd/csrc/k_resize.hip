@@ -3,16 +3,17 @@
 //
 // Replaces nppiResize_8u_C3R / _C1R (reference: NppResizeSurfacePacked3C_Impl::Run and NppResizeSurfacePlanar_Impl::Run,
 // src/TC/src/Tasks.cpp:1162-1203,1217-1261) and nppiResize_32f_C3R / _C1R (:1334-1445).  The reference resizer asks NPP for
-// Lanczos (:1190); north_star specifies bilinear, which is the default here (VPF_INTERP_LANCZOS3 selects Lanczos-3).
+// Lanczos (:1190), which is the Task layer's default here too (north_star benchmarks bilinear: VPF_INTERP_LINEAR).
 //
-// Kernel families, all bit-identical to one another (launch_resize / launch_resize_jobs pick):
+// Kernel families; within a filter all are bit-identical to one another (launch_resize / launch_resize_jobs pick):
 //   GatherTask, LanczosGatherTask, FloatGatherTask   gather forms: any size / alignment
 //   RowPairTask (k_resize_lds)    a wave stages the two source rows it needs in wave-private LDS strips (dynamic LDS sized per scale
 //                                 factor) and picks taps from LDS; taps with weight exactly 0 are skipped
 //   RowBandTask                   batches: R destination rows per wave, column taps once, each source row's horizontal lerp once per band
-//   TileTask<CH, LZ> (k_resize_tile), TileTaskF32   tiled + separable: horizontal pass once per (source row, column) into LDS, then the
-//                                 vertical pass (Lanczos-3 always; bilinear when the vertical scale is < 1)
-//   LanczosMarchTask              batches: a wave walks down a band with the six horizontal sums in a register ring (no barriers)
+//   TileTask (k_resize_tile), TileTaskF32   tiled + separable: horizontal pass once per (source row, column) into LDS, then the vertical pass
+//                                 (8-bit: bilinear up-scales of a single frame; float surfaces: Lanczos-3, bilinear with tuning 43)
+//   8-bit Lanczos-3               k_lanczos_mfma.hip (the i8 matrix cores) wherever its tap windows fit; LanczosTileTask below for the
+//                                 scale factors beyond them (above ~2.4); LanczosGatherTask for what is left
 //   HalfTask, Half3R16Task        exact 2x: quad-structured streaming kernels (no taps, no gathers; integer blend)
 //   odd integer factors on both axes   every filter returns the centre sample -> nearest kernel (Lanczos) / RowPairTask's byte-move path
 //   packed RGB taps               both taps of a row = 6 contiguous bytes: fetched as ONE 12-B window from the aligned address below

@@ -1,7 +1,7 @@
 /* vpf_plan_bounds.h — the LDS sizing bounds of the strip-staging resize kernels, as plain C so that the launchers (k_resize.hip,
- * k_convert_resize.hip) and a CPU property test (tests/test_plan_bounds_cpu.py, compiled with gcc) use the SAME formulas.
+ * k_convert_resize.hip, k_lanczos_mfma.hip through vpf_lzm_plan.h) and a CPU property test (tests/test_plan_bounds_cpu.py, compiled with gcc) use the SAME formulas.
  *
- * Every kernel of the row-pair / row-band / march families copies the source bytes its destination columns touch into wave-private LDS
+ * Every kernel of the row-pair / row-band / fused-strip / tiled families copies the source bytes its destination columns touch into wave-private LDS
  * strips whose size the HOST computes from the scale factors.  A bound that is one byte or one row short is silent memory corruption
  * on the device, so each formula here is checked on the CPU against the kernels' exact fp32 tap arithmetic over thousands of
  * (source size, destination size, position) combinations. */
@@ -22,16 +22,6 @@ static inline uint32_t vpf_bound_strip_bytes(int ch, uint32_t sw, uint32_t dw, u
 /* source rows a band of `r` destination rows can touch (bilinear): i1(last row) - i0(first row) + 1 <= floor((r - 1) scy) + 3 (+ fp32 slack) */
 static inline uint32_t vpf_bound_band_slots(int r, float scy) {
   return (uint32_t)((double)(r - 1) * (double)scy + 0.01) + 3u;
-}
-
-/* Lanczos march: 16-B units per strip of a plane whose waves own `wcols` destination columns: pad unit (replicated left margin) + base
- * alignment + six-tap span + replicated right margin and the tap run's over-read; 0 when the span does not fit two 1-KiB staging passes */
-#define VPF_MARCH_PAD 16u
-static inline uint32_t vpf_bound_march_rowq(int ch, uint32_t sw, uint32_t dw, uint32_t wcols) {
-  const double scx = (double)sw / (double)dw;
-  const uint32_t span_px = (uint32_t)(((double)wcols - 1.0) * scx) + 8;  /* taps of a wave's columns: floor((W - 1) scx) + 6 (+ fp32 slack) */
-  if ((uint32_t)ch * span_px > 2018u) return 0;
-  return (VPF_MARCH_PAD + 15u + (uint32_t)ch * span_px + 8u + 15u) / 16u;
 }
 
 /* fused convert + resize strip kernel: bytes per strip row of packed RGB for a wave's 256 destination columns (source span rounded out to
