@@ -422,6 +422,22 @@ def test_download_into_pinned_and_pageable_arrays(oracle):
     assert all(res)
 
 
+@pytest.mark.parametrize("fmt,ofmt", [(PF.RGB, "RGB"), (PF.NV12, "NV12"), (PF.YUV420, "YUV420")])
+def test_download_of_a_large_frame_into_a_pageable_array_goes_in_pieces(oracle, fmt, ofmt):
+    """Frames of 4 MB and more reach a pageable array piece by piece (DMA of piece k+1 under the host copy of piece k,
+    Tasks.cpp DownloadInto); the bytes are those of the direct DMA into AllocPinned memory and of the host frame, repeatedly"""
+    w, h = 3840, 2160
+    src = oracle.synth(getattr(oracle, ofmt), w, h, 77)
+    surf = upload(fmt, w, h, src)
+    want = host_frame(src)
+    dl = nvc.PySurfaceDownloader(w, h, fmt, GPU)
+    pinned = nvc.AllocPinned(want.size)
+    assert dl.DownloadSingleSurface(surf, pinned) and np.array_equal(pinned, want)
+    for i in range(4):
+        out = np.full(want.size if i % 2 else 5, 0xA5, np.uint8)
+        assert dl.DownloadSingleSurface(surf, out) and out.size == want.size and np.array_equal(out, want)
+
+
 def test_upload_from_pinned_memory():
     """AllocPinned: numpy array over page-locked memory; the uploader DMAs from it directly and the result is identical"""
     w, h = 640, 360
