@@ -181,7 +181,9 @@ VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /
   static_assert(PX == 4 || (PX == 8 && CH == 1), "8 pixels per lane: 1-channel planes");
   if (vec4) {
     if constexpr (CH == 3) {
-      stg3<true>(out, pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7]), pack4_trunc_inrange(o[8], o[9], o[10], o[11]));
+      uint32_t d0, d1, d2;
+      pack12_trunc(o, d0, d1, d2);
+      stg3<true>(out, d0, d1, d2);
     } else if constexpr (CH == 2) {
       stg<true, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
     } else {

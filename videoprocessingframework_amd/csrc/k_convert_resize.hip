@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, co
     const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
     if (vec_ok && nv == 4) {
-      stg3<false>(out, pack4_trunc_inrange(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc_inrange(o[1][1], o[b][1], o[a][2], o[1][2]),
-                  pack4_trunc_inrange(o[b][2], o[a][3], o[1][3], o[b][3]));
+      const float t[12] = {o[a][0], o[1][0], o[b][0], o[a][1], o[1][1], o[b][1], o[a][2], o[1][2], o[b][2], o[a][3], o[1][3], o[b][3]};
+      uint32_t d0, d1, d2;
+      pack12_trunc(t, d0, d1, d2);
+      stg3<false>(out, d0, d1, d2);
     } else {
       for (uint32_t i = 0; i < nv; i++) {
         out[3 * i] = (uint8_t)(uint32_t)(o[a][i]); out[3 * i + 1] = (uint8_t)(uint32_t)(o[1][i]); out[3 * i + 2] = (uint8_t)(uint32_t)(o[b][i]);
@@ -260,8 +262,10 @@ VPF_DEV void convert_resize_lds_task(const FrameDesc& f, const Yuv2RgbCoef& c, u
     const int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
     uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
     if (vec_ok && nv == 4) {
-      stg3<false>(out, pack4_trunc_inrange(o[a][0], o[1][0], o[b][0], o[a][1]), pack4_trunc_inrange(o[1][1], o[b][1], o[a][2], o[1][2]),
-                  pack4_trunc_inrange(o[b][2], o[a][3], o[1][3], o[b][3]));
+      const float t[12] = {o[a][0], o[1][0], o[b][0], o[a][1], o[1][1], o[b][1], o[a][2], o[1][2], o[b][2], o[a][3], o[1][3], o[b][3]};
+      uint32_t d0, d1, d2;
+      pack12_trunc(t, d0, d1, d2);
+      stg3<false>(out, d0, d1, d2);
     } else {
       for (uint32_t i = 0; i < nv; i++) {
         out[3 * i] = (uint8_t)(uint32_t)(o[a][i]); out[3 * i + 1] = (uint8_t)(uint32_t)(o[1][i]); out[3 * i + 2] = (uint8_t)(uint32_t)(o[b][i]);
@@ -474,8 +478,10 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
       constexpr int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
       uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
       if (vec_ok && nv == 4) {
-        stg3<false>(out, pack4_trunc_inrange(o[a], o[1], o[b], o[3 + a]), pack4_trunc_inrange(o[4], o[3 + b], o[6 + a], o[7]),
-                    pack4_trunc_inrange(o[6 + b], o[9 + a], o[10], o[9 + b]));
+        const float t[12] = {o[a], o[1], o[b], o[3 + a], o[4], o[3 + b], o[6 + a], o[7], o[6 + b], o[9 + a], o[10], o[9 + b]};
+        uint32_t d0, d1, d2;
+        pack12_trunc(t, d0, d1, d2);
+        stg3<false>(out, d0, d1, d2);
       } else {
         for (uint32_t j = 0; j < nv; j++) {
           out[3 * j] = (uint8_t)(uint32_t)o[3 * j + a]; out[3 * j + 1] = (uint8_t)(uint32_t)o[3 * j + 1]; out[3 * j + 2] = (uint8_t)(uint32_t)o[3 * j + b];

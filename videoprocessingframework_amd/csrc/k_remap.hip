@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_remap3_b(const BatchArgs args, uint32_t
 //     (just not stored) instead of being steered around the arithmetic;
 //   * sx - (float)(int)sx for sx >= 0 is v_fract_f32 (the subtraction is exact, so the bits are the same);
 //   * source offsets are 32-bit (v_mad_u32_u24; the launcher checks the surface is < 4 GiB) on a scalar base pointer;
-//   * blends of 8-bit samples stay inside [0, 255.5], so the pack needs no clamp (pack4_trunc_inrange).
+//   * blends of 8-bit samples stay inside [0, 255.5], and the pack is v_cvt_pk_u8_f32 under round-toward-zero (pack12_trunc).
 // Requires 4-B aligned src rows, 16-B aligned map rows, dw % 4 == 0, sw >= 4, sh * sp < 2^32.  Never reads past the
 // dword-rounded end of the last source row.
 
@@ -95,7 +95,7 @@ VPF_DEV void remap_blend4(const uint8_t* __restrict__ src, const uint32_t* o0, c
       for (int c = 0; c < 3; c++) o[3 * k + c] = bilerp(a0[c], a1[c], b0[c], b1[c], fx[k], fy[k]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    d[0] = pack4_trunc_inrange(o[0], o[1], o[2], o[3]); d[1] = pack4_trunc_inrange(o[4], o[5], o[6], o[7]); d[2] = pack4_trunc_inrange(o[8], o[9], o[10], o[11]);
+    pack12_trunc(o, d[0], d[1], d[2]);
   } else {
     TapWindow w0[4], w1[4];
     uint32_t lead[4];  // the pitch is a multiple of 4: both rows of a pixel share the lead

@@ -56,7 +56,7 @@ VPF_DEV void GatherTask<CH, INTERP>::run(const uint8_t* __restrict__ src, uint32
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if (vec_ok && x0 + 4 <= dw) {
     if constexpr (CH == 3) {
-      stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+      { uint32_t d0, d1, d2; pack12_trunc(o, d0, d1, d2); stg3<true>(out, d0, d1, d2); }
     } else if constexpr (CH == 2) {
       stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
     } else {
@@ -443,7 +443,7 @@ VPF_DEV void TileTask<CH, WPB>::run(const uint8_t* __restrict__ src, uint32_t sp
     uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
     if (P.vec_ok && x0 + 4 <= dw) {
       if constexpr (CH == 3) {
-        stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+        { uint32_t d0, d1, d2; pack12_trunc(o, d0, d1, d2); stg3<true>(out, d0, d1, d2); }
       } else if constexpr (CH == 2) {
         stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
       } else {
@@ -863,7 +863,7 @@ VPF_DEV void HalfTask<CH>::run(const uint8_t* __restrict__ src, uint32_t sp, uin
     }
   uint8_t* out = dst + (size_t)y * dp + (size_t)CH * x0;
   if constexpr (CH == 3) {
-    stg3<true>(out, pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7]), pack4_trunc(o[8], o[9], o[10], o[11]));
+    { uint32_t d0, d1, d2; pack12_trunc(o, d0, d1, d2); stg3<true>(out, d0, d1, d2); }
   } else if constexpr (CH == 2) {
     stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
   } else {

@@ -42,16 +42,44 @@ VPF_DEV uint32_t pack4(float a, float b, float c, float d) {
     return sat_rne_explicit(a) | (sat_rne_explicit(b) << 8) | (sat_rne_explicit(c) << 16) | (sat_rne_explicit(d) << 24);
   }
 }
-// four values already carrying +0.5: saturate + truncate (round half up), for resize / remap
+// four values already carrying +0.5: saturate + truncate (round half up), for resize / remap / RGB -> YUV.
+// v_cvt_pk_u8_f32 follows the fp32 rounding field of the MODE register (measured: tools/lab/probes/probe_rtz_pack.hip, profiles/
+// r03_probe_rtz_pack.txt — 0 of 4 M groups differ from med3 + v_cvt_u32_f32, values from -1e30 to 1e30 included), so under round-toward-zero
+// it IS "saturate, truncate, insert byte": four instructions per dword between two s_setreg instead of 4 v_med3 + 4 v_cvt_u32 + 3 v_lshl_or.
+// The two s_setreg sit inside the one asm statement, so no other floating-point instruction can run under the changed mode.
 VPF_DEV uint32_t pack4_trunc(float a, float b, float c, float d) {
-  return sat_trunc(a) | (sat_trunc(b) << 8) | (sat_trunc(c) << 16) | (sat_trunc(d) << 24);
+  uint32_t o;
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
+      "v_cvt_pk_u8_f32 %0, %4, 3, %0\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(o) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return o;
 }
-
-// the same for values known to lie in [0, 256): bilinear blends of 8-bit samples (plus the 0.5 of the rounding) never
-// leave that range — every fma result is the rounding of a point between two representable end points — so the
-// v_med3_f32 would be dead weight in the VALU-bound resize / remap kernels
-VPF_DEV uint32_t pack4_trunc_inrange(float a, float b, float c, float d) {
-  return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+// (values known to lie in [0, 256) — bilinear blends of 8-bit samples — used to skip the clamp; the instruction saturates for free now)
+VPF_DEV uint32_t pack4_trunc_inrange(float a, float b, float c, float d) { return pack4_trunc(a, b, c, d); }
+// twelve values -> three dwords under one mode switch (packed RGB: four pixels)
+VPF_DEV void pack12_trunc(const float* v, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(d0), "=&v"(d1), "=&v"(d2)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]));
 }
 // a * b + c for a, b < 2^24 (low 32 bits): v_mad_u32_u24, full rate (v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate)
 VPF_DEV uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
