@@ -11,6 +11,7 @@
 
 namespace vpf {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // operand pair of the packed-fp32 instructions
 struct Tap {
   uint32_t i0, i1;
   float f;
@@ -109,7 +110,6 @@ VPF_DEV void rowpair_blend4(const uint8_t* r0, const uint8_t* r1, bool row1, flo
     // PIXEL PAIRS (v_pk_add_f32 / v_pk_fma_f32: two independent IEEE operations per instruction at the issue cost of one —
     // profiles/r02_probe_valu_rate.txt), 3.5 instead of 7 VALU slots per pixel and channel.  Each component goes through exactly
     // bilerp()'s operations in bilerp()'s order -> bit-identical to the scalar form below and to the other kernels.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     float p00[4][CH], p01[4][CH], p10[4][CH], p11[4][CH];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -196,9 +196,11 @@ VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /
 }
 
 constexpr int kBandSlots = 8;  // source rows a wave's strips can hold (twice as many when a strip is a single 1-KiB staging pass: IT = 1)
+// Horizontal lerps of one strip row for a lane's PX pixels, kept as PIXEL PAIRS: H[j * CH + c] = {pixel 2j, pixel 2j + 1} of channel c — the
+// operand layout of v_pk_fma_f32, so the vertical blend consumes the pairs as they are (a pixel-major array in between cost 8 v_mov per
+// row and lane and turned the vertical subtractions into scalar ones).
 template <int CH, int PX = 4>
-VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, float* H) {  // H[k * CH + c] = horizontal lerp of pixel k, channel c
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, f32x2* H) {
   float p0[PX][CH], p1[PX][CH];
 #pragma unroll
   for (int k = 0; k < PX; k++) {
@@ -215,28 +217,40 @@ VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, float* H) {
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       const f32x2 a0 = {p0[2 * j][c], p0[2 * j + 1][c]}, a1 = {p1[2 * j][c], p1[2 * j + 1][c]};
-      const f32x2 h = __builtin_elementwise_fma(fx2, a1 - a0, a0);
-      H[2 * j * CH + c] = h[0]; H[(2 * j + 1) * CH + c] = h[1];
+      H[j * CH + c] = __builtin_elementwise_fma(fx2, a1 - a0, a0);
     }
   }
 }
-// Destination rows ya..yb (at most R) of a band whose source rows r_lo.. sit in LDS `rowbytes` apart: the two current source rows'
-// horizontal lerps stay in registers and move up (Hb -> Ha) as the destination rows walk down.  put(y, o) receives o[] = pixel-major, + 0.5 added.
+// The row taps (i0, i1, fy) of a band's destination rows ya..yb, row i on lane i: one make_tap for the whole band instead of one per row on
+// every lane (~12 VALU instructions per row).  Call it while ALL lanes of the wave are active (before the columns beyond the picture's
+// right edge leave): band_blend_rows reads lanes 0..R-1 with v_readlane.  The empty asm pins the computation to this place — without it the
+// compiler sinks it below the early return, where lanes that have left no longer compute their row.
+VPF_DEV Tap band_row_taps(uint32_t ya, uint32_t yb, float scy, uint32_t sh) {
+  const uint32_t ly = ya + (threadIdx.x & 63u);
+  Tap t = make_tap<VPF_INTERP_LINEAR>(ly < yb ? ly : yb, scy, sh);
+  asm volatile("" : "+v"(t.i0), "+v"(t.i1), "+v"(t.f));
+  return t;
+}
+// Destination rows ya..yb (at most R <= 64) of a band whose source rows r_lo.. sit in LDS `rowbytes` apart; `rows` = band_row_taps(ya, yb, ..).
+// The horizontal lerps of the two current source rows stay in registers and move up (Hb -> Ha) as the destination rows walk down.
+// put(y, o) receives o[] = pixel-major, + 0.5 added.
+// (Measured and not kept: exchanging the ROLES of Ha / Hb instead of copying — as a two-way branch the compiler folds the two blends back
+// into one behind more copies; as two alternating loops over the rows the walk is 1.7 x slower at R = 4: profiles/r03_band_walk_variants.txt.)
 template <int CH, int R, int PX = 4, class Put>
-VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, float scy, uint32_t sh, const ColTaps<CH, PX>& T, Put&& put) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  float Ha[PX * CH], Hb[PX * CH];       // horizontal lerps of source rows ida (upper tap) and idb (lower tap)
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const ColTaps<CH, PX>& T, Put&& put) {
+  static_assert(R <= 64, "one lane per row of the band");
+  constexpr int NP = PX / 2 * CH;
+  f32x2 Ha[NP], Hb[NP];  // horizontal lerps (pixel pairs, band_hlerp4) of source rows ida (upper tap) and idb (lower tap)
   uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
 #pragma unroll
   for (int i = 0; i < R; i++) {
     if (ya + i > yb) break;
-    const Tap t = make_tap<VPF_INTERP_LINEAR>(ya + i, scy, sh);
-    const uint32_t i0 = __builtin_amdgcn_readfirstlane(t.i0), i1 = __builtin_amdgcn_readfirstlane(t.i1);
-    const float fy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t.f)));
+    const uint32_t i0 = __builtin_amdgcn_readlane(rows.i0, i), i1 = __builtin_amdgcn_readlane(rows.i1, i);
+    const float fy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rows.f), i));
     if (i0 != ida) {
       if (i0 == idb) {
 #pragma unroll
-        for (int q = 0; q < PX * CH; q++) Ha[q] = Hb[q];
+        for (int q = 0; q < NP; q++) Ha[q] = Hb[q];
       } else {
         band_hlerp4<CH, PX>(strips + (size_t)(i0 - r_lo) * rowbytes, T, Ha);
       }
@@ -245,7 +259,7 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
     if (i1 != idb) {
       if (i1 == ida) {
 #pragma unroll
-        for (int q = 0; q < PX * CH; q++) Hb[q] = Ha[q];
+        for (int q = 0; q < NP; q++) Hb[q] = Ha[q];
       } else {
         band_hlerp4<CH, PX>(strips + (size_t)(i1 - r_lo) * rowbytes, T, Hb);
       }
@@ -254,10 +268,13 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
     float o[PX * CH];
     const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
 #pragma unroll
-    for (int q = 0; q < PX * CH; q += 2) {
-      const f32x2 top = {Ha[q], Ha[q + 1]}, bot = {Hb[q], Hb[q + 1]};
-      const f32x2 v = __builtin_elementwise_fma(fy2, bot - top, top) + half2;
-      o[q] = v[0]; o[q + 1] = v[1];
+    for (int j = 0; j < PX / 2; j++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const f32x2 t = Ha[j * CH + c], b = Hb[j * CH + c];
+        const f32x2 v = __builtin_elementwise_fma(fy2, b - t, t) + half2;
+        o[2 * j * CH + c] = v[0]; o[(2 * j + 1) * CH + c] = v[1];
+      }
     }
     put(ya + i, o);
   }

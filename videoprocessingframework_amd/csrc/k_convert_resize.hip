@@ -461,12 +461,13 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
     }
   }
   wave_lds_sync();
+  const Tap row_taps = band_row_taps(ya, yb, scy, sh);  // every lane still active here
   const uint32_t x0 = xs + lane * 4;
   if (x0 >= dw) return;
   const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
   const ColTaps<3> T = make_col_taps<3>(3 * base_px, x0, dw, sw, scx);  // once for the R rows
   // the band walk of RowBandTask: every strip row's horizontal lerp is evaluated once and shared by the destination rows that blend it
-  band_blend_rows<3, R>(strip, rowbytes, r_lo, ya, yb, scy, sh, T, [&](uint32_t y, const float* o) {  // o: pixel-major R G B, + 0.5 added
+  band_blend_rows<3, R>(strip, rowbytes, r_lo, ya, yb, row_taps, T, [&](uint32_t y, const float* o) {  // o: pixel-major R G B, + 0.5 added
     if constexpr (DST == FC_PLANAR) {
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) {

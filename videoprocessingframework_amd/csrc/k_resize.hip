@@ -313,12 +313,13 @@ VPF_DEV void RowBandTask<CH, R, IT, P1>::run(const uint8_t* __restrict__ src, ui
   for (int k = 0; k < kSlots; k++)
     if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, nq, lane);
   wave_lds_sync();
+  const Tap row_taps = band_row_taps(ya, yb, scy, sh);  // every lane still active here
   const uint32_t x0 = xs + lane * PX;
   if (x0 >= dw) return;
   const ColTaps<CH, PX> T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);
   const bool vec4 = G.vec_ok && x0 + PX <= dw;
   const uint32_t nv = dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX;
-  band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo, ya, yb, scy, sh, T, [&](uint32_t y, const float* o) {
+  band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo, ya, yb, row_taps, T, [&](uint32_t y, const float* o) {
     store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
   });
 }
