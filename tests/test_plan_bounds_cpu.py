@@ -21,7 +21,7 @@ def pb(tmp_path_factory):
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"),
                            os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so, "-lm"])
     L = C.CDLL(so)
-    for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]),
+    for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_band_rows_exact", [C.c_int, C.c_uint32, C.c_uint32]),
                        ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
                        ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]),
                        ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32])):
@@ -74,6 +74,7 @@ def test_band_slots_cover_every_band(pb):
             yb = np.minimum(ya + r - 1, dh - 1)
             need = int((i1[yb] - i0[ya] + 1).max())
             assert need <= pb.pb_band_slots(r, scy), (sh, dh, r, need)
+            assert need == pb.pb_band_rows_exact(r, sh, dh), (sh, dh, r, need)  # the walk the launchers size the LDS rows with
             if pb.pb_fused_rows_fit(r if r <= 8 else 8, scy, 8):
                 rr = r if r <= 8 else 8
                 ya = np.arange(0, dh, rr)

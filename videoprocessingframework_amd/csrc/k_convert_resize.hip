@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) void k_convert_half_one(VPF_ONE_SRC_PARAMS, ui
 constexpr int kStripRows = 8;  // source rows a wave's strip can hold
 template <int SRC, int DST, int R>
 VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy,
-                                int vec_ok, uint32_t rowq, uint32_t bx, uint32_t by) {
+                                int vec_ok, uint32_t rowq_rows, uint32_t bx, uint32_t by) {
+  const uint32_t rowq = rowq_rows & 0xffffu, srows = rowq_rows >> 16;  // 16-B units per strip row | strip rows per wave (<= kStripRows: what this launch's bands touch)
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t ya = (by * 4 + wv) * R;
   const uint32_t xs = bx * 256;
@@ -394,7 +395,7 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t base_px = first & ~7u;
   const uint32_t r_lo = make_tap<VPF_INTERP_LINEAR>(ya, scy, sh).i0, r_hi = make_tap<VPF_INTERP_LINEAR>(yb, scy, sh).i1;  // the launcher guarantees r_hi - r_lo < kStripRows
-  uint8_t* const strip = reinterpret_cast<uint8_t*>(dyn_strip + (size_t)wv * kStripRows * rowq);
+  uint8_t* const strip = reinterpret_cast<uint8_t*>(dyn_strip + (size_t)wv * srows * rowq);
   const uint32_t rowbytes = rowq * 16;
   constexpr int CMAX = kStripRows / 2 + 1;  // chroma rows under kStripRows luma rows
   const uint32_t c_lo = r_lo >> 1;
@@ -543,13 +544,18 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       else if (vpf_bound_fused_rows_fit(2, scy, kStripRows)) r = 2;
       if (dh < 64) r = r ? 2 : 0;  // short pictures: more, smaller tasks
       if (r == 8 && (uint64_t)((dw + 255) / 256) * ((dh + 31) / 32) * n < 2048) r = 4;  // keep the chip covered
-      const uint32_t lds1 = 4u * kStripRows * rowbytes;
+      // strip rows per wave: what the bands of this shape really touch (a walk with the kernel's tap arithmetic, vpf_plan_bounds.h), not
+      // the kStripRows the band height was chosen against — 1080p -> 720p: 6 rows, five workgroups per CU instead of four
+      static thread_local struct { int r; uint32_t sh, dh, rows; } seen = {0, 0, 0, 0};
+      if (r && !(seen.r == r && seen.sh == sh && seen.dh == dh)) { seen.r = r; seen.sh = sh; seen.dh = dh; seen.rows = vpf_band_rows_exact(r, sh, dh, scy); }
+      const uint32_t srows = r ? (seen.rows < (uint32_t)kStripRows ? seen.rows : (uint32_t)kStripRows) : (uint32_t)kStripRows;
+      const uint32_t lds1 = 4u * srows * rowbytes;
       // conversions per destination pixel: scx x ((r - 1) scy + 2) / r source pixels against the four taps of the per-tap kernel —
       // measured break-even near 2x (4K -> 1600x900, 2.4x: 9.5 us here vs 5.2 us per-tap; 1080p -> 720p: 2.36 vs 3.21; 1080p -> 4K: 15.0 vs 23.6)
       const double conv_per_px = r ? (double)scx * ((r - 1) * (double)scy + 2.0) / r : 1e9;
       if (r && lds1 <= 64u * 1024u && conv_per_px <= 3.0) {
         dim3 sgrid((dw + 255) / 256, (dh + 4 * r - 1) / (4 * r), n);
-#define VPF_STRIP1(S, D, RR) VPF_LAUNCH((k_convert_strip<S, D, RR>), sgrid, dim3(256), lds1, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes / 16)
+#define VPF_STRIP1(S, D, RR) VPF_LAUNCH((k_convert_strip<S, D, RR>), sgrid, dim3(256), lds1, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, (rowbytes / 16) | (srows << 16))
 #define VPF_STRIP(S, D) do { if (r == 8) VPF_STRIP1(S, D, 8); else if (r == 4) VPF_STRIP1(S, D, 4); else VPF_STRIP1(S, D, 2); } while (0)
 #define VPF_STRIPD(S) do { if (dst_fc == FC_RGB) VPF_STRIP(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_STRIP(S, FC_BGR); else VPF_STRIP(S, FC_PLANAR); } while (0)
         if (src_fc == FC_NV12) VPF_STRIPD(FC_NV12); else VPF_STRIPD(FC_YUV420);

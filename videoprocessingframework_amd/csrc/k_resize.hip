@@ -1246,6 +1246,27 @@ static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, cons
 constexpr uint32_t kBandMinGroups = 2048;
 struct BandShape { int rows; uint32_t slots; bool narrow; };
 static uint32_t band_slots(int r, float scy) { return vpf_bound_band_slots(r, scy); }  // (vpf_plan_bounds.h: checked on the CPU against the tap arithmetic)
+// The strips a launch ALLOCATES: the rows its bands really touch (vpf_band_rows_exact: a walk over the bands with make_tap's arithmetic),
+// never more than the closed-form bound that chose the band height.  1080p -> 720p with 4-row bands: 6 strips instead of 8, five
+// workgroups per CU instead of four.  The last shapes are remembered per thread (a launch per frame would walk dh / r taps every time).
+static uint32_t band_slots_exact(int r, int njobs, const ResizeJob* jobs, uint32_t bound) {
+  struct Seen { int r; uint32_t sh, dh, rows; };
+  static thread_local Seen seen[8];
+  static thread_local unsigned next = 0;
+  uint32_t most = 1;
+  for (int p = 0; p < njobs; p++) {
+    const ResizeJob& j = jobs[p];
+    uint32_t rows = 0;
+    for (const Seen& e : seen)
+      if (e.r == r && e.sh == j.sh && e.dh == j.dh && e.rows) rows = e.rows;
+    if (!rows) {
+      rows = vpf_band_rows_exact(r, j.sh, j.dh, (float)j.sh / (float)j.dh);
+      seen[next++ & 7] = Seen{r, j.sh, j.dh, rows};
+    }
+    most = rows > most ? rows : most;
+  }
+  return most < bound ? most : bound;
+}
 // pixels per lane for the 1-channel planes of a band launch: 8 (512 columns per wave) when such chunks fill every 1-channel row to >= 80 %
 // (1280 px: 3 chunks, 83 %; the 640-px chroma planes of a 720p YUV420 frame: 2 chunks, 62 % -> 4)
 static int band_p1(int njobs, const ResizeJob* jobs) {
@@ -1289,7 +1310,7 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
     if (slots > (uint32_t)(narrow ? 2 * kBandSlots : kBandSlots) || 4u * slots * rb + 16u > 64u * 1024u) continue;
     uint64_t groups = 0;
     for (int p = 0; p < njobs; p++) groups += (uint64_t)((jobs[p].dw + 64u * band_px(jobs[p].ch, p1) - 1) / (64u * band_px(jobs[p].ch, p1))) * ((jobs[p].dh + 4 * r - 1) / (4 * r)) * n;
-    if (forced || groups >= kBandMinGroups) return {r, slots, narrow};
+    if (forced || groups >= kBandMinGroups) return {r, band_slots_exact(r, njobs, jobs, slots), narrow};
   }
   return {1, 0, false};
 }

@@ -24,6 +24,26 @@ static inline uint32_t vpf_bound_band_slots(int r, float scy) {
   return (uint32_t)((double)(r - 1) * (double)scy + 0.01) + 3u;
 }
 
+/* the same, EXACT: the largest i1(last row) - i0(first row) + 1 over the bands of `r` destination rows of a sh -> dh resize, walked with
+ * make_tap's own fp32 arithmetic (k_bilinear_blend.h; scy = (float)sh / (float)dh as the launchers pass it).  The closed form above
+ * is one or two rows generous exactly where it costs most — 1080 -> 720 with r = 4 touches 6 rows, the bound says 8 — and LDS rows are
+ * what decides how many workgroups a CU holds.  dh / r iterations; the launchers remember the last shapes. */
+static inline uint32_t vpf_lin_i0(uint32_t d, float scale, uint32_t size) {
+  float s = fmaf((float)d + 0.5f, scale, -0.5f);
+  s = fmaxf(s, 0.f);
+  s = fminf(s, (float)(size - 1));
+  return (uint32_t)(int32_t)s;
+}
+static inline uint32_t vpf_band_rows_exact(int r, uint32_t sh, uint32_t dh, float scy) {
+  uint32_t most = 1;
+  for (uint32_t ya = 0; ya < dh; ya += (uint32_t)r) {
+    const uint32_t yb = ya + (uint32_t)r - 1 < dh - 1 ? ya + (uint32_t)r - 1 : dh - 1;
+    const uint32_t lo = vpf_lin_i0(ya, scy, sh), hi0 = vpf_lin_i0(yb, scy, sh), hi = hi0 + 1 < sh ? hi0 + 1 : sh - 1;
+    most = hi - lo + 1 > most ? hi - lo + 1 : most;
+  }
+  return most;
+}
+
 /* fused convert + resize strip kernel: bytes per strip row of packed RGB for a wave's 256 destination columns (source span rounded out to
  * 8-pixel conversion groups on both sides + the tap window's over-read), and whether `r` destination rows fit `strip_rows` source rows */
 static inline uint32_t vpf_bound_fused_rowbytes(float scx) {
