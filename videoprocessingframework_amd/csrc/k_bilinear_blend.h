@@ -185,10 +185,10 @@ VPF_DEV void store_blend4(uint8_t* out, const float* o, bool vec4, uint32_t nv /
       pack12_trunc(o, d0, d1, d2);
       stg3<true>(out, d0, d1, d2);
     } else if constexpr (CH == 2) {
-      stg<true, u32x2>(out, u32x2{pack4_trunc_inrange(o[0], o[1], o[2], o[3]), pack4_trunc_inrange(o[4], o[5], o[6], o[7])});
+      stg<true, u32x2>(out, u32x2{pack4_trunc(o[0], o[1], o[2], o[3]), pack4_trunc(o[4], o[5], o[6], o[7])});
     } else {
 #pragma unroll
-      for (int q = 0; q < PX / 4; q++) stg<true, uint32_t>(out + 4 * q, pack4_trunc_inrange(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]));
+      for (int q = 0; q < PX / 4; q++) stg<true, uint32_t>(out + 4 * q, pack4_trunc(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]));
     }
   } else {
     for (uint32_t i = 0; i < nv * CH; i++) out[i] = (uint8_t)(uint32_t)o[i];

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, co
   if constexpr (DST == FC_PLANAR) {
     for (int ch = 0; ch < 3; ch++) {
       uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
-      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc_inrange(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
       else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(uint32_t)(o[ch][i]);
     }
   } else {
@@ -255,7 +255,7 @@ VPF_DEV void convert_resize_lds_task(const FrameDesc& f, const Yuv2RgbCoef& c, u
   if constexpr (DST == FC_PLANAR) {
     for (int ch = 0; ch < 3; ch++) {
       uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
-      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc_inrange(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+      if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
       else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(uint32_t)(o[ch][i]);
     }
   } else {
@@ -473,7 +473,7 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) {
         uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
-        if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc_inrange(o[ch], o[3 + ch], o[6 + ch], o[9 + ch]));
+        if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch], o[3 + ch], o[6 + ch], o[9 + ch]));
         else for (uint32_t j = 0; j < nv; j++) out[j] = (uint8_t)(uint32_t)o[3 * j + ch];
       }
     } else {

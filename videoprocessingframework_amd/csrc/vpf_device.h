@@ -59,8 +59,6 @@ VPF_DEV uint32_t pack4_trunc(float a, float b, float c, float d) {
       : "=&v"(o) : "v"(a), "v"(b), "v"(c), "v"(d));
   return o;
 }
-// (values known to lie in [0, 256) — bilinear blends of 8-bit samples — used to skip the clamp; the instruction saturates for free now)
-VPF_DEV uint32_t pack4_trunc_inrange(float a, float b, float c, float d) { return pack4_trunc(a, b, c, d); }
 // twelve values -> three dwords under one mode switch (packed RGB: four pixels)
 VPF_DEV void pack12_trunc(const float* v, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
   asm volatile(
