@@ -422,11 +422,11 @@ def test_download_into_pinned_and_pageable_arrays(oracle):
     assert all(res)
 
 
-@pytest.mark.parametrize("fmt,ofmt", [(PF.RGB, "RGB"), (PF.NV12, "NV12"), (PF.YUV420, "YUV420")])
-def test_download_of_a_large_frame_into_a_pageable_array_goes_in_pieces(oracle, fmt, ofmt):
+@pytest.mark.parametrize("fmt,ofmt,w,h", [(PF.RGB, "RGB", 3840, 2160), (PF.NV12, "NV12", 3840, 2160), (PF.YUV420, "YUV420", 3840, 2160),
+                                          (PF.RGB, "RGB", 2502, 1407), (PF.NV12, "NV12", 4098, 1026), (PF.RGB, "RGB", 1400, 1000)])  # ragged last pieces; just above 4 MB
+def test_download_of_a_large_frame_into_a_pageable_array_goes_in_pieces(oracle, fmt, ofmt, w, h):
     """Frames of 4 MB and more reach a pageable array piece by piece (DMA of piece k+1 under the host copy of piece k,
     Tasks.cpp DownloadInto); the bytes are those of the direct DMA into AllocPinned memory and of the host frame, repeatedly"""
-    w, h = 3840, 2160
     src = oracle.synth(getattr(oracle, ofmt), w, h, 77)
     surf = upload(fmt, w, h, src)
     want = host_frame(src)
