@@ -49,10 +49,13 @@ inline LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_
 //   a wave costs S + R w (its fixed part — operand loads, first fetch, the latency chain of a short band — plus R tiles of work, w scaled
 //   by the vertical factor), the launch W = sum over planes of strips-of-four x bands x frames workgroups against the resident ones
 //   (512 / 768): every round, the last partial one too, costs one wave time.
-// S = 3.0, w = 1.0 / 0.5 tile units for 8- / 4-tile strips — except that a 4-tile strip of a 3-channel plane costs 0.8 (its 64 destination
-// bytes are 21 pixels under the same 64-B windows); bands are at least two tiles high.  Over the sweeps' 27 cases the model's pick is
-// within 4 % of the best measured shape on average (worst 14 %; tests/test_lzm_plan_cpu.py asserts <= 6 % / <= 20 % against the files in
-// profiles/).  Without weight tables S is three times that.
+// S = 2.0; w = 1.0 tile units for an 8-tile strip, 0.45 / 0.9 / 0.8 for a 4-tile strip of a 1- / 2- / 3-channel plane (a 4-tile strip of a
+// 3-channel plane is 21 pixels under the same 64-B windows; the interleaved chroma plane of NV12 wants the wide strips), scaled by the
+// vertical factor as 0.5 + 0.5 scy / 1.5 (8 tiles) or 0.3 + 0.7 scy / 1.5 (4 tiles: narrow strips pay more for the extra source rows);
+// bands are at least two tiles high.  Refitted at the end of round 3 to sweeps that take the minimum of three interleaved passes per
+// shape (clock drift over one pass had been several percent — as large as the differences being fitted): over the 27 cases the model's
+// pick is within 1.6 % of the best measured shape on average (worst 8 %; tests/test_lzm_plan_cpu.py asserts <= 6 % / <= 20 % against
+// the files in profiles/).  Without weight tables S is three times that.
 struct LzmPlaneIn { int ch; uint32_t sw, sh, dw, dh; };
 struct LzmPlan {
   bool ok;
@@ -83,7 +86,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
     if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
     LzmPlan q{false, cand, 0, 0, 0, 0, 0};
     if (!fits(cand, q)) continue;
-    const double S = 3.0 * (tables ? 1.0 : 3.0), slots = cand == 8 ? 512.0 : 768.0;
+    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 ? 512.0 : 768.0;
     uint32_t tmax = 0;
     for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
     const bool free_r = !(forced > 1 && (forced & 0xff));
@@ -95,8 +98,9 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         const uint32_t tiles = (jobs[p].dh + 15) / 16, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
         wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
         const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-        const double w = cand == 8 ? 1.0 : jobs[p].ch == 3 ? 0.8 : 0.5;
-        work = std::max(work, (double)std::min(r, tiles) * w * (0.3 + 0.7 * scy / 1.5));
+        const double w = cand == 8 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
+        const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
+        work = std::max(work, (double)std::min(r, tiles) * w * vert);
       }
       const double cost = (S + work) * std::ceil((double)wgs / slots);
       if (!P.ok || cost < best) { best = cost; P = q; P.ok = true; P.band_tiles = r; }
