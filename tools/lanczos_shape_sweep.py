@@ -29,7 +29,7 @@ for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420
         for rep in range(PASSES):  # whole passes over the shapes, the minimum per shape: clock / thermal drift over a pass is several percent
             for shape in (shapes if rep % 2 == 0 else shapes[::-1]):
                 capi.set_tuning(capi.TUNE_RESIZE_MFMA, shape)
-                t = timed(lambda: [capi.resize_batch(ex, fmt, 2, sw, sh, dw, dh, b) for b in batches], 3) / ring
+                t = timed(lambda: [capi.resize_batch(ex, fmt, 2, sw, sh, dw, dh, b) for b in batches], 3, 1) / ring
                 key = "policy" if shape == 0 else f"nt{shape >> 8} r{shape & 0xff}"
                 res[key] = min(res.get(key, 1e9), t)
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)

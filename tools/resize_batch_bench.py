@@ -1,6 +1,6 @@
 """vpf_resize_batch / vpf_remap_batch vs one dispatch per frame (and per plane): us per frame and fraction of the 8 TB/s HBM roofline on
 ALGORITHMIC bytes (whole source frame read once + destination written once; a down-scale that skips source rows reads less).
-Rings are sized past the 256 MiB Infinity Cache.  python tools/resize_batch_bench.py"""
+Rings are sized past the 256 MiB Infinity Cache.  Every number is the median of VPF_BENCH_PASSES (3) timed passes.  python tools/resize_batch_bench.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,14 +38,20 @@ def surf(fmt, w, h, rand):
     raise ValueError(fmt)
 
 
-def timed(fn, reps):
+PASSES = int(os.environ.get("VPF_BENCH_PASSES", "3"))  # timed passes per number; the MEDIAN is reported (one pass moves by several percent with the clocks)
+
+
+def timed(fn, reps, passes=None):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    out = []
+    for _ in range(passes or PASSES):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return sorted(out)[len(out) // 2]
 
 
 def main():
