@@ -308,7 +308,7 @@ def decode_leg():
 
 
 def other_configs(dev, main_wl):
-    """Short (a few steps each) measurements of BASELINE.json's other configs and of the per-Execute() dispatch mode, so
+    """Short (a few steps each, median of three blocks) measurements of BASELINE.json's other configs and of the per-Execute() dispatch mode, so
     the one JSON line also carries them.  Same ring discipline (device-resident, > Infinity Cache); informational only."""
     res = {}
     del main_wl.keep[:]
@@ -321,7 +321,7 @@ def other_configs(dev, main_wl):
             ("1080p_rgb_to_720p_bilinear_batched", "rgb_resize_1080p_720p_bilinear", 64, "batch", 10),   # vpf_resize_batch, north_star's filter
             ("1080p_rgb_to_720p_lanczos3_batched", "rgb_resize_1080p_720p_lanczos", 64, "batch", 10)):   # vpf_resize_batch, the reference resizer's filter
         wl = Workload(name, dev, ring, 0, mode)
-        _, ev = timed(wl, steps, 2, False)
+        ev = sorted(timed(wl, steps, 2, False)[1] for _ in range(3))[1]  # median of three short blocks (one block moves by several percent with the clocks)
         res[key] = {"Gpix_s_src": round(wl.px_per_step * steps / ev / 1e9, 1),
                     "algorithmic_GB_s": round(wl.bytes_per_step * steps / ev / 1e9, 0),
                     "frac_of_8TB_s": round(wl.bytes_per_step * steps / ev / 1e9 / HBM_PEAK_GBS, 3),
