@@ -107,8 +107,9 @@ template <int CH>
 VPF_DEV void rowpair_blend4(const uint8_t* r0, const uint8_t* r1, bool row1, float fy, const ColTaps<CH>& T, float* o) {
   if (row1 && T.allfx) {
     // The common case, on the packed-fp32 pipe: the four taps of all four pixels are fetched first, then every blend step runs on
-    // PIXEL PAIRS (v_pk_add_f32 / v_pk_fma_f32: two independent IEEE operations per instruction at the issue cost of one —
-    // profiles/r02_probe_valu_rate.txt), 3.5 instead of 7 VALU slots per pixel and channel.  Each component goes through exactly
+    // PIXEL PAIRS (v_pk_add_f32 / v_pk_fma_f32: two independent IEEE operations per instruction — 3.5 instead of 7 instructions per pixel
+    // and channel; in cycles the gain is small, a plain fp32 fma issues in ~2.4 cycles here and a packed one in ~4.4,
+    // profiles/r02_probe_valu_rate.txt).  Each component goes through exactly
     // bilerp()'s operations in bilerp()'s order -> bit-identical to the scalar form below and to the other kernels.
     float p00[4][CH], p01[4][CH], p10[4][CH], p11[4][CH];
 #pragma unroll
