@@ -18,6 +18,9 @@
 #include <vector>
 
 #include "vpf_hip.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace VPF {
 
@@ -35,6 +38,35 @@ constexpr auto TASK_EXEC_SUCCESS = TaskExecStatus::TASK_EXEC_SUCCESS;
 constexpr auto TASK_EXEC_FAIL = TaskExecStatus::TASK_EXEC_FAIL;
 
 std::atomic<int> g_extended{-1};
+
+// Host copy of a large block that nobody reads soon (pinned staging <-> a caller's frame): non-temporal stores.  A plain memcpy of 2 MB
+// pieces stays under glibc's non-temporal threshold, so every destination line is first READ (write-allocate) and then evicts something
+// useful: 3 bytes of memory traffic per byte copied instead of 2.  VPF_HIP_NT_COPY=0 keeps memcpy (A/B: tools/download_bench.py).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void copy_nt_avx2(uint8_t* d, const uint8_t* s, size_t n) {
+  const size_t head = (32 - ((uintptr_t)d & 31)) & 31;
+  if (head) { std::memcpy(d, s, head); d += head; s += head; n -= head; }
+  size_t i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 32));
+    const __m256i c = _mm256_loadu_si256((const __m256i*)(s + i + 64)), e = _mm256_loadu_si256((const __m256i*)(s + i + 96));
+    _mm256_stream_si256((__m256i*)(d + i), a); _mm256_stream_si256((__m256i*)(d + i + 32), b);
+    _mm256_stream_si256((__m256i*)(d + i + 64), c); _mm256_stream_si256((__m256i*)(d + i + 96), e);
+  }
+  _mm_sfence();
+  if (i < n) std::memcpy(d + i, s + i, n - i);
+}
+#endif
+void host_copy_large(void* dst, const void* src, size_t n) {
+#if defined(__x86_64__)
+  static const bool nt = [] {
+    const char* e = std::getenv("VPF_HIP_NT_COPY");
+    return !(e && e[0] == '0') && __builtin_cpu_supports("avx2");
+  }();
+  if (nt && n >= (256u << 10)) { copy_nt_avx2(static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n); return; }
+#endif
+  std::memcpy(dst, src, n);
+}
 
 // The reference's resizer / remaper / down- and uploader tasks block until their stream has drained (their cuda_stream_sync callback:
 // Tasks.cpp:1630-1640).  What they wait for here is mostly a kernel of 2 - 20 us, and hipStreamSynchronize puts the thread to sleep on an
@@ -655,7 +687,7 @@ TaskExecStatus CudaUploadFrame::Run() {
   const bool pinned_src = (hipPointerGetAttributes(&attr, src) == hipSuccess) && attr.type == hipMemoryTypeHost;
   if (!pinned_src) {
     (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error for us
-    std::memcpy(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
+    host_copy_large(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());
     src = stage->GetDataAs<uint8_t>();
   }
   // The surface of this slot was handed out two uploads ago; kernels that read it (converters on the task's stream)
@@ -778,14 +810,14 @@ TaskExecStatus CudaDownloadSurface::DownloadInto(Surface* s, void* dst, size_t d
     if (!ok) { (void)hipGetLastError(); sr->flag_failed = true; }
     for (const Piece& pc : pieces) {  // whatever was queued is consumed in order; a piece that does not arrive in time falls back to a stream sync
       if (!flag_wait(sr, pc.seq, 50 * sync_spin_ns())) (void)hipStreamSynchronize(st);
-      std::memcpy(static_cast<uint8_t*>(dst) + pc.off, target + pc.off, pc.len);
+      host_copy_large(static_cast<uint8_t*>(dst) + pc.off, target + pc.off, pc.len);
     }
     if (ok) return TASK_EXEC_SUCCESS;
     // fall through: redo the whole frame the plain way
   }
   if (!download_planes(s, target, (hipStream_t)pImpl->sref.str)) return TASK_EXEC_FAIL;
   hip_stream_sync(&pImpl->sref);
-  if (!pinned_dst) std::memcpy(dst, target, bytes);
+  if (!pinned_dst) host_copy_large(dst, target, bytes);
   return TASK_EXEC_SUCCESS;
 }
 
