@@ -44,7 +44,8 @@ std::atomic<int> g_extended{-1};
 // useful: 3 bytes of memory traffic per byte copied instead of 2.  VPF_HIP_NT_COPY=0 keeps memcpy (A/B: tools/download_bench.py).
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) void copy_nt_avx2(uint8_t* d, const uint8_t* s, size_t n) {
-  const size_t head = (32 - ((uintptr_t)d & 31)) & 31;
+  size_t head = (32 - ((uintptr_t)d & 31)) & 31;
+  if (head > n) head = n;
   if (head) { std::memcpy(d, s, head); d += head; s += head; n -= head; }
   size_t i = 0;
   for (; i + 128 <= n; i += 128) {
