@@ -652,6 +652,7 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
             sf, df = str(rng.choice(["NV12", "YUV420"])), str(rng.choice(["RGB", "BGR", "RGB_PLANAR"]))
             src = oracle.synth(getattr(oracle, sf), sw, sh, int(rng.integers(1 << 30)))
             _, want = oracle.convert_resize(getattr(oracle, sf), getattr(oracle, df), 1, 0, sw, sh, src, dw, dh)
+            _, exact = oracle.convert_resize(getattr(oracle, sf), getattr(oracle, df), 1, 0, sw, sh, src, dw, dh, oracle.EXACT)
             s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, df), dw, dh), align)
             prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
             try:
@@ -666,6 +667,9 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
                 sw, sh, dw, dh = sw + (sw & 1), sh + (sh & 1), dw + (dw & 1), dh + (dh & 1)
             src = oracle.synth(getattr(oracle, fmt), sw, sh, int(rng.integers(1 << 30)))
             _, want = oracle.resize(getattr(oracle, fmt), interp, sw, sh, src, dw, dh, oracle.FP32)
+            # (nearest picks ONE source sample: where the exact coordinate is a tie the fp32 coordinate may pick its neighbour — a whole
+            # pixel apart, not an LSB; the specification-level check applies to the two interpolating filters)
+            exact = oracle.resize(getattr(oracle, fmt), interp, sw, sh, src, dw, dh, oracle.EXACT)[1] if interp != capi.INTERP_NEAREST else None
             s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, fmt), dw, dh), align)
             prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
             try:
@@ -677,6 +681,8 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
         got, intact = d.download()
         assert intact, what
         assert_planes_equal(got, want, f"{what} {sw}x{sh}->{dw}x{dh} v{variant} a{align}")
+        if exact is not None:  # the independent link: within north_star's +-1 LSB of the exact-rational specification, every fuzz case
+            assert max(int(np.abs(g.astype(int) - e.astype(int)).max()) for g, e in zip(got, exact)) <= 1, f"{what} {sw}x{sh}->{dw}x{dh}: HIP vs EXACT > 1 LSB"
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
@@ -1207,3 +1213,7 @@ def test_fuzz_resize_batch(capi, oracle, seed):
             assert intact
             _, want = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.FP32)
             assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} mfma{march:#x} frame {i}")
+            if interp != capi.INTERP_NEAREST:  # (nearest: a coordinate tie moves a whole pixel, see test_fuzz_resize_and_fused)
+                _, exact = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.EXACT)
+                assert max(int(np.abs(g.astype(int) - e.astype(int)).max()) for g, e in zip(got, exact)) <= 1, \
+                    f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} frame {i}: HIP vs EXACT > 1 LSB"

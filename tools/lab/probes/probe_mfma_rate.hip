@@ -38,6 +38,34 @@ __global__ __launch_bounds__(512) void k_rate(int* out, int iters, unsigned long
       d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, d1, 0, 0, 0);
 #pragma unroll
       for (int k = 0; k < 16; k++) x[k] = __builtin_amdgcn_alignbyte(x[k], i, 1);
+    } else if constexpr (KIND == 6) {  // the CDNA3-era K = 32 form (8-byte operands): half the products — half the time?
+      const long la = ((long)a[1] << 32) | (unsigned)a[0], lb = ((long)b[1] << 32) | (unsigned)b[0];
+      c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_i32_16x16x32_i8(la, lb, c3, 0, 0, 0);
+    } else if constexpr (KIND == 7) {  // MFMA and VALU interleaved one to four INSIDE the instruction stream (KIND 3 has them in two blocks)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (q == 0) c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c0, 0, 0, 0);
+        if (q == 1) c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c1, 0, 0, 0);
+        if (q == 2) c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c2, 0, 0, 0);
+        if (q == 3) c3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c3, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[4 * q + k] = __builtin_amdgcn_alignbyte(x[4 * q + k], i, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (KIND == 8) {  // one MFMA per TWO VALU instructions (pass 2's ratio), interleaved
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (q % 4 == 0) c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c0, 0, 0, 0);
+        if (q % 4 == 1) c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c1, 0, 0, 0);
+        if (q % 4 == 2) c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c2, 0, 0, 0);
+        if (q % 4 == 3) c3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c3, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 2; k++) x[2 * q + k] = __builtin_amdgcn_alignbyte(x[2 * q + k], i, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {  // the 16 VALU alone
 #pragma unroll
       for (int k = 0; k < 16; k++) x[k] = __builtin_amdgcn_alignbyte(x[k], i, 1);
@@ -75,6 +103,9 @@ int main() {
   run<2>("v_mfma_f32_16x16x32_bf16", 256, 1); run<2>("v_mfma_f32_16x16x32_bf16", 256);
   run<3>("v_mfma_i32_16x16x64_i8 x4 + 16 v_alignbyte_b32", 256, 1); run<3>("v_mfma_i32_16x16x64_i8 x4 + 16 v_alignbyte_b32", 256, 2); run<3>("v_mfma_i32_16x16x64_i8 x4 + 16 v_alignbyte_b32", 256); run<3>("v_mfma_i32_16x16x64_i8 x4 + 16 v_alignbyte_b32", 512);
   run<4>("v_mfma_i32_32x32x32_i8 x2 + 16 v_alignbyte_b32", 256, 1); run<4>("v_mfma_i32_32x32x32_i8 x2 + 16 v_alignbyte_b32", 256, 2); run<4>("v_mfma_i32_32x32x32_i8 x2 + 16 v_alignbyte_b32", 256); run<4>("v_mfma_i32_32x32x32_i8 x2 + 16 v_alignbyte_b32", 512);
+  run<6>("v_mfma_i32_16x16x32_i8", 256, 1); run<6>("v_mfma_i32_16x16x32_i8", 256, 2); run<6>("v_mfma_i32_16x16x32_i8", 256);
+  run<7>("interleaved: (1 MFMA + 4 v_alignbyte_b32) x 4", 256, 1); run<7>("interleaved: (1 MFMA + 4 v_alignbyte_b32) x 4", 256, 2); run<7>("interleaved: (1 MFMA + 4 v_alignbyte_b32) x 4", 256); run<7>("interleaved: (1 MFMA + 4 v_alignbyte_b32) x 4", 512);
+  run<8>("interleaved: (1 MFMA + 2 v_alignbyte_b32) x 8 [per 2 MFMAs]", 256, 1); run<8>("interleaved: (1 MFMA + 2 v_alignbyte_b32) x 8 [per 2 MFMAs]", 256, 2); run<8>("interleaved: (1 MFMA + 2 v_alignbyte_b32) x 8 [per 2 MFMAs]", 256);
   run<5>("16 v_alignbyte_b32 alone", 256, 1); run<5>("16 v_alignbyte_b32 alone", 256); run<5>("16 v_alignbyte_b32 alone", 512);
   return 0;
 }

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh,
 template <int CH, int NT, int PF>
 VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                               const PlaneGeom& G, uint32_t bx, uint32_t by) {
-  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, P = G.a0, R = G.a1;
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, R = G.a1;
+  constexpr uint32_t P = lzm_pitch_of(PF);  // LDS pitch of a staged row: the variant's capacity (64 PF bytes) + 32, a compile-time constant (launcher: G.a0 == P)
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t dwb = dw * CH, ob0 = (bx * 4 + wv) * (16u * NT), ya = by * R;
@@ -313,12 +314,22 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   // edge reaches past the row (those bytes carry no weight and are never loaded: the LDS keeps whatever it held)
   const uint32_t nq_win = (wrel[NT - 1] + 64u) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
   const uint32_t nq = nq_win < nq_row ? nq_win : nq_row;
-  const uint32_t srow = lane >> 2, sq = lane & 3;  // staging: lane -> (row of the tile, unit (lane & 3) + 4 k)
-  // the units a lane stages: (lane & 3) + 4 k, clamped to the last one instead of predicated (all loads issue back to back; a clamped
-  // duplicate is loaded from AND stored to the last unit's place — the pitch need not hold 4 PF units)
-  uint32_t soff[PF];
+  // staging: lane -> (row, 16-B unit) of the tile, PF loads per lane.  Even PF: EIGHT consecutive lanes take eight consecutive units (128 B)
+  // of one row — the eight lanes a ds_write_b128 serves per LDS cycle then cover all 32 banks once (four lanes per row at a pitch of
+  // 32 mod 64 put two rows' units on the same banks: the 2-way conflicts the counters showed) — load k = (row half k / (PF / 2), unit
+  // column k % (PF / 2)): rows lane >> 3 and + 8, units (lane & 7) + 8 c.  Odd PF (the 320-B rows of the 2x down-scales): four lanes per row.
+  constexpr int HALF = PF % 2 == 0 ? PF / 2 : PF, LPR = PF % 2 == 0 ? 8 : 4;
+  auto k_row = [&](int k) -> uint32_t { return LPR == 8 ? (lane >> 3) + 8u * (uint32_t)(k / HALF) : lane >> 2; };
+  auto k_unit = [&](int k) -> uint32_t { return (lane & (LPR - 1)) + (uint32_t)LPR * (uint32_t)(k % HALF); };
+  // the units a lane stages, clamped to the strip's last one instead of predicated (all loads issue back to back; a clamped duplicate is
+  // loaded from the last unit's address and stored at its OWN place in the row, which the pitch has room for and no weight reaches).
+  // voff[k] = the lane's byte offset inside a 16-row source tile.  The tile itself is a scalar step on the base of a BUFFER descriptor that
+  // ends with the plane's last row: a fetch costs no vector arithmetic at all (it was 8 instructions per tile), and the rows of the
+  // picture's last, partial tile (sh % 16 != 0) that lie below the picture are out of the buffer's range — they read as zeros instead of
+  // faulting, and carry no weight (the row weights of clamped taps sit on the last real row)
+  uint32_t voff[PF];
 #pragma unroll
-  for (int k = 0; k < PF; k++) soff[k] = 16u * (sq + 4u * k < nq ? sq + 4u * k : nq - 1u);
+  for (int k = 0; k < PF; k++) voff[k] = mad24(k_row(k), sp, S0 + 16u * (k_unit(k) < nq ? k_unit(k) : nq - 1u));
   // Source tiles travel global memory -> registers -> LDS, TWO tiles ahead of the arithmetic (two register sets: the march is unrolled
   // four deep, so "which set" is a compile-time constant).  One tile ahead left the waves waiting for HBM: with two waves per SIMD a
   // tile's arithmetic lasts ~1 us, less than a loaded chip's memory latency (SQ_WAIT_ANY was 42 % of the wave cycles).
@@ -328,16 +339,16 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
     t_last = __builtin_amdgcn_readfirstlane(r >> 4);
   }
+  const uint32_t plane_bytes = sh * sp;  // < 2^32: launcher
   // (every fetch issues exactly PF loads, predicated on nothing — units past the strip are clamped duplicates, tiles past the band's last
   // re-read the last — so that the compiler can count: the wait in front of a commit is vmcnt(PF), not vmcnt(0))
   u32x4 pf[2][PF];
   auto fetch = [&](int32_t T, auto set_tag) {
     constexpr int SET = decltype(set_tag)::value;
-    int32_t r = 16 * (T < t_last ? T : t_last) + (int32_t)srow;
-    r = r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r;
-    const uint32_t row = mad24((uint32_t)r, sp, S0);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
+    const uint32_t toff = (uint32_t)(T < t_last ? T : t_last) * 16u * sp;  // scalar
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + toff, 0, plane_bytes - toff, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < PF; k++) pf[SET][k] = ldg<false, u32x4>(src + (row + soff[k]));
+    for (int k = 0; k < PF; k++) pf[SET][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k], 0, 0));
   };
   v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs)
 #pragma unroll
@@ -348,7 +359,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint8_t* aptr[NT];
 #pragma unroll
   for (int j = 0; j < NT; j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
-  uint8_t* const sdst = stage + srow * P;
+  uint8_t* const sdst = stage + (LPR == 8 ? (lane >> 3) : (lane >> 2)) * P + 16u * (lane & (LPR - 1));  // + 8 P per row half, + 16 LPR per unit column: immediates
 
   // pass 1 of source tile T into ring slot SLOT = (T - t_first) & 3 (a compile-time constant: the march below is unrolled four deep so
   // that the ring never moves in the register file)
@@ -356,7 +367,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int k = 0; k < PF; k++)
-      *reinterpret_cast<u32x4*>(sdst + soff[k]) = pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+      *reinterpret_cast<u32x4*>(sdst + (LPR == 8 ? (uint32_t)(k / HALF) * 8u * P : 0u) + (uint32_t)(k % HALF) * (16u * LPR)) =
+          pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
     fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
     wave_lds_sync();
     // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
@@ -365,9 +377,11 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #pragma unroll
     for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
     asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
-    // software pipeline over the N-tiles: the two MFMAs of tile j + 1 are issued BEFORE the eight VALU instructions that unpack tile j, so
-    // the unpacking runs while the matrix pipe works (left alone the compiler gives every tile the same result registers: MFMA, MFMA, wait
-    // for the pipe, unpack, next MFMA — the wave idles through every MFMA latency)
+    // software pipeline over the N-tiles, interleaved at instruction level: the matrix pipe takes a new MFMA every 16 cycles and a wave issues
+    // in order, so two MFMAs back to back park the wave for 12 cycles and the eight VALU instructions behind them then run with the pipe
+    // idle.  Order per tile: HI of tile j + 1 | the four shift-adds of tile j (16 cycles: the pipe's own time) | LO of tile j + 1 | the two
+    // v_perm_b32 + two xor of tile j.  (Left alone the compiler gives every tile the same result registers: MFMA, MFMA, wait for the pipe,
+    // unpack, next MFMA — the wave idles through every MFMA latency.)
     v4i hi[2], lo[2];
     hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1h[0], c128, 0, 0, 0);
     lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1l[0], c128, 0, 0, 0);
@@ -376,15 +390,19 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
     for (int j = 0; j < NT; j++) {
       if (j + 1 < NT) {
         hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      uint32_t h[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < NT) {
         lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (j + 4 < NT) {
         av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
       }
-      uint32_t h[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
       // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
       // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
       ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
@@ -405,27 +423,45 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   const uint32_t obase = mad24(lane >> LOGNT, dp, ob);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
   auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
     const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16), by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
-    const v4i hmask = {(int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u, (int)0xff00ff00u};
-    const v4i bx0 = (by0 << 8) & hmask, bx1 = (by1 << 8) & hmask;  // qh moves from the zl slot to the zh slot, the zl slots become 0
-    // software pipeline like pass 1: the four MFMAs of tile j + 1 go out before tile j is shifted, clamped and packed
+    // qh moves from the zl slot to the zh slot, the zl slots become 0: a left shift by 8 inside every 16-bit half (one v_pk_lshlrev_b16 per dword)
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v4i bx0 = __builtin_bit_cast(v4i, __builtin_bit_cast(v8s, by0) << 8), bx1 = __builtin_bit_cast(v4i, __builtin_bit_cast(v8s, by1) << 8);
+    // software pipeline like pass 1, interleaved at instruction level: the four MFMAs of tile j + 1 (64 cycles of the matrix pipe) go out one
+    // at a time between the ten VALU instructions that shift, clamp and pack tile j, instead of four in a row (the wave parked for 36
+    // cycles) and the VALU work behind them.  The VALU work trails the MFMAs by most of a tile — the combine of tile j reads X, Y of tile j
+    // three MFMA slots after Y was issued, its pack runs in tile j + 1's first two slots — so no VALU instruction waits out the matrix
+    // pipe's result latency in s_nops
     v4i x[2], y[2];
-    auto mm = [&](int j) {
-      v4i t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], bx0, czero, 0, 0, 0);
-      x[j & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], bx1, t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][0], by0, cy, 0, 0, 0);
-      y[j & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j][1], by1, t, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    mm(0);
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-      if (j + 1 < NT) mm(j + 1);
-      uint32_t w[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) w[r] = ((uint32_t)x[j & 1][r] << 8) + (uint32_t)y[j & 1][r];  // V / 256 + 2^11 (Q12): the byte is w >> 12, clamped
-      *reinterpret_cast<uint32_t*>(owr + 16u * j) = shift12_sat_pack4(w[0], w[1], w[2], w[3]);
+    {
+      v4i t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][0], bx0, czero, 0, 0, 0);
+      v4i u = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][0], by0, cy, 0, 0, 0);
+      x[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][1], bx1, t, 0, 0, 0);
+      y[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][1], by1, u, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    uint32_t pa = 0, pb = 0, w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const bool more = j + 1 < NT;
+      v4i t, u;
+      if (more) { t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][0], bx0, czero, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      if (j > 0) { shift12_sat_pack4_a(w[0], w[1], w[2], pa, pb); __builtin_amdgcn_sched_barrier(0); }
+      if (more) { u = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][0], by0, cy, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      if (j > 0) {
+        *reinterpret_cast<uint32_t*>(owr + 16u * (j - 1)) = shift12_sat_pack4_b(pa, pb, w[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) { x[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][1], bx1, t, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      w[0] = ((uint32_t)x[j & 1][0] << 8) + (uint32_t)y[j & 1][0];  // V / 256 + 2^11 (Q12): the byte is w >> 12, clamped
+      w[1] = ((uint32_t)x[j & 1][1] << 8) + (uint32_t)y[j & 1][1];
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { y[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][1], by1, u, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      w[2] = ((uint32_t)x[j & 1][2] << 8) + (uint32_t)y[j & 1][2];
+      w[3] = ((uint32_t)x[j & 1][3] << 8) + (uint32_t)y[j & 1][3];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    shift12_sat_pack4_a(w[0], w[1], w[2], pa, pb);
+    *reinterpret_cast<uint32_t*>(owr + 16u * (NT - 1)) = shift12_sat_pack4_b(pa, pb, w[3]);
     wave_lds_sync();
     const uint32_t orow = mad24(y0, dp, obase);
 #pragma unroll

@@ -84,6 +84,27 @@ VPF_DEV uint32_t shift12_sat_pack4(uint32_t w0, uint32_t w1, uint32_t w2, uint32
   return r;
 }
 
+// the same six instructions in two halves, so that a caller can put an MFMA between them (k_lanczos_mfma.hip interleaves its pack with the
+// next tile's MFMAs): a = {w0 >> 12, w1 >> 12}, b.lo = w2 >> 12 | then b.hi = w3 >> 12, r = sat(a) | sat(b) << 16
+VPF_DEV void shift12_sat_pack4_a(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t& a, uint32_t& b) {
+  asm("v_ashrrev_i32_e32 %0, 12, %2\n\t"
+      "v_ashrrev_i32_e32 %1, 12, %4\n\t"
+      "v_ashrrev_i32_sdwa %0, 12, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(a), "=&v"(b)
+      : "v"(w0), "v"(w1), "v"(w2));
+}
+VPF_DEV uint32_t shift12_sat_pack4_b(uint32_t a, uint32_t b, uint32_t w3) {
+  uint32_t r;
+  asm("v_ashrrev_i32_sdwa %1, 12, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+      "v_sat_pk_u8_i16_e32 %0, %2\n\t"
+      "v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(r), "+v"(b)
+      : "v"(a), "v"(w3));
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // Lanczos-3 taps (see the comment above LanczosGatherTask in k_resize.hip)
 // ------------------------------------------------------------------------------------------

@@ -18,6 +18,10 @@ namespace vpf {
 constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               // row-weight operands of four destination tiles (one "group" of 64 rows):
                                                                                  // per tile the Y operand of the ring's two K chunks (X is derived from it)
 constexpr uint32_t kLzmB1Chunk = 4;                                              // N-tiles whose column-weight operands are built per pass through LDS
+// staging loads per lane and source tile (PF) by strip span: 2 (rows of up to 128 B: up-scales), 4 (256 B), 5 (320 B: 2x down-scales with 8-tile
+// strips); the LDS pitch of a staged row is the variant's capacity + 32 — a compile-time constant of the kernel instantiation, = 32 (mod 64)
+constexpr int lzm_pf_of(uint32_t span) { return span <= 128u ? 2 : span <= 256u ? 4 : 5; }
+constexpr uint32_t lzm_pitch_of(int pf) { return 64u * (uint32_t)pf + 32u; }
 constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
 constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of wave-private LDS: staged tile | out tile, or the setup scratch
   const uint32_t run = 16u * pitch + 16u * lzm_out_pitch(nt), setup = 2u * kLzmB1Chunk * 1024u;
@@ -76,7 +80,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
       span = std::max(span, sp);
     }
     q.span = span;
-    q.pitch = vpf_bound_lzm_pitch(span);
+    q.pitch = lzm_pitch_of(lzm_pf_of(span));
     q.wave_lds = lzm_wave_lds(nt, q.pitch);
     q.group_lds = lzm_group_lds(nt, q.pitch);
     return span <= (nt == 8 ? 5u : 4u) * 64u && q.group_lds <= kLzmMaxLds;  // PF staging loads of 4 lanes x 16 B per row
