@@ -178,8 +178,11 @@ class RehearsalWorkload:
 
 
 def timed_block(wl, steps: int):
-    """EXACTLY `steps` steps bracketed by barrier + torch.cuda.synchronize on both sides -> (wall seconds incl. the closing barrier,
-    this rank's own device seconds from HIP events on the launch stream)"""
+    """EXACTLY `steps` steps bracketed by barrier + torch.cuda.synchronize on both sides -> (this rank's own host-clock seconds from its first
+    launch to the return of its own synchronize, wall seconds incl. the closing barrier, this rank's device seconds from HIP events on the
+    launch stream).  The job's time is the MAX over ranks of the FIRST figure: every rank starts behind the opening barrier, the slowest
+    rank's launch -> synchronize span is when the job's work is done, and the closing collective's own latency (tens to hundreds of
+    microseconds over RCCL — percent of a 3.7 ms region) is reported beside it (`barrier_ms`), not inside it."""
     gpu = wl.dev is not None
     if gpu:
         torch.cuda.synchronize()
@@ -197,7 +200,7 @@ def timed_block(wl, steps: int):
     t_own = time.perf_counter() - t0
     sharding.barrier(wl.dev)
     wall = time.perf_counter() - t0
-    return wall, (e0.elapsed_time(e1) * 1e-3 if gpu else t_own)
+    return t_own, wall, (e0.elapsed_time(e1) * 1e-3 if gpu else t_own)
 
 
 def preheat(wl, ms: float):
@@ -215,10 +218,11 @@ def preheat(wl, ms: float):
 
 
 def timed(wl, steps: int, warmup: int, dist_on: bool):
-    """one warm-up + one timed block (the sweeps' form)"""
+    """one warm-up + one timed block (the sweeps' form) -> (own host seconds, device seconds)"""
     for _ in range(warmup):
         wl.step()
-    return timed_block(wl, steps)
+    t_own, _, ev = timed_block(wl, steps)
+    return t_own, ev
 
 
 def effective_cpus() -> int:
@@ -430,13 +434,14 @@ def main():
     heated_ms = preheat(wl, 0.0 if a.rehearse_host else a.preheat_ms)
     for _ in range(a.warmup):
         wl.step()
-    blocks = []  # per repeat: (whole-job pixels, MAX wall over ranks, this rank's device seconds, every rank's device ms per step)
+    blocks = []  # per repeat: (whole-job pixels, MAX over ranks of the own launch -> synchronize time, this rank's device seconds, every rank's device ms per step, MAX wall incl. the closing barrier)
     for _ in range(max(1, a.repeats)):
-        wall, ev = timed_block(wl, a.steps)
-        px, wmax = sharding.aggregate(wl.px_per_step * a.steps, wall, red_dev)  # sum of pixels, MAX time over ranks
-        blocks.append((px, wmax, ev, [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)]))
+        t_own, wall, ev = timed_block(wl, a.steps)
+        px, tmax = sharding.aggregate(wl.px_per_step * a.steps, t_own, red_dev)  # sum of pixels, MAX time over ranks
+        _, wmax = sharding.aggregate(0, wall, red_dev)
+        blocks.append((px, tmax, ev, [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)], wmax))
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][1])
-    total_px, wall_max, ev, per_rank_ms = blocks[order[len(order) // 2]]  # the median block (same index on every rank: wmax is all-reduced)
+    total_px, wall_max, ev, per_rank_ms, wall_with_barrier = blocks[order[len(order) // 2]]  # the median block (same index on every rank: the times are all-reduced)
 
     if rank == 0:
         n_launch = wl.launches_per_step * a.steps
@@ -466,6 +471,7 @@ def main():
             "dtype": "f32",  # u8 pixels in/out, fp32 FMA arithmetic, round-to-nearest-even saturating pack
             "data": "synthetic",
             "per_rank_ms_per_step": per_rank_ms,
+            "barrier_ms": round(max(0.0, wall_with_barrier - wall_max) * 1e3, 4),  # the closing barrier's own cost over the timed block: outside `value`; ms_per_step x steps + barrier_ms = the block's wall time
             "repeats": len(blocks), "per_repeat_ms": [round(b[1] / a.steps * 1e3, 4) for b in blocks],  # ms_per_step is their median
             "preheat_ms": round(heated_ms, 1),
             "config": {"workload": f"{a.workload}: {wl.w}x{wl.h} NV12 -> {'RGB' if a.workload != 'nv12_planar_1080p' else 'RGB_PLANAR'}, BT.709 limited range, "

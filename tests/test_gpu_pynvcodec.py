@@ -452,6 +452,41 @@ def test_upload_from_pinned_memory():
         assert np.array_equal(download(up.UploadSingleFrame(a)), a)
 
 
+def test_uploaded_surface_is_complete_for_a_consumer_on_another_stream():
+    """the reference's upload blocks until the copy is done (src/TC/src/Tasks.cpp:617-618), so user code reads the returned surface from any
+    stream.  Default here: the same — a downloader on a DIFFERENT stream, which nothing orders behind the uploader's private copy stream,
+    sees the whole new frame every time (4K frames: the copy takes a few hundred microseconds, long enough to lose the race if the call
+    returned early).  SetAsync(True) is the opt-in to stream-ordered completion; it still yields the right frame to a consumer on the
+    uploader's own stream."""
+    w, h = 3840, 2160
+    n = w * h * 3 // 2
+    ctx = nvc.GetContext(GPU)
+    s_up, s_dl = torch.cuda.Stream(), torch.cuda.Stream()
+    up = nvc.PyFrameUploader(w, h, PF.NV12, ctx, s_up.cuda_stream)
+    assert up.GetAsync() is False
+    dl_other = nvc.PySurfaceDownloader(w, h, PF.NV12, ctx, s_dl.cuda_stream)
+    dl_same = nvc.PySurfaceDownloader(w, h, PF.NV12, ctx, s_up.cuda_stream)
+    rng = np.random.default_rng(77)
+    out = np.zeros(n, np.uint8)
+    pinned = nvc.AllocPinned(n)
+    for i in range(6):
+        frame = rng.integers(0, 256, n, dtype=np.uint8)
+        if i & 1:  # page-locked source: DMA'd in place
+            pinned[:] = frame
+            surf = up.UploadSingleFrame(pinned)
+        else:      # pageable source: staged
+            surf = up.UploadSingleFrame(frame)
+        assert dl_other.DownloadSingleSurface(surf, out)
+        assert np.array_equal(out, frame), f"frame {i}: a consumer on another stream read an incomplete upload"
+    up.SetAsync(True)
+    assert up.GetAsync() is True
+    for i in range(3):
+        frame = rng.integers(0, 256, n, dtype=np.uint8)
+        surf = up.UploadSingleFrame(frame)
+        assert dl_same.DownloadSingleSurface(surf, out)
+        assert np.array_equal(out, frame)
+
+
 def test_concurrent_threads_mixed_operations(oracle):
     """8 threads, each with its own stream and task objects, hammer converters / fused resize / resizer / remaper /
     uploader / downloader concurrently (GIL released inside the calls): every result must stay bit-exact.  Guards the

@@ -5,6 +5,7 @@ C=videoprocessingframework_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -fvisibility=hidden -Iinclude -I$C"
 OBJS=$(ls videoprocessingframework_amd/build/k_*.o videoprocessingframework_amd/build/vpf_abi.o | grep -v k_lanczos_mfma)
 for X in "$@"; do
+  if [ "$X" = prof ]; then hipcc $FLAGS -DVPF_LZM_PROF=1 -c $C/k_lanczos_mfma.hip -o /tmp/lzm_xprof.o 2>&1 | grep -v warning & continue; fi
   hipcc $FLAGS -DVPF_LZM_X=$X -c $C/k_lanczos_mfma.hip -o /tmp/lzm_x$X.o 2>&1 | grep -v warning &
 done
 wait

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "videoprocessingframework_amd"))
 import PyNvCodec as nvc
 
 W, H, N = 3840, 2160, 200
+ASYNC = "--async" in sys.argv  # uploaders return once their copy is queued (SetAsync(True)); default: the reference's blocking upload
 PF = nvc.PixelFormat
 frames = [np.random.default_rng(i).integers(0, 256, W * H * 3 // 2, dtype=np.uint8) for i in range(8)]
 if "--pinned" in sys.argv:  # frames decoded straight into page-locked memory: no staging memcpy
@@ -23,6 +24,7 @@ def run(kind, n=N, ctx=None, stream=None):
     ctx = nvc.GetContext(0) if ctx is None else ctx
     stream = nvc.GetStream(0) if stream is None else stream
     up = nvc.PyFrameUploader(W, H, PF.NV12, ctx, stream)
+    up.SetAsync(ASYNC)  # default: wait for every copy like the reference; --async: return once the copy is queued
     conv = nvc.PySurfaceConverter(W, H, PF.NV12, PF.RGB, ctx, stream)
     s = up.UploadSingleFrame(frames[0])
     conv.Execute(s, cc)

@@ -36,6 +36,13 @@ from videoprocessingframework_amd import sharding  # noqa: E402
 import PyNvCodec as nvc  # noqa: E402
 
 
+def _async(up):
+    """the pipeline's uploaders return once their copy is queued (additive SetAsync; the default waits for the copy like the reference): every
+    consumer here runs on the uploader's own stream, and the stand-in decoder never rewrites a frame the stream has not consumed"""
+    up.SetAsync(True)
+    return up
+
+
 class SyntheticClip:
     """Stand-in for demux + software decode of one clip: `distinct` NV12 frames in host memory, seeded per clip — page-locked (what a decoder
     writing into AllocPinned() buffers produces: DMA'd in place) or ordinary pageable numpy arrays (what an unmodified decoder produces: the
@@ -85,7 +92,7 @@ def main():
         stream = torch.cuda.Stream(device=dev)
         ctx = nvc.GetContext(gpu)
         chains.append({"clip": c, "src": SyntheticClip(c, w, h, pinned=a.source == "pinned"), "stream": stream,
-                       "up": nvc.PyFrameUploader(w, h, pf.NV12, ctx, stream.cuda_stream),
+                       "up": _async(nvc.PyFrameUploader(w, h, pf.NV12, ctx, stream.cuda_stream)),
                        "conv": nvc.PySurfaceConverter(w, h, pf.NV12, pf.RGB, ctx, stream.cuda_stream),
                        "down": nvc.PySurfaceDownloader(w, h, pf.RGB, ctx, stream.cuda_stream)})
 

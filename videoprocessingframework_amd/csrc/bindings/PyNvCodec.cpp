@@ -568,8 +568,9 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PyFrameUploader::GetFormat)
       .def("SetAsync", &PyFrameUploader::SetAsync, py::arg("on"),
-           "additive: frames in page-locked memory (AllocPinned) are DMA'd in place; True = do not wait for that copy (the caller will not reuse the "
-           "buffer before synchronising).  Pageable frames are staged and never wait.  VPF_HIP_UPLOAD_SYNC=1 restores the reference's blocking upload")
+           "additive: True = UploadSingleFrame returns once the copy is queued (the surface is valid in stream order on the uploader's stream; a "
+           "page-locked source frame must stay untouched until that stream is synchronised).  Default False = wait for the copy, like the reference. "
+           "VPF_HIP_UPLOAD_ASYNC=1 makes True the default")
       .def("GetAsync", &PyFrameUploader::GetAsync)
       .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size()); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>())

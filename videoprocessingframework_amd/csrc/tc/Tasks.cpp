@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -120,8 +121,15 @@ bool flag_ready(StreamRef* s) {  // the completion flag of this task, set up on 
 bool flag_wait(StreamRef* s, uint32_t want, int64_t budget_ns) {
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t i = 0;; i++) {
-    if ((int32_t)(*s->flag - want) >= 0) return true;
+    if ((int32_t)(*s->flag - want) >= 0) {
+      std::atomic_thread_fence(std::memory_order_acquire);  // what the stream wrote before the flag (a staged download's bytes) is read after it
+      return true;
+    }
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
     if ((i & 255u) == 255u && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > budget_ns) return false;
   }
 }
@@ -629,8 +637,7 @@ TaskExecStatus RemapSurface::RunBatch(Surface* const* ins, Surface* const* outs,
 struct CudaUploadFrame::Impl {
   static constexpr int kSlots = 4;  // staging buffers / device surfaces in rotation: the host copy of frame i + 1 overlaps the DMA of frame i
   StreamRef sref;
-  bool async_pinned = false;  // SetAsync(true): do not wait for the DMA out of caller-owned page-locked memory either
-  bool force_sync = false;    // VPF_HIP_UPLOAD_SYNC=1: block on every copy like the reference (Tasks.cpp:617-618)
+  bool async = false;  // SetAsync(true) / VPF_HIP_UPLOAD_ASYNC=1: Run() returns once the copy is QUEUED (default: it waits for the copy, like the reference's task, Tasks.cpp:617-618)
   Pixel_Format fmt;
   hipStream_t copy_stream = nullptr;
   hipEvent_t done[kSlots] = {};
@@ -651,7 +658,7 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
     : Task("HipUploadFrame", numInputs, numOutputs, hip_stream_sync, nullptr), pImpl(new Impl) {
   pImpl->sref = StreamRef{ctx, str};
   pImpl->fmt = f;
-  if (const char* e = std::getenv("VPF_HIP_UPLOAD_SYNC")) pImpl->force_sync = e[0] && e[0] != '0';
+  if (const char* e = std::getenv("VPF_HIP_UPLOAD_ASYNC")) pImpl->async = e[0] && e[0] != '0';
   DeviceScope scope(ctx);
   for (int i = 0; i < Impl::kSlots; i++) {
     pImpl->surf[i].reset(Surface::Make(f, w, h, ctx));
@@ -663,8 +670,8 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
   if (hipStreamCreateWithFlags(&pImpl->copy_stream, hipStreamNonBlocking) != hipSuccess) pImpl->copy_stream = nullptr;
 }
 CudaUploadFrame::~CudaUploadFrame() {}
-void CudaUploadFrame::SetAsync(bool on) { pImpl->async_pinned = on; }
-bool CudaUploadFrame::GetAsync() const { return pImpl->async_pinned; }
+void CudaUploadFrame::SetAsync(bool on) { pImpl->async = on; }
+bool CudaUploadFrame::GetAsync() const { return pImpl->async; }
 CudaUploadFrame* CudaUploadFrame::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
   return new CudaUploadFrame(str, ctx, w, h, f);
 }
@@ -705,15 +712,17 @@ TaskExecStatus CudaUploadFrame::Run() {
     src += wb * rows;
   }
   if (pImpl->done[slot] && cs != (hipStream_t)pImpl->sref.str) {
-    // order the task stream behind the copy.  A frame that was STAGED (pageable source) has left the caller's memory already: return
-    // without waiting — the returned surface is valid in stream order on the task's stream, where its consumers run, and the host goes
-    // on to decode / stage the next frame while this one crosses PCIe (round 3; rounds 1-2 blocked here like the reference's task,
-    // Tasks.cpp:617-618, which capped one uploader at 0.72 of the link).  A frame DMA'd straight out of caller-owned page-locked memory
-    // is still in use by the engine: block on the copy alone (kernels on the task stream keep running underneath) unless the caller
-    // promised not to touch the buffer before its next synchronisation (SetAsync(true)).
+    // order the task stream behind the copy, then — by default — wait for the copy itself, as the reference's task does (Tasks.cpp:617-618):
+    // the surface this call returns is complete for EVERY consumer, whichever stream it reads on (a converter built on another stream, a
+    // torch / DLPack view through PlanePtr().GpuMem(), SurfacePlane.Export).  Only the copy is waited for: kernels queued on the task stream
+    // keep running underneath.  SetAsync(true) (or VPF_HIP_UPLOAD_ASYNC=1) returns as soon as the copy is queued: the surface is then valid
+    // in stream order on the task's stream only, a page-locked source frame must not be rewritten before the caller's next
+    // synchronisation, and the host goes on to decode / stage the next frame while this one crosses PCIe (2 200 -> 3 000 frames/s at 4K
+    // from pageable memory, profiles/r03_pipeline_async_upload.txt).  Round 3 made that the default for staged (pageable) frames: a silent
+    // change of the reference's contract, taken back in round 4.
     if (!hip_ok(hipEventRecord(pImpl->done[slot], cs), "CudaUploadFrame: hipEventRecord")) return TASK_EXEC_FAIL;
     if (!hip_ok(hipStreamWaitEvent((hipStream_t)pImpl->sref.str, pImpl->done[slot], 0), "CudaUploadFrame: hipStreamWaitEvent")) return TASK_EXEC_FAIL;
-    if (pImpl->force_sync || (pinned_src && !pImpl->async_pinned)) {
+    if (!pImpl->async) {
       if (!hip_ok(hipEventSynchronize(pImpl->done[slot]), "CudaUploadFrame: hipEventSynchronize")) return TASK_EXEC_FAIL;
     }
   } else {

@@ -103,9 +103,10 @@ public:
   static CudaUploadFrame* Make(HipStream str, HipContext ctx, uint32_t width, uint32_t height, Pixel_Format format);
   ~CudaUploadFrame() override;
   TaskExecStatus Run() final;
-  // Additive.  Pageable frames are staged and return as soon as the DMA is queued (the surface is valid in stream order); frames in
-  // page-locked memory are DMA'd in place and Run() waits for that copy unless SetAsync(true) says the caller will not reuse the buffer
-  // before it synchronises the stream.  VPF_HIP_UPLOAD_SYNC=1 makes every Run() block like the reference's.
+  // Additive.  Default: Run() waits for the host-to-device copy, like the reference's task (src/TC/src/Tasks.cpp:617-618) — the returned
+  // surface is complete for consumers on ANY stream.  SetAsync(true) (or VPF_HIP_UPLOAD_ASYNC=1): Run() returns once the copy is queued; the
+  // surface is valid in stream order on the task's stream only, and a page-locked source frame must stay untouched until the caller's
+  // next synchronisation of that stream.
   void SetAsync(bool on);
   bool GetAsync() const;
 

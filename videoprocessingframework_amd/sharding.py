@@ -112,8 +112,10 @@ def gpu_numa_cpus(pci_addr: str, sysfs_pci: str = "/sys/bus/pci/devices") -> Tup
 
 
 def bind_to_gpu_numa(device_index: int, sysfs_pci: str = "/sys/bus/pci/devices") -> Dict[str, object]:
-    """Confine this process to the CPUs local to GPU `device_index` (intersection with the affinity it already has).  Call it BEFORE
-    allocating pinned buffers or starting worker threads.  Returns what was found and done; never raises for a missing sysfs."""
+    """Confine this process to the CPUs local to GPU `device_index` (intersection with the affinity it already has).  Call it first in a
+    rank, before pinned buffers are allocated.  sched_setaffinity(0, ...) moves the CALLING thread only, and asking torch for the PCI address
+    has started runtime threads by then (HIP, OpenMP, gloo) — so the mask is applied to every thread the process has (/proc/self/task);
+    threads created later inherit it.  Returns what was found and done; never raises for a missing sysfs."""
     info: Dict[str, object] = {"device": device_index, "numa_node": None, "bound": False}
     try:
         p = torch.cuda.get_device_properties(device_index)
@@ -129,6 +131,25 @@ def bind_to_gpu_numa(device_index: int, sysfs_pci: str = "/sys/bus/pci/devices")
     if node is None or not want or set(want) == set(allowed):
         info["why"] = "platform reports no NUMA locality for this device" if node is None or not cpus else "already confined to the local CPUs"
         return info
-    os.sched_setaffinity(0, want)
-    info.update(bound=True, cpus=len(want))
+    moved = _set_affinity_all_threads(want)
+    info.update(bound=True, cpus=len(want), threads=moved)
     return info
+
+
+def _set_affinity_all_threads(cpus, task_dir: str = "/proc/self/task") -> int:
+    """sched_setaffinity for every thread of this process; returns how many were moved (a thread that exits meanwhile is skipped)"""
+    try:
+        tids = [int(t) for t in os.listdir(task_dir)]
+    except (OSError, ValueError):
+        tids = []
+    moved = 0
+    for tid in tids or [0]:
+        try:
+            os.sched_setaffinity(tid, cpus)
+            moved += 1
+        except OSError:
+            pass
+    if not moved:
+        os.sched_setaffinity(0, cpus)
+        moved = 1
+    return moved
