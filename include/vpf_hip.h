@@ -161,6 +161,33 @@ VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_siz
 VPF_API vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size src_size, vpf_size dst_size, uint32_t n,
                                     const vpf_frame_io* frames);
 
+/* Scratch memory for the resize filters that keep per-shape operand tables (today: LANCZOS3 on 8-bit surfaces — column / row weight
+ * operands of the matrix-core kernel, built once per (source size, destination size) by two small kernels and read by every later call).
+ * NPP's pattern for this is a caller-provided buffer (nppiResizeGetBufferSize-style calls next to the NppResize*_Impl classes'
+ * own destination surface, Tasks.cpp:1134-1150); here:
+ *   - the caller owns `ptr` (device memory, 256-B aligned, `bytes` long) AND this struct: zero `opaque` once, then pass the same struct
+ *     with every call that should share the tables.  The library records in `opaque` which tables the region holds.
+ *   - a workspace is used on ONE stream at a time (its builds and its launches are ordered by that stream); a call on another stream, or
+ *     while the stream is being captured, or with a shape the region does not hold, rebuilds (a few microseconds) — never an error.
+ *   - too small a region (or ws == NULL, or the plain vpf_resize / vpf_resize_batch): the library's own small static arena is used
+ *     instead (4 MiB per device, least-recently-used eviction); shapes that fit neither evaluate their weights inside the kernel.
+ * Pixels are identical on every path.  Freeing `ptr` is the caller's business, after the stream has finished with it. */
+typedef struct vpf_workspace {
+  void* ptr;
+  uint64_t bytes;
+  uint64_t opaque[40];
+} vpf_workspace;
+
+/* Bytes of workspace that hold the tables of this resize for any batch size (0: this (fmt, interp, sizes) keeps no tables).
+ * Pure host logic; callable without a GPU. */
+VPF_API uint64_t vpf_resize_workspace_bytes(int fmt, int interp, vpf_size src_size, vpf_size dst_size);
+
+/* vpf_resize / vpf_resize_batch with a caller-owned workspace (may be NULL). */
+VPF_API vpf_status vpf_resize_ws(const vpf_exec* exec, int fmt, int interp, vpf_size src_size, const vpf_plane src[3], vpf_size dst_size,
+                                 const vpf_plane dst[3], vpf_workspace* ws);
+VPF_API vpf_status vpf_resize_batch_ws(const vpf_exec* exec, int fmt, int interp, vpf_size src_size, vpf_size dst_size, uint32_t n,
+                                       const vpf_frame_io* frames, vpf_workspace* ws);
+
 /* Per-pixel remap with bilinear sampling, packed RGB/BGR only (Tasks.cpp:1555-1602,
  * nppiRemap_8u_C3R + NPPI_INTER_LINEAR).  xmap/ymap are device pointers to float32 rows of
  * dst_size.width entries, row pitch in bytes.  Destination pixels whose source coordinate lies

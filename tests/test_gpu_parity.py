@@ -1076,6 +1076,50 @@ def test_lanczos_weight_tables_across_streams(capi, oracle):
         assert_planes_equal(got, oracle.resize(of, 2, sw, sh, src, dw, dh, oracle.FP32)[1], f"tables across streams: {fmt} {sw}x{sh}->{dw}x{dh} stream {si} knob {knob:#x}")
 
 
+def test_resize_with_a_caller_owned_workspace(capi, oracle):
+    """vpf_resize_workspace_bytes / vpf_resize_ws / vpf_resize_batch_ws (include/vpf_hip.h): the Lanczos tables of a shape live in memory the
+    CALLER owns (NPP's scratch-buffer pattern; ResizeSurface allocates one next to its destination surface).  One workspace serves shape
+    after shape (a new shape is built behind the old one's readers, stream-ordered), batches and single frames, two streams in turn; a
+    workspace that is too small, misaligned or absent falls back to the library's arena; filters without tables ask for none.  Every
+    result equals the oracle."""
+    assert capi.resize_workspace_bytes(capi.RGB, capi.INTERP_LINEAR, 1920, 1080, 1280, 720) == 0
+    assert capi.resize_workspace_bytes(capi.RGB_32F, capi.INTERP_LANCZOS3, 640, 360, 320, 180) == 0
+    need = capi.resize_workspace_bytes(capi.RGB, capi.INTERP_LANCZOS3, 1920, 1080, 1280, 720)
+    assert 256 * 1024 < need < 4 * 1024 * 1024
+    assert capi.resize_workspace_bytes(capi.NV12, capi.INTERP_LANCZOS3, 1920, 1080, 1280, 720) > need // 3
+    shapes = [("RGB", 1283, 211, 857, 140), ("NV12", 1920, 240, 1280, 160), ("Y", 811, 97, 1622, 194), ("RGB", 1283, 211, 640, 97), ("YUV420", 642, 130, 1000, 200)]
+    big = max(capi.resize_workspace_bytes(getattr(capi, f), 2, sw, sh, dw, dh) for f, sw, sh, dw, dh in shapes)
+    mem = torch.zeros(big + 512, dtype=torch.uint8, device="cuda")
+    base = (mem.data_ptr() + 255) // 256 * 256
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    variants = {"fits": capi.make_workspace(base, big), "small": capi.make_workspace(base, 4096), "misaligned": capi.make_workspace(base + 16, big - 16), "none": None}
+    jobs = []
+    for rnd in range(3):
+        for ci, (fmt, sw, sh, dw, dh) in enumerate(shapes):
+            f, of = getattr(capi, fmt), getattr(oracle, fmt)
+            for name, ws in variants.items():
+                st = streams[(rnd + ci) & 1] if name == "fits" else streams[0]   # the good workspace changes streams as it goes: that rebuilds, never corrupts
+                n = 1 + (rnd + ci) % 3
+                srcs = [oracle.synth(of, sw, sh, 9500 + 100 * rnd + 10 * ci + i) for i in range(n)]
+                with torch.cuda.stream(st):
+                    S, D = [DevPlanes(p) for p in srcs], [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+                    ex = capi.make_exec(st.cuda_stream)
+                    if n == 1:
+                        capi.resize_ws(ex, f, 2, sw, sh, S[0].desc(), dw, dh, D[0].desc(), ws)
+                    else:
+                        capi.resize_batch_ws(ex, f, 2, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]), ws)
+                if name == "fits":
+                    torch.cuda.synchronize()  # (the workspace is used on one stream AT A TIME: the next round may run on the other stream)
+                jobs.append((name, of, sw, sh, dw, dh, srcs, S, D))
+    torch.cuda.synchronize()
+    for name, of, sw, sh, dw, dh, srcs, S, D in jobs:
+        for src, d in zip(srcs, D):
+            got, intact = d.download()
+            assert intact
+            assert_planes_equal(got, oracle.resize(of, 2, sw, sh, src, dw, dh, oracle.FP32)[1], f"workspace {name}: {sw}x{sh}->{dw}x{dh}")
+    del mem
+
+
 def test_lanczos_weight_tables_from_concurrent_threads(capi, oracle):
     """Eight host threads, each with a stream of its own, resize the same few shapes (and some of their own) at the same time through
     vpf_resize_batch: the table cache is shared by every caller of the library in the process, and every thread's first use of a shape
@@ -1129,10 +1173,11 @@ def test_lanczos_weight_tables_from_concurrent_threads(capi, oracle):
 
 
 def test_lanczos_weight_table_arena_full(tmp_path):
-    """The per-shape weight tables live in a fixed arena of static device memory that is never recycled; when it is full, later shapes run
-    with their weights evaluated inside the kernel.  VPF_HIP_LANCZOS_TABLE_KB shrinks the arena so that this happens after a few shapes: in a
-    child process (the knob is read once) a dozen shapes, the first ones with tables and the rest without — some planes of one launch with a
-    table and others without —, all equal the oracle; with 0 KB nothing gets a table."""
+    """Without a caller-owned workspace the per-shape weight tables live in a small arena of static device memory with least-recently-used
+    eviction; a table larger than the arena is not kept at all and that plane runs with its weights evaluated inside the kernel.
+    VPF_HIP_LANCZOS_TABLE_KB shrinks the arena so that both happen after a few shapes: in a child process (the knob is read once) a dozen
+    shapes twice over — evictions behind events, some planes of one launch with a table and others without, three planes of equal shape
+    sharing one entry —, all equal the oracle; with 0 KB nothing gets a table."""
     import subprocess
     import textwrap
 

@@ -28,10 +28,25 @@ def lzp():
     L.lzp_cache_new.restype = C.c_void_p
     L.lzp_cache_new.argtypes = [C.c_uint64]
     L.lzp_cache_free.argtypes = [C.c_void_p]
-    L.lzp_cache_get.restype = C.c_uint32
-    L.lzp_cache_get.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int] + [C.c_uint32] * 5 + [C.c_uint64]
+    L.lzp_cache_launch.restype = C.c_uint32
+    L.lzp_cache_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int] + [C.c_uint32] * 5 + [C.c_uint64]
+    L.lzp_cache_launch2.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]
     L.lzp_cache_used.restype = C.c_uint64
     L.lzp_cache_used.argtypes = [C.c_void_p, C.c_int]
+    L.lzp_cache_entries.restype = C.c_uint32
+    L.lzp_cache_entries.argtypes = [C.c_void_p, C.c_int]
+    L.lzp_sync_complete.argtypes = [C.c_void_p, C.c_uint64]
+    L.lzp_sync_next.restype = C.c_uint64
+    L.lzp_sync_next.argtypes = [C.c_void_p]
+    L.lzp_sync_live.argtypes = [C.c_void_p]
+    L.lzp_sync_reset_device.argtypes = [C.c_void_p, C.c_int]
+    L.lzp_sync_log.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.lzp_ws_get.restype = C.c_uint32
+    L.lzp_ws_get.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int, C.c_int] + [C.c_uint32] * 5 + [C.c_uint64, C.c_uint32]
+    L.lzp_ws_n.restype = C.c_uint32
+    L.lzp_ws_n.argtypes = [C.POINTER(C.c_uint64)]
+    L.lzp_table_bytes_bound.restype = C.c_uint64
+    L.lzp_table_bytes_bound.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
     return L
 
 
@@ -105,32 +120,124 @@ def test_planner_limits_and_forced_shapes(lzp):
     assert without["r"] >= with_t["r"]                                          # a bigger fixed cost per wave never asks for shorter bands
 
 
+B = 0x80000000
+
+
+def _log(L, c):
+    buf = C.create_string_buffer(1 << 16)
+    L.lzp_sync_log(c, buf, len(buf))
+    return buf.value.decode().split()
+
+
 def test_table_cache_contract(lzp):
+    """the fallback arena (vpf_lzm_plan.h: LzmTableCache) against a recording stand-in for HIP events: what makes "a launch never reads a table
+    whose build it is not ordered behind" and "a table is never overwritten under a kernel that may still read it" true"""
     c = lzp.lzp_cache_new(1 << 20)
     try:
-        get = lambda st, dev=0, cap=0, kind=0, k=(3, 1920, 1280, 8), nbytes=100_000: lzp.lzp_cache_get(c, st, dev, cap, kind, *k, nbytes)
-        B = 0x80000000
-        a = get(0x1000)
+        go = lambda st, dev=0, cap=0, kind=0, k=(3, 1920, 1280, 8), nbytes=100_000: lzp.lzp_cache_launch(c, st, dev, cap, kind, *k, nbytes)
+        a = go(0x1000)
         assert a & B and (a & ~B) == 16                      # first use: allocated after the 256 unused bytes, build on this stream
-        assert get(0x1000) == 16                             # same stream again: ordered behind its own build, nothing to do
-        assert get(0x2000) == (16 | B)                       # another stream has not: it queues its own build of the SAME entry
-        assert get(0x2000) == 16 and get(0x1000) == 16
-        assert get(0x1000, cap=1) == (16 | B) and get(0x1000, cap=1) == (16 | B) and get(0x1000) == 16   # a capturing stream always builds, and is not remembered for it
-        fresh = get(0x3000, cap=1, k=(1, 640, 320, 4), nbytes=5000)
-        assert fresh & B and get(0x3000, k=(1, 640, 320, 4), nbytes=5000) & B   # first met under capture: the later plain call on that stream still builds
-        b = get(0x1000, kind=1, k=(1080, 720, 368, 0), nbytes=24_576)
-        assert b & B and (b & ~B) == 16 + (100_000 + 255) // 256 * 16 + (5000 + 255) // 256 * 16   # bump allocation in 256-B steps, entries never move
-        assert get(0x1000, dev=1) == (16 | B)                # arenas are per device
-        for st in (0x10, 0x20, 0x30, 0x40, 0x50):            # more streams than an entry remembers: the oldest is forgotten and simply builds again
-            assert get(st) & B
-        assert get(0x50) == 16 and get(0x20) == 16 and get(0x1000) & B
+        assert _log(lzp, c) == ["R1@4096d0", "R2@4096d0"]    # an event behind the build, one behind the launch that read the table
+        assert go(0x1000) == 16                              # same stream again: ordered behind its own build by the stream itself
+        assert _log(lzp, c) == ["R3@4096d0"]                 # (only the launch's last-use event; the previous one was released)
+        assert go(0x2000) == 16                              # another stream: no second build — it WAITS for the build's event
+        assert _log(lzp, c) == ["W1@8192", "R4@8192d0"]
+        lzp.lzp_sync_complete(c, 1)                          # the build is seen complete once ...
+        assert go(0x3000) == 16 and _log(lzp, c) == ["R5@12288d0"]      # ... and nobody waits for it again
+        assert go(0x2000) == 16 and go(0x1000) == 16
+        _log(lzp, c)
+        # a capturing stream always queues its own build (a captured build has not run), records nothing (an event recorded there would
+        # become a node of the graph), and pins the entry: a graph captured with it replays whenever it likes
+        assert go(0x1000, cap=1) == (16 | B) and go(0x1000, cap=1) == (16 | B) and _log(lzp, c) == []
+        fresh = go(0x3000, cap=1, k=(1, 640, 320, 4), nbytes=5000)
+        assert fresh & B and go(0x3000, k=(1, 640, 320, 4), nbytes=5000) & B   # first met under capture: its build never ran — the plain call builds
+        b = go(0x1000, kind=1, k=(1080, 720, 368, 0), nbytes=24_576)
+        assert b & B and (b & ~B) == 16 + (100_000 + 255) // 256 * 16 + (5000 + 255) // 256 * 16   # first fit in 256-B steps
+        assert go(0x1000, dev=1) == (16 | B)                 # arenas are per device
         used = lzp.lzp_cache_used(c, 0)
-        assert get(0x1000, k=(3, 3840, 1920, 8), nbytes=(1 << 20) - used + 1) == 0      # would not fit: no table, no build (the kernel evaluates its weights)
-        assert lzp.lzp_cache_used(c, 0) == used               # ... and nothing was taken
-        assert get(0x1000, k=(3, 3840, 1920, 8), nbytes=(1 << 20) - used - 256) & B     # what does fit still gets in
-        assert get(0x1000, dev=64) == 0 and get(0x1000, dev=-1) == 0
+        assert go(0x1000, k=(3, 9999, 9999, 8), nbytes=(1 << 20) + 1) == 0      # larger than the arena: no table, no build (the kernel evaluates its weights)
+        assert lzp.lzp_cache_used(c, 0) == used               # ... and nothing was taken or evicted for it
+        assert go(0x1000, dev=64) == 0 and go(0x1000, dev=-1) == 0
     finally:
         lzp.lzp_cache_free(c)
     z = lzp.lzp_cache_new(0)                                   # VPF_HIP_LANCZOS_TABLE_KB=0
-    assert lzp.lzp_cache_get(z, 1, 0, 0, 0, 3, 1920, 1280, 8, 1000) == 0
+    assert lzp.lzp_cache_launch(z, 1, 0, 0, 0, 3, 1920, 1280, 8, 1000) == 0
     lzp.lzp_cache_free(z)
+
+
+def test_table_cache_evicts_least_recently_used_behind_its_last_use(lzp):
+    """a full arena hands the least recently used entry's space to the new shape — after making the BUILDING stream wait for the event the
+    last launch left on that entry (unless that launch is known to have finished) — and never an entry of the launch in progress"""
+    c = lzp.lzp_cache_new(256 + 3 * 4096)                      # room for three 4-KiB tables
+    try:
+        go = lambda st, k, nbytes=4096: lzp.lzp_cache_launch(c, st, 0, 0, 0, k, 1, 1, 8, nbytes)
+        offs = [go(0x10, k) & ~B for k in (1, 2, 3)]
+        assert offs == [16, 16 + 256, 16 + 512] and lzp.lzp_cache_entries(c, 0) == 3
+        go(0x10, 1)                                            # shape 1 is used again: shape 2 is now the oldest
+        _log(lzp, c)
+        e_last_use_2 = 4                                       # events so far: (build, use) x 3 = 1..6, then use of shape 1 = 7; shape 2's last use = 4
+        d = go(0x20, 4)                                        # a fourth shape, from another stream
+        assert d == (offs[1] | B)                              # it took shape 2's place
+        lg = _log(lzp, c)
+        assert f"W{e_last_use_2}@32" in lg and "W3@32" in lg  # stream 0x20 waits for shape 2's last launch AND its (not yet seen complete) build
+        assert go(0x10, 2) & B                                 # shape 2 is gone: it is built again (evicting the oldest: shape 3)
+        assert lzp.lzp_cache_entries(c, 0) == 3
+        lzp.lzp_sync_complete(c, lzp.lzp_sync_next(c))         # everything queued so far has finished:
+        _log(lzp, c)
+        assert go(0x30, 5) & B and not [x for x in _log(lzp, c) if x.startswith("W")]   # an eviction then waits for nothing
+        # two tables of ONE launch never evict each other: with room for three, a launch that needs two new ones keeps both
+        out = (C.c_uint32 * 2)()
+        ka, kb = (C.c_uint32 * 5)(0, 77, 1, 1, 8), (C.c_uint32 * 5)(1, 77, 1, 1, 0)
+        lzp.lzp_cache_launch2(c, 0x10, 0, ka, 4096, kb, 4096, out)
+        assert out[0] & B and out[1] & B and (out[0] & ~B) != (out[1] & ~B)
+        big = (C.c_uint32 * 5)(0, 78, 1, 1, 8)
+        lzp.lzp_cache_launch2(c, 0x10, 0, kb, 4096, big, 2 * 4096 + 1, out)     # kb's table is in use by this launch: it may not make room for the big one ...
+        assert out[0] == (out[0] & ~B) and out[0] != 0 and out[1] == 0           # ... it is still there, untouched; the big one gets no table (weights in the kernel)
+        # 10 000 distinct shapes through an arena that holds three: every one of them gets a table (the arena never "fills up for good")
+        for k in range(1000, 11000):
+            assert go(0x10, k) & B
+        assert lzp.lzp_cache_entries(c, 0) <= 3
+        # a device reset: the host forgets the device's tables (static device memory is re-initialised) — the next launch builds again
+        last = go(0x10, 10999)
+        assert last == (last & ~B)
+        lzp.lzp_sync_reset_device(c, 0)
+        assert go(0x10, 10999) & B and lzp.lzp_cache_entries(c, 0) == 1
+    finally:
+        live_before = lzp.lzp_sync_live(c)
+        lzp.lzp_cache_free(c)
+    assert live_before <= 2 * 3 + 1                            # events are released as entries go: no leak over 10 000 evictions
+
+
+def test_workspace_record(lzp):
+    """the caller-owned workspace (vpf_workspace.opaque = LzmWorkspace): stream-ordered, no events.  Same shape on the same stream -> no
+    rebuild; another stream / a capturing stream / a new shape -> rebuild; no room -> everything is dropped and the region reused from its
+    start, except that the entries of the launch in progress are never dropped (the fallback arena serves that table instead)"""
+    ws = (C.c_uint64 * 40)()
+    region = 256 + 3 * 4096
+    get = lambda st, k, nbytes=4096, cap=0, dev=0, kind=0, pinned=99: lzp.lzp_ws_get(ws, region, st, dev, cap, kind, k, 1, 1, 8, nbytes, pinned)
+    assert get(0x10, 1) == (16 | B) and get(0x10, 1) == 16 and get(0x10, 1, kind=1) == ((16 + 256) | B)
+    assert get(0x10, 1, cap=1) == (16 | B)                     # captured: build again
+    assert get(0x20, 1) == (16 | B) and lzp.lzp_ws_n(ws) == 1  # another stream: nothing in the region is ordered for it — it starts over
+    assert get(0x20, 2) & B and get(0x20, 3) & B and lzp.lzp_ws_n(ws) == 3
+    assert get(0x20, 4) == (16 | B) and lzp.lzp_ws_n(ws) == 1  # full: reuse from the start (stream order keeps the old readers in front)
+    assert get(0x20, 5, pinned=0) & B and get(0x20, 6, pinned=0) & B
+    assert get(0x20, 7, pinned=0) == 0                         # full AND the entries in it belong to this very launch: not here
+    assert get(0x20, 8, nbytes=region) == 0                    # larger than the region: never
+    assert get(0x20, 1, dev=1) == (16 | B)                     # another device: a fresh record
+
+
+def test_workspace_bound_covers_every_plan(lzp):
+    """vpf_resize_workspace_bytes adds lzm_table_bytes_bound over the planes: it must cover what ANY launch shape the planner can pick needs
+    (column tables: strips x nt x 2 KiB; row tables: bands x groups per band x 8 KiB)"""
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        ch = int(rng.choice([1, 2, 3]))
+        dw, dh = int(rng.integers(2, 4000)), int(rng.integers(2, 2200))
+        bound = lzp.lzp_table_bytes_bound(ch, dw, dh)
+        for nt in (4, 8):
+            strips = (dw * ch + 16 * nt - 1) // (16 * nt)
+            for tiles in (1, 2, 3, 5, 8, 23, 64):
+                tiles = min(tiles, (dh + 15) // 16)  # (the planner never asks for more tiles per band than the picture has)
+                rows = 16 * tiles
+                need = (strips * nt * 2048 + 255) // 256 * 256 + (((dh + rows - 1) // rows) * ((rows + 63) // 64) * 8192 + 255) // 256 * 256
+                assert need <= bound, (ch, dw, dh, nt, tiles)

@@ -27,9 +27,14 @@ TUNE_RESIZE_MFMA = 5
 
 EXPORTS = [
     "vpf_convert", "vpf_convert_batch", "vpf_convert_supported", "vpf_resize", "vpf_remap", "vpf_convert_resize",
-    "vpf_convert_resize_batch", "vpf_resize_batch", "vpf_remap_batch",
+    "vpf_convert_resize_batch", "vpf_resize_batch", "vpf_remap_batch", "vpf_resize_ws", "vpf_resize_batch_ws", "vpf_resize_workspace_bytes",
     "vpf_status_string", "vpf_version", "vpf_device_count", "vpf_set_tuning", "vpf_trace_push", "vpf_trace_pop",
 ]
+
+
+class Workspace(C.Structure):
+    """vpf_workspace: caller-owned scratch region for per-shape filter tables (include/vpf_hip.h); `opaque` starts zeroed"""
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_uint64), ("opaque", C.c_uint64 * 40)]
 
 
 class Plane(C.Structure):
@@ -79,6 +84,10 @@ def lib() -> C.CDLL:
         L.vpf_convert_resize_batch.argtypes = [PE, C.c_int, C.c_int, C.c_int, C.c_int, Size, Size, C.c_uint32, PF]
         L.vpf_resize_batch.argtypes = [PE, C.c_int, C.c_int, Size, Size, C.c_uint32, PF]
         L.vpf_remap_batch.argtypes = [PE, C.c_int, Size, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Size, C.c_uint32, PF]
+        L.vpf_resize_ws.argtypes = [PE, C.c_int, C.c_int, Size, PP, Size, PP, C.POINTER(Workspace)]
+        L.vpf_resize_batch_ws.argtypes = [PE, C.c_int, C.c_int, Size, Size, C.c_uint32, PF, C.POINTER(Workspace)]
+        L.vpf_resize_workspace_bytes.argtypes = [C.c_int, C.c_int, Size, Size]
+        L.vpf_resize_workspace_bytes.restype = C.c_uint64
         L.vpf_status_string.argtypes = [C.c_int]
         L.vpf_status_string.restype = C.c_char_p
         L.vpf_version.restype = C.c_char_p
@@ -167,6 +176,32 @@ def resize_batch(ex: Exec, fmt, interp, sw, sh, dw, dh, batch, n=None, check=Tru
     st = lib().vpf_resize_batch(C.byref(ex), fmt, interp, Size(sw, sh), Size(dw, dh), len(batch) if n is None else n, batch)
     if check:
         _check(st, "vpf_resize_batch")
+    return st
+
+
+def resize_workspace_bytes(fmt, interp, sw, sh, dw, dh) -> int:
+    return int(lib().vpf_resize_workspace_bytes(fmt, interp, Size(sw, sh), Size(dw, dh)))
+
+
+def make_workspace(ptr: int, nbytes: int) -> Workspace:
+    """a zeroed vpf_workspace over `nbytes` of device memory at `ptr` (256-B aligned), which the caller keeps alive"""
+    ws = Workspace()
+    ws.ptr, ws.bytes = ptr, nbytes
+    return ws
+
+
+def resize_ws(ex: Exec, fmt, interp, sw, sh, src, dw, dh, dst, ws, check=True) -> int:
+    st = lib().vpf_resize_ws(C.byref(ex), fmt, interp, Size(sw, sh), planes(src), Size(dw, dh), planes(dst), C.byref(ws) if ws is not None else None)
+    if check:
+        _check(st, "vpf_resize_ws")
+    return st
+
+
+def resize_batch_ws(ex: Exec, fmt, interp, sw, sh, dw, dh, batch, ws, n=None, check=True) -> int:
+    st = lib().vpf_resize_batch_ws(C.byref(ex), fmt, interp, Size(sw, sh), Size(dw, dh), len(batch) if n is None else n, batch,
+                                   C.byref(ws) if ws is not None else None)
+    if check:
+        _check(st, "vpf_resize_batch_ws")
     return st
 
 

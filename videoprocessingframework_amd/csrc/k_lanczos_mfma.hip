@@ -90,21 +90,21 @@ template <int CH, int NT, int PF>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
   static constexpr int kGroupsPerCu = NT == 4 ? 3 : 2;  // register budget: 168 / 256 VGPRs
-  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
+                          const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab);  // the shape's column / row weight tables (nullptr: evaluate in place)
 };
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Weight operands.  They depend on the plane SHAPE only — not on the frame, and the column operands not on the band either — yet a
 // 32-frame launch of 1080p -> 720p evaluated each column set 64 times and each row set 256 times: 22 % of the kernel
-// (profiles/r03_lanczos_ablation.txt, "setup only").  They are built ONCE per shape by two small kernels into a table that lives in static
-// device memory (no allocation at run time: the C ABI still owns and allocates nothing), and the main kernel loads them — 16 B per lane
-// and operand — instead of evaluating ~130 instructions per set.  Entries are never evicted or rewritten with other bytes (a full arena
-// falls back to evaluating the weights in the kernel, as does VPF_TUNE_RESIZE_MFMA | 0x10000: same pixels), so a table in use by a
-// kernel on another stream can never change under it; a stream that has not built a shape itself queues its own (identical) build
-// in front of its first use instead of synchronising with the stream that did, and a capturing stream always does (a captured build
-// has not run).  Builds compose an image in LDS and copy it out whole: concurrent builds of a shape only ever write the final bytes.
+// (profiles/r03_lanczos_ablation.txt, "setup only").  They are built ONCE per shape by two small kernels into a table, and the main kernel
+// loads them — 16 B per lane and operand — instead of evaluating ~130 instructions per set.  Where the tables live (vpf_lzm_plan.h):
+// in the caller's workspace (vpf_resize_ws: NPP's scratch-buffer pattern, what the Task layer's ResizeSurface uses), else in a small
+// static arena of this library (4 MiB per device, least-recently-used eviction guarded by events) — the C ABI still allocates nothing.
+// Without a table (a shape larger than the arena, VPF_TUNE_RESIZE_MFMA | 0x10000) the same code evaluates the weights in place: same
+// pixels.  Builds compose an image in LDS and copy it out whole: concurrent builds of a shape only ever write the final bytes.
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kLzmArenaBytes = 48u << 20;
+constexpr uint32_t kLzmArenaBytes = 4u << 20;
 __device__ u32x4 g_lzm_arena[kLzmArenaBytes / 16];
 
 // window of the N-tile that starts at destination byte b: the 16-B aligned source byte below the first tap of its first pixel (tiles
@@ -196,7 +196,7 @@ VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb,
 // table builders: one wave per strip / per (group, band).  Column table of a plane row: [strip][plane hi | lo][tile][lane][16 B];
 // row table of a (plane height, band height): [band][group][kLzmWmBytes]
 template <int NT>
-__global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw, uint32_t dw, float scx, uint32_t off16) {
+__global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw, uint32_t dw, float scx, u32x4* __restrict__ tab) {
   __shared__ u32x4 scratch[2 * kLzmB1Chunk * 64];
   const uint32_t lane = threadIdx.x, dwb = dw * ch, ob0 = blockIdx.x * (16u * NT);
   v4i b1h[NT], b1l[NT];
@@ -206,14 +206,14 @@ __global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw,
     case 2: lzm_col_operands<2, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
     default: lzm_col_operands<3, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
   }
-  u32x4* const out = g_lzm_arena + off16 + (size_t)blockIdx.x * (NT * 128u);
+  u32x4* const out = tab + (size_t)blockIdx.x * (NT * 128u);
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     out[j * 64 + lane] = __builtin_bit_cast(u32x4, b1h[j]);
     out[(NT + j) * 64 + lane] = __builtin_bit_cast(u32x4, b1l[j]);
   }
 }
-__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, uint32_t off16) {
+__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, u32x4* __restrict__ tab) {
   __shared__ u32x4 wm[kLzmWmBytes / 16];
   const uint32_t lane = threadIdx.x, g = blockIdx.x, ya = blockIdx.y * R;
   if (ya >= dh) return;
@@ -221,14 +221,14 @@ __global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh,
   if (g > (yb - ya) / 64u) return;
   lzm_row_group(reinterpret_cast<uint8_t*>(wm), lane, ya, yb, g, scy, sh, lzm_band_first_tile(ya, scy, sh));
   wave_lds_sync();
-  u32x4* const out = g_lzm_arena + off16 + (size_t)(blockIdx.y * gridDim.x + g) * (kLzmWmBytes / 16);
+  u32x4* const out = tab + (size_t)(blockIdx.y * gridDim.x + g) * (kLzmWmBytes / 16);
 #pragma unroll
   for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) out[i * 64 + lane] = wm[i * 64 + lane];
 }
 
 template <int CH, int NT, int PF>
 VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
-                                              const PlaneGeom& G, uint32_t bx, uint32_t by) {
+                                              const PlaneGeom& G, uint32_t bx, uint32_t by, const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab) {
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, R = G.a1;
   constexpr uint32_t P = lzm_pitch_of(PF);  // LDS pitch of a staged row: the variant's capacity (64 PF bytes) + 32, a compile-time constant (launcher: G.a0 == P)
   const float scx = G.scx, scy = G.scy;
@@ -243,18 +243,17 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
   constexpr uint32_t PO = lzm_out_pitch(NT);
 
   // ---- row weights, shared by the workgroup.  Its four waves own four neighbouring strips of the SAME band: wave (G & 3) brings in group G
-  // (the 64 destination rows from ya + 64 G) for all four — a copy of the shape's row table (G.vec_ok: its offset in the arena), or, without
+  // (the 64 destination rows from ya + 64 G) for all four — a copy of the shape's row table (rtab), or, without
   // a table, evaluated here — into buffer G & 1, one group ahead of its use; the waves meet at one barrier per group.
   const int32_t t_first = __builtin_amdgcn_readfirstlane(lzm_band_first_tile(ya, scy, sh));  // first source tile of the band
   const uint32_t ngroups = (yb - ya) / 64u + 1u;
-  const uint32_t rtab = (uint32_t)G.vec_ok;
   auto produce = [&](uint32_t g) {
     uint8_t* const wm = wmb + (g & 1u) * kLzmWmBytes;
     if (rtab) {
       // a straight 8-KiB copy, global memory -> LDS: eight LDS-DMA instructions (lane l's 16 bytes land at M0 + offset + 16 l), no register
       // and no ds_write involved.  The compiler does not see these loads: the wave that issued them waits for them by hand (group_ready)
       // before the barrier that hands the group to the others.  M0 is the compiler's: saved, set and restored inside each statement.
-      const u32x4* const t = g_lzm_arena + rtab + (size_t)(by * ((R + 63u) / 64u) + g) * (kLzmWmBytes / 16);
+      const u32x4* const t = rtab + (size_t)(by * ((R + 63u) / 64u) + g) * (kLzmWmBytes / 16);
       const uint32_t voff = 16u * lane, ldst = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(wm));
       static_assert(kLzmWmBytes == 8192, "two statements of four 1-KiB pieces");
 #pragma unroll
@@ -295,11 +294,11 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #pragma unroll
   for (int j = 0; j < NT; j++) wrel[j] = __builtin_amdgcn_readfirstlane(lzm_window<CH>(ob0 + 16u * j, dwb, sw, scx)) - S0;
 
-  // ---- column weights -> pass-1 B operands: the strip's 2 NT operands from the shape's column table (G.a3: its offset in the arena), or
+  // ---- column weights -> pass-1 B operands: the strip's 2 NT operands from the shape's column table (ctab), or
   // evaluated here
   v4i b1h[NT], b1l[NT];
-  if (G.a3) {
-    const u32x4* const t = g_lzm_arena + G.a3 + (size_t)(bx * 4 + wv) * (NT * 128u);
+  if (ctab) {
+    const u32x4* const t = ctab + (size_t)(bx * 4 + wv) * (NT * 128u);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       b1h[j] = __builtin_bit_cast(v4i, t[j * 64 + lane]);
@@ -520,18 +519,22 @@ template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
 template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 
 // all planes of up to 32 frames in one dispatch (the k_planes_mp scheme of k_resize_common.h, with this family's register budget:
-// two workgroups per CU)
+// two workgroups per CU, and the planes' weight tables)
+struct LzmTableArgs {
+  const u32x4* ctab[3];
+  const u32x4* rtab[3];
+};
 template <template <int> class TaskCH>
-__global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T) {
+__global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T, const LzmTableArgs W) {
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): neighbouring strips and bands share one L2
   const uint32_t bx = b.x, by = b.y, bz = b.z;
   const FrameDesc& f = args.f[bz];
   const uint32_t pi = (uint32_t)(T.np > 1 && by >= T.by0[1]) + (uint32_t)(T.np > 2 && by >= T.by0[2]);
   const uint32_t k = T.k[pi], lby = by - T.by0[pi];
   switch (T.ch[pi]) {  // workgroup-uniform
-    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby); break;
-    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby); break;
-    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby); break;
+    case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby, W.ctab[pi], W.rtab[pi]); break;
+    case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby, W.ctab[pi], W.rtab[pi]); break;
+    default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, lby, W.ctab[pi], W.rtab[pi]); break;
   }
 }
 
@@ -553,14 +556,63 @@ static bool lzm_big_lds_ok() {
 
 // the per-shape weight tables' bookkeeping (vpf_lzm_plan.h); VPF_HIP_LANCZOS_TABLE_KB shrinks the part of the arena that is handed out
 // (0 = no tables at all): a test knob for the "arena full" path, read once
+// HIP events behind the fallback arena's bookkeeping (vpf_lzm_plan.h: LzmSync).  The caller of launch_lanczos_mfma holds a DeviceGuard: the
+// current device is the one the launch — and these events — belong to.
+struct LzmHipSync final : LzmSync {
+  hipEvent_t canary[64] = {};
+  void* record(const void* stream, int) override {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipEventRecord(e, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e); return nullptr; }
+    return e;
+  }
+  bool done(void* ev) override {
+    const hipError_t r = hipEventQuery((hipEvent_t)ev);
+    if (r != hipSuccess && r != hipErrorNotReady) (void)hipGetLastError();
+    return r != hipErrorNotReady;  // an event that can no longer be queried (device reset) holds nobody up
+  }
+  void wait(const void* stream, void* ev) override {
+    if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) != hipSuccess) (void)hipGetLastError();
+  }
+  void destroy(void* ev) override {
+    if (hipEventDestroy((hipEvent_t)ev) != hipSuccess) (void)hipGetLastError();
+  }
+  // a device reset frees the arena's contents (static device memory is re-initialised) and invalidates every event created before it: a
+  // never-recorded canary event per device answers hipSuccess while its context lives
+  bool device_alive(int dev) override {
+    if (canary[dev] && hipEventQuery(canary[dev]) == hipSuccess) return true;
+    const bool first = canary[dev] == nullptr;
+    (void)hipGetLastError();
+    canary[dev] = nullptr;
+    if (hipEventCreateWithFlags(&canary[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); canary[dev] = nullptr; }
+    return first;
+  }
+};
+// VPF_HIP_LANCZOS_TABLE_KB shrinks the part of the arena that is handed out (0 = no tables at all): a test knob, read once
 static LzmTableCache& lzm_tables() {
+  static LzmHipSync sync;
   static LzmTableCache cache([] {
     const char* e = std::getenv("VPF_HIP_LANCZOS_TABLE_KB");
     const uint64_t kb = e ? std::strtoull(e, nullptr, 10) : kLzmArenaBytes / 1024;
     return std::min<uint64_t>(kb * 1024, kLzmArenaBytes);
-  }());
+  }(), &sync);
   return cache;
 }
+static u32x4* lzm_arena_base(int dev) {  // the static arena's address on this device (hipGetSymbolAddress once per device)
+  static std::atomic<u32x4*> base[64];
+  u32x4* p = base[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_lzm_arena)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    p = static_cast<u32x4*>(q);
+    base[dev].store(p, std::memory_order_release);
+  }
+  return p;
+}
+// the workspace of the vpf_resize_ws / vpf_resize_batch_ws call this thread is inside (vpf_abi.hip sets it; nullptr otherwise)
+thread_local vpf_workspace* t_lzm_workspace = nullptr;
+void set_lanczos_workspace(vpf_workspace* ws) { t_lzm_workspace = ws; }
+uint64_t lanczos_table_bytes_bound(int ch, uint32_t dw, uint32_t dh) { return lzm_table_bytes_bound(ch, dw, dh); }
 
 bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT), knob = tuning(VPF_TUNE_RESIZE_MFMA);
@@ -585,48 +637,79 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const int nt = plan.nt;
   const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
   PlaneTable t{};
+  LzmTableArgs wt{};
   t.np = (uint32_t)njobs;
   uint32_t gx = 0, gy = 0;
   int dev = 0;
   bool capturing = false;
+  // where this launch's tables live: the caller's workspace when there is one on this thread and it is large enough for every plane,
+  // else the static arena (its cache is locked from the first lookup to the launch: builds and the kernel are queued under the lock)
+  vpf_workspace* const wsp = tables ? t_lzm_workspace : nullptr;
+  LzmWorkspace* const wrec = wsp && wsp->ptr && ((uintptr_t)wsp->ptr & 255u) == 0 ? reinterpret_cast<LzmWorkspace*>(wsp->opaque) : nullptr;
+  bool arena_locked = false;
+  int arena_ids[6], n_arena = 0;
+  u32x4* arena = nullptr;
   if (tables) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
     capturing = cs != hipStreamCaptureStatusNone;
   }
+  const uint32_t ws_first = wrec && wrec->magic == LzmWorkspace::kMagic && wrec->stream == (const void*)st && wrec->device == (uint32_t)dev ? wrec->n : 0u;
+  // one table of one plane: -> its address (nullptr: evaluate the weights in the kernel), building it first where nobody has
+  auto table = [&](uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes, auto&& build) -> const u32x4* {
+    if (wrec) {
+      const LzmTableCache::Hit h = wrec->get(wsp->bytes, st, dev, capturing, kind, k0, k1, k2, k3, bytes, ws_first);
+      if (h.off16) {
+        u32x4* const p = static_cast<u32x4*>(wsp->ptr) + h.off16;
+        if (h.build) { (void)hipGetLastError(); build(p); }
+        return p;
+      }
+    }
+    if (!arena_locked) { lzm_tables().begin(); arena_locked = true; arena = lzm_arena_base(dev); }
+    if (!arena) return nullptr;
+    const LzmTableCache::Hit h = lzm_tables().get(st, dev, capturing, kind, k0, k1, k2, k3, bytes);
+    if (!h.off16) return nullptr;
+    if (h.build) { (void)hipGetLastError(); build(arena + h.off16); lzm_tables().built(h.id, st, capturing); }
+    arena_ids[n_arena++] = h.id;
+    return arena + h.off16;
+  };
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
     const uint32_t rows = band_tiles * 16;
-    uint32_t ctab = 0, rtab = 0;
     if (tables) {
       const uint32_t strips = (j.dw * (uint32_t)j.ch + 16u * nt - 1) / (16u * nt), bands = (j.dh + rows - 1) / rows, gpb = (rows + 63) / 64;
-      const LzmTableCache::Hit c = lzm_tables().get(st, dev, capturing, 0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt, (uint64_t)strips * nt * 2048u);
-      if (c.build) {
-        (void)hipGetLastError();
-        if (nt == 8) hipLaunchKernelGGL(k_lzm_build_cols<8>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, c.off16);
-        else hipLaunchKernelGGL(k_lzm_build_cols<4>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, c.off16);
-      }
-      const LzmTableCache::Hit r = lzm_tables().get(st, dev, capturing, 1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes);
-      if (r.build) {
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, r.off16);
-      }
-      ctab = c.off16; rtab = r.off16;
+      wt.ctab[p] = table(0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt, (uint64_t)strips * nt * 2048u, [&](u32x4* out) {
+        if (nt == 8) hipLaunchKernelGGL(k_lzm_build_cols<8>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
+        else hipLaunchKernelGGL(k_lzm_build_cols<4>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
+      });
+      wt.rtab[p] = table(1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
+        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, out);
+      });
     }
-    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, (int)rtab, pitch, rows, wave_lds, ctab};
+    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, 0};
     t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
     const uint32_t bxs = ((j.dw * j.ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
     gx = bxs > gx ? bxs : gx;
     gy += (j.dh + rows - 1) / rows;
   }
+  // leaves the arena's lock on every way out; the launch's entries get their "last use" event once the kernel is queued (not under capture:
+  // an event recorded there would be a node of the graph, and entries a graph was captured with are simply not handed back: see below)
+  struct ArenaUnlock {
+    bool& locked; hipStream_t st; int dev; bool capturing; int* ids; int& n; bool launched = false;
+    ~ArenaUnlock() {
+      if (!locked) return;
+      if (launched && n && !capturing) lzm_tables().used(st, dev, ids, n);
+      lzm_tables().end();
+    }
+  } unlock{arena_locked, st, dev, capturing, arena_ids, n_arena};
   const dim3 grid(gx, gy, n);
   const uint32_t lds = plan.group_lds;
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
   if (lds > 64u * 1024u && !(nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
-                           hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t); } while (0)
+                           hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t, wt); unlock.launched = true; } while (0)
   if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);
   else if (nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzMfma8w);
   else if (nt == 8) VPF_LZM_GO(LzMfma8);

@@ -470,6 +470,24 @@ struct ResizeSurface::Impl {
   std::unique_ptr<Surface> out;
   int interp = VPF_INTERP_LANCZOS3;  // what the reference's resizer asks NPP for (NPPI_INTER_LANCZOS, Tasks.cpp:1190,1248,1373,1431)
   bool async = false;
+  // The filter's per-shape operand tables live in a workspace this task owns — like its destination surface (the reference's impls own
+  // theirs: Tasks.cpp:1134-1150), sized by vpf_resize_workspace_bytes for the source size last seen, used on the task's one stream.
+  std::unique_ptr<CudaBuffer> ws_mem;
+  vpf_workspace ws{};
+  uint32_t ws_sw = 0, ws_sh = 0;
+  int ws_interp = -1;
+  vpf_workspace* workspace(uint32_t sw, uint32_t sh) {
+    if (ws_interp == interp && ws_sw == sw && ws_sh == sh) return ws.ptr ? &ws : nullptr;
+    ws_interp = interp; ws_sw = sw; ws_sh = sh;
+    const uint64_t need = vpf_resize_workspace_bytes(fmt, interp, vpf_size{sw, sh}, vpf_size{w, h});
+    if (need > ws.bytes || !need) {
+      if (ws_mem) hip_stream_sync(&sref);  // kernels queued with the old region's tables must have finished before it is freed (a change of input size: rare)
+      ws_mem.reset(need ? CudaBuffer::Make(1, (size_t)need, sref.ctx) : nullptr);
+      ws = vpf_workspace{};
+      if (ws_mem && ws_mem->GpuMem()) { ws.ptr = (void*)ws_mem->GpuMem(); ws.bytes = need; }
+    }
+    return ws.ptr ? &ws : nullptr;  // (no memory for it: the library's own arena serves the call)
+  }
 };
 void ResizeSurface::SetAsync(bool on) { pImpl->async = on; }
 bool ResizeSurface::GetAsync() const { return pImpl->async; }
@@ -501,7 +519,9 @@ ResizeSurface::ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext 
   }
   pImpl->out.reset(Surface::Make(f, w, h, ctx));
 }
-ResizeSurface::~ResizeSurface() {}
+ResizeSurface::~ResizeSurface() {
+  if (pImpl && pImpl->ws_mem) hip_stream_sync(&pImpl->sref);  // queued resizes still read the workspace's tables
+}
 ResizeSurface* ResizeSurface::Make(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
   return new ResizeSurface(w, h, f, ctx, str);
 }
@@ -515,8 +535,8 @@ TaskExecStatus ResizeSurface::Run() {
   fill_planes(in, src);
   fill_planes(pImpl->out.get(), dst);
   const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
-  const vpf_status st = vpf_resize(&ex, pImpl->fmt, pImpl->interp, vpf_size{in->Width(), in->Height()}, src,
-                                   vpf_size{pImpl->w, pImpl->h}, dst);
+  const vpf_status st = vpf_resize_ws(&ex, pImpl->fmt, pImpl->interp, vpf_size{in->Width(), in->Height()}, src,
+                                      vpf_size{pImpl->w, pImpl->h}, dst, pImpl->workspace(in->Width(), in->Height()));
   if (!pImpl->async) hip_stream_sync(&pImpl->sref);  // the reference task is blocking (cuda_stream_sync callback); SetAsync(true) opts out
   if (st != VPF_OK) {
     std::cerr << "Failed to resize surface. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
@@ -542,7 +562,7 @@ TaskExecStatus ResizeSurface::RunBatch(Surface* const* ins, Surface* const* outs
     fill_planes(d, io[i].dst);
   }
   const vpf_exec ex = make_exec(pImpl->sref.ctx, pImpl->sref.str);
-  const vpf_status st = vpf_resize_batch(&ex, pImpl->fmt, pImpl->interp, vpf_size{sw, sh}, vpf_size{pImpl->w, pImpl->h}, n, io.data());
+  const vpf_status st = vpf_resize_batch_ws(&ex, pImpl->fmt, pImpl->interp, vpf_size{sw, sh}, vpf_size{pImpl->w, pImpl->h}, n, io.data(), pImpl->workspace(sw, sh));
   if (st != VPF_OK) {
     std::cerr << "Failed to resize surfaces. Error code: " << st << " (" << vpf_status_string(st) << ")" << std::endl;
     return TASK_EXEC_FAIL;

@@ -321,6 +321,30 @@ vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size ss, co
   return vpf_resize_batch(exec, fmt, interp, ss, ds, 1, &io);
 }
 
+// the workspace forms: the same calls with the caller's table region made known to the Lanczos launcher for their duration
+struct WorkspaceScope {
+  explicit WorkspaceScope(vpf_workspace* ws) { set_lanczos_workspace(ws); }
+  ~WorkspaceScope() { set_lanczos_workspace(nullptr); }
+};
+vpf_status vpf_resize_batch_ws(const vpf_exec* exec, int fmt, int interp, vpf_size ss, vpf_size ds, uint32_t n, const vpf_frame_io* frames, vpf_workspace* ws) {
+  const WorkspaceScope scope(ws);
+  return vpf_resize_batch(exec, fmt, interp, ss, ds, n, frames);
+}
+vpf_status vpf_resize_ws(const vpf_exec* exec, int fmt, int interp, vpf_size ss, const vpf_plane src[3], vpf_size ds, const vpf_plane dst[3], vpf_workspace* ws) {
+  const WorkspaceScope scope(ws);
+  return vpf_resize(exec, fmt, interp, ss, src, ds, dst);
+}
+uint64_t vpf_resize_workspace_bytes(int fmt, int interp, vpf_size ss, vpf_size ds) {
+  ResizeJob jobs[3];
+  bool f32 = false;
+  if (interp != VPF_INTERP_LANCZOS3 || !dims_ok(ss) || !dims_ok(ds)) return 0;
+  const int nj = resize_jobs(fmt, ss, ds, jobs, &f32);
+  if (!nj || f32) return 0;
+  uint64_t total = 256;  // (offset 0 of a region means "no table": its first 256 bytes stay unused)
+  for (int p = 0; p < nj; p++) total += lanczos_table_bytes_bound(jobs[p].ch, jobs[p].dw, jobs[p].dh);
+  return total;
+}
+
 vpf_status vpf_remap_batch(const vpf_exec* exec, int fmt, vpf_size ss, const float* xmap, uint32_t xp, const float* ymap, uint32_t yp, vpf_size ds,
                            uint32_t n, const vpf_frame_io* frames) {
   const Mark mark("vpf_remap_batch");

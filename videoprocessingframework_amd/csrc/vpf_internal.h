@@ -76,6 +76,9 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
 // 8-bit Lanczos-3 on the matrix cores (k_lanczos_mfma.hip): every plane in `jobs` over n frames in ONE dispatch; false when it does not apply
 // (window / ring bounds of vpf_plan_bounds.h, 16-B aligned rows) and nothing was launched
 bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a);
+// the caller-owned table workspace of the vpf_resize_ws / vpf_resize_batch_ws call the current thread is inside (nullptr: none)
+void set_lanczos_workspace(vpf_workspace* ws);
+uint64_t lanczos_table_bytes_bound(int ch, uint32_t dw, uint32_t dh);  // upper bound of one plane's table bytes under any launch shape
 hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t* src, uint32_t spitch,
                         const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch, uint32_t dw,
                         uint32_t dh, uint8_t* dst, uint32_t dpitch);

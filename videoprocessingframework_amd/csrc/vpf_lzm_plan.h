@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "vpf_plan_bounds.h"
@@ -113,52 +115,208 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
   return P;
 }
 
-// ---- weight-table bookkeeping.  One arena per device, bump-allocated, never freed or rewritten with other bytes.  An entry remembers the
-// (up to four) streams that have queued its build: a launch on one of them is ordered behind the build by the stream itself; any other
-// stream — and any stream that is being captured into a graph, whose build has not run — must queue the build again (idempotent: same
-// bytes).  Offsets are in 16-B units; 0 means "no table" (the first 256 B of the arena stay unused).
-struct LzmTab {
+// ---- weight-table bookkeeping.  The operand images of a plane shape (column weights per strip, row weights per band) are built once by two
+// small kernels and read by every launch of that shape.  They live
+//   (a) in a WORKSPACE the caller owns (vpf_resize_workspace_bytes / vpf_resize_ws, include/vpf_hip.h: NPP's scratch-buffer pattern; the
+//       Task layer's ResizeSurface allocates one per source shape next to its destination surface) — LzmWorkspace below: a handful of
+//       entries, everything ordered by the ONE stream the workspace is used on, no events;
+//   (b) else in a small static arena per device (4 MiB, a fallback) — LzmTableCache: hash lookup, least-recently-used eviction.  What
+//       makes it safe: an entry's build is followed by an event; a launch on any stream waits for that event until it has been seen
+//       complete once (then the table is final for everybody — until evicted); every launch leaves ONE "last use" event on its entries, and
+//       whoever evicts an entry makes its own stream wait for that event before the build kernel that overwrites the space.  A
+//       capturing stream always queues its own build (a captured build has not run; it rewrites the same bytes).  A device that was
+//       reset loses its tables: the canary check flushes the host's picture of it.
+// Offsets are in 16-B units from the region's base; 0 = "no table: evaluate the weights in the kernel".
+struct LzmKey {
   int dev;
   uint32_t kind, k0, k1, k2, k3;  // kind 0: columns (ch, sw, dw, nt) | 1: rows (sh, dh, band rows, 0)
-  uint32_t off16;
-  const void* streams[4];
-  int nstreams;
+  bool operator==(const LzmKey& o) const { return dev == o.dev && kind == o.kind && k0 == o.k0 && k1 == o.k1 && k2 == o.k2 && k3 == o.k3; }
+};
+struct LzmKeyHash {
+  size_t operator()(const LzmKey& k) const {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)k.dev;
+    for (uint32_t v : {k.kind, k.k0, k.k1, k.k2, k.k3}) h = (h ^ v) * 0xff51afd7ed558ccdull + (h >> 29);
+    return (size_t)h;
+  }
+};
+// the ordering primitives the cache needs (HIP events in the launcher, a recording fake in tests/test_lzm_plan_cpu.py)
+struct LzmSync {
+  virtual ~LzmSync() {}
+  virtual void* record(const void* stream, int dev) = 0;  // a new event recorded on `stream` (nullptr: could not)
+  virtual bool done(void* ev) = 0;                         // has it completed?  (non-blocking)
+  virtual void wait(const void* stream, void* ev) = 0;     // `stream` waits for it
+  virtual void destroy(void* ev) = 0;
+  virtual bool device_alive(int dev) = 0;                  // false once after the device was reset: the cache forgets the device's tables
 };
 class LzmTableCache {
  public:
-  explicit LzmTableCache(uint64_t arena_bytes) : cap16_(arena_bytes / 16) {}
-  struct Hit { uint32_t off16; bool build; };  // off16 == 0: no room (evaluate the weights in the kernel); build: queue the build kernel on this stream
+  LzmTableCache(uint64_t arena_bytes, LzmSync* sync) : cap16_((uint32_t)std::min<uint64_t>(arena_bytes / 16, 0x7fffffffu)), sync_(sync) {}
+  ~LzmTableCache() { for (auto& e : ents_) drop_events(e); }
+  struct Hit { uint32_t off16; bool build; int id; };  // id: handle for built() / used(); -1 with off16 == 0
+  // One launch = begin() .. get() x (2 per plane) .. [built() per build queued] .. used().  The mutex is held from begin() to end(): the
+  // build and the launch are QUEUED under it, so two host threads on one stream cannot interleave "entry exists" with "build queued".
+  void begin() { mu_.lock(); tick_++; }
+  void end() { mu_.unlock(); }
   Hit get(const void* stream, int dev, bool capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes) {
-    std::lock_guard<std::mutex> lock(mu_);
-    if (dev < 0 || dev >= 64) return Hit{0, false};
-    LzmTab* e = nullptr;
-    for (LzmTab& t : tabs_)
-      if (t.dev == dev && t.kind == kind && t.k0 == k0 && t.k1 == k1 && t.k2 == k2 && t.k3 == k3) { e = &t; break; }
-    if (!e) {
-      uint32_t& used = used16_[dev];
-      if (!used) used = 16;
-      const uint64_t need16 = (bytes + 255) / 256 * 16;
-      if ((uint64_t)used + need16 > cap16_) return Hit{0, false};
-      tabs_.push_back(LzmTab{dev, kind, k0, k1, k2, k3, used, {}, 0});
-      used += (uint32_t)need16;
-      e = &tabs_.back();
+    if (dev < 0 || dev >= 64 || !cap16_) return Hit{0, false, -1};
+    if (!sync_->device_alive(dev)) flush(dev);
+    const LzmKey key{dev, kind, k0, k1, k2, k3};
+    auto it = map_.find(key);
+    if (it != map_.end()) {
+      Ent& e = ents_[it->second];
+      e.tick = tick_;
+      if (capturing) { e.pinned = true; return Hit{e.off16, true, it->second}; }  // a graph captured with this table replays whenever it likes: the entry stays
+      if (!e.settled) {
+        if (!e.built) return Hit{e.off16, true, it->second};  // its build was never followed by an event (event creation failed): build again
+        if (sync_->done(e.built)) e.settled = true;
+        else if (e.built_stream != stream) sync_->wait(stream, e.built);
+      }
+      return Hit{e.off16, false, it->second};
     }
-    bool known = false;
-    for (int i = 0; i < e->nstreams; i++) known = known || e->streams[i] == stream;
-    if (known && !capturing) return Hit{e->off16, false};
-    if (!capturing) {
-      if (e->nstreams < 4) e->streams[e->nstreams++] = stream;
-      else { e->streams[0] = e->streams[1]; e->streams[1] = e->streams[2]; e->streams[2] = e->streams[3]; e->streams[3] = stream; }
+    const uint32_t need16 = (uint32_t)std::min<uint64_t>((bytes + 255) / 256 * 16, 0xffffffffu);
+    if (need16 > cap16_ - 16) return Hit{0, false, -1};
+    uint32_t off = 0;
+    while (!(off = first_fit(dev, need16))) {
+      const int victim = lru(dev);
+      if (victim < 0) return Hit{0, false, -1};  // everything left is pinned by this very launch
+      Ent& v = ents_[victim];
+      // the space is rewritten by a build kernel queued on `stream`: behind the last kernel that read the old table, and behind its build
+      if (v.last_use && v.last_use->ev && !sync_->done(v.last_use->ev)) sync_->wait(stream, v.last_use->ev);
+      if (v.built && !v.settled && !sync_->done(v.built)) sync_->wait(stream, v.built);
+      erase(victim);
     }
-    return Hit{e->off16, true};
+    int id;
+    if (!free_.empty()) { id = free_.back(); free_.pop_back(); } else { id = (int)ents_.size(); ents_.emplace_back(); }
+    Ent& e = ents_[id];
+    e = Ent{};
+    e.key = key; e.off16 = off; e.len16 = need16; e.tick = tick_; e.live = true; e.pinned = capturing;
+    map_[key] = id;
+    return Hit{off, true, id};
   }
-  uint64_t used_bytes(int dev) { std::lock_guard<std::mutex> lock(mu_); return dev >= 0 && dev < 64 ? (uint64_t)used16_[dev] * 16 : 0; }
+  // the entry's build kernel has been queued on `stream` (not under capture: a captured build proves nothing about the arena's bytes)
+  void built(int id, const void* stream, bool capturing) {
+    if (id < 0 || capturing) return;
+    Ent& e = ents_[id];
+    if (e.built) { sync_->destroy(e.built); e.built = nullptr; }
+    e.built = sync_->record(stream, e.key.dev);
+    e.built_stream = stream;
+    e.settled = false;
+  }
+  // the launch that read these entries has been queued on `stream`: one event for all of them
+  void used(const void* stream, int dev, const int* ids, int n) {
+    EvRef* r = nullptr;
+    for (int i = 0; i < n; i++) {
+      if (ids[i] < 0) continue;
+      if (!r) { r = new EvRef{sync_->record(stream, dev), 0}; }
+      Ent& e = ents_[ids[i]];
+      if (e.last_use == r) continue;  // the same entry twice in one launch (planes of equal shape share their tables)
+      unref(e.last_use);
+      e.last_use = r; r->refs++;
+    }
+    if (r && !r->refs) { if (r->ev) sync_->destroy(r->ev); delete r; }
+  }
+  uint64_t used_bytes(int dev) {
+    uint64_t u = 0;
+    for (const Ent& e : ents_) if (e.live && e.key.dev == dev) u += (uint64_t)e.len16 * 16;
+    return u;
+  }
+  uint32_t entries(int dev) { uint32_t n = 0; for (const Ent& e : ents_) n += e.live && e.key.dev == dev; return n; }
 
  private:
+  struct EvRef { void* ev; int refs; };
+  struct Ent {
+    LzmKey key{};
+    uint32_t off16 = 0, len16 = 0;
+    uint64_t tick = 0;
+    void* built = nullptr;
+    const void* built_stream = nullptr;
+    bool settled = false, live = false, pinned = false;
+    EvRef* last_use = nullptr;
+  };
+  void unref(EvRef*& r) {
+    if (r && --r->refs == 0) { if (r->ev) sync_->destroy(r->ev); delete r; }
+    r = nullptr;
+  }
+  void drop_events(Ent& e) {
+    if (e.built) { sync_->destroy(e.built); e.built = nullptr; }
+    unref(e.last_use);
+  }
+  void erase(int id) {
+    Ent& e = ents_[id];
+    drop_events(e);
+    map_.erase(e.key);
+    e.live = false;
+    free_.push_back(id);
+  }
+  void flush(int dev) {
+    for (int i = 0; i < (int)ents_.size(); i++)
+      if (ents_[i].live && ents_[i].key.dev == dev) erase(i);
+  }
+  int lru(int dev) const {
+    int best = -1;
+    for (int i = 0; i < (int)ents_.size(); i++)
+      if (ents_[i].live && !ents_[i].pinned && ents_[i].key.dev == dev && ents_[i].tick != tick_ && (best < 0 || ents_[i].tick < ents_[best].tick)) best = i;
+    return best;
+  }
+  // lowest offset >= 16 (the first 256 B stay unused: offset 0 means "no table") where need16 units are free; 0 = nowhere
+  uint32_t first_fit(int dev, uint32_t need16) const {
+    std::vector<std::pair<uint32_t, uint32_t>> r;
+    for (const Ent& e : ents_) if (e.live && e.key.dev == dev) r.emplace_back(e.off16, e.len16);
+    std::sort(r.begin(), r.end());
+    uint32_t at = 16;
+    for (const auto& x : r) {
+      if (x.first >= at && x.first - at >= need16) return at;
+      at = std::max(at, x.first + x.second);
+    }
+    return (cap16_ >= at && cap16_ - at >= need16) ? at : 0;
+  }
   std::mutex mu_;
-  std::vector<LzmTab> tabs_;
-  uint32_t used16_[64] = {};
-  uint64_t cap16_;
+  std::vector<Ent> ents_;
+  std::vector<int> free_;
+  std::unordered_map<LzmKey, int, LzmKeyHash> map_;
+  uint64_t tick_ = 0;
+  uint32_t cap16_;
+  LzmSync* sync_;
 };
+
+// ---- the caller-owned workspace (vpf_workspace, include/vpf_hip.h): its `opaque` words hold this record.  Used on ONE stream at a time:
+// builds and launches are ordered by that stream alone.  A launch on another stream, a captured launch or a shape the record does not
+// hold rebuilds (when the space is short: everything is dropped and the region reused from its start — the new builds queue behind the
+// kernels that read the old tables).
+struct LzmWorkspace {
+  static constexpr uint32_t kMagic = 0x4c5a4d57u;  // "LZMW"
+  static constexpr int kEntries = 8;               // three planes x {columns, rows} + two spare
+  uint32_t magic, n, used16, device;
+  const void* stream;
+  struct E { uint32_t kind, k0, k1, k2, k3, off16, len16, pad; } e[kEntries];
+  // -> off16 (0: does not fit, use the fallback) and whether the caller must queue the build
+  LzmTableCache::Hit get(uint64_t region_bytes, const void* st, int dev, bool capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes,
+                         uint32_t pinned_from) {
+    const uint32_t cap16 = (uint32_t)std::min<uint64_t>(region_bytes / 16, 0x7fffffffu);
+    if (magic != kMagic || device != (uint32_t)dev) { magic = kMagic; n = 0; used16 = 16; device = (uint32_t)dev; stream = st; }
+    if (stream != st) { n = 0; used16 = 16; stream = st; }  // another stream: nothing in here is ordered for it — start over
+    for (uint32_t i = 0; i < n; i++)
+      if (e[i].kind == kind && e[i].k0 == k0 && e[i].k1 == k1 && e[i].k2 == k2 && e[i].k3 == k3) return LzmTableCache::Hit{e[i].off16, capturing, (int)i};
+    const uint32_t need16 = (uint32_t)std::min<uint64_t>((bytes + 255) / 256 * 16, 0xffffffffu);
+    if (need16 > cap16 || cap16 < 16 || need16 > cap16 - 16) return LzmTableCache::Hit{0, false, -1};
+    if (n == (uint32_t)kEntries || used16 + need16 > cap16) {
+      if (pinned_from < n) return LzmTableCache::Hit{0, false, -1};  // entries of this very launch would go: the fallback takes this one
+      n = 0; used16 = 16;
+    }
+    e[n] = E{kind, k0, k1, k2, k3, used16, need16, 0};
+    used16 += need16;
+    return LzmTableCache::Hit{e[n].off16, true, (int)n++};
+  }
+};
+static_assert(sizeof(LzmWorkspace) <= 40 * 8, "fits vpf_workspace::opaque");
+
+// upper bound of the table bytes one plane needs under ANY launch shape the planner may pick (column tables: strips x nt x 2 KiB, largest
+// at 8-tile strips; row tables: (bands x groups per band) x 8 KiB, bands of at least two tiles) — what vpf_resize_workspace_bytes adds up
+inline uint64_t lzm_table_bytes_bound(int ch, uint32_t dw, uint32_t dh) {
+  const uint64_t dwb = (uint64_t)dw * (uint64_t)ch;
+  const uint64_t cols = ((dwb + 127) / 128 + 1) * 8 * 2048;
+  const uint64_t rows = ((uint64_t)(dh + 63) / 64 + (uint64_t)(dh + 15) / 16 + 1) * kLzmWmBytes;
+  return cols + rows + 2 * 256;
+}
 
 }  // namespace vpf
