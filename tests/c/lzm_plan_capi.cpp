@@ -43,7 +43,7 @@ void lzp_cache_free(void* c) { delete static_cast<Cache*>(c); }
 // one launch with ONE table: begin, get, [built], used, end -> off16 | build << 31
 uint32_t lzp_cache_launch(void* c, uint64_t stream, int dev, int capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes) {
   Cache* C = static_cast<Cache*>(c);
-  C->cache.begin();
+  C->cache.begin(dev);
   const vpf::LzmTableCache::Hit h = C->cache.get(reinterpret_cast<const void*>(stream), dev, capturing != 0, kind, k0, k1, k2, k3, bytes);
   if (h.off16 && h.build) C->cache.built(h.id, reinterpret_cast<const void*>(stream), capturing != 0);
   if (h.off16 && !capturing) C->cache.used(reinterpret_cast<const void*>(stream), dev, &h.id, 1);
@@ -53,7 +53,7 @@ uint32_t lzp_cache_launch(void* c, uint64_t stream, int dev, int capturing, uint
 // a launch with TWO tables (a plane's columns and rows): both must come out of one launch without evicting each other
 void lzp_cache_launch2(void* c, uint64_t stream, int dev, const uint32_t* ka, uint64_t bytes_a, const uint32_t* kb, uint64_t bytes_b, uint32_t* out) {
   Cache* C = static_cast<Cache*>(c);
-  C->cache.begin();
+  C->cache.begin(dev);
   const void* st = reinterpret_cast<const void*>(stream);
   const vpf::LzmTableCache::Hit a = C->cache.get(st, dev, false, ka[0], ka[1], ka[2], ka[3], ka[4], bytes_a);
   if (a.off16 && a.build) C->cache.built(a.id, st, false);
@@ -64,8 +64,8 @@ void lzp_cache_launch2(void* c, uint64_t stream, int dev, const uint32_t* ka, ui
   C->cache.end();
   out[0] = a.off16 | (a.build ? 0x80000000u : 0u); out[1] = b.off16 | (b.build ? 0x80000000u : 0u);
 }
-uint64_t lzp_cache_used(void* c, int dev) { Cache* C = static_cast<Cache*>(c); C->cache.begin(); const uint64_t u = C->cache.used_bytes(dev); C->cache.end(); return u; }
-uint32_t lzp_cache_entries(void* c, int dev) { Cache* C = static_cast<Cache*>(c); C->cache.begin(); const uint32_t u = C->cache.entries(dev); C->cache.end(); return u; }
+uint64_t lzp_cache_used(void* c, int dev) { Cache* C = static_cast<Cache*>(c); C->cache.begin(-1); const uint64_t u = C->cache.used_bytes(dev); C->cache.end(); return u; }
+uint32_t lzp_cache_entries(void* c, int dev) { Cache* C = static_cast<Cache*>(c); C->cache.begin(-1); const uint32_t u = C->cache.entries(dev); C->cache.end(); return u; }
 void lzp_sync_complete(void* c, uint64_t upto) { static_cast<Cache*>(c)->sync.completed_upto = upto; }
 uint64_t lzp_sync_next(void* c) { return static_cast<Cache*>(c)->sync.next; }
 int lzp_sync_live(void* c) { return static_cast<Cache*>(c)->sync.live; }

@@ -666,7 +666,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
         return p;
       }
     }
-    if (!arena_locked) { lzm_tables().begin(); arena_locked = true; arena = lzm_arena_base(dev); }
+    if (!arena_locked) { lzm_tables().begin(dev); arena_locked = true; arena = lzm_arena_base(dev); }
     if (!arena) return nullptr;
     const LzmTableCache::Hit h = lzm_tables().get(st, dev, capturing, kind, k0, k1, k2, k3, bytes);
     if (!h.off16) return nullptr;

@@ -122,8 +122,9 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
 //       entries, everything ordered by the ONE stream the workspace is used on, no events;
 //   (b) else in a small static arena per device (4 MiB, a fallback) — LzmTableCache: hash lookup, least-recently-used eviction.  What
 //       makes it safe: an entry's build is followed by an event; a launch on any stream waits for that event until it has been seen
-//       complete once (then the table is final for everybody — until evicted); every launch leaves ONE "last use" event on its entries, and
-//       whoever evicts an entry makes its own stream wait for that event before the build kernel that overwrites the space.  A
+//       complete once (then the table is final for everybody — until evicted); an entry remembers the (up to four) streams it has been used
+//       on — no HIP call per launch —, and whoever evicts it records an event on each of them THEN and makes its own stream wait for those
+//       before the build kernel that overwrites the space (an entry used on more streams than that gets an event per launch).  A
 //       capturing stream always queues its own build (a captured build has not run; it rewrites the same bytes).  A device that was
 //       reset loses its tables: the canary check flushes the host's picture of it.
 // Offsets are in 16-B units from the region's base; 0 = "no table: evaluate the weights in the kernel".
@@ -155,11 +156,10 @@ class LzmTableCache {
   struct Hit { uint32_t off16; bool build; int id; };  // id: handle for built() / used(); -1 with off16 == 0
   // One launch = begin() .. get() x (2 per plane) .. [built() per build queued] .. used().  The mutex is held from begin() to end(): the
   // build and the launch are QUEUED under it, so two host threads on one stream cannot interleave "entry exists" with "build queued".
-  void begin() { mu_.lock(); tick_++; }
+  void begin(int dev) { mu_.lock(); tick_++; if (dev >= 0 && dev < 64 && !sync_->device_alive(dev)) flush(dev); }
   void end() { mu_.unlock(); }
   Hit get(const void* stream, int dev, bool capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes) {
     if (dev < 0 || dev >= 64 || !cap16_) return Hit{0, false, -1};
-    if (!sync_->device_alive(dev)) flush(dev);
     const LzmKey key{dev, kind, k0, k1, k2, k3};
     auto it = map_.find(key);
     if (it != map_.end()) {
@@ -180,7 +180,13 @@ class LzmTableCache {
       const int victim = lru(dev);
       if (victim < 0) return Hit{0, false, -1};  // everything left is pinned by this very launch
       Ent& v = ents_[victim];
-      // the space is rewritten by a build kernel queued on `stream`: behind the last kernel that read the old table, and behind its build
+      // the space is rewritten by a build kernel queued on `stream`: behind everything queued so far on the streams that read the old
+      // table (an event recorded on each of them now), and behind its build
+      for (int i = 0; i < v.nusers; i++) {
+        if (v.users[i] == stream) continue;  // this stream's own earlier launches are in front of the build anyway
+        void* ev = sync_->record(v.users[i], dev);
+        if (ev) { sync_->wait(stream, ev); sync_->destroy(ev); }
+      }
       if (v.last_use && v.last_use->ev && !sync_->done(v.last_use->ev)) sync_->wait(stream, v.last_use->ev);
       if (v.built && !v.settled && !sync_->done(v.built)) sync_->wait(stream, v.built);
       erase(victim);
@@ -202,13 +208,19 @@ class LzmTableCache {
     e.built_stream = stream;
     e.settled = false;
   }
-  // the launch that read these entries has been queued on `stream`: one event for all of them
+  // the launch that read these entries has been queued on `stream`: the entries remember the stream (no HIP call); an entry that has met more
+  // streams than it can remember gets ONE event per launch instead (shared by such entries of the launch)
   void used(const void* stream, int dev, const int* ids, int n) {
     EvRef* r = nullptr;
     for (int i = 0; i < n; i++) {
       if (ids[i] < 0) continue;
-      if (!r) { r = new EvRef{sync_->record(stream, dev), 0}; }
       Ent& e = ents_[ids[i]];
+      bool known = false;
+      for (int k = 0; k < e.nusers; k++) known = known || e.users[k] == stream;
+      if (known && !e.many) continue;
+      if (!known && e.nusers < 4 && !e.many) { e.users[e.nusers++] = stream; continue; }
+      e.many = true;
+      if (!r) r = new EvRef{sync_->record(stream, dev), 0};
       if (e.last_use == r) continue;  // the same entry twice in one launch (planes of equal shape share their tables)
       unref(e.last_use);
       e.last_use = r; r->refs++;
@@ -230,7 +242,9 @@ class LzmTableCache {
     uint64_t tick = 0;
     void* built = nullptr;
     const void* built_stream = nullptr;
-    bool settled = false, live = false, pinned = false;
+    bool settled = false, live = false, pinned = false, many = false;
+    const void* users[4] = {nullptr, nullptr, nullptr, nullptr};  // streams whose launches read the table
+    int nusers = 0;
     EvRef* last_use = nullptr;
   };
   void unref(EvRef*& r) {
