@@ -243,8 +243,9 @@ VPF_API int vpf_set_tuning(int key, int value);
                                   (rows 4..64 in steps of 4, waves 4 or 8); same pixels whatever the shape */
 #define VPF_TUNE_RESIZE_MFMA 5 /* 8-bit Lanczos-3 on the matrix cores (k_lanczos_mfma.hip): 0 = policy, 1 = never (the tiled / gather kernels take Lanczos), else
                                   N-tiles per wave (0 = policy, 4 or 8) << 8 | destination 16-row tiles per band (0 = policy, 1..64); | 0x10000: the kernel
-                                  evaluates its filter weights itself instead of loading the per-shape tables (the path taken when the table arena is full);
-                                  same pixels whatever the value */
+                                  evaluates its filter weights itself instead of loading the per-shape tables (the path taken when no table fits);
+                                  | 0x20000: the two-role kernel form (pass 1 and pass 2 on different waves; measured slower on RGB, kept as a
+                                  measurement knob); same pixels whatever the value */
 #define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4, 8 or 16; same pixels whatever the value */
 
 #ifdef __cplusplus

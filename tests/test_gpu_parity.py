@@ -1242,8 +1242,8 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         band = int(rng.choice([0, 1, 2, 4, 8, 16]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
-        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64]))  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
-        if march != 1 and rng.integers(3) == 0:
+        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves)  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
+        if march != 1 and not (march & 0x20000) and rng.integers(3) == 0:
             march |= 0x10000                                                                # ... with its weights evaluated in the kernel, not loaded from the shape's tables
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, march)
         try:

@@ -512,11 +512,289 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 #undef VPF_LZM_STEP
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same filter with the two passes on DIFFERENT waves (round 4).  LanczosMfmaTask keeps the column operands (64 VGPRs), the ring (64) and
+// the prefetch sets in one wave: 230-250 registers, two waves per SIMD — and two in-order waves leave the SIMD's issue port 40 % idle
+// (DESIGN.md 4.2).  Here a workgroup of four waves owns TWO neighbouring strips of a band: waves 0, 1 run pass 1 of strip 0, 1 (column
+// operands + staging: ~150 registers), waves 2, 3 run pass 2 (ring + row weights: ~135), so three workgroups fit a CU and every SIMD holds
+// three waves of mixed roles.  A pass-1 wave hands each source tile's (zl, zh) pairs — 16 dwords per lane — to its partner through a QUEUE
+// of kLzpQueue 4-KiB LDS tiles guarded by two sequence words per slot (ready / freed): pass 2 is bursty (0, 1 or 2 destination tiles per
+// source tile), pass 1 is not, and a first form that met at one workgroup barrier per source tile lost more in lockstep than the third wave
+// brought (profiles/r04_lanczos_pair_sweep_barrier.txt).  No barrier after the start: the pass-2 waves read their row weights straight
+// from the shape's table (L2-resident, two 16-B loads per lane and destination tile, requested a tile ahead), so there are no shared
+// row-weight groups either; a launch without tables takes LanczosMfmaTask.
+// Same arithmetic on the same operands -> the same bytes as LanczosMfmaTask and the oracle.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kLzpQueue = 4;
+template <int CH, int PF>
+struct LanczosPairTask {
+  static constexpr int NT = 8;
+  static constexpr int kThreads = 256;
+  static constexpr int kGroupsPerCu = 3;
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
+                          const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab);
+};
+// a sequence word in LDS: written by one wave, polled by its partner.  Plain DS instructions on the word's LDS address (a generic pointer
+// would make these flat accesses, which also wait for every global load in flight); no s_waitcnt around the store: a CU's LDS serves one
+// wave's requests in the order they were issued, so the payload's ds_writes are in front of the word and the payload's ds_reads — issued
+// after the poll has returned — behind it.  The "memory" clobbers keep the compiler from moving its own LDS accesses across.
+VPF_DEV void lzp_post(uint32_t lds_addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr), "v"(v) : "memory");
+}
+VPF_DEV void lzp_await(uint32_t lds_addr, uint32_t v) {
+  for (uint32_t spin = 0; spin < (1u << 24); spin++) {  // (bounded: a protocol error must show as wrong pixels in a test, never as a hung GPU)
+    uint32_t got;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(lds_addr) : "memory");
+    if ((int32_t)(__builtin_amdgcn_readfirstlane(got) - v) >= 0) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+template <int CH, int PF>
+VPF_DEV void LanczosPairTask<CH, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                          uint32_t bx, uint32_t by, const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab) {
+  const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, R = G.a1;
+  constexpr uint32_t P = lzm_pitch_of(PF), PO = lzm_out_pitch(NT);
+  const float scx = G.scx, scy = G.scy;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const bool consumer = wv >= 2;                 // waves 2, 3: pass 2 of strip 0, 1
+  const uint32_t pr = wv & 1u;                   // the pair (= strip of the workgroup) this wave belongs to
+  const uint32_t dwb = dw * CH, strip = bx * 2 + pr, ob0 = strip * (16u * NT), ya = by * R;
+  // LDS: per pair the staged source tile | kLzpQueue hand-over tiles | out tile | 2 x kLzpQueue sequence words
+  constexpr uint32_t HX_B = 8u * 64u * 8u;       // hand-over tile: [N-tile][lane][two dwords of (zl, zh) pairs]
+  uint8_t* const pbase = reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)pr * lzm_pair_lds(PF);
+  uint8_t* const stage = pbase;                  // [16 rows][P]
+  uint8_t* const hx = pbase + 16u * P;           // [kLzpQueue][HX_B]
+  uint8_t* const ot = hx + kLzpQueue * HX_B;     // [16 rows][PO]
+  const uint32_t seq = (uint32_t)reinterpret_cast<uintptr_t>(ot + 16u * PO);  // LDS address of ready[kLzpQueue] | freed[kLzpQueue] (4 B each)
+  if (threadIdx.x < 4u * kLzpQueue) {            // both pairs' words start at 0 (workgroup-wide, before anybody leaves)
+    volatile uint32_t* const z = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(dyn_strip) + (size_t)(threadIdx.x / (2u * kLzpQueue)) * lzm_pair_lds(PF) + 16u * P +
+                                                                       kLzpQueue * HX_B + 16u * PO);
+    z[threadIdx.x % (2u * kLzpQueue)] = 0;
+  }
+  __syncthreads();
+  if (bx * 2 * (16u * NT) >= dwb || ya >= dh || ob0 >= dwb) return;  // a plane narrower / shorter than the launch grid; a pair without columns
+  const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
+  const int32_t t_first = __builtin_amdgcn_readfirstlane(lzm_band_first_tile(ya, scy, sh));
+  int32_t t_last;
+  {
+    int32_t r = ltap_i0(yb, scy) + 3;
+    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+    t_last = __builtin_amdgcn_readfirstlane(r >> 4);
+  }
+  const uint32_t ntiles = (uint32_t)(t_last - t_first + 1);  // source tiles of the band: hand-overs 1 .. ntiles
+
+  if (!consumer) {
+    // ================================================================== pass-1 wave
+    const uint32_t S0 = __builtin_amdgcn_readfirstlane(lzm_window<CH>(ob0, dwb, sw, scx));
+    uint32_t wrel[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) wrel[j] = __builtin_amdgcn_readfirstlane(lzm_window<CH>(ob0 + 16u * j, dwb, sw, scx)) - S0;
+    v4i b1h[NT], b1l[NT];
+    {
+      const u32x4* const t = ctab + (size_t)strip * (NT * 128u);
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        b1h[j] = __builtin_bit_cast(v4i, t[j * 64 + lane]);
+        b1l[j] = __builtin_bit_cast(v4i, t[(NT + j) * 64 + lane]);
+      }
+    }
+    const uint32_t nq_win = (wrel[NT - 1] + 64u) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
+    const uint32_t nq = nq_win < nq_row ? nq_win : nq_row;
+    constexpr int HALF = PF % 2 == 0 ? PF / 2 : PF, LPR = PF % 2 == 0 ? 8 : 4;
+    auto k_row = [&](int k) -> uint32_t { return LPR == 8 ? (lane >> 3) + 8u * (uint32_t)(k / HALF) : lane >> 2; };
+    auto k_unit = [&](int k) -> uint32_t { return (lane & (LPR - 1)) + (uint32_t)LPR * (uint32_t)(k % HALF); };
+    uint32_t voff[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) voff[k] = mad24(k_row(k), sp, S0 + 16u * (k_unit(k) < nq ? k_unit(k) : nq - 1u));
+    const uint32_t plane_bytes = sh * sp;
+    u32x4 pf[2][PF];
+    auto fetch = [&](int32_t T, auto set_tag) {
+      constexpr int SET = decltype(set_tag)::value;
+      const uint32_t toff = (uint32_t)(T < t_last ? T : t_last) * 16u * sp;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + toff, 0, plane_bytes - toff, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < PF; k++) pf[SET][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k], 0, 0));
+    };
+    const v4i c128 = {128, 128, 128, 128};
+    const uint8_t* aptr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
+    uint8_t* const sdst = stage + (LPR == 8 ? (lane >> 3) : (lane >> 2)) * P + 16u * (lane & (LPR - 1));
+    uint8_t* const hxw = hx + lane * 8u;
+    // tile number k (0-based) of the band: staged from register set k & 1, handed over in queue slot k % kLzpQueue
+    auto pass1 = [&](uint32_t k, auto par_tag) {
+      constexpr int PAR = decltype(par_tag)::value;
+#pragma unroll
+      for (int q = 0; q < PF; q++)
+        *reinterpret_cast<u32x4*>(sdst + (LPR == 8 ? (uint32_t)(q / HALF) * 8u * P : 0u) + (uint32_t)(q % HALF) * (16u * LPR)) =
+            pf[PAR][q] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+      fetch(t_first + (int32_t)k + 2, std::integral_constant<int, PAR>{});
+      wave_lds_sync();
+      v4i av[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
+      asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+      const uint32_t slot = k % kLzpQueue;
+      if (k >= kLzpQueue) lzp_await(seq + 4u * (kLzpQueue + slot), k - kLzpQueue + 1u);  // the partner has taken hand-over k - kLzpQueue + 1 out of this slot
+      uint8_t* const hxs = hxw + slot * HX_B;
+      v4i hi[2], lo[2];
+      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1h[0], c128, 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1l[0], c128, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        if (j + 1 < NT) {
+          hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NT) {
+          lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j + 4 < NT) av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
+        const u32x2 d = {__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u, __builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u};
+        *reinterpret_cast<u32x2*>(hxs + j * 512u) = d;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lzp_post(seq + 4u * slot, k + 1u);
+    };
+    fetch(t_first, std::integral_constant<int, 0>{});
+    fetch(t_first + 1, std::integral_constant<int, 1>{});
+    for (uint32_t k = 0; k < ntiles; k += 2) {
+      pass1(k, std::integral_constant<int, 0>{});
+      if (k + 1 < ntiles) pass1(k + 1, std::integral_constant<int, 1>{});
+    }
+    return;
+  }
+
+  // ==================================================================== pass-2 wave
+  const uint32_t gpb = (R + 63u) / 64u;
+  v4i ring[NT][2];
+#pragma unroll
+  for (int j = 0; j < NT; j++) { ring[j][0] = v4i{0, 0, 0, 0}; ring[j][1] = v4i{0, 0, 0, 0}; }
+  const v4i cy = {(1 << 19) + (1 << 11), (1 << 19) + (1 << 11), (1 << 19) + (1 << 11), (1 << 19) + (1 << 11)};
+  const v4i czero = {0, 0, 0, 0};
+  constexpr uint32_t LOGNT = 3, RPI = 64 / NT;
+  uint8_t* const owr = ot + (lane & 15) * PO + 4u * (lane >> 4);
+  const uint8_t* const ord = ot + (lane >> LOGNT) * PO + 16u * (lane & (NT - 1));
+  const uint32_t ob = ob0 + 16u * (lane & (NT - 1));
+  const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
+  const uint32_t obase = mad24(lane >> LOGNT, dp, ob);
+  const uint8_t* const hxr = hx + lane * 8u;
+  // row-weight operands of destination tile number n of the band (group n / 4, tile n % 4): the Y operand of the ring's two K chunks
+  v4i byr[2];
+  auto preload = [&](uint32_t n) {
+    const u32x4* const t = rtab + (size_t)(by * gpb + (n >> 2)) * (kLzmWmBytes / 16) + (size_t)((n & 3u) * 2u) * 64u + lane;
+    byr[0] = __builtin_bit_cast(v4i, t[0]);
+    byr[1] = __builtin_bit_cast(v4i, t[64]);
+  };
+  auto emit = [&](uint32_t y0) {
+    const v4i by0 = byr[0], by1 = byr[1];
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v4i bx0 = __builtin_bit_cast(v4i, __builtin_bit_cast(v8s, by0) << 8), bx1 = __builtin_bit_cast(v4i, __builtin_bit_cast(v8s, by1) << 8);
+    v4i x[2], y[2];
+    {
+      v4i tt = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][0], bx0, czero, 0, 0, 0);
+      v4i uu = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][0], by0, cy, 0, 0, 0);
+      x[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][1], bx1, tt, 0, 0, 0);
+      y[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][1], by1, uu, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t pa = 0, pb = 0, w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const bool more = j + 1 < NT;
+      v4i tt, uu;
+      if (more) { tt = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][0], bx0, czero, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      if (j > 0) { shift12_sat_pack4_a(w[0], w[1], w[2], pa, pb); __builtin_amdgcn_sched_barrier(0); }
+      if (more) { uu = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][0], by0, cy, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      if (j > 0) {
+        *reinterpret_cast<uint32_t*>(owr + 16u * (j - 1)) = shift12_sat_pack4_b(pa, pb, w[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) { x[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][1], bx1, tt, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      w[0] = ((uint32_t)x[j & 1][0] << 8) + (uint32_t)y[j & 1][0];
+      w[1] = ((uint32_t)x[j & 1][1] << 8) + (uint32_t)y[j & 1][1];
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { y[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][1], by1, uu, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+      w[2] = ((uint32_t)x[j & 1][2] << 8) + (uint32_t)y[j & 1][2];
+      w[3] = ((uint32_t)x[j & 1][3] << 8) + (uint32_t)y[j & 1][3];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    shift12_sat_pack4_a(w[0], w[1], w[2], pa, pb);
+    *reinterpret_cast<uint32_t*>(owr + 16u * (NT - 1)) = shift12_sat_pack4_b(pa, pb, w[3]);
+    wave_lds_sync();
+    const uint32_t orow = mad24(y0, dp, obase);
+#pragma unroll
+    for (int it = 0; it < NT / 4; it++) {
+      const uint32_t yy = y0 + (lane >> LOGNT) + RPI * it;
+      if (yy <= yb) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ord + RPI * it * PO);
+        uint8_t* const out = dst + (orow + (uint32_t)(RPI * it) * dp);
+        if (ofull) {
+          stg<true, u32x4>(out, v);
+        } else if (opart) {
+          const uint32_t nb = dwb - ob;
+          for (uint32_t i = 0; i < nb; i++) out[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
+        }
+      }
+    }
+    wave_lds_sync();
+  };
+  auto group_tmax = [&](uint32_t g) -> int32_t {
+    const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
+    int32_t r = ltap_i0(yrow, scy) + 3;
+    r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
+    return r >> 4;
+  };
+  uint32_t n_next = 0, y_next = ya;               // number / first row of the next destination tile
+  int32_t tmax_l = group_tmax(0);
+  bool done = false;
+  preload(0);
+  // hand-over k + 1 (source tile t_first + k) into ring slot k & 3, then every destination tile it completes
+  auto consume = [&](uint32_t k, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const uint32_t qs = k % kLzpQueue;
+    lzp_await(seq + 4u * qs, k + 1u);
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const u32x2 d = *reinterpret_cast<const u32x2*>(hxr + qs * HX_B + j * 512u);
+      ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)d[0];
+      ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)d[1];
+    }
+    asm volatile("" : "+v"(ring[0][SLOT >> 1]), "+v"(ring[NT - 1][SLOT >> 1]));  // (the reads are complete before the slot is given back)
+    lzp_post(seq + 4u * (kLzpQueue + qs), k + 1u);
+    const int32_t Tc = t_first + (int32_t)k;
+    for (;;) {
+      const uint32_t tl = n_next & 3u;
+      if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + 15) > Tc) break;
+      emit(y_next);
+      y_next += 16; n_next++;
+      if (y_next > yb) { done = true; break; }
+      if (tl == 3) tmax_l = group_tmax(n_next >> 2);
+      preload(n_next);
+    }
+  };
+  for (uint32_t k = 0; k < ntiles && !done;) {
+    consume(k, std::integral_constant<int, 0>{}); if (++k >= ntiles || done) break;
+    consume(k, std::integral_constant<int, 1>{}); if (++k >= ntiles || done) break;
+    consume(k, std::integral_constant<int, 2>{}); if (++k >= ntiles || done) break;
+    consume(k, std::integral_constant<int, 3>{}); ++k;
+  }
+}
+
 template <int CH> struct LzMfma8 : LanczosMfmaTask<CH, 8, 4> {};   // strips of 8 tiles, staged rows of up to 256 B
 template <int CH> struct LzMfma8n : LanczosMfmaTask<CH, 8, 2> {};  // ... of up to 128 B (up-scales)
 template <int CH> struct LzMfma8w : LanczosMfmaTask<CH, 8, 5> {};  // ... of up to 320 B (2x down-scales)
 template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
 template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
+template <int CH> struct LzPair : LanczosPairTask<CH, 4> {};    // the two-role form: two 8-tile strips per workgroup, three workgroups per CU
+template <int CH> struct LzPairN : LanczosPairTask<CH, 2> {};
+template <int CH> struct LzPairW : LanczosPairTask<CH, 5> {};
 
 // all planes of up to 32 frames in one dispatch (the k_planes_mp scheme of k_resize_common.h, with this family's register budget:
 // two workgroups per CU, and the planes' weight tables)
@@ -618,6 +896,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT), knob = tuning(VPF_TUNE_RESIZE_MFMA);
   const int forced = knob & 0xffff;           // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
   const bool tables = !(knob & 0x10000);      // | 0x10000: evaluate the weights in the kernel (the path a full arena takes)
+  const bool pair = (knob & 0x20000) != 0;    // | 0x20000: the two-role form (LanczosPairTask): 8-tile strips only
   if (tune == 9 || tune == 40 || forced == 1) return false;
   if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return false;
   for (int p = 0; p < njobs; p++) {
@@ -632,7 +911,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   }
   LzmPlaneIn in[3];
   for (int p = 0; p < njobs; p++) in[p] = LzmPlaneIn{jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh};
-  const LzmPlan plan = lzm_plan(njobs, in, n, forced, tables);  // launch shape by the cost model of vpf_lzm_plan.h
+  const LzmPlan plan = lzm_plan(njobs, in, n, pair ? ((8 << 8) | (forced & 0xff)) : forced, tables);  // launch shape by the cost model of vpf_lzm_plan.h
   if (!plan.ok) return false;
   const int nt = plan.nt;
   const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
@@ -690,7 +969,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     }
     t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, 0};
     t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
-    const uint32_t bxs = ((j.dw * j.ch + 16u * nt - 1) / (16u * nt) + 3) / 4;
+    const uint32_t strips_p = (j.dw * j.ch + 16u * nt - 1) / (16u * nt), bxs = pair ? (strips_p + 1) / 2 : (strips_p + 3) / 4;
     gx = bxs > gx ? bxs : gx;
     gy += (j.dh + rows - 1) / rows;
   }
@@ -705,12 +984,16 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     }
   } unlock{arena_locked, st, dev, capturing, arena_ids, n_arena};
   const dim3 grid(gx, gy, n);
-  const uint32_t lds = plan.group_lds;
+  const uint32_t lds = pair ? lzm_pair_group_lds(lzm_pf_of(span)) : plan.group_lds;
+  if (pair) for (int p = 0; p < njobs; p++) if (!wt.ctab[p] || !wt.rtab[p]) return false;  // the two-role form reads both tables
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
   if (lds > 64u * 1024u && !(nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
                            hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t, wt); unlock.launched = true; } while (0)
-  if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);
+  if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);
+  else if (pair && nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzPairW);
+  else if (pair && nt == 8) VPF_LZM_GO(LzPair);
+  else if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);
   else if (nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzMfma8w);
   else if (nt == 8) VPF_LZM_GO(LzMfma8);
   else if (narrow) VPF_LZM_GO(LzMfma4n);

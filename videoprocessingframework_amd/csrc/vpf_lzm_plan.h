@@ -30,6 +30,9 @@ constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                       
   return run > setup ? run : setup;
 }
 constexpr uint32_t lzm_group_lds(int nt, uint32_t pitch) { return 4u * lzm_wave_lds(nt, pitch) + 2u * kLzmWmBytes; }  // + the workgroup's two row-weight buffers
+// the two-role form (LanczosPairTask): per pair one staged tile, a queue of four 4-KiB hand-over tiles, one out tile, the queue's sequence words
+constexpr uint32_t lzm_pair_lds(int pf) { return 16u * lzm_pitch_of(pf) + 4u * 4096u + 16u * lzm_out_pitch(8) + 64u; }
+constexpr uint32_t lzm_pair_group_lds(int pf) { return 2u * lzm_pair_lds(pf); }
 constexpr uint32_t kLzmMaxLds = 80u * 1024u;  // two workgroups per CU share its 160 KB
 
 // ---- does a plane shape fit the kernel's windows (vpf_plan_bounds.h: the tiles are walked with the kernel's own coordinate arithmetic)?
