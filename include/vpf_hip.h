@@ -245,7 +245,8 @@ VPF_API int vpf_set_tuning(int key, int value);
                                   N-tiles per wave (0 = policy, 4 or 8) << 8 | destination 16-row tiles per band (0 = policy, 1..64); | 0x10000: the kernel
                                   evaluates its filter weights itself instead of loading the per-shape tables (the path taken when no table fits);
                                   | 0x20000: the two-role kernel form (pass 1 and pass 2 on different waves; measured slower on RGB, kept as a
-                                  measurement knob); same pixels whatever the value */
+                                  measurement knob); | 0x40000: one small plane per dispatch takes the matrix-core kernel too (the policy sends it to
+                                  the tile kernel, whose single-launch latency is lower); same pixels whatever the value */
 #define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4, 8 or 16; same pixels whatever the value */
 
 #ifdef __cplusplus

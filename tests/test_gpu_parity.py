@@ -933,7 +933,7 @@ def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
     if shape is not None:
         assert capi.set_tuning(capi.TUNE_RESIZE_TILE, shape[0] | (shape[1] << 8)) >= 0
     try:
-        for mfma in (0, 1):
+        for mfma in (0, 1, 0x40000):  # policy (small single frames: the tile kernel) | never the matrix cores | the matrix cores wherever they fit
             capi.set_tuning(capi.TUNE_RESIZE_MFMA, mfma)
             for fmt, sw, sh, dw, dh, n in cases:
                 f, of = getattr(capi, fmt), getattr(oracle, fmt)
@@ -1242,7 +1242,7 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         band = int(rng.choice([0, 1, 2, 4, 8, 16]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
-        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves)  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
+        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5, 0x40000]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves); 0x40000: small single frames on the matrix cores too  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
         if march != 1 and not (march & 0x20000) and rng.integers(3) == 0:
             march |= 0x10000                                                                # ... with its weights evaluated in the kernel, not loaded from the shape's tables
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, march)

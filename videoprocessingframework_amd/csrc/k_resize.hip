@@ -999,6 +999,20 @@ static bool launch_resize_tile(hipStream_t st, int ch, uint32_t sw, uint32_t sh,
   return true;
 }
 
+// ONE plane of ONE frame per dispatch (what an unmodified PySurfaceResizer.Execute loop issues): the matrix-core Lanczos kernel's waves are
+// few and long — operand tables, a ring to fill, two passes — and a lone launch of them is one latency chain of 5-6 us whatever the picture;
+// the tile kernel's waves are short and many, so a small single frame leaves it sooner although its throughput is 2.5x lower.  The tile
+// kernel's time grows with the DESTINATION (taps per output sample), the matrix-core kernel's with the source: over 63 measured shapes
+// (tools/lanczos_single_sweep.py, profiles/r04_lanczos_single_sweep.txt: RGB 1080p -> 720p 6.9 against 8.9 us, Y 4.7 against 6.9) the rule
+// "source bytes / 2 + 3 x destination bytes below 25.5 MB (3 channels) / 14 MB (1 channel)" picks the faster kernel but for 1 us summed over
+// all of them.  Same bytes either way (both kernels are the integer definition of the filter).  VPF_TUNE_RESIZE_MFMA | 0x40000, or a forced
+// launch shape: always the matrix-core kernel.
+static bool lanczos_single_prefers_tile(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
+  if (tuning(VPF_TUNE_RESIZE_MFMA) & 0x4ffff) return false;
+  const uint64_t src_b = (uint64_t)sw * sh * (uint32_t)ch, dst_b = (uint64_t)dw * dh * (uint32_t)ch;
+  return src_b + 6u * dst_b <= (ch == 1 ? 28000000ull : ch == 2 ? 40000000ull : 51000000ull);
+}
+
 hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32_t sh, const uint8_t* src,
                          uint32_t sp, uint32_t dw, uint32_t dh, uint8_t* dst, uint32_t dp) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
@@ -1027,26 +1041,28 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
     return hipGetLastError();
   }
   if (interp == VPF_INTERP_LANCZOS3) {
-    {  // the matrix-core kernel (k_lanczos_mfma.hip) wherever its windows fit; else the gather form
+    // the matrix-core kernel (k_lanczos_mfma.hip) wherever its windows fit; the tiled separable form for strong down-scales (beyond those
+    // windows) — and, tried FIRST, for one small plane per dispatch (lanczos_single_prefers_tile below); the gather form for what is left
+    auto mfma = [&]() -> bool {
       BatchArgs a;
       std::memset(&a, 0, sizeof(a));
       a.f[0].s[0] = src; a.f[0].sp[0] = sp; a.f[0].d[0] = dst; a.f[0].dp[0] = dp;
       const ResizeJob j{ch, 0, sw, sh, dw, dh};
-      if (launch_lanczos_mfma(st, 1, &j, 1, a)) return hipGetLastError();
-    }
-    // strong down-scales (beyond the matrix-core kernel's windows): the tiled separable form; the gather form for what is left
-    if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 && !(((uintptr_t)src | sp) & 15)) {
+      return launch_lanczos_mfma(st, 1, &j, 1, a);
+    };
+    auto tile = [&]() -> bool {
+      if (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 9 || tuning(VPF_TUNE_NV12_RGB_VARIANT) == 40 || (((uintptr_t)src | sp) & 15)) return false;
       const TileShape t = plan_tile(true, 1, &ch, &dw, &dh, &scx, &scy, 1);
-      if (t.ok) {
-        const dim3 tgrid((dw + 63) / 64, (dh + t.ty - 1) / t.ty);
+      if (!t.ok) return false;
+      const dim3 tgrid((dw + 63) / 64, (dh + t.ty - 1) / t.ty);
 #define VPF_LZT3(C, W) VPF_LAUNCH((k_resize_lztile<C, W>), tgrid, dim3(64 * W), t.lds, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy, t.ty, t.nr, t.rowq, t.lshift, vec_ok)
 #define VPF_LZT(C) do { if (t.wpb == 8) VPF_LZT3(C, 8); else VPF_LZT3(C, 4); } while (0)
-        if (ch == 1) VPF_LZT(1); else if (ch == 2) VPF_LZT(2); else VPF_LZT(3);
+      if (ch == 1) VPF_LZT(1); else if (ch == 2) VPF_LZT(2); else VPF_LZT(3);
 #undef VPF_LZT
 #undef VPF_LZT3
-        return hipGetLastError();
-      }
-    }
+      return true;
+    };
+    if (lanczos_single_prefers_tile(ch, sw, sh, dw, dh) ? (tile() || mfma()) : (mfma() || tile())) return hipGetLastError();
     dim3 lgrid((dw + 63) / 64, (dh + 3) / 4);
     if (ch == 1) VPF_LAUNCH((k_resize_lanczos<1>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);
     else if (ch == 2) VPF_LAUNCH((k_resize_lanczos<2>), lgrid, dim3(256), 0, st, src, sp, sw, sh, dst, dp, dw, dh, scx, scy);

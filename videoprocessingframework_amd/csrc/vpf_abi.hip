@@ -288,7 +288,7 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
   if (guard.err != hipSuccess) return status_of(guard.err);
   hipStream_t st = static_cast<hipStream_t>(exec->stream);
   const int np = num_planes(fmt);
-  const bool forced_family = tuning(VPF_TUNE_RESIZE_MFMA) >= 2 || tuning(VPF_TUNE_RESIZE_BAND) >= 2;  // measurement runs: the batch kernels on one frame
+  const bool forced_family = (tuning(VPF_TUNE_RESIZE_MFMA) & 0xffff) >= 2 || tuning(VPF_TUNE_RESIZE_BAND) >= 2;  // measurement runs: the batch kernels on one frame
   if (n == 1 && nj == 1 && !forced_family) {  // one plane of one frame: the scalar-argument kernel entries (kernarg preload)
     const vpf_plane &s0 = frames[0].src[0], &d0 = frames[0].dst[0];
     const hipError_t e = f32 ? launch_resize_f32(st, jobs[0].ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(s0.ptr), s0.pitch, ds.width, ds.height,
@@ -449,7 +449,7 @@ int vpf_set_tuning(int key, int value) {
   }
   if (key == VPF_TUNE_RESIZE_MFMA) {
     const int shape = value & 0xffff, nt = shape >> 8, tiles = shape & 0xff;  // | 0x10000: no weight tables; | 0x20000: the two-role kernel form
-    if (value < 0 || (value & ~0x3ffff)) return -1;
+    if (value < 0 || (value & ~0x7ffff)) return -1;
     if (shape != 0 && shape != 1 && ((nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
     return g_tune_mfma.exchange(value);
   }
