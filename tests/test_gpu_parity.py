@@ -957,17 +957,21 @@ def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
 
 
-@pytest.mark.parametrize("band", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("band", [1, 2, 4, 8, 16, 0x104, 0x204, 0x304, 0x804])
 def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 16 / 8 / 4 / 2 for launches with >= 2048
     workgroups, 1 otherwise).  Every value writes the oracle's pixels: general and > 2x down-scales, shared and disjoint source rows,
     heights that are not a multiple of the band, one-row pictures, ragged widths, fx == 0 columns (even integer factor on x only), an
-    up-scale forced onto the row-pair family (variant 40: repeated source rows), multi-plane formats, and a 33-frame batch"""
+    up-scale forced onto the row-pair family (variant 40: repeated source rows), multi-plane formats, and a 33-frame batch.
+    4 | nb << 8: the march form (nb 4-row bands per wave, the next band's rows in flight while this one is blended, the walk's lerps carried
+    from band to band) on the down-scales of wide 1-channel planes, the plain 4-row form everywhere else."""
     cases = [("RGB", 640, 360, 427, 240, 0, 3), ("RGB", 1920, 96, 416, 37, 0, 2), ("NV12", 1280, 72, 854, 48, 0, 3), ("YUV420", 642, 90, 300, 31, 0, 2),
              ("RGB", 300, 5, 200, 1, 0, 2), ("Y", 997, 61, 333, 47, 0, 2), ("RGB", 512, 90, 128, 61, 0, 2), ("RGB", 200, 50, 333, 77, 40, 2),
              ("NV12", 200, 50, 320, 96, 40, 2), ("RGB", 640, 360, 224, 224, 0, 33), ("RGB", 1919, 64, 1280, 43, 0, 2),
              ("RGB", 320, 180, 1280, 720, 0, 2), ("YUV420", 96, 54, 160, 90, 0, 3),                                # up-scales (the band family by policy when forced)
              ("Y", 1500, 40, 1000, 27, 0, 2), ("YUV444", 600, 40, 500, 31, 0, 2), ("NV12", 1200, 40, 2040, 68, 0, 2),  # 1-channel planes that 512-column chunks fill well: 8 px per lane
+             ("Y", 1920, 300, 1280, 200, 0, 3), ("NV12", 1920, 270, 1280, 180, 0, 2), ("Y", 1030, 131, 1025, 67, 0, 2), ("NV12", 1600, 98, 1100, 66, 0, 2),  # ... down-scales: the march form
+             ("Y", 1100, 77, 1100, 77, 0, 2), ("YUV444", 1536, 50, 1024, 34, 0, 2), ("Y", 2000, 9, 1999, 5, 0, 2),
              ("RGB", 1, 1, 9, 7, 0, 2), ("RGB", 2, 3, 300, 5, 0, 2), ("Y", 3, 2, 5, 70, 0, 2), ("NV12", 4, 4, 18, 10, 0, 2), ("RGB", 5, 2, 3, 1, 0, 2)]  # tiny pictures
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, band) >= 0
     try:
@@ -990,6 +994,25 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     finally:
         capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 32) == -1
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x208) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x904) == -1  # bands per wave: 4-row bands only, at most 8
+
+
+@pytest.mark.parametrize("fmt", ["Y", "NV12"])
+def test_bilinear_march_form_by_policy(capi, oracle, fmt):
+    """a launch large enough that the POLICY picks the march form for the 1-channel plane (32 frames of 1080p -> 720p: 8-row bands would
+    run; instead 4-row bands, two per wave): every frame equals the oracle"""
+    sw, sh, dw, dh, n = 1920, 1080, 1280, 720, 32
+    f, of = getattr(capi, fmt), getattr(oracle, fmt)
+    srcs = [oracle.synth(of, sw, sh, 7300 + i) for i in range(3)]
+    wants = [oracle.resize(of, 1, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+    S = [DevPlanes(srcs[i % 3]) for i in range(n)]
+    D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+    capi.resize_batch(capi.make_exec(stream_handle()), f, 1, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+    torch.cuda.synchronize()
+    for i in range(n):
+        got, intact = D[i].download()
+        assert intact
+        assert_planes_equal(got, wants[i % 3], f"march by policy {fmt} frame {i}")
 
 
 @pytest.mark.parametrize("fmt,interp,sizes", [("RGB", 1, (1920, 1080, 1280, 720)), ("RGB", 2, (1920, 1080, 1280, 720)), ("NV12", 1, (1920, 1080, 1280, 720)),
@@ -1239,7 +1262,7 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         srcs = [oracle.synth(of, sw, sh, int(rng.integers(1 << 30))) for _ in range(n)]
         S = [DevPlanes(p, align) for p in srcs]
         D = [DevPlanes(oracle.alloc(of, dw, dh), align) for _ in range(n)]
-        band = int(rng.choice([0, 1, 2, 4, 8, 16]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy)
+        band = int(rng.choice([0, 1, 2, 4, 8, 16, 0x104, 0x204, 0x304]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy); 4 | nb << 8: the march form
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
         march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5, 0x40000]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves); 0x40000: small single frames on the matrix cores too  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)

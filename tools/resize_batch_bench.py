@@ -11,7 +11,7 @@ ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 NAMES = {0: "nearest", 1: "bilinear", 2: "lanczos3"}
 if len(sys.argv) > 1:  # e.g. 43: the tiled kernel for bilinear down-scales too (A/B against the row-pair kernel)
     capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, int(sys.argv[1]))
-BAND = int(os.environ.get("VPF_BENCH_BAND", "0"))        # rows per wave of the row-pair kernels (0 = policy)
+BAND = int(os.environ.get("VPF_BENCH_BAND", "0"), 0)        # rows per wave of the row-pair kernels (0 = policy)
 ONLY = os.environ.get("VPF_BENCH_ONLY", "")              # "bilinear": skip the Lanczos lines and the remap section
 capi.set_tuning(capi.TUNE_RESIZE_BAND, BAND)
 capi.set_tuning(capi.TUNE_RESIZE_MFMA, int(os.environ.get("VPF_BENCH_MFMA", "0"), 0))  # Lanczos matrix-core kernel: 0 policy, 1 never, nt << 8 | tiles per band

@@ -237,34 +237,42 @@ VPF_DEV Tap band_row_taps(uint32_t ya, uint32_t yb, float scy, uint32_t sh) {
 // put(y, o) receives o[] = pixel-major, + 0.5 added.
 // (Measured and not kept: exchanging the ROLES of Ha / Hb instead of copying — as a two-way branch the compiler folds the two blends back
 // into one behind more copies; as two alternating loops over the rows the walk is 1.7 x slower at R = 4: profiles/r03_band_walk_variants.txt.)
+// The walk's state: the horizontal lerps (pixel pairs, band_hlerp4) of source rows ida (upper tap) and idb (lower tap).  A wave that walks
+// down several bands in a row (RowBandTask with bands per wave > 1) keeps it from band to band: the next band's first source rows are
+// this band's last, and their lerps are not evaluated again.
+template <int CH, int PX = 4>
+struct BandWalk {
+  static constexpr int NP = PX / 2 * CH;
+  f32x2 Ha[NP], Hb[NP];
+  uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
+};
 template <int CH, int R, int PX = 4, class Put>
-VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const ColTaps<CH, PX>& T, Put&& put) {
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const ColTaps<CH, PX>& T, BandWalk<CH, PX>& w,
+                             Put&& put) {
   static_assert(R <= 64, "one lane per row of the band");
   constexpr int NP = PX / 2 * CH;
-  f32x2 Ha[NP], Hb[NP];  // horizontal lerps (pixel pairs, band_hlerp4) of source rows ida (upper tap) and idb (lower tap)
-  uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
 #pragma unroll
   for (int i = 0; i < R; i++) {
     if (ya + i > yb) break;
     const uint32_t i0 = __builtin_amdgcn_readlane(rows.i0, i), i1 = __builtin_amdgcn_readlane(rows.i1, i);
     const float fy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rows.f), i));
-    if (i0 != ida) {
-      if (i0 == idb) {
+    if (i0 != w.ida) {
+      if (i0 == w.idb) {
 #pragma unroll
-        for (int q = 0; q < NP; q++) Ha[q] = Hb[q];
+        for (int q = 0; q < NP; q++) w.Ha[q] = w.Hb[q];
       } else {
-        band_hlerp4<CH, PX>(strips + (size_t)(i0 - r_lo) * rowbytes, T, Ha);
+        band_hlerp4<CH, PX>(strips + (size_t)(i0 - r_lo) * rowbytes, T, w.Ha);
       }
-      ida = i0;
+      w.ida = i0;
     }
-    if (i1 != idb) {
-      if (i1 == ida) {
+    if (i1 != w.idb) {
+      if (i1 == w.ida) {
 #pragma unroll
-        for (int q = 0; q < NP; q++) Hb[q] = Ha[q];
+        for (int q = 0; q < NP; q++) w.Hb[q] = w.Ha[q];
       } else {
-        band_hlerp4<CH, PX>(strips + (size_t)(i1 - r_lo) * rowbytes, T, Hb);
+        band_hlerp4<CH, PX>(strips + (size_t)(i1 - r_lo) * rowbytes, T, w.Hb);
       }
-      idb = i1;
+      w.idb = i1;
     }
     float o[PX * CH];
     const f32x2 fy2 = {fy, fy}, half2 = {0.5f, 0.5f};
@@ -272,13 +280,18 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
     for (int j = 0; j < PX / 2; j++) {
 #pragma unroll
       for (int c = 0; c < CH; c++) {
-        const f32x2 t = Ha[j * CH + c], b = Hb[j * CH + c];
+        const f32x2 t = w.Ha[j * CH + c], b = w.Hb[j * CH + c];
         const f32x2 v = __builtin_elementwise_fma(fy2, b - t, t) + half2;
         o[2 * j * CH + c] = v[0]; o[(2 * j + 1) * CH + c] = v[1];
       }
     }
     put(ya + i, o);
   }
+}
+template <int CH, int R, int PX = 4, class Put>
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const ColTaps<CH, PX>& T, Put&& put) {
+  BandWalk<CH, PX> w;
+  band_blend_rows<CH, R, PX>(strips, rowbytes, r_lo, ya, yb, rows, T, w, static_cast<Put&&>(put));
 }
 
 // strip bytes a wave needs for the source span of its `cols` destination columns (vpf_bound_strip_bytes, checked on the CPU);

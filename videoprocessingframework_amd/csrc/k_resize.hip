@@ -19,10 +19,14 @@
 //   packed RGB taps               both taps of a row = 6 contiguous bytes: fetched as ONE 12-B window from the aligned address below
 //                                 (global or LDS) and cut out with v_alignbyte_b32
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "k_resize_common.h"
 
+#ifndef VPF_BL_X
+#define VPF_BL_X 0  // timing ablations of the row-band bilinear kernel: lab builds only (tools/lab/ablate/build_bl.sh)
+#endif
 namespace vpf {
 
 // CH interleaved channels per pixel (1, 2 or 3); 4 destination pixels per lane
@@ -281,47 +285,90 @@ VPF_DEV void RowPairTask<CH, IT>::run(const uint8_t* __restrict__ src, uint32_t 
 // destination pixels per lane: 4, or 8 = 512 columns per wave on 1-channel planes in the `P1 = 8` instantiations (a wave's per-row fixed
 // work is the same whatever the channel count; the launcher picks them when 512-column chunks fill the planes' rows well)
 constexpr int band_px(int ch, int p1) { return ch == 1 ? p1 : 4; }
-template <int CH, int R, int IT = 2 /* 1-KiB staging passes per strip */, int P1 = 4 /* pixels per lane on 1-channel planes */>
+template <int CH, int R, int IT = 2 /* 1-KiB staging passes per strip */, int P1 = 4 /* pixels per lane on 1-channel planes */, bool MULTI = false /* several bands per wave */>
 struct RowBandTask {
   static constexpr int kThreads = 256;
-  static constexpr int kSlots = kBandSlots * 2 / IT;
+  static constexpr int kSlots = kBandSlots * 2 / IT < 2 * R + 1 ? kBandSlots * 2 / IT : 2 * R + 1;  // a band touches at most floor((R - 1) scy) + 3 source rows, scy <= 2
   static constexpr int kPx = band_px(CH, P1);
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
 };
-template <int CH, int R, int IT, int P1>
-VPF_DEV void RowBandTask<CH, R, IT, P1>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+template <int CH, int R, int IT, int P1, bool MULTI>
+VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
                                          uint32_t bx, uint32_t by) {
   constexpr int PX = kPx;
   constexpr uint32_t W = 64 * PX;  // destination columns per wave
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, slots = G.a1;
+  const uint32_t nb = (MULTI && G.a2) ? G.a2 : 1u;  // bands per wave (launcher): the wave walks down nb consecutive bands of its columns
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t ya = (by * 4 + wv) * R;
+  uint32_t ya = (by * 4 + wv) * (R * nb);
   if (ya >= dh || bx * W >= dw) return;
-  const uint32_t yb = (ya + R - 1 < dh - 1) ? ya + R - 1 : dh - 1;
   const uint32_t xs = bx * W, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
   const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
-  const uint32_t r_lo = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(ya, scy, sh).i0);
-  const uint32_t r_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(yb, scy, sh).i1);  // the launcher guarantees r_hi - r_lo < slots <= kSlots
   u32x4* const strips = dyn_strip + (size_t)wv * slots * rowq;
+  // the source rows [i0(first row), i1(last row)] of one band (the launcher guarantees r_hi - r_lo < slots <= kSlots) ...
+  uint32_t yb, r_lo, r_hi;
+  auto rows_of = [&](uint32_t y0) {
+    yb = (y0 + R - 1 < dh - 1) ? y0 + R - 1 : dh - 1;
+    r_lo = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(y0, scy, sh).i0);
+    r_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(yb, scy, sh).i1);
+  };
+  // ... requested (all loads in flight together) ...
   Span<IT> rows[kSlots];
+  auto request = [&]() {
+#if VPF_BL_X != 2 && VPF_BL_X != 3  // (timing ablations of a lab build, tools/lab/ablate/build_bl.sh: 2 / 3 leave the staging out)
 #pragma unroll
-  for (int k = 0; k < kSlots; k++)
-    if (r_lo + k <= r_hi) rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane);
+    for (int k = 0; k < kSlots; k++)
+      if (r_lo + k <= r_hi) rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane);
+#endif
+  };
+  // ... and written to the wave's strips
+  auto commit = [&]() {
+#if VPF_BL_X != 2 && VPF_BL_X != 3
 #pragma unroll
-  for (int k = 0; k < kSlots; k++)
-    if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, nq, lane);
-  wave_lds_sync();
-  const Tap row_taps = band_row_taps(ya, yb, scy, sh);  // every lane still active here
+    for (int k = 0; k < kSlots; k++)
+      if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, nq, lane);
+#endif
+    wave_lds_sync();
+  };
   const uint32_t x0 = xs + lane * PX;
-  if (x0 >= dw) return;
-  const ColTaps<CH, PX> T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);
+  const bool draws = x0 < dw;  // lanes past the picture's right edge stage, but blend nothing
   const bool vec4 = G.vec_ok && x0 + PX <= dw;
-  const uint32_t nv = dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX;
-  band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo, ya, yb, row_taps, T, [&](uint32_t y, const float* o) {
-    store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
-  });
+  const uint32_t nv = !draws ? 0u : dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX;
+  rows_of(ya);
+  request();
+  const ColTaps<CH, PX> T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);  // once for all rows of all bands (evaluated while the first band's rows are in flight)
+  // With nb > 1 the source rows of band k + 1 are requested right after band k's have been written to the strips — the registers are free
+  // again — and arrive while band k is blended: the wave hides its own memory latency, and its fixed part (task decode, column taps) is
+  // paid once per nb bands.  Measured on 1- and 2-channel planes, whose waves are short (profiles/r04_bilinear_ablate.txt: staging, blend
+  // and the fixed part are nearly additive there).
+  BandWalk<CH, PX> walk;
+  for (uint32_t k = 0; k < nb; k++) {
+    commit();
+    const Tap row_taps = band_row_taps(ya, yb, scy, sh);  // every lane active here
+    const uint32_t ya_k = ya, yb_k = yb, r_lo_k = r_lo;
+    ya += R;
+    const bool more = k + 1 < nb && ya < dh;
+    if (more) { rows_of(ya); request(); }
+    if (draws) {
+#if VPF_BL_X == 1 || VPF_BL_X == 3  // ablation: no blend — every destination row gets bytes straight from the strips
+      for (uint32_t y = ya_k; y <= yb_k; y++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(strips) + ((y - ya_k) * rowq * 4 + lane * (PX * CH / 4));
+        float o[PX * CH];
+#pragma unroll
+        for (int i = 0; i < PX * CH; i++) o[i] = __uint_as_float(q[i / 4] | 0x3f000000u);
+        store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
+      }
+#else
+      band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo_k, ya_k, yb_k, row_taps, T, walk, [&](uint32_t y, const float* o) {
+        store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
+      });
+#endif
+    }
+    if (!more) return;
+    wave_lds_sync();  // the blend's LDS reads are done before the next band's rows overwrite the strips
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -821,6 +868,7 @@ template <int CH> struct RowBand8n : RowBandTask<CH, 8, 1> {};    // narrow stri
 template <int CH> struct RowBand16n : RowBandTask<CH, 16, 1> {};
 template <int CH> struct RowBand8w : RowBandTask<CH, 8, 1, 8> {};   // ... and 8 pixels per lane on 1-channel planes
 template <int CH> struct RowBand16w : RowBandTask<CH, 16, 1, 8> {};
+template <int CH> struct RowBand4wm : RowBandTask<CH, 4, 1, 8, true> {};  // the march form: 4-row bands, several per wave (plan_band)
 
 // ------------------------------------------------------------------------------------------
 // Exact 2x bilinear down-scale (4K -> 1080p ...): s = 2 d + 0.5 exactly, so every destination pixel is the fx = fy = 0.5
@@ -1308,7 +1356,7 @@ static uint32_t band_strip_bytes(int njobs, const ResizeJob* jobs, uint32_t n, c
   return rbmax;
 }
 static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32_t n, int p1 = 4) {
-  const int forced = tuning(VPF_TUNE_RESIZE_BAND);
+  const int forced = tuning(VPF_TUNE_RESIZE_BAND) & 0xff;  // (bits 8..: bands per wave of the march form, plan_band)
   if (forced == 1 || rb == 0 || rb > 2048) return {1, 0, false};
   float scy = 0.f;
   for (int p = 0; p < njobs; p++) {
@@ -1330,18 +1378,38 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
   }
   return {1, 0, false};
 }
-// the whole decision: 8 pixels per lane on the 1-channel planes only with the 16-slot (narrow-strip) instantiations that exist for it
-struct BandPlan { int rows; uint32_t slots; bool narrow; int p1; uint32_t rb; };
+// the whole decision: 8 pixels per lane on the 1-channel planes only with the 16-slot (narrow-strip) instantiations that exist for it.
+// Where that form would run 8-row bands on a DOWN-scale (every plane's vertical factor in [1, 2]) the launch takes the MARCH form instead
+// (RowBand4wm): bands of 4 rows, nb of them per wave one below the other — the next band's source rows are requested while this band is
+// blended, the walk's lerps and the column taps carry over — with half the LDS per wave (four waves per SIMD instead of three) and the
+// wave's fixed part paid once per 4 nb rows.  nb = 2 or 3 while the launch keeps kBandMinGroups workgroups.  Measured on the 1- / 2-channel
+// planes of Y / NV12 (profiles/r04_bilinear_march.txt: Y 1080p -> 720p 0.85 -> 0.79 us, NV12 1.14 -> 1.06); 3-channel planes and up-scales
+// lose with it and keep their forms.  VPF_TUNE_RESIZE_BAND = 4 | nb << 8 forces it where it applies.
+struct BandPlan { int rows; uint32_t slots; bool narrow; int p1; uint32_t rb; uint32_t nb; };
 static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
-  const int p1 = band_p1(njobs, jobs);
+  const int p1 = band_p1(njobs, jobs), knob = tuning(VPF_TUNE_RESIZE_BAND), forced_nb = knob >> 8;
   if (p1 == 8) {
     const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 8);
     const BandShape bs = band_rows(njobs, jobs, rb, n, 8);
-    if (bs.rows >= 8 && bs.narrow) return {bs.rows, bs.slots, true, 8, rb};
+    bool down = rb != 0 && rb <= 1024;
+    float scy = 1.f;
+    for (int p = 0; p < njobs && down; p++) {
+      const float s = (float)jobs[p].sh / (float)jobs[p].dh;
+      down = s >= 1.0f && s <= 2.0f;
+      scy = s > scy ? s : scy;
+    }
+    if (down && (forced_nb ? bs.rows == 4 : (knob == 0 && bs.rows == 8 && bs.narrow))) {
+      uint64_t groups = 0;
+      for (int p = 0; p < njobs; p++) groups += (uint64_t)((jobs[p].dw + 64u * band_px(jobs[p].ch, 8) - 1) / (64u * band_px(jobs[p].ch, 8))) * ((jobs[p].dh + 15) / 16) * n;
+      const uint32_t nb = forced_nb ? (uint32_t)forced_nb : (uint32_t)std::min<uint64_t>(3, groups / kBandMinGroups);
+      const uint32_t slots = band_slots_exact(4, njobs, jobs, band_slots(4, scy));
+      if (nb >= (forced_nb ? 1u : 2u) && slots <= 9u && 4u * slots * rb + 16u <= 64u * 1024u) return {4, slots, true, 8, rb, nb};
+    }
+    if (bs.rows >= 8 && bs.narrow) return {bs.rows, bs.slots, true, 8, rb, 0};
   }
   const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 4);
   const BandShape bs = band_rows(njobs, jobs, rb, n, 4);
-  return {bs.rows, bs.slots, bs.narrow, 4, rb};
+  return {bs.rows, bs.slots, bs.narrow, 4, rb, 0};
 }
 
 hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
@@ -1462,9 +1530,10 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     t.np = (uint32_t)njobs;
     uint32_t gx = 0, gy = 0, it = 1, rb = 0;
     for (int p = 0; p < njobs && all_rowpair; p++) rb = rowb[p] > rb ? rowb[p] : rb;
-    const BandPlan bs = all_rowpair ? plan_band(njobs, jobs, n, a) : BandPlan{1, 0, false, 4, 0};
+    const BandPlan bs = all_rowpair ? plan_band(njobs, jobs, n, a) : BandPlan{1, 0, false, 4, 0, 0};
     const int band = bs.rows;
     if (band > 1) rb = bs.rb;
+    const uint32_t band_nb = bs.nb ? bs.nb : 1u;  // bands per wave (the march form)
     for (int p = 0; p < njobs; p++) {
       t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
       if (all_tile) {
@@ -1475,7 +1544,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       } else {
         const uint32_t wcols = band > 1 ? 64u * band_px(jobs[p].ch, bs.p1) : 256u, bx = (jobs[p].dw + wcols - 1) / wcols;
         gx = bx > gx ? bx : gx;
-        gy += (jobs[p].dh + 4 * band - 1) / (4 * band);
+        gy += (jobs[p].dh + 4 * band * band_nb - 1) / (4 * band * band_nb);
       }
     }
     const dim3 grid(gx, gy, n);
@@ -1483,10 +1552,11 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       if (ts.wpb == 8) launch_planes_mp<TileBl8>(st, grid, ts.lds, a, t);
       else launch_planes_mp<TileBl4>(st, grid, ts.lds, a, t);
     } else {
-      for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; }  // one strip size for the launch (the widest plane's)
+      for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; t.g[p].a2 = bs.nb; }  // one strip size for the launch (the widest plane's)
       it = (rb + 1023) / 1024;
       const uint32_t lds = band > 1 ? 4 * bs.slots * rb + 16 : 4 * 2 * rb + 16;
-      if (band == 16 && bs.p1 == 8) launch_planes_mp<RowBand16w>(st, grid, lds, a, t);
+      if (band == 4 && bs.p1 == 8) launch_planes_mp<RowBand4wm>(st, grid, lds, a, t);
+      else       if (band == 16 && bs.p1 == 8) launch_planes_mp<RowBand16w>(st, grid, lds, a, t);
       else if (band == 8 && bs.p1 == 8) launch_planes_mp<RowBand8w>(st, grid, lds, a, t);
       else if (band == 16) launch_planes_mp<RowBand16n>(st, grid, lds, a, t);
       else if (band == 8 && bs.narrow) launch_planes_mp<RowBand8n>(st, grid, lds, a, t);
@@ -1557,11 +1627,11 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       const BandPlan bs = plan_band(1, &j, n, a);
       const int band = bs.rows;
       if (band > 1) {
-        g[p].a0 = bs.rb / 16; g[p].a1 = bs.slots;
-        const uint32_t wcols = 64u * band_px(j.ch, bs.p1);
-        const dim3 bgrid((j.dw + wcols - 1) / wcols, (j.dh + 4 * band - 1) / (4 * band), n);
+        g[p].a0 = bs.rb / 16; g[p].a1 = bs.slots; g[p].a2 = bs.nb;
+        const uint32_t wcols = 64u * band_px(j.ch, bs.p1), nbw = bs.nb ? bs.nb : 1u;
+        const dim3 bgrid((j.dw + wcols - 1) / wcols, (j.dh + 4 * band * nbw - 1) / (4 * band * nbw), n);
         const uint32_t blds = 4 * bs.slots * bs.rb + 16;
-#define VPF_RBB(C) do { if (band == 16 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 16, 1, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 8, 1, 8>>(st, bgrid, blds, a, j.k, g[p]); \
+#define VPF_RBB(C) do { if (band == 4 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 4, 1, 8, true>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 16 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 16, 1, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.p1 == 8) launch_plane_batch<RowBandTask<C, 8, 1, 8>>(st, bgrid, blds, a, j.k, g[p]); \
                         else if (band == 16) launch_plane_batch<RowBandTask<C, 16, 1>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 8 && bs.narrow) launch_plane_batch<RowBandTask<C, 8, 1>>(st, bgrid, blds, a, j.k, g[p]); \
                         else if (band == 8) launch_plane_batch<RowBandTask<C, 8>>(st, bgrid, blds, a, j.k, g[p]); else if (band == 4) launch_plane_batch<RowBandTask<C, 4>>(st, bgrid, blds, a, j.k, g[p]); \
                         else launch_plane_batch<RowBandTask<C, 2>>(st, bgrid, blds, a, j.k, g[p]); } while (0)

@@ -453,7 +453,11 @@ int vpf_set_tuning(int key, int value) {
     if (shape != 0 && shape != 1 && ((nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
     return g_tune_mfma.exchange(value);
   }
-  if (key == VPF_TUNE_RESIZE_BAND) return (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? g_tune_band.exchange(value) : -1;
+  if (key == VPF_TUNE_RESIZE_BAND) {
+    const int rows = value & 0xff, nb = value >> 8;  // nb: bands per wave of the march form (4-row bands only)
+    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4);
+    return ok ? g_tune_band.exchange(value) : -1;
+  }
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
     case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: return g_tune_variant.exchange(value);
