@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../../.."
 C=videoprocessingframework_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -fvisibility=hidden -Iinclude -I$C"
 OBJS=$(ls videoprocessingframework_amd/build/k_*.o videoprocessingframework_amd/build/vpf_abi.o | grep -v "k_resize.o")
-for X in "$@"; do D="-DVPF_BL_X=$X"; [ "$X" = m ] && D="-DVPF_BL_MULTI=1"; hipcc $FLAGS $D -c $C/k_resize.hip -o /tmp/bl_x$X.o 2>&1 | grep -v warning & done
+for X in "$@"; do D="-DVPF_BL_X=$X"; [ "$X" = nowin ] && D="-DVPF_BL_NOWIN=1"; hipcc $FLAGS $D -c $C/k_resize.hip -o /tmp/bl_x$X.o 2>&1 | grep -v warning & done
 wait
 for X in "$@"; do hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lab/ablate/libvpfhip_bl$X.so $OBJS /tmp/bl_x$X.o; done
 ls -la tools/lab/ablate/*.so

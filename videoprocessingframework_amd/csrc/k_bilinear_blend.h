@@ -85,6 +85,19 @@ struct ColTaps {
   uint32_t a[PX], b[PX];  // byte offsets of tap 0 / tap 1 from the strips' first byte
   float f[PX];
   bool allfx;  // wave-uniform: for each of the pixels some lane has fx != 0 (no exact-alignment shortcut applies on x)
+  // 2-channel planes and 1-channel planes at 8 pixels per lane, the row-band walk (band_hlerp4): the four tap bytes of one pixel (CH = 2:
+  // U V of tap 0, U V of tap 1) or of a pixel PAIR (CH = 1: a, a + 1 of both pixels) come out of ONE 8-byte LDS window that starts at the
+  // dword below the first of them — wa = that dword's byte offset, ws = the v_perm_b32 selector that picks the four bytes out of the window —
+  // instead of four ds_read_u8.  Tap 1 is read at a + CH whatever i1 says: where i1 == i0 (the picture's right edge) its weight is exactly
+  // 0 and fma(0, finite, p) == p.  A pair's bytes fit the window up to a horizontal factor of 3; the 8-pixel forms exist for strips of at
+  // most 1 KiB = 512 columns x 2 (plan_band), so the choice is a compile-time one and a / b cost no registers where the windows are used.
+#ifdef VPF_BL_NOWIN  // (lab builds switch the windows off for same-box A/B runs: tools/lab/ablate/build_bl.sh nowin)
+  static constexpr bool kWindowed = false;
+#else
+  static constexpr bool kWindowed = CH == 2 || (CH == 1 && PX == 8);
+#endif
+  static constexpr int NW = CH == 1 ? PX / 2 : PX;
+  uint32_t wa[NW], ws[NW];
 };
 template <int CH, int PX = 4>
 VPF_DEV ColTaps<CH, PX> make_col_taps(uint32_t base, uint32_t x0, uint32_t dw, uint32_t sw, float scx) {
@@ -95,6 +108,21 @@ VPF_DEV ColTaps<CH, PX> make_col_taps(uint32_t base, uint32_t x0, uint32_t dw, u
     const Tap t = make_tap<VPF_INTERP_LINEAR>((x0 + k < dw) ? x0 + k : dw - 1, scx, sw);
     T.a[k] = CH * t.i0 - base; T.b[k] = CH * t.i1 - base; T.f[k] = t.f;
     T.allfx = T.allfx && __builtin_amdgcn_ballot_w64(t.f != 0.f) != 0;
+  }
+  if constexpr (ColTaps<CH, PX>::kWindowed && CH == 1) {
+#pragma unroll
+    for (int j = 0; j < PX / 2; j++) {
+      const uint32_t A = T.a[2 * j] & ~3u, o0 = T.a[2 * j] - A, o1 = T.a[2 * j + 1] - A;  // a never decreases with the column; o1 <= 3 + 2
+      T.wa[j] = A;
+      T.ws[j] = o0 | (o0 + 1u) << 8 | (o1 & 7u) << 16 | ((o1 + 1u) & 7u) << 24;
+    }
+  } else if constexpr (ColTaps<CH, PX>::kWindowed) {
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+      const uint32_t A = T.a[k] & ~3u, o = T.a[k] - A;  // 0 or 2: a is even
+      T.wa[k] = A;
+      T.ws[k] = o | (o + 1u) << 8 | (o + 2u) << 16 | (o + 3u) << 24;
+    }
   }
   return T;
 }
@@ -203,6 +231,23 @@ constexpr int kBandSlots = 8;  // source rows a wave's strips can hold (twice as
 template <int CH, int PX = 4>
 VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, f32x2* H) {
   float p0[PX][CH], p1[PX][CH];
+  if constexpr (ColTaps<CH, PX>::kWindowed) {
+    if constexpr (CH == 1) {
+#pragma unroll
+      for (int j = 0; j < PX / 2; j++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(r + T.wa[j]);
+        const uint32_t w = __builtin_amdgcn_perm(q[1], q[0], T.ws[j]);  // [tap 0, tap 1 of pixel 2j | tap 0, tap 1 of pixel 2j + 1]
+        p0[2 * j][0] = ubyte<0>(w); p1[2 * j][0] = ubyte<1>(w); p0[2 * j + 1][0] = ubyte<2>(w); p1[2 * j + 1][0] = ubyte<3>(w);
+      }
+    } else if constexpr (CH == 2) {
+#pragma unroll
+      for (int k = 0; k < PX; k++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(r + T.wa[k]);
+        const uint32_t w = __builtin_amdgcn_perm(q[1], q[0], T.ws[k]);  // [U V of tap 0 | U V of tap 1]
+        p0[k][0] = ubyte<0>(w); p0[k][1] = ubyte<1>(w); p1[k][0] = ubyte<2>(w); p1[k][1] = ubyte<3>(w);
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < PX; k++) {
     if constexpr (CH == 3) {
@@ -211,6 +256,7 @@ VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, f32x2* H) {
 #pragma unroll
       for (int c = 0; c < CH; c++) { p0[k][c] = (float)r[T.a[k] + c]; p1[k][c] = (float)r[T.b[k] + c]; }
     }
+  }
   }
 #pragma unroll
   for (int j = 0; j < PX / 2; j++) {
