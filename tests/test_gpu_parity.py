@@ -1071,6 +1071,71 @@ def test_lanczos_mfma_kernel_shapes_write_the_oracle_pixels(capi, oracle, shape)
     assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, (3 << 8) | 2) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, -1) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, (8 << 8) | 65) == -1
 
 
+@pytest.mark.parametrize("knob", [0, 0x10000, (4 << 8) | 1, 0x10000 | (4 << 8) | 3])
+def test_lanczos_two_chunk_windows_write_the_oracle_pixels(capi, oracle, knob):
+    """Horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network): the taps of 16 destination bytes spread over more than 64
+    source bytes, and the matrix-core kernel takes them with 128-B windows — pass 1 chains two MFMAs per product (LzMfma4k4 / k6 / k8 by
+    the length of the staged rows).  Tables and in-kernel weights, policy and forced band heights: 1-, 2- and 3-channel planes, every
+    staging width, ragged widths (partial last strip / last tile), picture edges, multi-plane formats, a 33-frame batch."""
+    cases = [("Y", 1408, 90, 640, 41, 2), ("RGB", 1920, 270, 416, 104, 3), ("RGB", 2200, 100, 400, 45, 2), ("NV12", 1920, 270, 640, 120, 2),
+             ("YUV420", 1280, 180, 400, 70, 2), ("RGB", 1999, 131, 417, 51, 2), ("Y", 1920, 1080, 416, 416, 2), ("RGB", 640, 360, 224, 224, 33),
+             ("YUV444", 1000, 64, 217, 29, 2), ("Y", 3000, 40, 520, 17, 2), ("RGB", 700, 33, 130, 13, 2), ("NV12", 3840, 128, 1000, 50, 2)]
+    assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, knob) >= 0
+    try:
+        for fmt, sw, sh, dw, dh, n in cases:
+            f, of = getattr(capi, fmt), getattr(oracle, fmt)
+            srcs = [oracle.synth(of, sw, sh, 7500 + i) for i in range(min(n, 3))]
+            S = [DevPlanes(srcs[i % len(srcs)]) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+            capi.resize_batch(capi.make_exec(stream_handle()), f, 2, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+            torch.cuda.synchronize()
+            wants = [oracle.resize(of, 2, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+            exact = oracle.resize(of, 2, sw, sh, srcs[0], dw, dh, oracle.EXACT)[1]
+            for i in range(n):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, wants[i % len(srcs)], f"two-chunk windows knob {knob:#x} {fmt} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+            got0 = D[0].download()[0]
+            assert max(int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max()) for a, b in zip(got0, exact)) <= 1
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
+
+
+def test_kernel_selection_of_the_round_4_forms():
+    """which kernel a launch takes is policy, and policy regressions are silent (same pixels): the launch log (VPF_HIP_LOG=2) names the
+    two-chunk matrix-core Lanczos kernel for a network-input down-scale, the tile kernel for one small Lanczos plane per dispatch, and the
+    march form of the row-band bilinear kernel for a large batch of Y planes"""
+    import subprocess
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import torch
+from videoprocessingframework_amd import capi
+ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
+def planes(w, h, c):
+    p = (w * c + 255) // 256 * 256
+    t = torch.zeros((h, p), dtype=torch.uint8, device="cuda")
+    return t, [(t.data_ptr(), p)]
+def batch(fmt, c, interp, sw, sh, dw, dh, n):
+    S = [planes(sw, sh, c) for _ in range(n)]; D = [planes(dw, dh, c) for _ in range(n)]
+    capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)]))
+    torch.cuda.synchronize()
+    return S, D
+print("A", file=sys.stderr); batch(capi.RGB, 3, 2, 1920, 1080, 416, 416, 4)
+print("B", file=sys.stderr); s, d = planes(1920, 1080, 3), planes(1280, 720, 3)
+capi.resize(ex, capi.RGB, 2, 1920, 1080, capi.planes(s[1]), 1280, 720, capi.planes(d[1])); torch.cuda.synchronize()
+print("C", file=sys.stderr); batch(capi.Y, 1, 1, 1920, 1080, 1280, 720, 32)
+print("done")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, VPF_HIP_LOG="2"), timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, r.stdout + r.stderr
+    a, rest = r.stderr.split("\nB\n", 1)[0], r.stderr.split("\nB\n", 1)[1]
+    b, c = rest.split("\nC\n", 1)
+    assert "LzMfma4k" in a, a
+    assert "k_resize_lztile" in b and "k_lanczos_mfma" not in b, b
+    assert "RowBand4wm" in c, c
+
+
 def test_lanczos_weight_tables_across_streams(capi, oracle):
     """The matrix-core Lanczos kernel loads its filter weights from per-shape tables that the first launch of a shape builds on ITS stream.
     A second stream using the same shape right away — before the first stream's build need have run — queues its own build instead of

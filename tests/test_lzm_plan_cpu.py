@@ -52,9 +52,9 @@ def lzp():
 
 def plan(L, planes, n, forced=0, tables=True):
     a = (C.c_uint32 * (5 * len(planes)))(*[v for p in planes for v in p])
-    out = (C.c_uint32 * 7)()
+    out = (C.c_uint32 * 8)()
     L.lzp_plan(len(planes), a, n, forced, int(tables), out)
-    return dict(ok=bool(out[0]), nt=out[1], r=out[2], span=out[3], pitch=out[4], wave_lds=out[5], group_lds=out[6])
+    return dict(ok=bool(out[0]), nt=out[1], r=out[2], span=out[3], pitch=out[4], wave_lds=out[5], group_lds=out[6], kc=out[7])
 
 
 def planes_of(fmt, sw, sh, dw, dh):
@@ -106,7 +106,10 @@ def test_planner_limits_and_forced_shapes(lzp):
             n_no += 1
             continue
         n_ok += 1
-        assert p["group_lds"] <= 80 * 1024 and p["span"] <= (5 if p["nt"] == 8 else 4) * 64 and p["pitch"] >= p["span"] and p["pitch"] % 64 == 32
+        assert p["kc"] in (1, 2) and (p["kc"] == 1 or p["nt"] == 4)
+        assert p["group_lds"] <= 80 * 1024 and p["span"] <= (8 if p["kc"] == 2 else 5 if p["nt"] == 8 else 4) * 64 and p["pitch"] >= p["span"] and p["pitch"] % 64 == 32
+        if p["kc"] == 2:  # two-chunk windows are the fallback: no one-chunk shape holds this plane's taps
+            assert p["pitch"] in (288, 416, 544)
         assert p["group_lds"] == 4 * p["wave_lds"] + 16384 and p["wave_lds"] >= 16 * p["pitch"] + 16 * (16 * p["nt"] + 16)
         assert 1 <= p["r"] <= (dh + 15) // 16
     assert n_ok > 150 and n_no > 30
@@ -114,8 +117,13 @@ def test_planner_limits_and_forced_shapes(lzp):
     assert plan(lzp, base, 32, (8 << 8) | 5)["r"] == 5 and plan(lzp, base, 32, (8 << 8) | 5)["nt"] == 8
     assert plan(lzp, base, 32, (4 << 8) | 64)["r"] == 45 and plan(lzp, base, 32, (4 << 8))["nt"] == 4   # more tiles than the picture has: one band
     assert plan(lzp, base, 32, 7)["r"] == 7
-    assert not plan(lzp, [(3, 1920, 1080, 416, 416)], 32)["ok"]                 # 4.6 x: the taps of 16 destination bytes do not fit a 64-B window
+    net = plan(lzp, [(3, 1920, 1080, 416, 416)], 32)                            # 4.6 x 2.6: the taps of 16 destination bytes do not fit a 64-B window,
+    assert net["ok"] and net["kc"] == 2 and net["nt"] == 4 and net["span"] <= 384   # they fit a 128-B one: pass 1 with two K chunks
+    assert plan(lzp, base, 32)["kc"] == 1
+    assert not plan(lzp, [(3, 1920, 1080, 224, 224)], 32)["ok"]                 # 8.6 x 4.8: out of every window
     assert not plan(lzp, base + [(1, 1920, 1080, 224, 224)], 32)["ok"]          # one plane out -> the launch is out
+    mixed = plan(lzp, [(1, 1920, 1080, 640, 480), (2, 960, 540, 320, 240)], 8)  # NV12 3 x 2.25: both planes on two-chunk windows
+    assert mixed["ok"] and mixed["kc"] == 2
     with_t, without = plan(lzp, base, 1, 0, True), plan(lzp, base, 1, 0, False)
     assert without["r"] >= with_t["r"]                                          # a bigger fixed cost per wave never asks for shorter bands
 

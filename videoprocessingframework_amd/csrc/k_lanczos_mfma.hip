@@ -85,11 +85,12 @@ VPF_DEV uint32_t opaque(uint32_t v) {
   asm("" : "+v"(v));
   return v;
 }
-// PF = staging loads a lane keeps in flight = ceil(16-B units per staged row / 4)
-template <int CH, int NT, int PF>
+// PF = staging loads a lane keeps in flight = ceil(16-B units per staged row / 4); KC = 64-B K chunks of a pass-1 window (2: the taps of a
+// tile's 16 bytes spread over up to 128 source bytes — horizontal factors of ~2.2 .. 6 — and pass 1 chains two MFMAs per product)
+template <int CH, int NT, int PF, int KC = 1>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
-  static constexpr int kGroupsPerCu = NT == 4 ? 3 : 2;  // register budget: 168 / 256 VGPRs
+  static constexpr int kGroupsPerCu = NT == 4 && KC == 1 ? 3 : 2;  // register budget: 168 / 256 VGPRs
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
                           const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab);  // the shape's column / row weight tables (nullptr: evaluate in place)
 };
@@ -117,15 +118,18 @@ VPF_DEV uint32_t lzm_window(uint32_t b, uint32_t dwb, uint32_t sw, float scx) {
   return ((uint32_t)CH * (uint32_t)p0) & ~15u;
 }
 
-// column weights of the strip that starts at destination byte ob0 -> pass-1 B operands, kLzmB1Chunk tiles at a time through an 8-KiB LDS
-// scratch.  Operand image in LDS: [plane][tile][lane 16 g + n][16 bytes]; zero it, evaluate the sets of the chunk's pixels (one per lane),
-// scatter their bytes, read the operands back.  Clamped taps add their weights on the edge pixel's slot: image edges cost nothing.
-template <int CH, int NT>
-VPF_DEV void lzm_col_operands(uint8_t* lds, uint32_t lane, uint32_t ob0, uint32_t dwb, uint32_t sw, float scx, v4i (&b1h)[NT], v4i (&b1l)[NT]) {
+// column weights of the strip that starts at destination byte ob0 -> pass-1 B operands (b1h / b1l [K chunk * NT + tile]), kLzmB1Chunk / KC
+// tiles at a time through an 8-KiB LDS scratch.  Operand image in LDS: [hi | lo][K chunk][tile][lane 16 g + n][16 bytes]; zero it, evaluate
+// the sets of the chunk's pixels (one per lane), scatter their bytes, read the operands back.  Clamped taps add their weights on the edge
+// pixel's slot: image edges cost nothing.
+template <int CH, int NT, int KC = 1>
+VPF_DEV void lzm_col_operands(uint8_t* lds, uint32_t lane, uint32_t ob0, uint32_t dwb, uint32_t sw, float scx, v4i (&b1h)[NT * KC], v4i (&b1l)[NT * KC]) {
+  constexpr int TPC = (int)kLzmB1Chunk / KC;       // tiles per pass through the scratch
+  constexpr uint32_t PLANE = KC * TPC * 1024u;     // bytes of the hi image (= kLzmB1Chunk KiB)
   const uint32_t ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb;
 #pragma unroll
-  for (int ck = 0; ck < NT / (int)kLzmB1Chunk; ck++) {
-    const uint32_t cb0 = ob0 + 64u * ck, cb1 = cb0 + 64u < ob1 ? cb0 + 64u : ob1;  // destination bytes of the chunk
+  for (int ck = 0; ck < NT / TPC; ck++) {
+    const uint32_t cb0 = ob0 + 16u * TPC * ck, cb1 = cb0 + 16u * TPC < ob1 ? cb0 + 16u * TPC : ob1;  // destination bytes of the chunk
     u32x4* z = reinterpret_cast<u32x4*>(lds);
 #pragma unroll
     for (int i = 0; i < 2 * (int)kLzmB1Chunk; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
@@ -146,20 +150,22 @@ VPF_DEV void lzm_col_operands(uint8_t* lds, uint32_t lane, uint32_t ob0, uint32_
 #pragma unroll
           for (int k = 0; k < 6; k++) {
             if (m.pos[k] < 0) continue;
-            const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 (vpf_bound_lzm_span)
-            uint8_t* const a = cell + (kk >> 4) * 256 + (kk & 15);
+            const uint32_t kk = (uint32_t)CH * (uint32_t)m.pos[k] + c - wsj;  // < 64 KC (vpf_bound_lzm_span_win)
+            uint8_t* const a = cell + (kk >> 6) * (TPC * 1024u) + ((kk >> 4) & 3u) * 256 + (kk & 15);
             a[0] = (uint8_t)whi[k];
-            a[kLzmB1Chunk * 1024] = (uint8_t)wlo[k];
+            a[PLANE] = (uint8_t)wlo[k];
           }
         }
       }
     }
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < (int)kLzmB1Chunk; j++) {
-      b1h[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + (j * 64 + lane) * 16);
-      b1l[ck * kLzmB1Chunk + j] = *reinterpret_cast<const v4i*>(lds + kLzmB1Chunk * 1024 + (j * 64 + lane) * 16);
-    }
+    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+      for (int j = 0; j < TPC; j++) {
+        b1h[kc * NT + ck * TPC + j] = *reinterpret_cast<const v4i*>(lds + kc * (TPC * 1024u) + (j * 64 + lane) * 16);
+        b1l[kc * NT + ck * TPC + j] = *reinterpret_cast<const v4i*>(lds + PLANE + kc * (TPC * 1024u) + (j * 64 + lane) * 16);
+      }
     wave_lds_sync();
   }
 }
@@ -193,24 +199,24 @@ VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb,
   }
 }
 
-// table builders: one wave per strip / per (group, band).  Column table of a plane row: [strip][plane hi | lo][tile][lane][16 B];
+// table builders: one wave per strip / per (group, band).  Column table of a plane row: [strip][plane hi | lo][K chunk][tile][lane][16 B];
 // row table of a (plane height, band height): [band][group][kLzmWmBytes]
-template <int NT>
+template <int NT, int KC>
 __global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw, uint32_t dw, float scx, u32x4* __restrict__ tab) {
   __shared__ u32x4 scratch[2 * kLzmB1Chunk * 64];
   const uint32_t lane = threadIdx.x, dwb = dw * ch, ob0 = blockIdx.x * (16u * NT);
-  v4i b1h[NT], b1l[NT];
+  v4i b1h[NT * KC], b1l[NT * KC];
   uint8_t* const lds = reinterpret_cast<uint8_t*>(scratch);
   switch (ch) {
-    case 1: lzm_col_operands<1, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
-    case 2: lzm_col_operands<2, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
-    default: lzm_col_operands<3, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
+    case 1: lzm_col_operands<1, NT, KC>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
+    case 2: lzm_col_operands<2, NT, KC>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
+    default: lzm_col_operands<3, NT, KC>(lds, lane, ob0, dwb, sw, scx, b1h, b1l); break;
   }
-  u32x4* const out = tab + (size_t)blockIdx.x * (NT * 128u);
+  u32x4* const out = tab + (size_t)blockIdx.x * (NT * KC * 128u);
 #pragma unroll
-  for (int j = 0; j < NT; j++) {
-    out[j * 64 + lane] = __builtin_bit_cast(u32x4, b1h[j]);
-    out[(NT + j) * 64 + lane] = __builtin_bit_cast(u32x4, b1l[j]);
+  for (int i = 0; i < NT * KC; i++) {
+    out[i * 64 + lane] = __builtin_bit_cast(u32x4, b1h[i]);
+    out[(NT * KC + i) * 64 + lane] = __builtin_bit_cast(u32x4, b1l[i]);
   }
 }
 __global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, u32x4* __restrict__ tab) {
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh,
   for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) out[i * 64 + lane] = wm[i * 64 + lane];
 }
 
-template <int CH, int NT, int PF>
-VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
+template <int CH, int NT, int PF, int KC>
+VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                               const PlaneGeom& G, uint32_t bx, uint32_t by, const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab) {
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, R = G.a1;
   constexpr uint32_t P = lzm_pitch_of(PF);  // LDS pitch of a staged row: the variant's capacity (64 PF bytes) + 32, a compile-time constant (launcher: G.a0 == P)
@@ -296,22 +302,22 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
 
   // ---- column weights -> pass-1 B operands: the strip's 2 NT operands from the shape's column table (ctab), or
   // evaluated here
-  v4i b1h[NT], b1l[NT];
+  v4i b1h[NT * KC], b1l[NT * KC];  // [K chunk * NT + tile]
   if (ctab) {
-    const u32x4* const t = ctab + (size_t)(bx * 4 + wv) * (NT * 128u);
+    const u32x4* const t = ctab + (size_t)(bx * 4 + wv) * (NT * KC * 128u);
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      b1h[j] = __builtin_bit_cast(v4i, t[j * 64 + lane]);
-      b1l[j] = __builtin_bit_cast(v4i, t[(NT + j) * 64 + lane]);
+    for (int i = 0; i < NT * KC; i++) {
+      b1h[i] = __builtin_bit_cast(v4i, t[i * 64 + lane]);
+      b1l[i] = __builtin_bit_cast(v4i, t[(NT * KC + i) * 64 + lane]);
     }
   } else {
-    lzm_col_operands<CH, NT>(lds, lane, ob0, dwb, sw, scx, b1h, b1l);
+    lzm_col_operands<CH, NT, KC>(lds, lane, ob0, dwb, sw, scx, b1h, b1l);
   }
 
   // ---- the march
   // 16-B units of a staged row (<= 4 PF, <= P / 16: host), cut at the row's last unit: the last window of a strip at the right image
   // edge reaches past the row (those bytes carry no weight and are never loaded: the LDS keeps whatever it held)
-  const uint32_t nq_win = (wrel[NT - 1] + 64u) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
+  const uint32_t nq_win = (wrel[NT - 1] + 64u * KC) / 16u, nq_row = (sw * CH + 15u - S0) / 16u;
   const uint32_t nq = nq_win < nq_row ? nq_win : nq_row;
   // staging: lane -> (row, 16-B unit) of the tile, PF loads per lane.  Even PF: EIGHT consecutive lanes take eight consecutive units (128 B)
   // of one row — the eight lanes a ds_write_b128 serves per LDS cycle then cover all 32 banks once (four lanes per row at a pitch of
@@ -370,43 +376,85 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF>::run(const uint8_t* __restrict__ src, u
           pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
     fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
     wave_lds_sync();
-    // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
-    // flight and the wave waits four times per tile); the other four are requested one by one into the registers the MFMAs free
-    v4i av[4];
+    if constexpr (KC == 1) {
+      // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
+      // flight and the wave waits four times per tile); the other four are requested one by one into the registers the MFMAs free
+      v4i av[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
-    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
-    // software pipeline over the N-tiles, interleaved at instruction level: the matrix pipe takes a new MFMA every 16 cycles and a wave issues
-    // in order, so two MFMAs back to back park the wave for 12 cycles and the eight VALU instructions behind them then run with the pipe
-    // idle.  Order per tile: HI of tile j + 1 | the four shift-adds of tile j (16 cycles: the pipe's own time) | LO of tile j + 1 | the two
-    // v_perm_b32 + two xor of tile j.  (Left alone the compiler gives every tile the same result registers: MFMA, MFMA, wait for the pipe,
-    // unpack, next MFMA — the wave idles through every MFMA latency.)
-    v4i hi[2], lo[2];
-    hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1h[0], c128, 0, 0, 0);
-    lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1l[0], c128, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
+      asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
+      // software pipeline over the N-tiles, interleaved at instruction level: the matrix pipe takes a new MFMA every 16 cycles and a wave issues
+      // in order, so two MFMAs back to back park the wave for 12 cycles and the eight VALU instructions behind them then run with the pipe
+      // idle.  Order per tile: HI of tile j + 1 | the four shift-adds of tile j (16 cycles: the pipe's own time) | LO of tile j + 1 | the two
+      // v_perm_b32 + two xor of tile j.  (Left alone the compiler gives every tile the same result registers: MFMA, MFMA, wait for the pipe,
+      // unpack, next MFMA — the wave idles through every MFMA latency.)
+      v4i hi[2], lo[2];
+      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1h[0], c128, 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[0], b1l[0], c128, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      if (j + 1 < NT) {
-        hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
+      for (int j = 0; j < NT; j++) {
+        if (j + 1 < NT) {
+          hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NT) {
+          lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j + 4 < NT) {
+          av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
+        }
+        // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
+        // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
+        ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
+        ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
         __builtin_amdgcn_sched_barrier(0);
       }
-      uint32_t h[4];
+    } else {
+      // two K chunks per window: every product is two chained MFMAs (the second accumulates onto the first), four per N-tile against the same
+      // eight VALU instructions — pass 1 is matrix-pipe-bound here.  Both chunks of all A operands are requested up front (NT = 4: 32 registers);
+      // per tile: first-chunk HI of tile j + 1 | the four shift-adds of tile j | first-chunk LO | perm / xor of tile j | the two second chunks
+      static_assert(KC == 2 && NT == 4, "two-chunk windows: 4-tile strips");
+      v4i a0[NT], a1[NT];
 #pragma unroll
-      for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
+      for (int j = 0; j < NT; j++) { a0[j] = *reinterpret_cast<const v4i*>(aptr[j]); a1[j] = *reinterpret_cast<const v4i*>(aptr[j] + 64); }
+      asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+      v4i hi[2], lo[2];
+      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[0], b1h[0], c128, 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[0], b1l[0], c128, 0, 0, 0);
+      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[0], b1h[NT], hi[0], 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[0], b1l[NT], lo[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (j + 1 < NT) {
-        lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const int n = (j + 1) & 1;
+        if (j + 1 < NT) {
+          hi[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[j + 1], b1h[j + 1], c128, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
         __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NT) {
+          lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[j + 1], b1l[j + 1], c128, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
+        ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NT) {
+          hi[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[j + 1], b1h[NT + j + 1], hi[n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[j + 1], b1l[NT + j + 1], lo[n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (j + 4 < NT) {
-        av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
-      }
-      // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
-      // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
-      ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
-      ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
-      __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_sync();  // the next tile's staging stores must not pass these reads
   };
@@ -792,6 +840,9 @@ template <int CH> struct LzMfma8n : LanczosMfmaTask<CH, 8, 2> {};  // ... of up 
 template <int CH> struct LzMfma8w : LanczosMfmaTask<CH, 8, 5> {};  // ... of up to 320 B (2x down-scales)
 template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
 template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
+template <int CH> struct LzMfma4k4 : LanczosMfmaTask<CH, 4, 4, 2> {};  // two-chunk windows (strong horizontal down-scales): staged rows of up to 256 B
+template <int CH> struct LzMfma4k6 : LanczosMfmaTask<CH, 4, 6, 2> {};  // ... 384 B
+template <int CH> struct LzMfma4k8 : LanczosMfmaTask<CH, 4, 8, 2> {};  // ... 512 B
 template <int CH> struct LzPair : LanczosPairTask<CH, 4> {};    // the two-role form: two 8-tile strips per workgroup, three workgroups per CU
 template <int CH> struct LzPairN : LanczosPairTask<CH, 2> {};
 template <int CH> struct LzPairW : LanczosPairTask<CH, 5> {};
@@ -913,7 +964,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   for (int p = 0; p < njobs; p++) in[p] = LzmPlaneIn{jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh};
   const LzmPlan plan = lzm_plan(njobs, in, n, pair ? ((8 << 8) | (forced & 0xff)) : forced, tables);  // launch shape by the cost model of vpf_lzm_plan.h
   if (!plan.ok) return false;
-  const int nt = plan.nt;
+  const int nt = plan.nt, kc = plan.kc;
   const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
   PlaneTable t{};
   LzmTableArgs wt{};
@@ -959,9 +1010,10 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     const uint32_t rows = band_tiles * 16;
     if (tables) {
       const uint32_t strips = (j.dw * (uint32_t)j.ch + 16u * nt - 1) / (16u * nt), bands = (j.dh + rows - 1) / rows, gpb = (rows + 63) / 64;
-      wt.ctab[p] = table(0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt, (uint64_t)strips * nt * 2048u, [&](u32x4* out) {
-        if (nt == 8) hipLaunchKernelGGL(k_lzm_build_cols<8>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
-        else hipLaunchKernelGGL(k_lzm_build_cols<4>, dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
+      wt.ctab[p] = table(0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt | (uint32_t)kc << 8, (uint64_t)strips * nt * kc * 2048u, [&](u32x4* out) {
+        if (nt == 8) hipLaunchKernelGGL((k_lzm_build_cols<8, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
+        else if (kc == 2) hipLaunchKernelGGL((k_lzm_build_cols<4, 2>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
+        else hipLaunchKernelGGL((k_lzm_build_cols<4, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
       });
       wt.rtab[p] = table(1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
         hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, out);
@@ -987,10 +1039,14 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const uint32_t lds = pair ? lzm_pair_group_lds(lzm_pf_of(span)) : plan.group_lds;
   if (pair) for (int p = 0; p < njobs; p++) if (!wt.ctab[p] || !wt.rtab[p]) return false;  // the two-role form reads both tables
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
-  if (lds > 64u * 1024u && !(nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
+  if (lds > 64u * 1024u && !(kc == 2 ? (lzm_pf_of(span, 2) == 8 ? lzm_big_lds_ok<LzMfma4k8>() : lzm_pf_of(span, 2) == 6 ? lzm_big_lds_ok<LzMfma4k6>() : lzm_big_lds_ok<LzMfma4k4>())
+                             : nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
                            hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t, wt); unlock.launched = true; } while (0)
-  if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);
+  if (kc == 2 && lzm_pf_of(span, 2) == 8) VPF_LZM_GO(LzMfma4k8);
+  else if (kc == 2 && lzm_pf_of(span, 2) == 6) VPF_LZM_GO(LzMfma4k6);
+  else if (kc == 2) VPF_LZM_GO(LzMfma4k4);
+  else if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);
   else if (pair && nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzPairW);
   else if (pair && nt == 8) VPF_LZM_GO(LzPair);
   else if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);

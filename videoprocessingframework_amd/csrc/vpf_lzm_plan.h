@@ -21,8 +21,8 @@ constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               
                                                                                  // per tile the Y operand of the ring's two K chunks (X is derived from it)
 constexpr uint32_t kLzmB1Chunk = 4;                                              // N-tiles whose column-weight operands are built per pass through LDS
 // staging loads per lane and source tile (PF) by strip span: 2 (rows of up to 128 B: up-scales), 4 (256 B), 5 (320 B: 2x down-scales with 8-tile
-// strips); the LDS pitch of a staged row is the variant's capacity + 32 — a compile-time constant of the kernel instantiation, = 32 (mod 64)
-constexpr int lzm_pf_of(uint32_t span) { return span <= 128u ? 2 : span <= 256u ? 4 : 5; }
+// strips), 6 / 8 (384 / 512 B: the two-chunk windows of strong down-scales); the LDS pitch of a staged row is the variant's capacity + 32 — a compile-time constant of the kernel instantiation, = 32 (mod 64)
+constexpr int lzm_pf_of(uint32_t span, int kc = 1) { return kc == 2 ? (span <= 256u ? 4 : span <= 384u ? 6 : 8) : span <= 128u ? 2 : span <= 256u ? 4 : 5; }
 constexpr uint32_t lzm_pitch_of(int pf) { return 64u * (uint32_t)pf + 32u; }
 constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
 constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of wave-private LDS: staged tile | out tile, or the setup scratch
@@ -37,16 +37,19 @@ constexpr uint32_t kLzmMaxLds = 80u * 1024u;  // two workgroups per CU share its
 
 // ---- does a plane shape fit the kernel's windows (vpf_plan_bounds.h: the tiles are walked with the kernel's own coordinate arithmetic)?
 // A per-frame caller asks the same question every call: a small per-thread cache answers it.
-struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8; bool rows_ok; };
+struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2; bool rows_ok; };  // span4k2: 4-tile strips with 128-B windows (two K chunks in pass 1)
 inline LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
   thread_local LzmShape cache[8] = {};
   thread_local uint32_t next = 0;
   for (const LzmShape& c : cache)
     if (c.ch == ch && c.sw == sw && c.sh == sh && c.dw == dw && c.dh == dh) return c;
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
-  LzmShape s{ch, sw, sh, dw, dh, 0, 0, false};
+  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, false};
   s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) != 0;
-  if (s.rows_ok) { s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8); }
+  if (s.rows_ok) {
+    s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8);
+    if (!s.span4) s.span4k2 = vpf_bound_lzm_span_win(ch, sw, dw, scx, 4, 128u);  // (asked for only where the 64-B windows do not hold the taps)
+  }
   cache[next++ & 7] = s;
   return s;
 }
@@ -71,31 +74,36 @@ struct LzmPlan {
   int nt;               // N-tiles per wave: 8 or 4
   uint32_t band_tiles;  // 16-row destination tiles per band
   uint32_t span, pitch, wave_lds, group_lds;
+  int kc;               // 64-B K chunks per pass-1 window: 1, or 2 (4-tile strips only) where a tile's taps spread over up to 128 source bytes —
+                        // horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network): taken only when no one-chunk shape fits
 };
 // forced: 0 policy | (nt << 8 | band tiles): measurement and test knob (either part may be 0 = policy)
 inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int forced, bool tables) {
-  LzmPlan P{false, 0, 0, 0, 0, 0, 0};
-  auto fits = [&](int nt, LzmPlan& q) {
+  LzmPlan P{false, 0, 0, 0, 0, 0, 0, 1};
+  auto fits = [&](int nt, int kc, LzmPlan& q) {
     uint32_t span = 0;
     for (int p = 0; p < njobs; p++) {
       const LzmShape s = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh);
       if (!s.rows_ok) return false;
-      const uint32_t sp = nt == 8 ? s.span8 : s.span4;
-      if (!sp) return false;  // some tile's taps do not fit the 64-B window
+      // (a plane whose taps fit 64-B windows fits 128-B ones: its strips are 64 B longer then)
+      const uint32_t sp = kc == 2 ? (s.span4 ? s.span4 + 64u : s.span4k2) : nt == 8 ? s.span8 : s.span4;
+      if (!sp) return false;  // some tile's taps do not fit the window
       span = std::max(span, sp);
     }
     q.span = span;
-    q.pitch = lzm_pitch_of(lzm_pf_of(span));
+    q.pitch = lzm_pitch_of(lzm_pf_of(span, kc));
     q.wave_lds = lzm_wave_lds(nt, q.pitch);
     q.group_lds = lzm_group_lds(nt, q.pitch);
-    return span <= (nt == 8 ? 5u : 4u) * 64u && q.group_lds <= kLzmMaxLds;  // PF staging loads of 4 lanes x 16 B per row
+    return span <= (kc == 2 ? 8u : nt == 8 ? 5u : 4u) * 64u && q.group_lds <= kLzmMaxLds;  // PF staging loads of 16 B per lane and row
   };
   double best = 0.0;
-  for (int cand = 8; cand >= 4; cand -= 4) {
+  for (int ci = 0; ci < 3; ci++) {
+    const int cand = ci == 0 ? 8 : 4, kc = ci == 2 ? 2 : 1;
+    if (kc == 2 && P.ok) break;  // two-chunk windows: the fallback
     if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
-    LzmPlan q{false, cand, 0, 0, 0, 0, 0};
-    if (!fits(cand, q)) continue;
-    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 ? 512.0 : 768.0;
+    LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc};
+    if (!fits(cand, kc, q)) continue;
+    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 || kc == 2 ? 512.0 : 768.0;
     uint32_t tmax = 0;
     for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
     const bool free_r = !(forced > 1 && (forced & 0xff));
@@ -107,7 +115,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         const uint32_t tiles = (jobs[p].dh + 15) / 16, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
         wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
         const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-        const double w = cand == 8 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
+        const double w = cand == 8 || kc == 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
         const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
         work = std::max(work, (double)std::min(r, tiles) * w * vert);
       }
@@ -327,11 +335,11 @@ struct LzmWorkspace {
 };
 static_assert(sizeof(LzmWorkspace) <= 40 * 8, "fits vpf_workspace::opaque");
 
-// upper bound of the table bytes one plane needs under ANY launch shape the planner may pick (column tables: strips x nt x 2 KiB, largest
-// at 8-tile strips; row tables: (bands x groups per band) x 8 KiB, bands of at least two tiles) — what vpf_resize_workspace_bytes adds up
+// upper bound of the table bytes one plane needs under ANY launch shape the planner may pick (column tables: strips x nt x K chunks x 2 KiB,
+// largest with two-chunk windows; row tables: (bands x groups per band) x 8 KiB, bands of at least two tiles) — what vpf_resize_workspace_bytes adds up
 inline uint64_t lzm_table_bytes_bound(int ch, uint32_t dw, uint32_t dh) {
   const uint64_t dwb = (uint64_t)dw * (uint64_t)ch;
-  const uint64_t cols = ((dwb + 127) / 128 + 1) * 8 * 2048;
+  const uint64_t cols = ((dwb + 127) / 128 + 1) * 8 * 2048 * 2;  // (x 2: the two-chunk windows of strong down-scales)
   const uint64_t rows = ((uint64_t)(dh + 63) / 64 + (uint64_t)(dh + 15) / 16 + 1) * kLzmWmBytes;
   return cols + rows + 2 * 256;
 }
