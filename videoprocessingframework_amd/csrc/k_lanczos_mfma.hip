@@ -38,7 +38,10 @@
 //     memory (see "Weight operands" below), the main kernel loads its strip's 2 NT column operands (16 B per lane each) and copies the row
 //     operands of 64 destination rows to LDS by LDS-DMA.  Without a table (arena full / tuning flag) the same code evaluates them in place.
 //   * blocks are numbered XCD-aware (picture_order, k_resize_common.h): neighbouring strips and bands run on one L2.
-// VGPRs: 2 x 4 x NT column operands + 2 x 4 x NT ring + two staging sets: NT = 8 -> two waves per SIMD, NT = 4 -> three.
+//   * two-chunk windows (KC = 2, 4-tile strips): where the taps of a tile's 16 bytes spread over more than 64 source bytes — horizontal
+//     factors of ~2.2 .. 6, the resize in front of a network — the window is 128 bytes and every pass-1 product two chained MFMAs (K chunk 1
+//     accumulates onto chunk 0); column operands [hi | lo][K chunk][tile].  Everything after pass 1 is the same.
+// VGPRs: 2 x 4 x NT x KC column operands + 2 x 4 x NT ring + two staging sets: NT = 8 -> two waves per SIMD, NT = 4 -> three (KC = 2: two).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
