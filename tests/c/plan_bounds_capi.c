@@ -9,5 +9,6 @@ int pb_fused_rows_fit(int r, float scy, int strip_rows) { return vpf_bound_fused
 uint32_t pb_tile_rows(uint32_t ty, float scy, int taps) { return vpf_bound_tile_rows(ty, scy, taps); }
 uint32_t pb_tile_rowq(float scx, int taps, int ch, int elem) { return vpf_bound_tile_rowq(scx, taps, ch, elem); }
 uint32_t pb_lzm_span(int ch, uint32_t sw, uint32_t dw, int nt) { return vpf_bound_lzm_span(ch, sw, dw, (float)sw / (float)dw, nt); }
+uint32_t pb_lzm_span_win(int ch, uint32_t sw, uint32_t dw, int nt, uint32_t win) { return vpf_bound_lzm_span_win(ch, sw, dw, (float)sw / (float)dw, nt, win); }
 uint32_t pb_lzm_pitch(uint32_t span) { return vpf_bound_lzm_pitch(span); }
 int pb_lzm_rows_ok(uint32_t sh, uint32_t dh) { return vpf_bound_lzm_rows_ok(sh, dh, (float)sh / (float)dh); }

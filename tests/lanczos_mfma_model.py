@@ -11,7 +11,7 @@ costs seconds instead of a GPU visit.  The weights come from the oracle (vpfo_la
 Layout facts modelled (kernel comments carry the same names):
   N-tile j of a strip   16 consecutive destination BYTES (pixel b / CH, channel b % CH); the strip = NT tiles
   window ws_j           16-B aligned source byte offset below the first tap of the tile's first pixel; all taps of the tile's 16 bytes
-                        lie in [ws_j, ws_j + 64)  (host bound, vpf_plan_bounds.h)
+                        lie in [ws_j, ws_j + 64 kc)  (host bound, vpf_plan_bounds.h; kc = 2: two chained MFMAs per product)
   pass 1                D[row i][n] = sum_k A[i][k] B[k][n],  A = source bytes - 128 (16 rows x 64 window bytes),
                         B = Q14 weight split into two signed bytes (w = 256 wh + wl): two MFMAs -> HI, LO;  h'' = ((HI + 128) << 8) + LO + 128
                         bits 8..23 of h'' = z + 128 with z = Hr - 8192 = 256 zh + zl: byte 2 = zh (signed), byte 1 ^ 0x80 = zl (signed)
@@ -56,13 +56,14 @@ def mfma_i8(A, B, c):
 
 
 class Model:
-    def __init__(self, ch, sw, sh, dw, dh, taps_x, taps_y, nt=8, band_rows=32, pitch=None, garbage_seed=1):
+    def __init__(self, ch, sw, sh, dw, dh, taps_x, taps_y, nt=8, band_rows=32, pitch=None, garbage_seed=1, kc=1):
         self.ch, self.sw, self.sh, self.dw, self.dh, self.nt, self.band = ch, sw, sh, dw, dh, nt, band_rows
+        self.kc, self.win = kc, 64 * kc   # K chunks of a pass-1 window (2: the two-chunk windows of strong horizontal down-scales, 4-tile strips)
         self.i0x, self.qx = taps_x
         self.i0y, self.qy = taps_y
         self.P = pitch
         self.rng = np.random.default_rng(garbage_seed)
-        self.max_k = 0          # largest window-relative source byte offset seen (< 64 required)
+        self.max_k = 0          # largest window-relative source byte offset seen (< 64 kc required)
         self.max_strip = 0      # largest strip-relative end of a window (<= P required)
         self.max_tile_span = 0  # largest Tmax - Tmin of a destination tile (<= 3 required)
 
@@ -87,18 +88,18 @@ class Model:
             ws.append((ch * pos0) & ~15)
         S0 = ws[0]
         # ---- pass-1 weight operands: B1[plane][j][k][n]
-        B1 = np.zeros((2, nt, 64, 16), np.int8)
+        B1 = np.zeros((2, nt, self.win, 16), np.int8)   # (K slot k of the window: chunk k >> 6, slot k & 63 of that chunk's MFMA)
         for b in range(ob0, min(ob0 + 16 * nt, dwb)):
             px, c, j, n = b // ch, b % ch, (b - ob0) >> 4, (b - ob0) & 15
             for pos, w in merged_taps(int(self.i0x[px]), self.qx[6 * px:6 * px + 6], sw):
                 k = ch * pos + c - ws[j]
-                assert 0 <= k < 64, (k, b, j)
+                assert 0 <= k < self.win, (k, b, j)
                 self.max_k = max(self.max_k, k)
                 assert B1[0, j, k, n] == 0 and B1[1, j, k, n] == 0
                 B1[0, j, k, n], B1[1, j, k, n] = split_i8(w)
-        self.max_strip = max(self.max_strip, ws[-1] - S0 + 64)
-        P = self.P if self.P else ((ws[-1] - S0 + 64 + 255) & ~255) + 32
-        assert ws[-1] - S0 + 64 <= P
+        self.max_strip = max(self.max_strip, ws[-1] - S0 + self.win)
+        P = self.P if self.P else ((ws[-1] - S0 + self.win + 255) & ~255) + 32
+        assert ws[-1] - S0 + self.win <= P
         # ---- the march
         ring = np.zeros((2, nt, 4, 16, 16), np.int8)   # [byte s: zl, zh][j][slot p][row i of the tile][n]
         ring[:] = self.rng.integers(-128, 128, ring.shape, dtype=np.int8)  # whatever it held before first use must not matter: poison
@@ -148,9 +149,11 @@ class Model:
             stage[i, :n] = src[r, S0:S0 + n]
         st8 = (stage ^ 0x80).view(np.int8)
         for j in range(nt):
-            A = st8[:, ws[j] - S0: ws[j] - S0 + 64]
-            HI = mfma_i8(A, B1[0, j], 128)
-            LO = mfma_i8(A, B1[1, j], 128)
+            HI, LO = np.int32(128), np.int32(128)
+            for c in range(self.kc):   # chunk c accumulates onto chunk c - 1 (the MFMA's C operand)
+                A = st8[:, ws[j] - S0 + 64 * c: ws[j] - S0 + 64 * c + 64]
+                HI = mfma_i8(A, B1[0, j, 64 * c:64 * c + 64], 0) + HI
+                LO = mfma_i8(A, B1[1, j, 64 * c:64 * c + 64], 0) + LO
             h2 = ((HI.astype(np.int64) << 8) + LO).astype(np.int64) & 0xffffffff
             zh = ((h2 >> 16) & 0xff).astype(np.uint8).view(np.int8)
             zl = (((h2 >> 8) & 0xff) ^ 0x80).astype(np.uint8).view(np.int8)

@@ -6,7 +6,7 @@ import pytest
 from lanczos_mfma_model import Model
 
 
-def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3):
+def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1):
     fmt = {1: oracle.Y, 3: oracle.RGB}.get(ch)
     rng = np.random.default_rng(seed)
     if ch == 2:   # a 2-channel plane = the chroma plane of an NV12 picture twice as large
@@ -17,7 +17,7 @@ def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3):
         src = [rng.integers(0, 256, (sh, sw * ch), dtype=np.uint8)]
         _, want = oracle.resize(fmt, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.FP32)
         plane, want = src[0], want[0]
-    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band)
+    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band, kc=kc)
     got = m.run(plane)
     assert np.array_equal(got, want), f"ch{ch} {sw}x{sh}->{dw}x{dh} nt{nt} band{band}: {np.argwhere(got != want)[:5]}"
     return m
@@ -29,6 +29,15 @@ def test_model_equals_the_oracle(oracle, ch):
                                        (37, 29, 53, 71, 4, 64), (7, 5, 40, 33, 8, 16), (120, 90, 57, 43, 8, 32), (40, 200, 40, 97, 4, 96),
                                        (3, 3, 9, 9, 4, 16), (1, 1, 5, 4, 4, 16), (200, 17, 95, 40, 8, 16)):
         _run(oracle, ch, sw, sh, dw, dh, nt, band)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_model_with_two_chunk_windows(oracle, ch):
+    """horizontal factors whose taps do not fit a 64-B window (the model asserts k < 64 kc for every tap): the 128-B windows hold them, the
+    second K chunk accumulating onto the first; 4-tile strips"""
+    for (sw, sh, dw, dh, band) in ((300, 40, 65, 17, 16), (480, 54, 104, 26, 32), (333, 29, 111, 23, 16), (200, 20, 37, 11, 16)):
+        m = _run(oracle, ch, sw, sh, dw, dh, 4, band, kc=2)
+        assert 64 <= m.max_k < 128   # (these shapes need the second chunk)
 
 
 def test_model_flat_and_extremes(oracle):

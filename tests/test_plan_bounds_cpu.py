@@ -23,7 +23,7 @@ def pb(tmp_path_factory):
     L = C.CDLL(so)
     for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_band_rows_exact", [C.c_int, C.c_uint32, C.c_uint32]),
                        ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
-                       ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]),
+                       ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]), ("pb_lzm_span_win", [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]),
                        ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32])):
         getattr(L, name).argtypes, getattr(L, name).restype = args, C.c_uint32
     L.pb_fused_rows_fit.argtypes, L.pb_fused_rows_fit.restype = [C.c_int, C.c_float, C.c_int], C.c_int
@@ -197,6 +197,40 @@ def test_lanczos_mfma_windows_ring_and_strip(pb, ch):
     assert n_ok > 100 and n_no > 20
     for (S, D) in ((1920, 1280), (3840, 1920), (1280, 1920), (1920, 3840), (1080, 720), (2160, 1080), (720, 1080), (960, 640), (640, 960)):
         assert pb.pb_lzm_span(ch, S, D, 8) and pb.pb_lzm_span(ch, S, D, 4) and pb.pb_lzm_rows_ok(S, D), (S, D)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_lanczos_mfma_two_chunk_windows(pb, ch):
+    """the same walk with 128-B windows (vpf_bound_lzm_span_win, two K chunks in pass 1): a non-zero span means every tap of every N-tile lies
+    in [window, window + 128) and every 4-tile strip fits the span; a shape that fits the 64-B windows fits these with strips 64 B longer;
+    the network-input shapes (1080p -> 416 / 640 wide, 720p -> 416 / 320, 4K -> 1440) are in, 1080p -> 224 is out"""
+    rng = np.random.default_rng(177 + ch)
+    n_k2 = 0
+    for (S, D) in size_pairs(rng, 400, 1.5, 8.0):
+        dwb = D * ch
+        b = np.arange(dwb)
+        px, c = b // ch, b % ch
+        i0 = lz_i0(np.arange(D), S, D)
+        lo = np.clip(i0 - 2, 0, S - 1)[px] * ch + c
+        hi = np.clip(i0 + 3, 0, S - 1)[px] * ch + c
+        first_b = np.minimum((b // 16) * 16, dwb - 1)
+        ws = (np.clip(i0 - 2, 0, S - 1)[first_b // ch] * ch) & ~15
+        span = pb.pb_lzm_span_win(ch, S, D, 4, 128)
+        one = pb.pb_lzm_span(ch, S, D, 4)
+        if one:
+            assert span == one + 64, (S, D)
+        if span:
+            assert bool((lo >= ws).all() and (hi - ws < 128).all()), (S, D, int((hi - ws).max()))
+            wst = ws[::16]
+            for s0 in range(0, len(wst), 4):
+                assert wst[min(s0 + 4, len(wst)) - 1] - wst[s0] + 128 <= span, (S, D, s0)
+            n_k2 += not one
+        else:
+            assert (hi - ws).max() + ch - 1 >= 128, (S, D)
+    assert n_k2 > 60
+    for (S, D) in ((1920, 416), (1920, 640), (1280, 416), (1280, 320), (3840, 1440), (2560, 640)):
+        assert pb.pb_lzm_span_win(ch, S, D, 4, 128) and (ch != 3 or not pb.pb_lzm_span(ch, S, D, 4)), (S, D)   # (a 1-channel plane fits 64 B up to ~2.7 x)
+    assert not pb.pb_lzm_span_win(ch, 1920, 224, 4, 128)
 
 
 def test_lanczos_mfma_pitch_is_conflict_free_for_the_a_operand_reads():
