@@ -56,8 +56,9 @@ def mfma_i8(A, B, c):
 
 
 class Model:
-    def __init__(self, ch, sw, sh, dw, dh, taps_x, taps_y, nt=8, band_rows=32, pitch=None, garbage_seed=1, kc=1):
+    def __init__(self, ch, sw, sh, dw, dh, taps_x, taps_y, nt=8, band_rows=32, pitch=None, garbage_seed=1, kc=1, rt=16):
         self.ch, self.sw, self.sh, self.dw, self.dh, self.nt, self.band = ch, sw, sh, dw, dh, nt, band_rows
+        self.rt = rt   # destination rows a 16-row tile carries: 16, or 8 (half tiles: rows 8 .. 15 repeat row 7 and are never stored)
         self.kc, self.win = kc, 64 * kc   # K chunks of a pass-1 window (2: the two-chunk windows of strong horizontal down-scales, 4-tile strips)
         self.i0x, self.qx = taps_x
         self.i0y, self.qy = taps_y
@@ -105,11 +106,14 @@ class Model:
         ring[:] = self.rng.integers(-128, 128, ring.shape, dtype=np.int8)  # whatever it held before first use must not matter: poison
         t_first = None
         t_done = None
-        ngroups = (yb - ya + 64) // 64
+        rt = self.rt
+        GR = 4 * rt                               # destination rows of a group of four tiles
+        ngroups = (yb - ya) // GR + 1
         for G in range(ngroups):
-            rows = [min(ya + 64 * G + l, yb) for l in range(64)]
+            # lane l = (tile l >> 4, row l & 15) of the group: rows past the tile's rt repeat its last one, rows past the band repeat yb
+            rows = [min(ya + GR * G + rt * (l >> 4) + min(l & 15, rt - 1), yb) for l in range(64)]
             taps = [merged_taps(int(self.i0y[y]), self.qy[6 * y:6 * y + 6], sh) for y in rows]
-            ntile = min(4, (yb - (ya + 64 * G)) // 16 + 1)
+            ntile = min(4, (yb - (ya + GR * G)) // rt + 1)
             if t_first is None:
                 t_first = taps[0][0][0] >> 4          # first source tile of the band: ring slots are numbered from it
             # vertical weight operands of the group's four destination tiles: Wm[t][X | Y][chunk c][k slot = 16 g + 8 (p & 1) + 2 r + s][y]
@@ -126,7 +130,7 @@ class Model:
                     Wm[t, 1, p >> 1, slot, y], Wm[t, 1, p >> 1, slot + 1, y] = qh, ql   # Y: qh against zl, ql against zh
             for t in range(ntile):
                 tmin = taps[16 * t][0][0] >> 4
-                tmax = taps[16 * t + 15][-1][0] >> 4
+                tmax = taps[16 * t + rt - 1][-1][0] >> 4
                 self.max_tile_span = max(self.max_tile_span, tmax - tmin)
                 assert tmax - tmin <= 3
                 if t_done is None:
@@ -136,7 +140,7 @@ class Model:
                     self.pass1(src, ring, B1, ws, S0, P, t_done, t_first)
                 # every source tile this destination tile needs is one of the last four produced
                 assert tmin >= t_done - 3
-                self.emit(dst, ring, Wm[t], ob0, ya + 64 * G + 16 * t, yb)
+                self.emit(dst, ring, Wm[t], ob0, ya + GR * G + rt * t, yb)
 
     def pass1(self, src, ring, B1, ws, S0, P, T, t_first):
         ch, nt, sw, sh = self.ch, self.nt, self.sw, self.sh
@@ -178,7 +182,7 @@ class Model:
             V = (X.astype(np.int64) << 8) + Y
             assert np.all(np.abs(V) < 2 ** 31)
             out = np.clip(V >> 12, 0, 255).astype(np.uint8)   # [n][y]
-            for y in range(16):
+            for y in range(self.rt):
                 if y0 + y > yb:
                     break
                 for n in range(16):

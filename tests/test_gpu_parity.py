@@ -1075,11 +1075,14 @@ def test_lanczos_mfma_kernel_shapes_write_the_oracle_pixels(capi, oracle, shape)
 def test_lanczos_two_chunk_windows_write_the_oracle_pixels(capi, oracle, knob):
     """Horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network): the taps of 16 destination bytes spread over more than 64
     source bytes, and the matrix-core kernel takes them with 128-B windows — pass 1 chains two MFMAs per product (LzMfma4k4 / k6 / k8 by
-    the length of the staged rows).  Tables and in-kernel weights, policy and forced band heights: 1-, 2- and 3-channel planes, every
+    the length of the staged rows).  Vertical factors of ~2.9 .. 6 (thumbnails): half tiles.  Tables and in-kernel weights, policy and forced band heights: 1-, 2- and 3-channel planes, every
     staging width, ragged widths (partial last strip / last tile), picture edges, multi-plane formats, a 33-frame batch."""
     cases = [("Y", 1408, 90, 640, 41, 2), ("RGB", 1920, 270, 416, 104, 3), ("RGB", 2200, 100, 400, 45, 2), ("NV12", 1920, 270, 640, 120, 2),
              ("YUV420", 1280, 180, 400, 70, 2), ("RGB", 1999, 131, 417, 51, 2), ("Y", 1920, 1080, 416, 416, 2), ("RGB", 640, 360, 224, 224, 33),
-             ("YUV444", 1000, 64, 217, 29, 2), ("Y", 3000, 40, 520, 17, 2), ("RGB", 700, 33, 130, 13, 2), ("NV12", 3840, 128, 1000, 50, 2)]
+             ("YUV444", 1000, 64, 217, 29, 2), ("Y", 3000, 40, 520, 17, 2), ("RGB", 700, 33, 130, 13, 2), ("NV12", 3840, 128, 1000, 50, 2),
+             # vertical factors of ~2.9 .. 6: HALF tiles (8 destination rows per 16-row MFMA tile), with one- and two-chunk windows
+             ("RGB", 1920, 1080, 480, 270, 2), ("Y", 1280, 720, 224, 224, 2), ("NV12", 1920, 1080, 384, 216, 2), ("YUV420", 1280, 720, 224, 224, 2),
+             ("RGB", 640, 1000, 427, 201, 3), ("Y", 500, 900, 700, 190, 2), ("RGB", 1000, 333, 250, 71, 2), ("Y", 300, 599, 120, 101, 33)]
     assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, knob) >= 0
     try:
         for fmt, sw, sh, dw, dh, n in cases:

@@ -6,7 +6,7 @@ import pytest
 from lanczos_mfma_model import Model
 
 
-def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1):
+def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1, rt=16):
     fmt = {1: oracle.Y, 3: oracle.RGB}.get(ch)
     rng = np.random.default_rng(seed)
     if ch == 2:   # a 2-channel plane = the chroma plane of an NV12 picture twice as large
@@ -17,7 +17,7 @@ def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1):
         src = [rng.integers(0, 256, (sh, sw * ch), dtype=np.uint8)]
         _, want = oracle.resize(fmt, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.FP32)
         plane, want = src[0], want[0]
-    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band, kc=kc)
+    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band, kc=kc, rt=rt)
     got = m.run(plane)
     assert np.array_equal(got, want), f"ch{ch} {sw}x{sh}->{dw}x{dh} nt{nt} band{band}: {np.argwhere(got != want)[:5]}"
     return m
@@ -38,6 +38,17 @@ def test_model_with_two_chunk_windows(oracle, ch):
     for (sw, sh, dw, dh, band) in ((300, 40, 65, 17, 16), (480, 54, 104, 26, 32), (333, 29, 111, 23, 16), (200, 20, 37, 11, 16)):
         m = _run(oracle, ch, sw, sh, dw, dh, 4, band, kc=2)
         assert 64 <= m.max_k < 128   # (these shapes need the second chunk)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_model_with_half_tiles(oracle, ch):
+    """vertical factors at which 16 destination rows need more than the ring's four source tiles (the model asserts the span of every tile):
+    8 rows per tile do not; with one- and two-chunk windows"""
+    for (sw, sh, dw, dh, band, kc) in ((64, 200, 40, 47, 16, 1), (300, 160, 65, 33, 8, 2), (480, 300, 104, 55, 24, 2), (90, 131, 60, 23, 32, 1)):
+        m = _run(oracle, ch, sw, sh, dw, dh, 4, band, kc=kc, rt=8)
+        assert m.max_tile_span <= 3
+    with pytest.raises(AssertionError):   # (the same shape with full tiles does not fit the ring)
+        _run(oracle, ch, 64, 200, 40, 47, 4, 16)
 
 
 def test_model_flat_and_extremes(oracle):

@@ -52,9 +52,9 @@ def lzp():
 
 def plan(L, planes, n, forced=0, tables=True):
     a = (C.c_uint32 * (5 * len(planes)))(*[v for p in planes for v in p])
-    out = (C.c_uint32 * 8)()
+    out = (C.c_uint32 * 9)()
     L.lzp_plan(len(planes), a, n, forced, int(tables), out)
-    return dict(ok=bool(out[0]), nt=out[1], r=out[2], span=out[3], pitch=out[4], wave_lds=out[5], group_lds=out[6], kc=out[7])
+    return dict(ok=bool(out[0]), nt=out[1], r=out[2], span=out[3], pitch=out[4], wave_lds=out[5], group_lds=out[6], kc=out[7], rts=out[8])
 
 
 def planes_of(fmt, sw, sh, dw, dh):
@@ -100,7 +100,7 @@ def test_planner_limits_and_forced_shapes(lzp):
     for _ in range(400):
         ch = int(rng.choice([1, 2, 3]))
         sw, sh = int(rng.integers(16, 4000)), int(rng.integers(8, 2200))
-        dw, dh = max(2, int(sw / rng.uniform(0.3, 3.5))), max(2, int(sh / rng.uniform(0.3, 3.5)))
+        dw, dh = max(2, int(sw / rng.uniform(0.3, 9.0))), max(2, int(sh / rng.uniform(0.3, 9.0)))   # (refused: beyond ~6 on either axis)
         p = plan(lzp, [(ch, sw, sh, dw, dh)], int(rng.choice([1, 4, 32])))
         if not p["ok"]:
             n_no += 1
@@ -111,7 +111,7 @@ def test_planner_limits_and_forced_shapes(lzp):
         if p["kc"] == 2:  # two-chunk windows are the fallback: no one-chunk shape holds this plane's taps
             assert p["pitch"] in (288, 416, 544)
         assert p["group_lds"] == 4 * p["wave_lds"] + 16384 and p["wave_lds"] >= 16 * p["pitch"] + 16 * (16 * p["nt"] + 16)
-        assert 1 <= p["r"] <= (dh + 15) // 16
+        assert p["rts"] in (3, 4) and 1 <= p["r"] <= (dh + (1 << p["rts"]) - 1) >> p["rts"]
     assert n_ok > 150 and n_no > 30
     base = [(3, 1920, 1080, 1280, 720)]
     assert plan(lzp, base, 32, (8 << 8) | 5)["r"] == 5 and plan(lzp, base, 32, (8 << 8) | 5)["nt"] == 8
@@ -121,6 +121,9 @@ def test_planner_limits_and_forced_shapes(lzp):
     assert net["ok"] and net["kc"] == 2 and net["nt"] == 4 and net["span"] <= 384   # they fit a 128-B one: pass 1 with two K chunks
     assert plan(lzp, base, 32)["kc"] == 1
     assert not plan(lzp, [(3, 1920, 1080, 224, 224)], 32)["ok"]                 # 8.6 x 4.8: out of every window
+    thumb = plan(lzp, [(3, 1920, 1080, 480, 270)], 32)                          # 4 x 4: a 16-row tile needs more than four source tiles, 8 rows do not
+    assert thumb["ok"] and thumb["rts"] == 3 and thumb["kc"] == 2 and plan(lzp, base, 32)["rts"] == 4
+    assert plan(lzp, [(1, 1280, 720, 224, 224), (1, 640, 360, 112, 112), (1, 640, 360, 112, 112)], 32)["rts"] == 3   # YUV420 720p -> 224 x 224 (5.7 x 3.2)
     assert not plan(lzp, base + [(1, 1920, 1080, 224, 224)], 32)["ok"]          # one plane out -> the launch is out
     mixed = plan(lzp, [(1, 1920, 1080, 640, 480), (2, 960, 540, 320, 240)], 8)  # NV12 3 x 2.25: both planes on two-chunk windows
     assert mixed["ok"] and mixed["kc"] == 2

@@ -1,4 +1,4 @@
-"""Strong horizontal down-scales (factors ~2.2 .. 6: the resize in front of a network), batched Lanczos-3: the matrix-core kernel with two-chunk
+"""Strong down-scales (horizontal factors ~2.2 .. 6: the resize in front of a network; SWEEP_THUMBS=1: both axes 3 .. 6, thumbnails), batched Lanczos-3: the matrix-core kernel with two-chunk
 windows (policy; forced band heights 4 << 8 | r) against the tile kernel (VPF_TUNE_RESIZE_MFMA = 1).  us/frame, 32 frames per dispatch, rings past
 the Infinity Cache, medians of three passes.  python tools/lanczos_k2_sweep.py"""
 import os, sys
@@ -11,6 +11,9 @@ from resize_batch_bench import surf, timed
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 SHAPES = ((1920, 1080, 416, 416), (1920, 1080, 640, 480), (1920, 1080, 480, 480), (1280, 720, 416, 416), (1280, 720, 320, 320), (3840, 2160, 1440, 810),
           (3840, 2160, 1080, 1080), (2560, 1440, 640, 640))
+if os.environ.get("SWEEP_THUMBS"):  # vertical factors of ~2.9 .. 6: half tiles
+    SHAPES = ((1920, 1080, 480, 270), (1920, 1080, 384, 216), (3840, 2160, 960, 540), (3840, 2160, 1024, 576), (1920, 1080, 512, 288), (1280, 720, 224, 224),
+              (2560, 1440, 640, 360), (1920, 1080, 416, 234))
 RS = [int(v) for v in os.environ.get("SWEEP_R", "1 2 3 4 6 8").split()]
 for fmt, fname in ((capi.RGB, "RGB"), (capi.Y, "Y"), (capi.NV12, "NV12")):
     for sw, sh, dw, dh in SHAPES:

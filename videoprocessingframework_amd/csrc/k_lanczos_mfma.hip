@@ -41,6 +41,8 @@
 //   * two-chunk windows (KC = 2, 4-tile strips): where the taps of a tile's 16 bytes spread over more than 64 source bytes — horizontal
 //     factors of ~2.2 .. 6, the resize in front of a network — the window is 128 bytes and every pass-1 product two chained MFMAs (K chunk 1
 //     accumulates onto chunk 0); column operands [hi | lo][K chunk][tile].  Everything after pass 1 is the same.
+//   * half tiles (G.a3 = 3): where 16 destination rows would need more than the ring's four source tiles — vertical factors of ~2.9 .. 6 —
+//     a tile carries 8 destination rows (rows 8 .. 15 of the MFMA tile repeat row 7 and are never stored): lzm_group_row.
 // VGPRs: 2 x 4 x NT x KC column operands + 2 x 4 x NT ring + two staging sets: NT = 8 -> two waves per SIMD, NT = 4 -> three (KC = 2: two).
 #include <algorithm>
 #include <cmath>
@@ -184,8 +186,14 @@ VPF_DEV int32_t lzm_band_first_tile(uint32_t ya, float scy, uint32_t sh) {  // f
 // t = lane >> 4 owns [chunk c][lane 16 g' + y][16 B] of the Y operand; the source tile in ring slot p = (T - t_first) & 3 sits in chunk p >> 1,
 // and source row 16 T + 4 g' + r owns the byte pair 8 (p & 1) + 2 r (zl) / + 1 (zh): Y carries qh against zl and ql against zh (the X operand —
 // qh against zh, nothing against zl — is (Y << 8) & 0xff00ff00: pass 2 derives it)
-VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb, uint32_t g, float scy, uint32_t sh, int32_t t_first) {
-  const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
+// rts = log2 of the destination rows a 16-row MFMA tile really carries: 4, or 3 — HALF tiles, for vertical factors of ~2.9 .. 6 where 16 rows
+// would need more than the ring's four source tiles: rows 8 .. 15 of every tile then repeat its row 7 and are never stored
+VPF_DEV uint32_t lzm_group_row(uint32_t lane, uint32_t ya, uint32_t yb, uint32_t g, uint32_t rts) {  // the destination row of lane (tile lane >> 4, row lane & 15) of group g
+  const uint32_t rt = 1u << rts, rr = (lane & 15u) < rt ? (lane & 15u) : rt - 1u, row = ya + (g << (rts + 2u)) + ((lane >> 4) << rts) + rr;
+  return row < yb ? row : yb;
+}
+VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb, uint32_t g, float scy, uint32_t sh, int32_t t_first, uint32_t rts) {
+  const uint32_t yrow = lzm_group_row(lane, ya, yb, g, rts);
   const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
   u32x4* z = reinterpret_cast<u32x4*>(wm);
 #pragma unroll
@@ -222,13 +230,13 @@ __global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw,
     out[(NT * KC + i) * 64 + lane] = __builtin_bit_cast(u32x4, b1l[i]);
   }
 }
-__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, u32x4* __restrict__ tab) {
+__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, uint32_t rts, u32x4* __restrict__ tab) {
   __shared__ u32x4 wm[kLzmWmBytes / 16];
   const uint32_t lane = threadIdx.x, g = blockIdx.x, ya = blockIdx.y * R;
   if (ya >= dh) return;
   const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
-  if (g > (yb - ya) / 64u) return;
-  lzm_row_group(reinterpret_cast<uint8_t*>(wm), lane, ya, yb, g, scy, sh, lzm_band_first_tile(ya, scy, sh));
+  if (g > (yb - ya) >> (rts + 2u)) return;
+  lzm_row_group(reinterpret_cast<uint8_t*>(wm), lane, ya, yb, g, scy, sh, lzm_band_first_tile(ya, scy, sh), rts);
   wave_lds_sync();
   u32x4* const out = tab + (size_t)(blockIdx.y * gridDim.x + g) * (kLzmWmBytes / 16);
 #pragma unroll
@@ -239,6 +247,7 @@ template <int CH, int NT, int PF, int KC>
 VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                               const PlaneGeom& G, uint32_t bx, uint32_t by, const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab) {
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, R = G.a1;
+  const uint32_t rts = G.a3, rt = 1u << rts;  // destination rows per 16-row tile: 16, or 8 (half tiles: vertical factors of ~2.9 .. 6, see lzm_group_row)
   constexpr uint32_t P = lzm_pitch_of(PF);  // LDS pitch of a staged row: the variant's capacity (64 PF bytes) + 32, a compile-time constant (launcher: G.a0 == P)
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -255,14 +264,14 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
   // (the 64 destination rows from ya + 64 G) for all four — a copy of the shape's row table (rtab), or, without
   // a table, evaluated here — into buffer G & 1, one group ahead of its use; the waves meet at one barrier per group.
   const int32_t t_first = __builtin_amdgcn_readfirstlane(lzm_band_first_tile(ya, scy, sh));  // first source tile of the band
-  const uint32_t ngroups = (yb - ya) / 64u + 1u;
+  const uint32_t ngroups = ((yb - ya) >> (rts + 2u)) + 1u;  // a group = four tiles
   auto produce = [&](uint32_t g) {
     uint8_t* const wm = wmb + (g & 1u) * kLzmWmBytes;
     if (rtab) {
       // a straight 8-KiB copy, global memory -> LDS: eight LDS-DMA instructions (lane l's 16 bytes land at M0 + offset + 16 l), no register
       // and no ds_write involved.  The compiler does not see these loads: the wave that issued them waits for them by hand (group_ready)
       // before the barrier that hands the group to the others.  M0 is the compiler's: saved, set and restored inside each statement.
-      const u32x4* const t = rtab + (size_t)(by * ((R + 63u) / 64u) + g) * (kLzmWmBytes / 16);
+      const u32x4* const t = rtab + (size_t)(by * ((R + (4u << rts) - 1u) >> (rts + 2u)) + g) * (kLzmWmBytes / 16);
       const uint32_t voff = 16u * lane, ldst = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(wm));
       static_assert(kLzmWmBytes == 8192, "two statements of four 1-KiB pieces");
 #pragma unroll
@@ -275,7 +284,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
                      : "=&s"(keep) : "s"(reinterpret_cast<const uint8_t*>(t) + 4096 * h), "v"(voff), "s"(ldst + 4096u * h) : "memory");
       }
     } else {
-      lzm_row_group(wm, lane, ya, yb, g, scy, sh, t_first);
+      lzm_row_group(wm, lane, ya, yb, g, scy, sh, t_first, rts);
     }
   };
   // the wave that brought group g in by DMA: everything it has in flight must have landed before it enters the barrier in front of g's use
@@ -516,8 +525,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
     const uint32_t orow = mad24(y0, dp, obase);
 #pragma unroll
     for (int it = 0; it < NT / 4; it++) {
-      const uint32_t y = y0 + (lane >> LOGNT) + RPI * it;
-      if (y <= yb) {
+      const uint32_t rl = (lane >> LOGNT) + RPI * it, y = y0 + rl;  // row of the tile
+      if (rl < rt && y <= yb) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(ord + RPI * it * PO);
         uint8_t* const out = dst + (orow + (uint32_t)(RPI * it) * dp);
         if (ofull) {
@@ -533,7 +542,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
 
   // the last source tile each row of the current group needs (lane = row), for the emit test below
   auto group_tmax = [&](uint32_t g) -> int32_t {
-    const uint32_t yrow = ya + 64u * g + lane < yb ? ya + 64u * g + lane : yb;
+    const uint32_t yrow = lzm_group_row(lane, ya, yb, g, rts);
     int32_t r = ltap_i0(yrow, scy) + 3;
     r = r < 0 ? 0 : (r > (int32_t)sh - 1 ? (int32_t)sh - 1 : r);
     return r >> 4;
@@ -550,10 +559,10 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
   pass1(T, std::integral_constant<int, S>{});                                                                       \
   T++;                                                                                                              \
   for (;;) {                                                                                                        \
-    const uint32_t tl = ((y_next - ya) >> 4) & 3u;                                                                  \
-    if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + 15) >= T) break;                                                \
+    const uint32_t tl = ((y_next - ya) >> rts) & 3u;                                                                \
+    if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + rt - 1) >= T) break;                                            \
     emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next);                                                               \
-    y_next += 16;                                                                                                   \
+    y_next += rt;                                                                                                   \
     if (y_next > yb) return;                                                                                        \
     if (tl == 3) { next_group(grp); grp++; tmax_l = group_tmax(grp); }                                              \
   }
@@ -968,6 +977,8 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const LzmPlan plan = lzm_plan(njobs, in, n, pair ? ((8 << 8) | (forced & 0xff)) : forced, tables);  // launch shape by the cost model of vpf_lzm_plan.h
   if (!plan.ok) return false;
   const int nt = plan.nt, kc = plan.kc;
+  const uint32_t rts = (uint32_t)plan.rts;  // log2 of the destination rows per tile: 4, or 3 (half tiles)
+  if (pair && rts != 4) return false;
   const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
   PlaneTable t{};
   LzmTableArgs wt{};
@@ -1010,19 +1021,19 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
     const float scx = (float)j.sw / (float)j.dw, scy = (float)j.sh / (float)j.dh;
-    const uint32_t rows = band_tiles * 16;
+    const uint32_t rows = band_tiles << rts;
     if (tables) {
-      const uint32_t strips = (j.dw * (uint32_t)j.ch + 16u * nt - 1) / (16u * nt), bands = (j.dh + rows - 1) / rows, gpb = (rows + 63) / 64;
+      const uint32_t strips = (j.dw * (uint32_t)j.ch + 16u * nt - 1) / (16u * nt), bands = (j.dh + rows - 1) / rows, gpb = (rows + (4u << rts) - 1) >> (rts + 2u);
       wt.ctab[p] = table(0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt | (uint32_t)kc << 8, (uint64_t)strips * nt * kc * 2048u, [&](u32x4* out) {
         if (nt == 8) hipLaunchKernelGGL((k_lzm_build_cols<8, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
         else if (kc == 2) hipLaunchKernelGGL((k_lzm_build_cols<4, 2>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
         else hipLaunchKernelGGL((k_lzm_build_cols<4, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
       });
-      wt.rtab[p] = table(1, j.sh, j.dh, rows, 0, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
-        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, out);
+      wt.rtab[p] = table(1, j.sh, j.dh, rows, rts, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
+        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, rts, out);
       });
     }
-    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, 0};
+    t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, rts};
     t.k[p] = (uint32_t)j.k; t.ch[p] = (uint32_t)j.ch; t.by0[p] = gy;
     const uint32_t strips_p = (j.dw * j.ch + 16u * nt - 1) / (16u * nt), bxs = pair ? (strips_p + 1) / 2 : (strips_p + 3) / 4;
     gx = bxs > gx ? bxs : gx;

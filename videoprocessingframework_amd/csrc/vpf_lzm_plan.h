@@ -37,15 +37,17 @@ constexpr uint32_t kLzmMaxLds = 80u * 1024u;  // two workgroups per CU share its
 
 // ---- does a plane shape fit the kernel's windows (vpf_plan_bounds.h: the tiles are walked with the kernel's own coordinate arithmetic)?
 // A per-frame caller asks the same question every call: a small per-thread cache answers it.
-struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2; bool rows_ok; };  // span4k2: 4-tile strips with 128-B windows (two K chunks in pass 1)
+// span4k2: 4-tile strips with 128-B windows (two K chunks in pass 1); rows_ok: 0 no | 4 a 16-row destination tile finds its source rows in the
+// ring's four source tiles | 3 only a HALF tile (8 rows) does: vertical factors of ~2.9 .. 6 (the log2 of the rows a tile carries)
+struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2; int rows_ok; };
 inline LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
   thread_local LzmShape cache[8] = {};
   thread_local uint32_t next = 0;
   for (const LzmShape& c : cache)
     if (c.ch == ch && c.sw == sw && c.sh == sh && c.dw == dw && c.dh == dh) return c;
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
-  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, false};
-  s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) != 0;
+  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, 0};
+  s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) ? 4 : vpf_bound_lzm_rows_ok_rt(sh, dh, scy, 8u) ? 3 : 0;
   if (s.rows_ok) {
     s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8);
     if (!s.span4) s.span4k2 = vpf_bound_lzm_span_win(ch, sw, dw, scx, 4, 128u);  // (asked for only where the 64-B windows do not hold the taps)
@@ -76,10 +78,18 @@ struct LzmPlan {
   uint32_t span, pitch, wave_lds, group_lds;
   int kc;               // 64-B K chunks per pass-1 window: 1, or 2 (4-tile strips only) where a tile's taps spread over up to 128 source bytes —
                         // horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network): taken only when no one-chunk shape fits
+  int rts;              // log2 of the destination rows a 16-row tile carries: 4, or 3 (half tiles) where some plane's vertical factor needs it
 };
 // forced: 0 policy | (nt << 8 | band tiles): measurement and test knob (either part may be 0 = policy)
 inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int forced, bool tables) {
-  LzmPlan P{false, 0, 0, 0, 0, 0, 0, 1};
+  LzmPlan P{false, 0, 0, 0, 0, 0, 0, 1, 4};
+  int rts = 4;  // one tile height for the launch: the smallest any plane needs
+  for (int p = 0; p < njobs; p++) {
+    const int ok = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh).rows_ok;
+    if (!ok) return P;
+    rts = std::min(rts, ok);
+  }
+  const uint32_t rt = 1u << rts;
   auto fits = [&](int nt, int kc, LzmPlan& q) {
     uint32_t span = 0;
     for (int p = 0; p < njobs; p++) {
@@ -101,18 +111,18 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
     const int cand = ci == 0 ? 8 : 4, kc = ci == 2 ? 2 : 1;
     if (kc == 2 && P.ok) break;  // two-chunk windows: the fallback
     if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
-    LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc};
+    LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc, rts};
     if (!fits(cand, kc, q)) continue;
     const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 || kc == 2 ? 512.0 : 768.0;
     uint32_t tmax = 0;
-    for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15) / 16);
+    for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + rt - 1) / rt);
     const bool free_r = !(forced > 1 && (forced & 0xff));
     for (uint32_t r = free_r ? std::min(2u, tmax) : 1u; r <= std::min(tmax, 64u); r++) {
       if (forced > 1 && (forced & 0xff) && (uint32_t)(forced & 0xff) != r && !((uint32_t)(forced & 0xff) > tmax && r == std::min(tmax, 64u))) continue;
       uint64_t wgs = 0;
       double work = 0.0;
       for (int p = 0; p < njobs; p++) {
-        const uint32_t tiles = (jobs[p].dh + 15) / 16, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
+        const uint32_t tiles = (jobs[p].dh + rt - 1) / rt, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
         wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
         const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
         const double w = cand == 8 || kc == 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
@@ -340,7 +350,7 @@ static_assert(sizeof(LzmWorkspace) <= 40 * 8, "fits vpf_workspace::opaque");
 inline uint64_t lzm_table_bytes_bound(int ch, uint32_t dw, uint32_t dh) {
   const uint64_t dwb = (uint64_t)dw * (uint64_t)ch;
   const uint64_t cols = ((dwb + 127) / 128 + 1) * 8 * 2048 * 2;  // (x 2: the two-chunk windows of strong down-scales)
-  const uint64_t rows = ((uint64_t)(dh + 63) / 64 + (uint64_t)(dh + 15) / 16 + 1) * kLzmWmBytes;
+  const uint64_t rows = ((uint64_t)(dh + 31) / 32 + (uint64_t)(dh + 15) / 16 + 1) * kLzmWmBytes;  // (groups of four HALF tiles: 32 rows)
   return cols + rows + 2 * 256;
 }
 

@@ -89,12 +89,13 @@ static inline uint32_t vpf_bound_lzm_span_win(int ch, uint32_t sw, uint32_t dw, 
 static inline uint32_t vpf_bound_lzm_span(int ch, uint32_t sw, uint32_t dw, float scx, int nt) { return vpf_bound_lzm_span_win(ch, sw, dw, scx, nt, 64u); }
 static inline uint32_t vpf_bound_lzm_pitch(uint32_t span) { return ((span + 31u) & ~63u) + 32u; }
 /* every 16-row destination tile (tiles start at multiples of 16: bands are whole tiles) spans at most four 16-row source tiles */
-static inline int vpf_bound_lzm_rows_ok(uint32_t sh, uint32_t dh, float scy) {
-  for (uint32_t y0 = 0; y0 < dh; y0 += 16) {
-    const uint32_t y1 = y0 + 15u < dh - 1u ? y0 + 15u : dh - 1u;
+static inline int vpf_bound_lzm_rows_ok_rt(uint32_t sh, uint32_t dh, float scy, uint32_t rt /* destination rows a tile carries: 16, or 8 (half tiles) */) {
+  for (uint32_t y0 = 0; y0 < dh; y0 += rt) {
+    const uint32_t y1 = y0 + rt - 1u < dh - 1u ? y0 + rt - 1u : dh - 1u;
     if ((vpf_lz_clamp(vpf_lz_i0(y1, scy) + 3, sh) >> 4) - (vpf_lz_clamp(vpf_lz_i0(y0, scy) - 2, sh) >> 4) > 3u) return 0;
   }
   return 1;
 }
+static inline int vpf_bound_lzm_rows_ok(uint32_t sh, uint32_t dh, float scy) { return vpf_bound_lzm_rows_ok_rt(sh, dh, scy, 16u); }
 
 #endif /* VPF_PLAN_BOUNDS_H_ */
