@@ -1322,8 +1322,8 @@ def test_fuzz_resize_batch(capi, oracle, seed):
             sw, sh = int(rng.integers(8, 200)), int(rng.integers(6, 40))
             dw, dh = int(sw * rng.uniform(1.0, 3.0)), int(sh * rng.uniform(1.0, 3.0))
         else:              # general down-scale
-            sw, sh = int(rng.integers(32, 900)), int(rng.integers(10, 90))
-            dw, dh = max(2, int(sw / rng.uniform(1.0, 4.0))), max(2, int(sh / rng.uniform(1.0, 4.0)))
+            sw, sh = int(rng.integers(32, 900)), int(rng.integers(10, 200))
+            dw, dh = max(2, int(sw / rng.uniform(1.0, 6.5))), max(2, int(sh / rng.uniform(1.0, 6.5)))   # (2.2 .. 6: two-chunk windows / half tiles of the matrix-core Lanczos kernel)
         n = int(rng.choice([1, 2, 3, 5]))
         align, variant = int(rng.choice([256, 256, 16, 4, 1])), int(rng.choice([0, 0, 0, 40, 43, 9]))
         f, of = getattr(capi, fmt), getattr(oracle, fmt)
