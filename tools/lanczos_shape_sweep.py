@@ -13,7 +13,8 @@ dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 PASSES = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-for fmt, fname in ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")):
+FMTS = ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")) if not os.environ.get("SWEEP_Y") else ((capi.Y, "Y"),)  # SWEEP_Y=1: one 1-channel plane
+for fmt, fname in FMTS:
     for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080), (1280, 720, 1920, 1080)):
         ring = max(N, min(128, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // N * N))
         S = [surf(fmt, sw, sh, True) for _ in range(ring)]
