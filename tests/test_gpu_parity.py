@@ -1082,7 +1082,10 @@ def test_lanczos_two_chunk_windows_write_the_oracle_pixels(capi, oracle, knob):
              ("YUV444", 1000, 64, 217, 29, 2), ("Y", 3000, 40, 520, 17, 2), ("RGB", 700, 33, 130, 13, 2), ("NV12", 3840, 128, 1000, 50, 2),
              # vertical factors of ~2.9 .. 6: HALF tiles (8 destination rows per 16-row MFMA tile), with one- and two-chunk windows
              ("RGB", 1920, 1080, 480, 270, 2), ("Y", 1280, 720, 224, 224, 2), ("NV12", 1920, 1080, 384, 216, 2), ("YUV420", 1280, 720, 224, 224, 2),
-             ("RGB", 640, 1000, 427, 201, 3), ("Y", 500, 900, 700, 190, 2), ("RGB", 1000, 333, 250, 71, 2), ("Y", 300, 599, 120, 101, 33)]
+             ("RGB", 640, 1000, 427, 201, 3), ("Y", 500, 900, 700, 190, 2), ("RGB", 1000, 333, 250, 71, 2), ("Y", 300, 599, 120, 101, 33),
+             # horizontal factors of ~6 .. 10: three-chunk (192-B) windows on 2-tile strips (LzMfma2k6 / 2k8) — the reference's sample resize
+             ("YUV420", 1920, 1080, 224, 224, 2), ("RGB", 1920, 270, 224, 56, 3), ("NV12", 3840, 540, 416, 104, 2), ("Y", 2000, 100, 201, 37, 2),
+             ("RGB", 3840, 200, 416, 77, 2), ("YUV444", 1500, 64, 170, 13, 2), ("RGB", 1283, 90, 131, 19, 33)]
     assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, knob) >= 0
     try:
         for fmt, sw, sh, dw, dh, n in cases:
@@ -1106,8 +1109,9 @@ def test_lanczos_two_chunk_windows_write_the_oracle_pixels(capi, oracle, knob):
 
 def test_kernel_selection_of_the_round_4_forms():
     """which kernel a launch takes is policy, and policy regressions are silent (same pixels): the launch log (VPF_HIP_LOG=2) names the
-    two-chunk matrix-core Lanczos kernel for a network-input down-scale, the tile kernel for one small Lanczos plane per dispatch, and the
-    march form of the row-band bilinear kernel for a large batch of Y planes"""
+    two-chunk matrix-core Lanczos kernel for a network-input down-scale, the tile kernel for one small Lanczos plane (or small multi-plane
+    frame) per dispatch, the three-chunk form for the batched sample resize, and the march form of the row-band bilinear kernel for a
+    large batch of Y planes"""
     import subprocess
     code = f"""
 import sys
@@ -1128,15 +1132,27 @@ print("A", file=sys.stderr); batch(capi.RGB, 3, 2, 1920, 1080, 416, 416, 4)
 print("B", file=sys.stderr); s, d = planes(1920, 1080, 3), planes(1280, 720, 3)
 capi.resize(ex, capi.RGB, 2, 1920, 1080, capi.planes(s[1]), 1280, 720, capi.planes(d[1])); torch.cuda.synchronize()
 print("C", file=sys.stderr); batch(capi.Y, 1, 1, 1920, 1080, 1280, 720, 32)
+def yuv420(w, h):
+    t = [planes(w, h, 1), planes(w // 2, h // 2, 1), planes(w // 2, h // 2, 1)]
+    return t, [q[1][0] for q in t]
+print("D", file=sys.stderr)
+S = [yuv420(1920, 1080) for _ in range(8)]; D = [yuv420(224, 224) for _ in range(8)]
+capi.resize(ex, capi.YUV420, 2, 1920, 1080, capi.planes(S[0][1]), 224, 224, capi.planes(D[0][1])); torch.cuda.synchronize()
+print("E", file=sys.stderr)
+capi.resize_batch(ex, capi.YUV420, 2, 1920, 1080, 224, 224, capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])); torch.cuda.synchronize()
 print("done")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, VPF_HIP_LOG="2"), timeout=300)
     assert r.returncode == 0 and "done" in r.stdout, r.stdout + r.stderr
     a, rest = r.stderr.split("\nB\n", 1)[0], r.stderr.split("\nB\n", 1)[1]
-    b, c = rest.split("\nC\n", 1)
+    b, rest = rest.split("\nC\n", 1)
+    c, rest = rest.split("\nD\n", 1)
+    d, e = rest.split("\nE\n", 1)
     assert "LzMfma4k" in a, a
     assert "k_resize_lztile" in b and "k_lanczos_mfma" not in b, b
     assert "RowBand4wm" in c, c
+    assert "TileLz" in d and "k_lanczos_mfma" not in d, d   # the reference sample's resize (YUV420 1080p -> 224 x 224), one frame per dispatch: the tile kernel
+    assert "LzMfma2k" in e, e                                # ... batched: three-chunk windows on the matrix cores
 
 
 def test_lanczos_weight_tables_across_streams(capi, oracle):

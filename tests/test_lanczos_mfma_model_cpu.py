@@ -51,6 +51,14 @@ def test_model_with_half_tiles(oracle, ch):
         _run(oracle, ch, 64, 200, 40, 47, 4, 16)
 
 
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_model_with_three_chunk_windows(oracle, ch):
+    """horizontal factors up to ~10 (1080p -> 224 x 224): 192-B windows, 2-tile strips, half tiles"""
+    for (sw, sh, dw, dh, band) in ((480, 135, 56, 28, 8), (700, 90, 77, 23, 16), (960, 64, 104, 17, 8)):
+        m = _run(oracle, ch, sw, sh, dw, dh, 2, band, kc=3, rt=8)
+        assert 128 <= m.max_k < 192
+
+
 def test_model_flat_and_extremes(oracle):
     """0 / 255 pictures exercise the signed-byte offsets: every constant that is off shows up as a uniform error"""
     for val in (0, 255, 128, 127):

@@ -100,15 +100,15 @@ def test_planner_limits_and_forced_shapes(lzp):
     for _ in range(400):
         ch = int(rng.choice([1, 2, 3]))
         sw, sh = int(rng.integers(16, 4000)), int(rng.integers(8, 2200))
-        dw, dh = max(2, int(sw / rng.uniform(0.3, 9.0))), max(2, int(sh / rng.uniform(0.3, 9.0)))   # (refused: beyond ~6 on either axis)
+        dw, dh = max(2, int(sw / rng.uniform(0.3, 14.0))), max(2, int(sh / rng.uniform(0.3, 9.0)))   # (refused: beyond ~10 across / ~6 down)
         p = plan(lzp, [(ch, sw, sh, dw, dh)], int(rng.choice([1, 4, 32])))
         if not p["ok"]:
             n_no += 1
             continue
         n_ok += 1
-        assert p["kc"] in (1, 2) and (p["kc"] == 1 or p["nt"] == 4)
-        assert p["group_lds"] <= 80 * 1024 and p["span"] <= (8 if p["kc"] == 2 else 5 if p["nt"] == 8 else 4) * 64 and p["pitch"] >= p["span"] and p["pitch"] % 64 == 32
-        if p["kc"] == 2:  # two-chunk windows are the fallback: no one-chunk shape holds this plane's taps
+        assert (p["kc"], p["nt"]) in ((1, 8), (1, 4), (2, 4), (3, 2))
+        assert p["group_lds"] <= 80 * 1024 and p["span"] <= (8 if p["kc"] >= 2 else 5 if p["nt"] == 8 else 4) * 64 and p["pitch"] >= p["span"] and p["pitch"] % 64 == 32
+        if p["kc"] >= 2:  # multi-chunk windows are the fallbacks: no cheaper shape holds this plane's taps
             assert p["pitch"] in (288, 416, 544)
         assert p["group_lds"] == 4 * p["wave_lds"] + 16384 and p["wave_lds"] >= 16 * p["pitch"] + 16 * (16 * p["nt"] + 16)
         assert p["rts"] in (3, 4) and 1 <= p["r"] <= (dh + (1 << p["rts"]) - 1) >> p["rts"]
@@ -120,11 +120,15 @@ def test_planner_limits_and_forced_shapes(lzp):
     net = plan(lzp, [(3, 1920, 1080, 416, 416)], 32)                            # 4.6 x 2.6: the taps of 16 destination bytes do not fit a 64-B window,
     assert net["ok"] and net["kc"] == 2 and net["nt"] == 4 and net["span"] <= 384   # they fit a 128-B one: pass 1 with two K chunks
     assert plan(lzp, base, 32)["kc"] == 1
-    assert not plan(lzp, [(3, 1920, 1080, 224, 224)], 32)["ok"]                 # 8.6 x 4.8: out of every window
+    res = plan(lzp, [(1, 1920, 1080, 224, 224), (1, 960, 540, 112, 112), (1, 960, 540, 112, 112)], 32)   # the reference's sample: YUV420 1080p -> 224 x 224,
+    assert res["ok"] and res["kc"] == 3 and res["nt"] == 2 and res["rts"] == 3 and res["span"] <= 384       # 8.6 x 4.8: 192-B windows, 2-tile strips, half tiles
+    assert not plan(lzp, [(3, 1920, 1080, 224, 224)], 32)["ok"] and plan(lzp, [(3, 1920, 1080, 224, 224)], 32, (4 << 8) | 2)["kc"] == 3   # packed RGB: by force only (the tile kernel is faster)
+    assert plan(lzp, [(1, 3840, 2160, 416, 416), (2, 1920, 1080, 208, 208)], 32)["kc"] == 3
+    assert not plan(lzp, [(3, 1920, 1080, 120, 120)], 32)["ok"]                 # 16 x 9: out of every window
     thumb = plan(lzp, [(3, 1920, 1080, 480, 270)], 32)                          # 4 x 4: a 16-row tile needs more than four source tiles, 8 rows do not
     assert thumb["ok"] and thumb["rts"] == 3 and thumb["kc"] == 2 and plan(lzp, base, 32)["rts"] == 4
     assert plan(lzp, [(1, 1280, 720, 224, 224), (1, 640, 360, 112, 112), (1, 640, 360, 112, 112)], 32)["rts"] == 3   # YUV420 720p -> 224 x 224 (5.7 x 3.2)
-    assert not plan(lzp, base + [(1, 1920, 1080, 224, 224)], 32)["ok"]          # one plane out -> the launch is out
+    assert not plan(lzp, base + [(1, 1920, 1080, 120, 120)], 32)["ok"]          # one plane out -> the launch is out
     mixed = plan(lzp, [(1, 1920, 1080, 640, 480), (2, 960, 540, 320, 240)], 8)  # NV12 3 x 2.25: both planes on two-chunk windows
     assert mixed["ok"] and mixed["kc"] == 2
     with_t, without = plan(lzp, base, 1, 0, True), plan(lzp, base, 1, 0, False)

@@ -231,6 +231,11 @@ def test_lanczos_mfma_two_chunk_windows(pb, ch):
     for (S, D) in ((1920, 416), (1920, 640), (1280, 416), (1280, 320), (3840, 1440), (2560, 640)):
         assert pb.pb_lzm_span_win(ch, S, D, 4, 128) and (ch != 3 or not pb.pb_lzm_span(ch, S, D, 4)), (S, D)   # (a 1-channel plane fits 64 B up to ~2.7 x)
     assert not pb.pb_lzm_span_win(ch, 1920, 224, 4, 128)
+    # ... which the 192-B windows of the three-chunk form hold (2-tile strips), like 4K -> 416; 1080p -> 120 is out of those too
+    for (S, D) in ((1920, 224), (3840, 416), (960, 112)):
+        span = pb.pb_lzm_span_win(ch, S, D, 2, 192)
+        assert 192 < span <= 512, (S, D, span)
+    assert not pb.pb_lzm_span_win(ch, 1920, 120, 2, 192)
 
 
 def test_lanczos_mfma_pitch_is_conflict_free_for_the_a_operand_reads():

@@ -14,6 +14,8 @@ SHAPES = ((1920, 1080, 416, 416), (1920, 1080, 640, 480), (1920, 1080, 480, 480)
 if os.environ.get("SWEEP_THUMBS"):  # vertical factors of ~2.9 .. 6: half tiles
     SHAPES = ((1920, 1080, 480, 270), (1920, 1080, 384, 216), (3840, 2160, 960, 540), (3840, 2160, 1024, 576), (1920, 1080, 512, 288), (1280, 720, 224, 224),
               (2560, 1440, 640, 360), (1920, 1080, 416, 234))
+if os.environ.get("SWEEP_SHAPES"):  # "sw,sh,dw,dh ..."
+    SHAPES = tuple(tuple(int(v) for v in t.split(",")) for t in os.environ["SWEEP_SHAPES"].split())
 RS = [int(v) for v in os.environ.get("SWEEP_R", "1 2 3 4 6 8").split()]
 for fmt, fname in ((capi.RGB, "RGB"), (capi.Y, "Y"), (capi.NV12, "NV12")):
     for sw, sh, dw, dh in SHAPES:

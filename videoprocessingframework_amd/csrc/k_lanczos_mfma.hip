@@ -129,15 +129,16 @@ VPF_DEV uint32_t lzm_window(uint32_t b, uint32_t dwb, uint32_t sw, float scx) {
 // pixel's slot: image edges cost nothing.
 template <int CH, int NT, int KC = 1>
 VPF_DEV void lzm_col_operands(uint8_t* lds, uint32_t lane, uint32_t ob0, uint32_t dwb, uint32_t sw, float scx, v4i (&b1h)[NT * KC], v4i (&b1l)[NT * KC]) {
-  constexpr int TPC = (int)kLzmB1Chunk / KC;       // tiles per pass through the scratch
-  constexpr uint32_t PLANE = KC * TPC * 1024u;     // bytes of the hi image (= kLzmB1Chunk KiB)
+  constexpr int TPC = (int)kLzmB1Chunk / KC > NT ? NT : ((int)kLzmB1Chunk / KC ? (int)kLzmB1Chunk / KC : 1);  // tiles per pass through the scratch (4, 2, 1 for KC = 1, 2, 3)
+  constexpr uint32_t PLANE = KC * TPC * 1024u;     // bytes of the hi image (<= kLzmB1Chunk KiB)
+  static_assert(NT % TPC == 0 && 2u * PLANE <= 2u * kLzmB1Chunk * 1024u, "the scratch holds both images of a pass");
   const uint32_t ob1 = ob0 + 16u * NT < dwb ? ob0 + 16u * NT : dwb;
 #pragma unroll
   for (int ck = 0; ck < NT / TPC; ck++) {
     const uint32_t cb0 = ob0 + 16u * TPC * ck, cb1 = cb0 + 16u * TPC < ob1 ? cb0 + 16u * TPC : ob1;  // destination bytes of the chunk
     u32x4* z = reinterpret_cast<u32x4*>(lds);
 #pragma unroll
-    for (int i = 0; i < 2 * (int)kLzmB1Chunk; i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
+    for (int i = 0; i < (int)(2u * PLANE / 1024u); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
     if (cb0 < cb1) {
       const uint32_t px_first = cb0 / CH, px_last = (cb1 - 1) / CH;
       for (uint32_t px = px_first + lane; px <= px_last; px += 64) {
@@ -428,25 +429,29 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // two K chunks per window: every product is two chained MFMAs (the second accumulates onto the first), four per N-tile against the same
-      // eight VALU instructions — pass 1 is matrix-pipe-bound here.  Both chunks of all A operands are requested up front (NT = 4: 32 registers);
-      // per tile: first-chunk HI of tile j + 1 | the four shift-adds of tile j | first-chunk LO | perm / xor of tile j | the two second chunks
-      static_assert(KC == 2 && NT == 4, "two-chunk windows: 4-tile strips");
-      v4i a0[NT], a1[NT];
+      // KC K chunks per window: every product is KC chained MFMAs (chunk c accumulates onto chunk c - 1), 2 KC per N-tile against the same
+      // eight VALU instructions — pass 1 is matrix-pipe-bound here.  All chunks of all A operands are requested up front (NT KC <= 8 reads);
+      // per tile: the first-chunk HI of tile j + 1 | the four shift-adds of tile j | first-chunk LO | perm / xor of tile j | the other chunks
+      static_assert(KC >= 2 && NT * KC <= 8, "multi-chunk windows: 4-tile strips with two chunks, 2-tile strips with three");
+      v4i ac[NT][KC];
 #pragma unroll
-      for (int j = 0; j < NT; j++) { a0[j] = *reinterpret_cast<const v4i*>(aptr[j]); a1[j] = *reinterpret_cast<const v4i*>(aptr[j] + 64); }
-      asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+      for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int c = 0; c < KC; c++) ac[j][c] = *reinterpret_cast<const v4i*>(aptr[j] + 64 * c);
       v4i hi[2], lo[2];
-      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[0], b1h[0], c128, 0, 0, 0);
-      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[0], b1l[0], c128, 0, 0, 0);
-      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[0], b1h[NT], hi[0], 0, 0, 0);
-      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[0], b1l[NT], lo[0], 0, 0, 0);
+      hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[0][0], b1h[0], c128, 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[0][0], b1l[0], c128, 0, 0, 0);
+#pragma unroll
+      for (int c = 1; c < KC; c++) {
+        hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[0][c], b1h[c * NT], hi[0], 0, 0, 0);
+        lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[0][c], b1l[c * NT], lo[0], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NT; j++) {
         const int n = (j + 1) & 1;
         if (j + 1 < NT) {
-          hi[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[j + 1], b1h[j + 1], c128, 0, 0, 0);
+          hi[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[j + 1][0], b1h[j + 1], c128, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t h[4];
@@ -454,17 +459,20 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
         for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < NT) {
-          lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[j + 1], b1l[j + 1], c128, 0, 0, 0);
+          lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[j + 1][0], b1l[j + 1], c128, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
         ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < NT) {
-          hi[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[j + 1], b1h[NT + j + 1], hi[n], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[j + 1], b1l[NT + j + 1], lo[n], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 1; c < KC; c++) {
+            hi[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[j + 1][c], b1h[c * NT + j + 1], hi[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[j + 1][c], b1l[c * NT + j + 1], lo[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -474,7 +482,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
   // pass 2 + store of one destination tile: rows y0 .. y0 + 15, weight operands of tile t of the current group
   const v4i cy = {(1 << 19) + (1 << 11), (1 << 19) + (1 << 11), (1 << 19) + (1 << 11), (1 << 19) + (1 << 11)};  // 8192 * 16384 / 256 + the rounding half
   const v4i czero = {0, 0, 0, 0};
-  constexpr uint32_t LOGNT = NT == 8 ? 3 : 2, RPI = 64 / NT;  // read-back: lane -> (row lane >> LOGNT (+ RPI per pass), unit lane & (NT - 1))
+  constexpr uint32_t LOGNT = NT == 8 ? 3 : NT == 4 ? 2 : 1, RPI = 64 / NT;  // read-back: lane -> (row lane >> LOGNT (+ RPI per pass), unit lane & (NT - 1))
   uint8_t* const owr = ot + (lane & 15) * PO + 4u * (lane >> 4);      // lane (y, g') writes bytes 4 g' .. 4 g' + 3 of every tile of row y
   const uint8_t* const ord = ot + (lane >> LOGNT) * PO + 16u * (lane & (NT - 1));
   const uint32_t ob = ob0 + 16u * (lane & (NT - 1));                   // first destination byte of the unit this lane stores
@@ -524,8 +532,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
     wave_lds_sync();
     const uint32_t orow = mad24(y0, dp, obase);
 #pragma unroll
-    for (int it = 0; it < NT / 4; it++) {
-      const uint32_t rl = (lane >> LOGNT) + RPI * it, y = y0 + rl;  // row of the tile
+    for (int it = 0; it < (NT + 3) / 4; it++) {
+      const uint32_t rl = (lane >> LOGNT) + RPI * it, y = y0 + rl;  // row of the tile (2-tile strips: lanes 32 .. 63 have none)
       if (rl < rt && y <= yb) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(ord + RPI * it * PO);
         uint8_t* const out = dst + (orow + (uint32_t)(RPI * it) * dp);
@@ -855,6 +863,8 @@ template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 template <int CH> struct LzMfma4k4 : LanczosMfmaTask<CH, 4, 4, 2> {};  // two-chunk windows (strong horizontal down-scales): staged rows of up to 256 B
 template <int CH> struct LzMfma4k6 : LanczosMfmaTask<CH, 4, 6, 2> {};  // ... 384 B
 template <int CH> struct LzMfma4k8 : LanczosMfmaTask<CH, 4, 8, 2> {};  // ... 512 B
+template <int CH> struct LzMfma2k6 : LanczosMfmaTask<CH, 2, 6, 3> {};  // three-chunk windows, 2-tile strips (factors up to ~10): staged rows of up to 384 B
+template <int CH> struct LzMfma2k8 : LanczosMfmaTask<CH, 2, 8, 3> {};  // ... 512 B
 template <int CH> struct LzPair : LanczosPairTask<CH, 4> {};    // the two-role form: two 8-tile strips per workgroup, three workgroups per CU
 template <int CH> struct LzPairN : LanczosPairTask<CH, 2> {};
 template <int CH> struct LzPairW : LanczosPairTask<CH, 5> {};
@@ -1027,6 +1037,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
       wt.ctab[p] = table(0, (uint32_t)j.ch, j.sw, j.dw, (uint32_t)nt | (uint32_t)kc << 8, (uint64_t)strips * nt * kc * 2048u, [&](u32x4* out) {
         if (nt == 8) hipLaunchKernelGGL((k_lzm_build_cols<8, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
         else if (kc == 2) hipLaunchKernelGGL((k_lzm_build_cols<4, 2>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
+        else if (kc == 3) hipLaunchKernelGGL((k_lzm_build_cols<2, 3>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
         else hipLaunchKernelGGL((k_lzm_build_cols<4, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
       });
       wt.rtab[p] = table(1, j.sh, j.dh, rows, rts, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
@@ -1053,11 +1064,13 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const uint32_t lds = pair ? lzm_pair_group_lds(lzm_pf_of(span)) : plan.group_lds;
   if (pair) for (int p = 0; p < njobs; p++) if (!wt.ctab[p] || !wt.rtab[p]) return false;  // the two-role form reads both tables
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
-  if (lds > 64u * 1024u && !(kc == 2 ? (lzm_pf_of(span, 2) == 8 ? lzm_big_lds_ok<LzMfma4k8>() : lzm_pf_of(span, 2) == 6 ? lzm_big_lds_ok<LzMfma4k6>() : lzm_big_lds_ok<LzMfma4k4>())
+  if (lds > 64u * 1024u && !(kc == 3 ? (lzm_pf_of(span, 3) == 8 ? lzm_big_lds_ok<LzMfma2k8>() : lzm_big_lds_ok<LzMfma2k6>()) : kc == 2 ? (lzm_pf_of(span, 2) == 8 ? lzm_big_lds_ok<LzMfma4k8>() : lzm_pf_of(span, 2) == 6 ? lzm_big_lds_ok<LzMfma4k6>() : lzm_big_lds_ok<LzMfma4k4>())
                              : nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
                            hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t, wt); unlock.launched = true; } while (0)
-  if (kc == 2 && lzm_pf_of(span, 2) == 8) VPF_LZM_GO(LzMfma4k8);
+  if (kc == 3 && lzm_pf_of(span, 3) == 8) VPF_LZM_GO(LzMfma2k8);
+  else if (kc == 3) VPF_LZM_GO(LzMfma2k6);
+  else if (kc == 2 && lzm_pf_of(span, 2) == 8) VPF_LZM_GO(LzMfma4k8);
   else if (kc == 2 && lzm_pf_of(span, 2) == 6) VPF_LZM_GO(LzMfma4k6);
   else if (kc == 2) VPF_LZM_GO(LzMfma4k4);
   else if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);

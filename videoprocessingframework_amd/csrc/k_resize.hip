@@ -1470,32 +1470,44 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
   {  // every plane Lanczos: one matrix-core launch for the whole format (k_lanczos_mfma.hip); planes it cannot take fall back to the gather form
     bool all_mfma = !f32;
     for (int p = 0; p < njobs; p++) all_mfma = all_mfma && fam[p] == FAM_LZ_MFMA;
-    if (all_mfma && launch_lanczos_mfma(st, njobs, jobs, n, a)) return hipGetLastError();
-    for (int p = 0; p < njobs; p++)
-      if (fam[p] == FAM_LZ_MFMA && !launch_lanczos_mfma(st, 1, &jobs[p], n, a)) fam[p] = FAM_LZ_GATHER;
-    // what the matrix-core kernel does not take (strong down-scales): the tiled separable kernel — one launch for the whole format when
-    // every plane is in that position, else plane by plane — and the gather kernel for what is left
-    bool all_lzt = !f32;
-    for (int p = 0; p < njobs; p++) all_lzt = all_lzt && fam[p] == FAM_LZ_GATHER && lz_tile_ok[p];
-    if (all_lzt) {
+    // the tiled separable kernel for every plane in ONE launch; false when it does not apply
+    auto tile_all_planes = [&]() -> bool {
       int ch[3]; uint32_t dw[3], dh[3]; float sx[3], sy[3];
       for (int p = 0; p < njobs; p++) { ch[p] = jobs[p].ch; dw[p] = jobs[p].dw; dh[p] = jobs[p].dh; sx[p] = g[p].scx; sy[p] = g[p].scy; }
       const TileShape tl = plan_tile(true, njobs, ch, dw, dh, sx, sy, n);
-      if (tl.ok) {
-        PlaneTable t{};
-        t.np = (uint32_t)njobs;
-        uint32_t gx = 0, gy = 0;
-        for (int p = 0; p < njobs; p++) {
-          t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
-          t.g[p].a0 = tl.ty; t.g[p].a1 = tl.nr; t.g[p].a2 = tl.rowq; t.g[p].a3 = tl.lshift;
-          gx = std::max(gx, (jobs[p].dw + 63) / 64);
-          gy += (jobs[p].dh + tl.ty - 1) / tl.ty;
-        }
-        if (tl.wpb == 8) launch_planes_mp<TileLz8>(st, dim3(gx, gy, n), tl.lds, a, t);
-        else launch_planes_mp<TileLz4>(st, dim3(gx, gy, n), tl.lds, a, t);
-        return hipGetLastError();
+      if (!tl.ok) return false;
+      PlaneTable t{};
+      t.np = (uint32_t)njobs;
+      uint32_t gx = 0, gy = 0;
+      for (int p = 0; p < njobs; p++) {
+        t.g[p] = g[p]; t.k[p] = (uint32_t)jobs[p].k; t.ch[p] = (uint32_t)jobs[p].ch; t.by0[p] = gy;
+        t.g[p].a0 = tl.ty; t.g[p].a1 = tl.nr; t.g[p].a2 = tl.rowq; t.g[p].a3 = tl.lshift;
+        gx = std::max(gx, (jobs[p].dw + 63) / 64);
+        gy += (jobs[p].dh + tl.ty - 1) / tl.ty;
       }
+      if (tl.wpb == 8) launch_planes_mp<TileLz8>(st, dim3(gx, gy, n), tl.lds, a, t);
+      else launch_planes_mp<TileLz4>(st, dim3(gx, gy, n), tl.lds, a, t);
+      return true;
+    };
+    // ONE frame of a multi-plane format per dispatch with a small destination (all planes together <= 1 MB: up to ~1100 x 640): a lone launch
+    // of the matrix-core kernel is a latency chain of 8-9 us whatever the picture (lanczos_single_prefers_tile above has the single-plane
+    // rule), the tile kernel — whose time follows the destination — leaves such a frame after 6-7 (profiles/r04_lanczos_single_multiplane.txt:
+    // YUV420 1080p -> 224 x 224 5.9 against 7.9 us, NV12 1080p -> 416 x 416 6.8 against 9.0; 1080p -> 720p stays on the matrix cores, 7.5
+    // against 8.3).  Only where ONE tile launch takes every plane (the chroma plane of NV12 at 8 x falls out of its windows).
+    if (all_mfma && n == 1 && njobs > 1 && !(tuning(VPF_TUNE_RESIZE_MFMA) & 0x4ffff)) {
+      uint64_t dst_b = 0;
+      bool tile_ok = true;
+      for (int p = 0; p < njobs; p++) { dst_b += (uint64_t)jobs[p].dw * jobs[p].dh * (uint32_t)jobs[p].ch; tile_ok = tile_ok && lz_tile_ok[p]; }
+      if (tile_ok && dst_b <= 1000000ull && tile_all_planes()) return hipGetLastError();
     }
+    if (all_mfma && launch_lanczos_mfma(st, njobs, jobs, n, a)) return hipGetLastError();
+    for (int p = 0; p < njobs; p++)
+      if (fam[p] == FAM_LZ_MFMA && !launch_lanczos_mfma(st, 1, &jobs[p], n, a)) fam[p] = FAM_LZ_GATHER;
+    // what the matrix-core kernel does not take (the strongest down-scales): the tiled separable kernel — one launch for the whole format when
+    // every plane is in that position, else plane by plane — and the gather kernel for what is left
+    bool all_lzt = !f32;
+    for (int p = 0; p < njobs; p++) all_lzt = all_lzt && fam[p] == FAM_LZ_GATHER && lz_tile_ok[p];
+    if (all_lzt && tile_all_planes()) return hipGetLastError();
     for (int p = 0; p < njobs; p++)
       if (fam[p] == FAM_LZ_GATHER && lz_tile_ok[p]) {
         const float sx = g[p].scx, sy = g[p].scy;

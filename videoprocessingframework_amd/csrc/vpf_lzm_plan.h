@@ -22,7 +22,7 @@ constexpr uint32_t kLzmWmBytes = 4 * 2 * 64 * 16;                               
 constexpr uint32_t kLzmB1Chunk = 4;                                              // N-tiles whose column-weight operands are built per pass through LDS
 // staging loads per lane and source tile (PF) by strip span: 2 (rows of up to 128 B: up-scales), 4 (256 B), 5 (320 B: 2x down-scales with 8-tile
 // strips), 6 / 8 (384 / 512 B: the two-chunk windows of strong down-scales); the LDS pitch of a staged row is the variant's capacity + 32 — a compile-time constant of the kernel instantiation, = 32 (mod 64)
-constexpr int lzm_pf_of(uint32_t span, int kc = 1) { return kc == 2 ? (span <= 256u ? 4 : span <= 384u ? 6 : 8) : span <= 128u ? 2 : span <= 256u ? 4 : 5; }
+constexpr int lzm_pf_of(uint32_t span, int kc = 1) { return kc == 3 ? (span <= 384u ? 6 : 8) : kc == 2 ? (span <= 256u ? 4 : span <= 384u ? 6 : 8) : span <= 128u ? 2 : span <= 256u ? 4 : 5; }
 constexpr uint32_t lzm_pitch_of(int pf) { return 64u * (uint32_t)pf + 32u; }
 constexpr uint32_t lzm_out_pitch(int nt) { return 16u * (uint32_t)nt + 16u; }   // out-transpose tile: + 16 keeps ds_write_b32 at 2-way (free)
 constexpr uint32_t lzm_wave_lds(int nt, uint32_t pitch) {                         // bytes of wave-private LDS: staged tile | out tile, or the setup scratch
@@ -39,18 +39,19 @@ constexpr uint32_t kLzmMaxLds = 80u * 1024u;  // two workgroups per CU share its
 // A per-frame caller asks the same question every call: a small per-thread cache answers it.
 // span4k2: 4-tile strips with 128-B windows (two K chunks in pass 1); rows_ok: 0 no | 4 a 16-row destination tile finds its source rows in the
 // ring's four source tiles | 3 only a HALF tile (8 rows) does: vertical factors of ~2.9 .. 6 (the log2 of the rows a tile carries)
-struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2; int rows_ok; };
+struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2, span2k3; int rows_ok; };  // span2k3: 2-tile strips, 192-B windows
 inline LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
   thread_local LzmShape cache[8] = {};
   thread_local uint32_t next = 0;
   for (const LzmShape& c : cache)
     if (c.ch == ch && c.sw == sw && c.sh == sh && c.dw == dw && c.dh == dh) return c;
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
-  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, 0};
+  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, 0, 0};
   s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) ? 4 : vpf_bound_lzm_rows_ok_rt(sh, dh, scy, 8u) ? 3 : 0;
   if (s.rows_ok) {
     s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8);
     if (!s.span4) s.span4k2 = vpf_bound_lzm_span_win(ch, sw, dw, scx, 4, 128u);  // (asked for only where the 64-B windows do not hold the taps)
+    if (!s.span4 && !s.span4k2) s.span2k3 = vpf_bound_lzm_span_win(ch, sw, dw, scx, 2, 192u);
   }
   cache[next++ & 7] = s;
   return s;
@@ -76,8 +77,9 @@ struct LzmPlan {
   int nt;               // N-tiles per wave: 8 or 4
   uint32_t band_tiles;  // 16-row destination tiles per band
   uint32_t span, pitch, wave_lds, group_lds;
-  int kc;               // 64-B K chunks per pass-1 window: 1, or 2 (4-tile strips only) where a tile's taps spread over up to 128 source bytes —
-                        // horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network): taken only when no one-chunk shape fits
+  int kc;               // 64-B K chunks per pass-1 window: 1; 2 (4-tile strips only) where a tile's taps spread over up to 128 source bytes —
+                        // horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network); 3 (2-tile strips) up to 192 bytes: factors up to
+                        // ~10 (1080p -> 224 x 224).  Each taken only when nothing cheaper fits
   int rts;              // log2 of the destination rows a 16-row tile carries: 4, or 3 (half tiles) where some plane's vertical factor needs it
 };
 // forced: 0 policy | (nt << 8 | band tiles): measurement and test knob (either part may be 0 = policy)
@@ -95,8 +97,10 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
     for (int p = 0; p < njobs; p++) {
       const LzmShape s = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh);
       if (!s.rows_ok) return false;
-      // (a plane whose taps fit 64-B windows fits 128-B ones: its strips are 64 B longer then)
-      const uint32_t sp = kc == 2 ? (s.span4 ? s.span4 + 64u : s.span4k2) : nt == 8 ? s.span8 : s.span4;
+      // (a plane whose taps fit 64-B windows fits 128-B ones: its strips are 64 B longer then; the 2-tile strips of the three-chunk form are
+      // walked for every plane of such a launch)
+      const uint32_t sp = kc == 3 ? (s.span2k3 ? s.span2k3 : vpf_bound_lzm_span_win(jobs[p].ch, jobs[p].sw, jobs[p].dw, (float)jobs[p].sw / (float)jobs[p].dw, 2, 192u))
+                          : kc == 2 ? (s.span4 ? s.span4 + 64u : s.span4k2) : nt == 8 ? s.span8 : s.span4;
       if (!sp) return false;  // some tile's taps do not fit the window
       span = std::max(span, sp);
     }
@@ -104,16 +108,21 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
     q.pitch = lzm_pitch_of(lzm_pf_of(span, kc));
     q.wave_lds = lzm_wave_lds(nt, q.pitch);
     q.group_lds = lzm_group_lds(nt, q.pitch);
-    return span <= (kc == 2 ? 8u : nt == 8 ? 5u : 4u) * 64u && q.group_lds <= kLzmMaxLds;  // PF staging loads of 16 B per lane and row
+    return span <= (kc >= 2 ? 8u : nt == 8 ? 5u : 4u) * 64u && q.group_lds <= kLzmMaxLds;  // PF staging loads of 16 B per lane and row
   };
   double best = 0.0;
-  for (int ci = 0; ci < 3; ci++) {
-    const int cand = ci == 0 ? 8 : 4, kc = ci == 2 ? 2 : 1;
-    if (kc == 2 && P.ok) break;  // two-chunk windows: the fallback
-    if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand) continue;
+  for (int ci = 0; ci < 4; ci++) {
+    const int cand = ci == 0 ? 8 : ci == 3 ? 2 : 4, kc = ci == 2 ? 2 : ci == 3 ? 3 : 1;
+    if (kc >= 2 && P.ok) break;  // multi-chunk windows: the fallbacks, in the order of their cost
+    if (kc == 3 && !(forced > 1)) {  // 2-tile strips are 32 destination BYTES: measured against the tile kernel they win on 1- and 2-channel planes
+      bool packed3 = false;          // (Y 4K -> 416 x 416 1.94 -> 1.44 us, NV12 1080p -> 224 x 224 0.85 -> 0.70) and lose on packed RGB (1.30 -> 1.58):
+      for (int p = 0; p < njobs; p++) packed3 = packed3 || jobs[p].ch == 3;  // profiles/r04_lanczos_three_chunk_sweep.txt.  A forced shape takes them anyway
+      if (packed3) continue;
+    }
+    if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand && !(kc == 3 && (forced >> 8) == 4)) continue;  // (forced 4-tile strips that do not fit: the 2-tile form may still take the launch)
     LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc, rts};
     if (!fits(cand, kc, q)) continue;
-    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 || kc == 2 ? 512.0 : 768.0;
+    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 || kc >= 2 ? 512.0 : 768.0;
     uint32_t tmax = 0;
     for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + rt - 1) / rt);
     const bool free_r = !(forced > 1 && (forced & 0xff));
@@ -125,7 +134,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         const uint32_t tiles = (jobs[p].dh + rt - 1) / rt, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
         wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
         const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-        const double w = cand == 8 || kc == 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
+        const double w = cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
         const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
         work = std::max(work, (double)std::min(r, tiles) * w * vert);
       }
@@ -349,7 +358,7 @@ static_assert(sizeof(LzmWorkspace) <= 40 * 8, "fits vpf_workspace::opaque");
 // largest with two-chunk windows; row tables: (bands x groups per band) x 8 KiB, bands of at least two tiles) — what vpf_resize_workspace_bytes adds up
 inline uint64_t lzm_table_bytes_bound(int ch, uint32_t dw, uint32_t dh) {
   const uint64_t dwb = (uint64_t)dw * (uint64_t)ch;
-  const uint64_t cols = ((dwb + 127) / 128 + 1) * 8 * 2048 * 2;  // (x 2: the two-chunk windows of strong down-scales)
+  const uint64_t cols = ((dwb + 127) / 128 + 1) * 8 * 2048 * 3;  // (x 3: the three-chunk windows of the strongest down-scales)
   const uint64_t rows = ((uint64_t)(dh + 31) / 32 + (uint64_t)(dh + 15) / 16 + 1) * kLzmWmBytes;  // (groups of four HALF tiles: 32 rows)
   return cols + rows + 2 * 256;
 }
