@@ -30,5 +30,29 @@ int main(void) {
   const double t2 = now();
   printf("[abi] 1080p NV12->RGB_PLANAR from C: host issue %.2f us/call, end to end %.2f us/frame (%.0f Gpix/s)\n", (t1 - t0) / N * 1e6,
          (t2 - t0) / N * 1e6, (double)W * H * N / (t2 - t0) / 1e9);
+  /* one vpf_resize per frame from C over a ring of frames past the Infinity Cache (what a per-frame caller pays without Python in the loop):
+   * packed RGB 1080p -> 720p, bilinear and Lanczos-3; a 1-channel plane */
+  enum { RING = 48, DW = 1280, DH = 720, SP = 3 * 1920, DP = 3 * 1280, M = 4000 };
+  unsigned char *rs[RING], *rd[RING];
+  for (int i = 0; i < RING; i++)
+    if (hipMalloc((void**)&rs[i], (size_t)SP * H) != hipSuccess || hipMalloc((void**)&rd[i], (size_t)DP * DH) != hipSuccess) return 4;
+  const vpf_size dsz = {DW, DH};
+  for (int fmt = 0; fmt < 2; fmt++)
+    for (int interp = 1; interp <= 2; interp++) {
+      const int f = fmt ? VPF_FMT_Y : VPF_FMT_RGB;
+      const unsigned sp = fmt ? 1920 : SP, dp = fmt ? 1280 : DP;
+      for (int i = 0; i < 200; i++) { vpf_plane a[3] = {{rs[i % RING], sp, 0}}, b[3] = {{rd[i % RING], dp, 0}}; vpf_resize(&ex, f, interp, sz, a, dsz, b); }
+      hipStreamSynchronize(st);
+      const double r0 = now();
+      for (int i = 0; i < M; i++) {
+        vpf_plane a[3] = {{rs[i % RING], sp, 0}}, b[3] = {{rd[i % RING], dp, 0}};
+        if (vpf_resize(&ex, f, interp, sz, a, dsz, b) != VPF_OK) return 5;
+      }
+      const double r1 = now();
+      hipStreamSynchronize(st);
+      const double r2 = now();
+      printf("[abi] %s 1920x1080->1280x720 %s, one vpf_resize per frame from C: host issue %.2f us/call, end to end %.2f us/frame\n", fmt ? "Y  " : "RGB",
+             interp == 1 ? "bilinear" : "lanczos3", (r1 - r0) / M * 1e6, (r2 - r0) / M * 1e6);
+    }
   return 0;
 }
