@@ -1,4 +1,5 @@
 #!/bin/bash
+# (apply tools/lab/bilinear_band_ablation_hooks.patch first: the product source carries no lab hooks)
 # builds tools/lab/ablate/libvpfhip_bl<N>.so = the product library with k_resize.hip compiled under -DVPF_BL_X=N (timing ablations of the row-band
 # bilinear kernel: 1 no blend, 2 no staging, 3 neither; wrong pixels) — or, for N = a file name ending in .hip, with that file in k_resize.hip's place
 cd "$(dirname "$0")/../../.."

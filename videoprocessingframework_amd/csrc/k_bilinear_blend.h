@@ -91,11 +91,7 @@ struct ColTaps {
   // instead of four ds_read_u8.  Tap 1 is read at a + CH whatever i1 says: where i1 == i0 (the picture's right edge) its weight is exactly
   // 0 and fma(0, finite, p) == p.  A pair's bytes fit the window up to a horizontal factor of 3; the 8-pixel forms exist for strips of at
   // most 1 KiB = 512 columns x 2 (plan_band), so the choice is a compile-time one and a / b cost no registers where the windows are used.
-#ifdef VPF_BL_NOWIN  // (lab builds switch the windows off for same-box A/B runs: tools/lab/ablate/build_bl.sh nowin)
-  static constexpr bool kWindowed = false;
-#else
   static constexpr bool kWindowed = CH == 2 || (CH == 1 && PX == 8);
-#endif
   static constexpr int NW = CH == 1 ? PX / 2 : PX;
   uint32_t wa[NW], ws[NW];
 };

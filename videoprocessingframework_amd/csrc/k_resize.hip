@@ -24,9 +24,6 @@
 
 #include "k_resize_common.h"
 
-#ifndef VPF_BL_X
-#define VPF_BL_X 0  // timing ablations of the row-band bilinear kernel: lab builds only (tools/lab/ablate/build_bl.sh)
-#endif
 namespace vpf {
 
 // CH interleaved channels per pixel (1, 2 or 3); 4 destination pixels per lane
@@ -317,19 +314,15 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ 
   // ... requested (all loads in flight together) ...
   Span<IT> rows[kSlots];
   auto request = [&]() {
-#if VPF_BL_X != 2 && VPF_BL_X != 3  // (timing ablations of a lab build, tools/lab/ablate/build_bl.sh: 2 / 3 leave the staging out)
 #pragma unroll
     for (int k = 0; k < kSlots; k++)
       if (r_lo + k <= r_hi) rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane);
-#endif
   };
   // ... and written to the wave's strips
   auto commit = [&]() {
-#if VPF_BL_X != 2 && VPF_BL_X != 3
 #pragma unroll
     for (int k = 0; k < kSlots; k++)
       if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, nq, lane);
-#endif
     wave_lds_sync();
   };
   const uint32_t x0 = xs + lane * PX;
@@ -352,19 +345,9 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ 
     const bool more = k + 1 < nb && ya < dh;
     if (more) { rows_of(ya); request(); }
     if (draws) {
-#if VPF_BL_X == 1 || VPF_BL_X == 3  // ablation: no blend — every destination row gets bytes straight from the strips
-      for (uint32_t y = ya_k; y <= yb_k; y++) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(strips) + ((y - ya_k) * rowq * 4 + lane * (PX * CH / 4));
-        float o[PX * CH];
-#pragma unroll
-        for (int i = 0; i < PX * CH; i++) o[i] = __uint_as_float(q[i / 4] | 0x3f000000u);
-        store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
-      }
-#else
       band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo_k, ya_k, yb_k, row_taps, T, walk, [&](uint32_t y, const float* o) {
         store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
       });
-#endif
     }
     if (!more) return;
     wave_lds_sync();  // the blend's LDS reads are done before the next band's rows overwrite the strips
