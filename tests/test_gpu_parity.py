@@ -1194,7 +1194,8 @@ def test_resize_with_a_caller_owned_workspace(capi, oracle):
     need = capi.resize_workspace_bytes(capi.RGB, capi.INTERP_LANCZOS3, 1920, 1080, 1280, 720)
     assert 256 * 1024 < need < 4 * 1024 * 1024
     assert capi.resize_workspace_bytes(capi.NV12, capi.INTERP_LANCZOS3, 1920, 1080, 1280, 720) > need // 3
-    shapes = [("RGB", 1283, 211, 857, 140), ("NV12", 1920, 240, 1280, 160), ("Y", 811, 97, 1622, 194), ("RGB", 1283, 211, 640, 97), ("YUV420", 642, 130, 1000, 200)]
+    shapes = [("RGB", 1283, 211, 857, 140), ("NV12", 1920, 240, 1280, 160), ("Y", 811, 97, 1622, 194), ("RGB", 1283, 211, 640, 97), ("YUV420", 642, 130, 1000, 200),
+              ("RGB", 1920, 270, 416, 104), ("YUV420", 1920, 540, 224, 112), ("NV12", 1920, 540, 480, 136)]   # two- / three-chunk windows, half tiles: larger column tables
     big = max(capi.resize_workspace_bytes(getattr(capi, f), 2, sw, sh, dw, dh) for f, sw, sh, dw, dh in shapes)
     mem = torch.zeros(big + 512, dtype=torch.uint8, device="cuda")
     base = (mem.data_ptr() + 255) // 256 * 256
