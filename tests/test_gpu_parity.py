@@ -22,6 +22,7 @@ from gpu_util import DevPlanes, assert_planes_equal, stream_handle  # noqa: E402
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_FUZZ_SEEDS = range(int(os.environ.get("VPF_FUZZ_FIRST", "0")), int(os.environ.get("VPF_FUZZ_FIRST", "0")) + int(os.environ.get("VPF_FUZZ_SEEDS", "64")))
 MATS = [(0, 0), (0, 1), (1, 0), (1, 1)]
 
 
@@ -597,7 +598,7 @@ FUZZ_PAIRS = [("NV12", "RGB"), ("NV12", "BGR"), ("NV12", "RGB_PLANAR"), ("YUV420
               ("NV12", "Y"), ("Y", "YUV444"), ("P10", "NV12"), ("RGB", "RGB_32F"), ("RGB_PLANAR", "YUV420"), ("YUV420", "RGB_PLANAR")]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))  # soak: VPF_FUZZ_SEEDS=500
+@pytest.mark.parametrize("seed", _FUZZ_SEEDS)  # soak: VPF_FUZZ_SEEDS=500 (VPF_FUZZ_FIRST=n: seeds n .. n + VPF_FUZZ_SEEDS - 1, fresh cases)
 def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     for _ in range(12):
@@ -630,7 +631,7 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
         _convert(capi, oracle, getattr(capi, s), getattr(capi, d), cs, cr, w, h, src, align, extra, offset, variant=variant)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
+@pytest.mark.parametrize("seed", _FUZZ_SEEDS)
 def test_fuzz_resize_and_fused(capi, oracle, seed):
     """random (format, filter, source size, destination size, alignment, kernel family): the tiled / row-pair / gather
     resize kernels and the LDS / gather fused kernels against the oracle, bit for bit"""
@@ -685,7 +686,7 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
             assert max(int(np.abs(g.astype(int) - e.astype(int)).max()) for g, e in zip(got, exact)) <= 1, f"{what} {sw}x{sh}->{dw}x{dh}: HIP vs EXACT > 1 LSB"
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
+@pytest.mark.parametrize("seed", _FUZZ_SEEDS)
 def test_fuzz_remap(capi, oracle, seed):
     """random source size, map size (!= source size), map family (affine / noisy / mostly out of range, with NaN and Inf
     entries), pixel format, alignment, kernel: out-of-range destinations keep their previous content"""
@@ -1318,7 +1319,7 @@ def test_lanczos_weight_table_arena_full(tmp_path):
         assert r.returncode == 0 and "ARENA-OK 24" in r.stdout, (kb, r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VPF_FUZZ_SEEDS", "64"))))
+@pytest.mark.parametrize("seed", _FUZZ_SEEDS)
 def test_fuzz_resize_batch(capi, oracle, seed):
     """random format (multi-plane formats exercise the one-launch-for-all-planes kernels, odd sizes give the chroma planes their own
     scale factors), filter, size pair (incl. exact 2x, odd integer factors, up-scales), frame count, alignment and kernel family: every
