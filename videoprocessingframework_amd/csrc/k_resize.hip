@@ -652,9 +652,10 @@ __global__ __launch_bounds__(64 * WPB) void k_resize_tile(const uint8_t* __restr
   TileTask<CH, WPB>::run(src, sp, dst, dp, PlaneGeom{sw, sh, dw, dh, scx, scy, vec_ok, tile_rows, nr_cap, rowq, lshift}, blockIdx.x, blockIdx.y);
 }
 // ------------------------------------------------------------------------------------------
-// Tiled, separable 8-bit LANCZOS-3 for the shapes the matrix-core kernel (k_lanczos_mfma.hip) cannot hold — scale factors above ~2.4,
-// i.e. the 1080p -> 416 x 416 / 608 x 608 / 224 x 224 resizes in front of a network, where its 64-B tap windows or its four-tile ring are
-// too small.  Same integer filter definition as that kernel, the gather kernel and the oracle: exact Q14 horizontal sums,
+// Tiled, separable 8-bit LANCZOS-3 for what the matrix-core kernel (k_lanczos_mfma.hip) does not take: packed RGB beyond ~6 x and any plane
+// beyond ~10 x across / ~6 x down (its tap windows and its four-tile ring end there), and ONE small frame per dispatch, where this kernel's
+// short waves finish sooner than that kernel's latency chain (lanczos_single_prefers_tile, launch_resize_jobs).
+// Same integer filter definition as that kernel, the gather kernel and the oracle: exact Q14 horizontal sums,
 // Hr = (H + 128) >> 8, vertical taps on byte-wide partial products with clamped taps merged per source row.  A workgroup of WPB waves owns
 // a tile of 64 columns x TY rows:
 //   phase 0  the tile's whole source window goes to LDS in one sweep of dense 16-B loads (edge tiles: the pixels clamped taps fall on are
