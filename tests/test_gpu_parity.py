@@ -923,8 +923,9 @@ def test_tiled_resize_shapes_write_identical_pixels(capi, oracle, shape):
 
 @pytest.mark.parametrize("shape", [None, (8, 4), (8, 8), (16, 8), (32, 8), (12, 4)])
 def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
-    """The tiled separable Lanczos kernel (LanczosTileTask) takes what the matrix-core kernel cannot hold — scale factors above ~2.4: the
-    resizes in front of a network — and, with that kernel switched off (VPF_TUNE_RESIZE_MFMA = 1), everything else as well.  By policy and
+    """The tiled separable Lanczos kernel (LanczosTileTask) takes what the matrix-core kernel does not — the strongest down-scales, one small
+    frame per dispatch — and, with that kernel switched off (VPF_TUNE_RESIZE_MFMA = 1), everything else as well.  By policy, with the matrix
+    cores forced onto single frames too (| 0x40000), and
     with forced tile shapes (VPF_TUNE_RESIZE_TILE): strong and mild down-scales, up-scales, tiles on the left / right image edge (margins
     replicated), clamped rows merged at the top / bottom, pictures smaller than the filter, multi-plane formats in one launch, planes of a
     format that go different ways (NV12 chroma past the window limit), a 33-frame batch, single frames through vpf_resize."""

@@ -12,8 +12,9 @@
 //   RowBandTask                   batches: R destination rows per wave, column taps once, each source row's horizontal lerp once per band
 //   TileTask (k_resize_tile), TileTaskF32   tiled + separable: horizontal pass once per (source row, column) into LDS, then the vertical pass
 //                                 (8-bit: bilinear up-scales of a single frame; float surfaces: Lanczos-3, bilinear with tuning 43)
-//   8-bit Lanczos-3               k_lanczos_mfma.hip (the i8 matrix cores) wherever its tap windows fit; LanczosTileTask below for the
-//                                 scale factors beyond them (above ~2.4); LanczosGatherTask for what is left
+//   8-bit Lanczos-3               k_lanczos_mfma.hip (the i8 matrix cores) wherever its tap windows fit (down-scales up to ~6 x, 1- / 2-channel
+//                                 planes ~10 x across); LanczosTileTask below beyond them and for one small frame per dispatch;
+//                                 LanczosGatherTask for what is left
 //   HalfTask, Half3R16Task        exact 2x: quad-structured streaming kernels (no taps, no gathers; integer blend)
 //   odd integer factors on both axes   every filter returns the centre sample -> nearest kernel (Lanczos) / RowPairTask's byte-move path
 //   packed RGB taps               both taps of a row = 6 contiguous bytes: fetched as ONE 12-B window from the aligned address below
