@@ -87,7 +87,7 @@ def lib() -> C.CDLL:
     return _lib
 
 
-A2_CHROMA_UPSAMPLE, A6_CHROMA_DECIMATE, A8_RESIZE_COORDS = 2, 6, 8
+A2_CHROMA_UPSAMPLE, A6_CHROMA_DECIMATE, A8_RESIZE_COORDS, A10_LANCZOS_MINIFY = 2, 6, 8, 10
 
 
 class assume:

@@ -5,7 +5,7 @@
  * Every function cites the reference lines (relative to /root/reference) whose behaviour it
  * restates.  The arithmetic itself is NOT in the reference tree (closed-source NPP); formulas are
  * the ones published in NPP's colour-conversion documentation and the BT.601/BT.709 matrices
- * (assumption register A1-A9).
+ * (assumption register A1-A10).
  */
 #include "vpf_oracle.h"
 
@@ -41,17 +41,19 @@ void vpfo_release_threads(void) {
  * moves results by far more than 1 LSB.  Defaults are the conventions the HIP kernels implement.  Non-default values
  * change VPFO_EXACT only (FP32 restates the kernels and returns VPFO_UNSUPPORTED under a non-default switch), so that a
  * mismatch on first contact with real NPP output (tests/test_reference_fixtures.py) is settled by flipping a switch. */
-static int g_a2 = 0, g_a6 = 0, g_a8 = 0;
+static int g_a2 = 0, g_a6 = 0, g_a8 = 0, g_a10 = 0;
 int vpfo_set_assumption(int key, int value) {
-  int* g = key == VPFO_A2_CHROMA_UPSAMPLE ? &g_a2 : key == VPFO_A6_CHROMA_DECIMATE ? &g_a6 : key == VPFO_A8_RESIZE_COORDS ? &g_a8 : 0;
-  const int hi = key == VPFO_A6_CHROMA_DECIMATE ? 1 : 2;
+  int* g = key == VPFO_A2_CHROMA_UPSAMPLE ? &g_a2 : key == VPFO_A6_CHROMA_DECIMATE ? &g_a6 : key == VPFO_A8_RESIZE_COORDS ? &g_a8
+           : key == VPFO_A10_LANCZOS_MINIFY ? &g_a10 : 0;
+  const int hi = key == VPFO_A6_CHROMA_DECIMATE || key == VPFO_A10_LANCZOS_MINIFY ? 1 : 2;
   if (!g || value < 0 || value > hi) return -1;
   const int prev = *g;
   *g = value;
   return prev;
 }
 int vpfo_get_assumption(int key) {
-  return key == VPFO_A2_CHROMA_UPSAMPLE ? g_a2 : key == VPFO_A6_CHROMA_DECIMATE ? g_a6 : key == VPFO_A8_RESIZE_COORDS ? g_a8 : -1;
+  return key == VPFO_A2_CHROMA_UPSAMPLE ? g_a2 : key == VPFO_A6_CHROMA_DECIMATE ? g_a6 : key == VPFO_A8_RESIZE_COORDS ? g_a8
+         : key == VPFO_A10_LANCZOS_MINIFY ? g_a10 : -1;
 }
 const char* vpfo_version(void) { return "vpf-oracle 1 (parity unpinned: NPP closed source)"; }
 
@@ -704,7 +706,12 @@ static int resize_plane(int mode, int interp, int ch, uint32_t sw, uint32_t sh, 
  * Lanczos-3 (interp = 2).  The reference's resizer asks NPP for NPPI_INTER_LANCZOS (Tasks.cpp:1190,1248); NPP's
  * exact kernel support / normalisation is unpublished, so this is the textbook separable Lanczos-3:
  *   s = (d + 0.5) * S/D - 0.5;  i0 = floor(s);  f = s - i0;  taps i0-2 .. i0+3 (indices clamped to the image),
- *   w_k = L(f - (k - 2)),  L(t) = sinc(t) sinc(t/3),  weights normalised to sum 1, no widening when minifying.
+ *   w_k = L(f - (k - 2)),  L(t) = sinc(t) sinc(t/3),  weights normalised to sum 1, no widening when minifying [A10 = 0].
+ * A10 = 1 (EXACT mode only; round 5): the OTHER plausible reading of "NPPI_INTER_LANCZOS" — the anti-aliasing form PIL and
+ * swscale implement: when minifying, the kernel is stretched by fs = max(1, S/D) per axis, taps = every source sample i with
+ * |i - s| < 3 fs, w_i = L((i - s) / fs), normalised (resize_plane_lanczos_wide).  On up-scales (fs = 1) the two coincide tap for tap;
+ * on a 1.5 x down-scale they differ by a mean of ~8 LSB (max 30+) on noise, so which one NPP follows decides whether the kernels'
+ * six-tap windows are the right filter at all (the pin kit classifies it from NPP's impulse response).
  * EXACT: double + libm.  FP32: the kernels' arithmetic — sin(pi f), sin(pi f/3), cos(pi f/3) from fixed fma polynomials (so host
  * and device agree bit for bit), the six taps from angle-addition identities; on 8-bit surfaces BOTH passes then run in integers on
  * Q14 weights (lanczos_weights_q14) with the row sums rounded to Q6 in between and the vertical products formed from byte-wide partial
@@ -811,8 +818,74 @@ int vpfo_lanczos_taps_q14(uint32_t S, uint32_t D, int32_t* i0, int32_t* q) {
   }
   return VPFO_OK;
 }
+/* A10 = 1: Lanczos-3 with the support scaled by the minification factor (EXACT arithmetic: double + libm; 8-bit: round half up, clamp;
+ * float: no rounding).  Separable, horizontal pass first into a double image, indices beyond the picture clamp onto the edge sample
+ * (the same border rule as the six-tap form, so that A10 is the ONLY thing the switch changes: at fs = 1 the taps are i0-2 .. i0+3 with
+ * the same weights).  Source coordinate by A8. */
+typedef struct { int32_t first, n; double* w; } wtap;
+static int make_wtaps(uint32_t S, uint32_t D, wtap** out) {
+  const double fs = (double)S / (double)D > 1.0 ? (double)S / (double)D : 1.0, sup = 3.0 * fs;
+  wtap* t = (wtap*)calloc(D, sizeof(wtap));
+  if (!t) return 0;
+  for (uint32_t d = 0; d < D; d++) {
+    const double s = src_coord(d, S, D);
+    const int32_t lo = (int32_t)ceil(s - sup), hi = (int32_t)floor(s + sup);
+    t[d].first = lo; t[d].n = hi - lo + 1;
+    t[d].w = (double*)malloc(sizeof(double) * (size_t)t[d].n);
+    if (!t[d].w) { for (uint32_t k = 0; k < d; k++) free(t[k].w); free(t); return 0; }
+    double sum = 0;
+    for (int32_t k = 0; k < t[d].n; k++) {
+      const double x = ((double)(lo + k) - s) / fs;
+      const double w = x == 0.0 ? 1.0 : fabs(x) >= 3.0 ? 0.0 : 3.0 * sin(M_PI * x) * sin(M_PI * x / 3.0) / (M_PI * M_PI * x * x);
+      t[d].w[k] = w; sum += w;
+    }
+    for (int32_t k = 0; k < t[d].n; k++) t[d].w[k] /= sum;
+  }
+  *out = t;
+  return 1;
+}
+static void free_wtaps(wtap* t, uint32_t D) { if (t) { for (uint32_t d = 0; d < D; d++) free(t[d].w); free(t); } }
+static int resize_plane_lanczos_wide(int is_f32, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw, uint32_t dh, const vpfo_plane* d) {
+  wtap *tx = 0, *ty = 0;
+  const size_t rowv = (size_t)dw * (size_t)ch;
+  double* H = (double*)malloc(sizeof(double) * rowv * sh);
+  if (!H || !make_wtaps(sw, dw, &tx) || !make_wtaps(sh, dh, &ty)) { free(H); free_wtaps(tx, dw); free_wtaps(ty, dh); return VPFO_BAD_ARG; }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int64_t y = 0; y < (int64_t)sh; y++) {
+    const uint8_t* r8 = prow(s, (uint32_t)y);
+    const float* rf = (const float*)r8;
+    for (uint32_t x = 0; x < dw; x++)
+      for (int c = 0; c < ch; c++) {
+        double a = 0;
+        for (int32_t k = 0; k < tx[x].n; k++) {
+          int32_t i = tx[x].first + k;
+          i = i < 0 ? 0 : (i > (int32_t)sw - 1 ? (int32_t)sw - 1 : i);
+          a += tx[x].w[k] * (is_f32 ? (double)rf[ch * i + c] : (double)r8[ch * i + c]);
+        }
+        H[(size_t)y * rowv + (size_t)ch * x + c] = a;
+      }
+  }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int64_t y = 0; y < (int64_t)dh; y++) {
+    uint8_t* o8 = prow(d, (uint32_t)y);
+    float* of = (float*)o8;
+    for (size_t v = 0; v < rowv; v++) {
+      double a = 0;
+      for (int32_t k = 0; k < ty[y].n; k++) {
+        int32_t i = ty[y].first + k;
+        i = i < 0 ? 0 : (i > (int32_t)sh - 1 ? (int32_t)sh - 1 : i);
+        a += ty[y].w[k] * H[(size_t)i * rowv + v];
+      }
+      if (is_f32) of[v] = (float)a;
+      else { const double r = floor(a + 0.5); o8[v] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
+    }
+  }
+  free(H); free_wtaps(tx, dw); free_wtaps(ty, dh);
+  return VPFO_OK;
+}
 static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw, uint32_t dh,
                                 const vpfo_plane* d) {
+  if (mode == VPFO_EXACT && g_a10 == 1) return resize_plane_lanczos_wide(0, ch, sw, sh, s, dw, dh, d);
   ltap* tx = (ltap*)malloc(sizeof(ltap) * dw);
   ltap* ty = (ltap*)malloc(sizeof(ltap) * dh);
   if (!tx || !ty) { free(tx); free(ty); return VPFO_BAD_ARG; }
@@ -870,6 +943,7 @@ static int resize_plane_lanczos(int mode, int ch, uint32_t sw, uint32_t sh, cons
 static int resize_plane_f32(int mode, int interp, int ch, uint32_t sw, uint32_t sh, const vpfo_plane* s, uint32_t dw,
                             uint32_t dh, const vpfo_plane* d) {
   if (interp == 2) {
+    if (mode == VPFO_EXACT && g_a10 == 1) return resize_plane_lanczos_wide(1, ch, sw, sh, s, dw, dh, d);
     ltap* tx = (ltap*)malloc(sizeof(ltap) * dw);
     ltap* ty = (ltap*)malloc(sizeof(ltap) * dh);
     if (!tx || !ty) { free(tx); free(ty); return VPFO_BAD_ARG; }
@@ -932,7 +1006,7 @@ static int resize_plane_f32(int mode, int interp, int ch, uint32_t sw, uint32_t 
 int vpfo_resize(int mode, int fmt, int interp, uint32_t sw, uint32_t sh, const vpfo_plane s[3], uint32_t dw,
                 uint32_t dh, const vpfo_plane d[3]) {
   if (interp != 0 && interp != 1 && interp != 2) return VPFO_UNSUPPORTED;
-  if (mode != VPFO_EXACT && g_a8) return VPFO_UNSUPPORTED; /* FP32 restates the kernels: default convention only */
+  if (mode != VPFO_EXACT && (g_a8 || (g_a10 && interp == 2))) return VPFO_UNSUPPORTED; /* FP32 restates the kernels: default conventions only */
   if (!sw || !sh || !dw || !dh) return VPFO_BAD_ARG;
   if (!check_planes(fmt, sw, s) || !check_planes(fmt, dw, d)) return (nplanes(fmt) ? VPFO_BAD_ARG : VPFO_UNSUPPORTED);
   switch (fmt) {

@@ -22,6 +22,11 @@ struct FakeSync final : vpf::LzmSync {
   void wait(const void* stream, void* ev) override { log += "W" + std::to_string((uint64_t)(uintptr_t)ev) + "@" + std::to_string((uint64_t)(uintptr_t)stream) + " "; }
   void destroy(void*) override { live--; }
   bool device_alive(int dev) override { const bool a = alive[dev]; alive[dev] = true; return a; }
+  uint64_t capturing = 0, gone = 0;  // one stream each the test declares "under capture" / "destroyed"
+  int stream_state(const void* stream) override {
+    const uint64_t s = (uint64_t)(uintptr_t)stream;
+    return s && s == capturing ? 1 : s && s == gone ? 2 : 0;
+  }
 };
 struct Cache {
   FakeSync sync;
@@ -69,6 +74,7 @@ uint32_t lzp_cache_entries(void* c, int dev) { Cache* C = static_cast<Cache*>(c)
 void lzp_sync_complete(void* c, uint64_t upto) { static_cast<Cache*>(c)->sync.completed_upto = upto; }
 uint64_t lzp_sync_next(void* c) { return static_cast<Cache*>(c)->sync.next; }
 int lzp_sync_live(void* c) { return static_cast<Cache*>(c)->sync.live; }
+void lzp_sync_stream_states(void* c, uint64_t capturing, uint64_t gone) { static_cast<Cache*>(c)->sync.capturing = capturing; static_cast<Cache*>(c)->sync.gone = gone; }
 void lzp_sync_reset_device(void* c, int dev) { static_cast<Cache*>(c)->sync.alive[dev] = false; }
 // copies the log (and clears it) -> length
 int lzp_sync_log(void* c, char* out, int cap) {
@@ -81,9 +87,9 @@ int lzp_sync_log(void* c, char* out, int cap) {
 }
 // the workspace record: ws = 40 zeroed uint64 the caller owns -> off16 | build << 31
 uint32_t lzp_ws_get(uint64_t* opaque, uint64_t region_bytes, uint64_t stream, int dev, int capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3,
-                    uint64_t bytes, uint32_t pinned_from) {
+                    uint64_t bytes, uint32_t* touched) {
   vpf::LzmWorkspace* w = reinterpret_cast<vpf::LzmWorkspace*>(opaque);
-  const vpf::LzmTableCache::Hit h = w->get(region_bytes, reinterpret_cast<const void*>(stream), dev, capturing != 0, kind, k0, k1, k2, k3, bytes, pinned_from);
+  const vpf::LzmTableCache::Hit h = w->get(region_bytes, reinterpret_cast<const void*>(stream), dev, capturing != 0, kind, k0, k1, k2, k3, bytes, touched);
   return h.off16 | (h.build ? 0x80000000u : 0u);
 }
 uint32_t lzp_ws_n(const uint64_t* opaque) { return reinterpret_cast<const vpf::LzmWorkspace*>(opaque)->n; }

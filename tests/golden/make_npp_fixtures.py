@@ -90,7 +90,8 @@ def synth(fmt, w, h, seed, dist="A"):
 
 
 def verify_only(out_dir):
-    """Per fixture: the A2 / A6 / A8 combinations (oracle EXACT mode) within 1 LSB of every recorded output, and the quirk classification."""
+    """Per fixture: the A2 / A6 / A8 (/ A10 for resizes) combinations (oracle EXACT mode) within 1 LSB of every recorded output, the quirk
+    classification, and for every recorded down-scale which reading of A10 (Lanczos support when minifying) it follows."""
     root = os.path.dirname(os.path.dirname(HERE))
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "tests"))
@@ -124,7 +125,9 @@ def verify_only(out_dir):
             for key in (k for k in z.files if k.startswith("out_")):
                 dw, dh = (int(v) for v in key[4:].split("x"))
                 run = lambda: o.resize(getattr(o, fmt), o.LANCZOS3, w, h, src, dw, dh, o.EXACT)  # noqa: E731
-                lines.append(f"-> {dw}x{dh}: {T.describe_hits(T.which_assumptions(o, run, z[key]), default)}")
+                lines.append(f"-> {dw}x{dh}: {T.describe_hits(T.which_assumptions(o, run, z[key], lanczos=True), default)}")
+                if (dw < w or dh < h) and quirk != "R2":
+                    lines.append(f"-> {dw}x{dh}: assumption A10 -> {T.classify_a10(o, fmt, w, h, src, dw, dh, z[key])}")
                 if quirk == "R2":
                     lines.append(f"-> {dw}x{dh}: quirk R2 -> {T.classify_r2(o, w, h, src, dw, dh, z[key])}")
         elif kind == "remap":

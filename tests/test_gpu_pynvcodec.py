@@ -609,6 +609,22 @@ def test_resizer_and_remaper_execute_batch(oracle):
         assert np.array_equal(download(rm.Execute(srcs[i]))[inside], want[inside])
 
 
+def test_one_resizer_fed_many_source_shapes_with_a_shared_width(oracle):
+    """ResizeSurface keeps ONE table workspace for its destination size, whatever the sources.  Sources that share a width
+    share their column tables (a HIT in the workspace record) while every new height adds row tables — until the eight-entry record is
+    full and the launch that has just hit the column tables misses on the row tables: round 4 started the record over there and handed the
+    hit tables' bytes to the new build (one corrupted frame).  Now that table goes to the arena.  Every frame equals the oracle."""
+    dw, dh = 640, 360
+    for name in ("NV12", "YUV420", "RGB"):
+        fmt, ofmt = getattr(PF, name), getattr(oracle, name)
+        rs = nvc.PySurfaceResizer(dw, dh, fmt, GPU)   # default filter: Lanczos-3, the one with tables
+        for rnd, (w, h) in enumerate([(960, 540), (960, 544), (960, 536), (960, 528), (960, 520), (960, 512), (960, 540), (968, 540), (960, 544), (960, 504)]):
+            planes = oracle.synth(ofmt, w, h, 700 + rnd)
+            got = download(rs.Execute(upload(fmt, w, h, planes)))
+            want = host_frame(oracle.resize(ofmt, 2, w, h, planes, dw, dh, oracle.FP32)[1])
+            assert np.array_equal(got, want), (name, rnd, w, h)
+
+
 def test_resizer_and_remaper_async_opt_out(oracle):
     """additive SetAsync(True): Execute() stops waiting for the stream (default: blocking, like the reference's cuda_stream_sync callback);
     same pixels once the stream is synchronised"""

@@ -40,9 +40,10 @@ def lzp():
     L.lzp_sync_next.argtypes = [C.c_void_p]
     L.lzp_sync_live.argtypes = [C.c_void_p]
     L.lzp_sync_reset_device.argtypes = [C.c_void_p, C.c_int]
+    L.lzp_sync_stream_states.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.lzp_sync_log.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.lzp_ws_get.restype = C.c_uint32
-    L.lzp_ws_get.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int, C.c_int] + [C.c_uint32] * 5 + [C.c_uint64, C.c_uint32]
+    L.lzp_ws_get.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int, C.c_int] + [C.c_uint32] * 5 + [C.c_uint64, C.POINTER(C.c_uint32)]
     L.lzp_ws_n.restype = C.c_uint32
     L.lzp_ws_n.argtypes = [C.POINTER(C.c_uint64)]
     L.lzp_table_bytes_bound.restype = C.c_uint64
@@ -231,21 +232,70 @@ def test_table_cache_evicts_least_recently_used_behind_its_last_use(lzp):
     assert live_before <= 2 * 3 + 1                            # events are released as entries go: no leak over 10 000 evictions
 
 
+def test_table_cache_eviction_leaves_foreign_streams_alone_when_it_must(lzp):
+    """the streams an entry remembers are somebody else's handles from earlier launches.  At eviction a reader stream that is under
+    capture is not recorded on (the record would become a node of that graph): its entry is not a victim for this launch; a handle the
+    runtime no longer knows (destroyed stream) is dropped without a record"""
+    c = lzp.lzp_cache_new(256 + 2 * 4096)                      # room for two 4-KiB tables
+    try:
+        go = lambda st, k: lzp.lzp_cache_launch(c, st, 0, 0, 0, k, 1, 1, 8, 4096)
+        a, b = go(0x10, 1) & ~B, go(0x20, 2) & ~B              # shape 1 read on stream 0x10 (the older entry), shape 2 on 0x20
+        _log(lzp, c)
+        lzp.lzp_sync_stream_states(c, 0x10, 0)                 # stream 0x10 has begun a capture since
+        d = go(0x30, 3)
+        lg = _log(lzp, c)
+        assert d == (b | B)                                    # the older entry is left alone: shape 2's place is taken instead ...
+        assert not [x for x in lg if x.startswith("R") and "@16d" in x]   # ... and nothing was recorded on the capturing stream
+        assert go(0x10, 1) == a                                # shape 1 is still there
+        lzp.lzp_sync_stream_states(c, 0, 0x10)                 # capture over, and stream 0x10 has been destroyed
+        go(0x30, 3)                                            # (shape 3 is now the most recent: shape 1 is the victim)
+        _log(lzp, c)
+        e = go(0x40, 4)
+        lg = _log(lzp, c)
+        assert e == (a | B) and not [x for x in lg if x.startswith("R") and "@16d" in x]   # no record on a handle that names no stream
+        # both entries read by capturing streams: no victim — the launch gets no table (weights in the kernel) instead of a wrong one
+        lzp.lzp_sync_stream_states(c, 0x30, 0)
+        go(0x30, 4)                                            # both live entries (3, 4) have 0x30 among their readers
+        assert go(0x50, 5) == 0 and lzp.lzp_cache_entries(c, 0) == 2
+        lzp.lzp_sync_stream_states(c, 0, 0)
+        assert go(0x50, 5) & B
+    finally:
+        lzp.lzp_cache_free(c)
+
+
 def test_workspace_record(lzp):
     """the caller-owned workspace (vpf_workspace.opaque = LzmWorkspace): stream-ordered, no events.  Same shape on the same stream -> no
     rebuild; another stream / a capturing stream / a new shape -> rebuild; no room -> everything is dropped and the region reused from its
     start, except that the entries of the launch in progress are never dropped (the fallback arena serves that table instead)"""
     ws = (C.c_uint64 * 40)()
     region = 256 + 3 * 4096
-    get = lambda st, k, nbytes=4096, cap=0, dev=0, kind=0, pinned=99: lzp.lzp_ws_get(ws, region, st, dev, cap, kind, k, 1, 1, 8, nbytes, pinned)
+
+    def get(st, k, nbytes=4096, cap=0, dev=0, kind=0, launch=None):
+        """one lookup; `launch` = the mask of a launch in progress (a fresh one per call otherwise: every lookup its own launch)"""
+        m = launch if launch is not None else C.c_uint32(0)
+        return lzp.lzp_ws_get(ws, region, st, dev, cap, kind, k, 1, 1, 8, nbytes, C.byref(m))
+
     assert get(0x10, 1) == (16 | B) and get(0x10, 1) == 16 and get(0x10, 1, kind=1) == ((16 + 256) | B)
     assert get(0x10, 1, cap=1) == (16 | B)                     # captured: build again
     assert get(0x20, 1) == (16 | B) and lzp.lzp_ws_n(ws) == 1  # another stream: nothing in the region is ordered for it — it starts over
     assert get(0x20, 2) & B and get(0x20, 3) & B and lzp.lzp_ws_n(ws) == 3
     assert get(0x20, 4) == (16 | B) and lzp.lzp_ws_n(ws) == 1  # full: reuse from the start (stream order keeps the old readers in front)
-    assert get(0x20, 5, pinned=0) & B and get(0x20, 6, pinned=0) & B
-    assert get(0x20, 7, pinned=0) == 0                         # full AND the entries in it belong to this very launch: not here
+    m = C.c_uint32(0)
+    assert get(0x20, 5, launch=m) & B and get(0x20, 6, launch=m) & B and m.value == 0b110
+    assert get(0x20, 7, launch=m) == 0                         # full AND the entries in it belong to this very launch: not here
     assert get(0x20, 8, nbytes=region) == 0                    # larger than the region: never
+    # ADVICE r4: a launch that HIT an old entry and then misses on a full record must not be handed the hit table's bytes a second time
+    m = C.c_uint32(0)
+    assert get(0x20, 4, launch=m) == 16 and m.value == 1       # hit: the first entry, at offset 16
+    assert get(0x20, 9, launch=m) == 0 and lzp.lzp_ws_n(ws) == 3  # miss on the full record: the fallback arena, nothing dropped
+    assert get(0x20, 4, launch=m) == 16 and get(0x20, 5, launch=m) == 16 + 256  # ... and the tables it was given are still there
+    assert get(0x20, 9) == (16 | B) and lzp.lzp_ws_n(ws) == 1  # the NEXT launch may start over
+    # the same with the entry count as the limit (eight small tables) instead of the bytes
+    ws2, m = (C.c_uint64 * 40)(), C.c_uint32(0)
+    g2 = lambda k, launch: lzp.lzp_ws_get(ws2, 1 << 20, 0x30, 0, 0, 0, k, 1, 1, 8, 256, C.byref(launch))
+    offs = [g2(k, C.c_uint32(0)) & ~B for k in range(8)]
+    assert len(set(offs)) == 8 and lzp.lzp_ws_n(ws2) == 8
+    assert g2(3, m) == offs[3] and g2(100, m) == 0 and lzp.lzp_ws_n(ws2) == 8 and g2(3, m) == offs[3]
     assert get(0x20, 1, dev=1) == (16 | B)                     # another device: a fresh record
 
 

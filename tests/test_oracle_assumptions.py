@@ -1,4 +1,5 @@
-"""The oracle's assumption switches (A2 chroma up-sampling, A6 chroma decimation, A8 resize coordinates).
+"""The oracle's assumption switches (A2 chroma up-sampling, A6 chroma decimation, A8 resize coordinates; DESIGN.md §2: A10
+Lanczos support when minifying).
 Each alternative is checked against a separate numpy/float64 restatement written here from its definition, so that when real
 NPP output arrives (tests/test_reference_fixtures.py) flipping a switch is known to do what its name says."""
 import numpy as np
@@ -123,7 +124,73 @@ def test_a8_resize_coordinate_conventions(oracle, conv, sizes):
         assert got[0][0, 0] == src[0][0, 0] and got[0][-1, -1] == src[0][-1, -1] and lz[0][0, 0] == src[0][0, 0]
 
 
+def _lanczos_wide(src, dw, dh):
+    """A10 = 1 written from its definition in float64 numpy: per axis fs = max(1, S/D), every source sample i with |i - s| <= 3 fs weighted
+    L((i - s) / fs), normalised, indices clamped to the picture; horizontal pass first"""
+    def axis(p, S, D):  # p: (S, n) -> (D, n)
+        fs = max(1.0, S / D)
+        out = np.zeros((D, p.shape[1]))
+        for d in range(D):
+            s = (d + 0.5) * (S / D) - 0.5
+            i = np.arange(int(np.ceil(s - 3 * fs)), int(np.floor(s + 3 * fs)) + 1)
+            x = (i - s) / fs
+            w = np.where(np.abs(x) >= 3, 0.0, np.sinc(x) * np.sinc(x / 3))
+            out[d] = (w / w.sum()) @ p[np.clip(i, 0, S - 1)]
+        return out
+    sh, sw = src.shape
+    return _rhu(axis(axis(src.astype(np.float64).T, sw, dw).T, sh, dh))
+
+
+@pytest.mark.parametrize("sizes", [((200, 120), (133, 80)), ((90, 70), (30, 35)), ((64, 48), (11, 7)), ((40, 30), (40, 30)), ((31, 23), (80, 61))])
+def test_a10_lanczos_support_scaled_when_minifying(oracle, sizes):
+    """A10: the reference asks NPP for NPPI_INTER_LANCZOS (Tasks.cpp:1190,1248) and NPP does not say whether the kernel widens when
+    minifying.  0 = six taps whatever the scale (what the HIP kernels implement); 1 = support scaled by max(1, S/D) (PIL / swscale)."""
+    o = oracle
+    (sw, sh), (dw, dh) = sizes
+    src = o.synth(o.Y, sw, sh, 12)
+    st, six = o.resize(o.Y, o.LANCZOS3, sw, sh, src, dw, dh, o.EXACT)
+    assert st == 0
+    with o.assume(o.A10_LANCZOS_MINIFY, 1):
+        st, wide = o.resize(o.Y, o.LANCZOS3, sw, sh, src, dw, dh, o.EXACT)
+        assert st == 0
+        assert o.resize(o.Y, o.LANCZOS3, sw, sh, src, dw, dh, o.FP32)[0] == 1   # FP32 = the kernels = six taps only
+        assert o.resize(o.Y, o.LINEAR, sw, sh, src, dw, dh, o.FP32)[0] == 0     # ... the other filters are not touched by the switch
+        d = np.abs(wide[0].astype(int) - _lanczos_wide(src[0], dw, dh).astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 0.01                          # the switch does what its definition says (ties only)
+        flat = o.alloc(o.Y, sw, sh, fill=173)
+        assert (o.resize(o.Y, o.LANCZOS3, sw, sh, flat, dw, dh, o.EXACT)[1][0] == 173).all()   # a flat picture stays flat
+        rgb = o.synth(o.RGB, sw, sh, 13)
+        st, w3 = o.resize(o.RGB, o.LANCZOS3, sw, sh, rgb, dw, dh, o.EXACT)      # packed: each channel is the 1-channel filter
+        assert st == 0 and np.array_equal(w3[0][:, 1::3], o.resize(o.Y, o.LANCZOS3, sw, sh, [np.ascontiguousarray(rgb[0][:, 1::3])], dw, dh, o.EXACT)[1][0])
+    assert o.lib().vpfo_get_assumption(o.A10_LANCZOS_MINIFY) == 0
+    if sw <= dw and sh <= dh:   # identity and up-scales: the two readings are the same filter
+        assert np.array_equal(wide[0], six[0])
+        if (sw, sh) == (dw, dh):
+            assert np.array_equal(wide[0], src[0])
+    else:                       # minifying noise: they are NOT — this is what the pin kit's classifier decides on NPP's output
+        d = np.abs(wide[0].astype(int) - six[0].astype(int))
+        assert d.mean() > 3 and d.max() > 15
+
+
+def test_a10_equals_pil_lanczos_on_a_mid_range_down_scale(oracle):
+    """... and reading 1 IS what PIL calls LANCZOS: interior pixels of a 1.5 x down-scale agree to <= 2 LSB (PIL rounds the horizontal pass
+    to 8 bits and uses Q22 weights; mid-range input keeps its clamped intermediate out of play), while reading 0 is ~8 LSB away on average"""
+    Image = pytest.importorskip("PIL.Image")
+    o = oracle
+    sw, sh, dw, dh = 200, 120, 133, 80
+    rng = np.random.default_rng(5)
+    src = [np.ascontiguousarray(rng.integers(64, 192, (sh, sw), dtype=np.uint8))]
+    pil = np.asarray(Image.fromarray(src[0], "L").resize((dw, dh), Image.LANCZOS)).astype(int)
+    with o.assume(o.A10_LANCZOS_MINIFY, 1):
+        wide = o.resize(o.Y, o.LANCZOS3, sw, sh, src, dw, dh, o.EXACT)[1][0].astype(int)
+    six = o.resize(o.Y, o.LANCZOS3, sw, sh, src, dw, dh, o.EXACT)[1][0].astype(int)
+    inner = (slice(6, -6), slice(6, -6))
+    assert np.abs(wide - pil)[inner].max() <= 2 and np.abs(wide - pil)[inner].mean() < 0.5
+    assert np.abs(six - pil)[inner].mean() > 3
+
+
 def test_switch_rejects_unknown_keys_and_values(oracle):
     L = oracle.lib()
     assert L.vpfo_set_assumption(3, 0) == -1 and L.vpfo_set_assumption(oracle.A6_CHROMA_DECIMATE, 2) == -1
     assert L.vpfo_set_assumption(oracle.A8_RESIZE_COORDS, 3) == -1 and L.vpfo_get_assumption(oracle.A8_RESIZE_COORDS) == 0
+    assert L.vpfo_set_assumption(oracle.A10_LANCZOS_MINIFY, 2) == -1 and L.vpfo_get_assumption(oracle.A10_LANCZOS_MINIFY) == 0

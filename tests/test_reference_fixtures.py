@@ -64,23 +64,54 @@ def lsb_report(got, want):
     return float(d.max()), float((d > 1).mean())
 
 
-def which_assumptions(o, run, want):
-    """EXACT mode under every combination of the switches: the ones that land within 1 LSB of `want`"""
+def which_assumptions(o, run, want, lanczos=False):
+    """EXACT mode under every combination of the switches: the ones that land within 1 LSB of `want` (A10 only where the run is a Lanczos
+    resize: it touches nothing else)"""
     hits = []
-    for a2, a6, a8 in itertools.product(range(3), range(2), range(3)):
-        with o.assume(o.A2_CHROMA_UPSAMPLE, a2), o.assume(o.A6_CHROMA_DECIMATE, a6), o.assume(o.A8_RESIZE_COORDS, a8):
+    for a2, a6, a8, a10 in itertools.product(range(3), range(2), range(3), range(2 if lanczos else 1)):
+        with o.assume(o.A2_CHROMA_UPSAMPLE, a2), o.assume(o.A6_CHROMA_DECIMATE, a6), o.assume(o.A8_RESIZE_COORDS, a8), o.assume(o.A10_LANCZOS_MINIFY, a10):
             st, got = run()
         if st == 0 and lsb_report(join_planes(got), want)[0] <= 1:
-            hits.append({"A2": a2, "A6": a6, "A8": a8})
+            hits.append({"A2": a2, "A6": a6, "A8": a8, **({"A10": a10} if lanczos else {})})
     return hits
 
 
 def describe_hits(hits, default):
     if not hits:
         return "NO assumption combination lands within 1 LSB  MISMATCH"
-    if default in hits:
-        return f"the default (A2 = A6 = A8 = 0) matches ({len(hits)} of 18 combinations do)"
-    return "the default does NOT match; these do: " + ", ".join(f"A2={h['A2']} A6={h['A6']} A8={h['A8']}" for h in hits)
+    n = 36 if any("A10" in h for h in hits) else 18
+    if any(all(h.get(k, 0) == 0 for k in ("A2", "A6", "A8", "A10")) for h in hits):
+        return f"the default (A2 = A6 = A8 = A10 = 0) matches ({len(hits)} of {n} combinations do)"
+    return "the default does NOT match; these do: " + ", ".join(" ".join(f"{k}={v}" for k, v in h.items()) for h in hits)
+
+
+def classify_a10(o, fmt, w, h, src_planes, dw, dh, want_flat):
+    """Assumption A10 (the reference asks NPP for NPPI_INTER_LANCZOS, Tasks.cpp:1190,1248, and NPP does not say whether the
+    kernel widens when minifying): which reading a recorded DOWN-scale follows — 0 = six taps whatever the scale (what the HIP kernels
+    implement), 1 = support scaled by max(1, S/D) (PIL / swscale).  Tried under every A8 coordinate convention; when neither lands within
+    1 LSB the closer one (mean |diff|) is named, so that a third filter still says which family it belongs to.  The two readings are
+    ~8 LSB apart on noise and differ in the footprint of a single lit pixel (16 -> 5: two output samples per axis against all five), so
+    the impulse fixture and 848x464 -> 283x155 both decide it."""
+    if dw >= w and dh >= h:
+        return "not a minification: both readings are the same six taps"
+    best = {}
+    for a10 in (0, 1):
+        for a8 in range(3):
+            with o.assume(o.A8_RESIZE_COORDS, a8), o.assume(o.A10_LANCZOS_MINIFY, a10):
+                st, got = o.resize(getattr(o, fmt), o.LANCZOS3, w, h, src_planes, dw, dh, o.EXACT)
+            assert st == 0
+            d = np.abs(join_planes(got).astype(np.int64) - np.asarray(want_flat).astype(np.int64))
+            if a10 not in best or d.mean() < best[a10][1]:
+                best[a10] = (int(d.max()), float(d.mean()), a8)
+    a, b = best[0][0] <= 1, best[1][0] <= 1
+    tail = f"(A10=0: max {best[0][0]} mean {best[0][1]:.2f} at A8={best[0][2]}; A10=1: max {best[1][0]} mean {best[1][1]:.2f} at A8={best[1][2]})"
+    if a and b:
+        return "matches both readings " + tail
+    if a:
+        return "A10 = 0: six taps, no widening (this repo's kernels) " + tail
+    if b:
+        return "A10 = 1: support scaled by S/D — the HIP Lanczos kernels implement the OTHER filter when minifying " + tail
+    return f"neither reading within 1 LSB, closer to A10 = {0 if best[0][1] <= best[1][1] else 1}  MISMATCH " + tail
 
 
 def resolve_like_the_reference(sf, df, ctx):
@@ -219,7 +250,7 @@ def test_oracle_exact_matches_reference_resizer(oracle, path):
             assert verdict.startswith("stacked"), f"{os.path.basename(path)} -> {dw}x{dh}: {verdict}"
             continue  # the fixture shows the reference's stacked-plane resize: classified, deliberately not matched
         assert mx <= 1, (f"{os.path.basename(path)} -> {dw}x{dh}: max |diff| {mx}, {frac:.2%} of bytes off by more than 1 LSB; switches that would match: "
-                         f"{which_assumptions(o, run, z[key])}")
+                         f"{which_assumptions(o, run, z[key], lanczos=True)}; A10: {classify_a10(o, fmt, w, h, src, dw, dh, z[key])}")
 
 
 @pytest.mark.parametrize("path", cases("remap") or [None], ids=lambda p: os.path.basename(p)[:-4] if p else "none")
@@ -332,6 +363,36 @@ def test_quirk_classifiers_tell_the_two_readings_apart(oracle):
     assert classify_c13(o, w, h, flat, (0, 0), planar).startswith("planar")
     assert classify_c13(o, w, h, flat, (0, 0), quirk).startswith("packed")
     assert describe_hits([], {"A2": 0, "A6": 0, "A8": 0}).endswith("MISMATCH")
+
+
+def test_a10_classifier_reads_the_impulse_response_and_the_848_case(oracle):
+    """The A10 classifier on synthetic 'NPP' outputs made by the oracle under either reading: the recorded impulse response
+    (make_npp_fixtures.py: resize_RGB_impulse_16x16 -> 5x5 / 8x8) and a 848x464 -> 283x155 down-scale (run here at a fifth of the size, same
+    ratio) name the reading they were made with; an up-scale says it cannot tell; a third filter is a MISMATCH with the closer family named."""
+    o = oracle
+    imp = np.zeros((16, 16, 3), np.uint8)
+    imp[5, 7] = (255, 128, 64)
+    imp[12, 2] = (32, 255, 200)
+    cases = [("RGB", 16, 16, [imp.reshape(16, 48)], 5, 5), ("RGB", 16, 16, [imp.reshape(16, 48)], 8, 8), ("RGB", 170, 93, o.synth(o.RGB, 170, 93, 6), 57, 31),
+             ("NV12", 170, 94, o.synth(o.NV12, 170, 94, 7), 56, 32)]
+    for fmt, w, h, src, dw, dh in cases:
+        made = {}
+        for a10 in (0, 1):
+            with o.assume(o.A10_LANCZOS_MINIFY, a10):
+                made[a10] = join_planes(o.resize(getattr(o, fmt), o.LANCZOS3, w, h, src, dw, dh, o.EXACT)[1])
+        assert classify_a10(o, fmt, w, h, src, dw, dh, made[0]).startswith("A10 = 0"), (fmt, dw, dh)
+        assert classify_a10(o, fmt, w, h, src, dw, dh, made[1]).startswith("A10 = 1"), (fmt, dw, dh)
+        hits = which_assumptions(o, lambda: o.resize(getattr(o, fmt), o.LANCZOS3, w, h, src, dw, dh, o.EXACT), made[1], lanczos=True)
+        assert hits and all(hh["A10"] == 1 for hh in hits) and "A10=1" in describe_hits(hits, None)
+    # the footprint of ONE lit pixel, 16 -> 5: six taps reach two output samples per axis, the widened kernel all five
+    with o.assume(o.A10_LANCZOS_MINIFY, 1):
+        wide = o.resize(o.RGB, o.LANCZOS3, 16, 16, [imp.reshape(16, 48)], 5, 5, o.EXACT)[1][0].reshape(5, 5, 3)
+    six = o.resize(o.RGB, o.LANCZOS3, 16, 16, [imp.reshape(16, 48)], 5, 5, o.EXACT)[1][0].reshape(5, 5, 3)
+    assert (six[:, :, 0] > 0).sum() <= 4 < (wide[:, :, 0] > 0).sum()
+    up = join_planes(o.resize(o.RGB, o.LANCZOS3, 16, 16, [imp.reshape(16, 48)], 40, 40, o.EXACT)[1])
+    assert classify_a10(o, "RGB", 16, 16, [imp.reshape(16, 48)], 40, 40, up).startswith("not a minification")
+    blur = join_planes(o.resize(o.RGB, o.LINEAR, 170, 93, cases[2][3], 57, 31, o.EXACT)[1])
+    assert "MISMATCH" in classify_a10(o, "RGB", 170, 93, cases[2][3], 57, 31, blur)
 
 
 @pytest.mark.gpu

@@ -909,6 +909,7 @@ static bool lzm_big_lds_ok() {
 // (0 = no tables at all): a test knob for the "arena full" path, read once
 // HIP events behind the fallback arena's bookkeeping (vpf_lzm_plan.h: LzmSync).  The caller of launch_lanczos_mfma holds a DeviceGuard: the
 // current device is the one the launch — and these events — belong to.
+static std::atomic<u32x4*> g_lzm_arena_base[64];  // the static arena's address per device (lzm_arena_base)
 struct LzmHipSync final : LzmSync {
   hipEvent_t canary[64] = {};
   void* record(const void* stream, int) override {
@@ -929,14 +930,23 @@ struct LzmHipSync final : LzmSync {
     if (hipEventDestroy((hipEvent_t)ev) != hipSuccess) (void)hipGetLastError();
   }
   // a device reset frees the arena's contents (static device memory is re-initialised) and invalidates every event created before it: a
-  // never-recorded canary event per device answers hipSuccess while its context lives
+  // never-recorded canary event per device answers hipSuccess while its context lives.  A detected reset also forgets the arena's cached
+  // address (the code object is loaded again: lzm_arena_base asks anew); the stale canary handle is dropped, never destroyed
   bool device_alive(int dev) override {
     if (canary[dev] && hipEventQuery(canary[dev]) == hipSuccess) return true;
     const bool first = canary[dev] == nullptr;
     (void)hipGetLastError();
     canary[dev] = nullptr;
+    g_lzm_arena_base[dev].store(nullptr, std::memory_order_release);
     if (hipEventCreateWithFlags(&canary[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); canary[dev] = nullptr; }
     return first;
+  }
+  // asked at eviction about a stream handle remembered from an earlier launch (vpf_lzm_plan.h): capturing -> hands off; a handle the
+  // runtime no longer knows -> nothing to order
+  int stream_state(const void* stream) override {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); return 2; }
+    return cs != hipStreamCaptureStatusNone ? 1 : 0;
   }
 };
 // VPF_HIP_LANCZOS_TABLE_KB shrinks the part of the arena that is handed out (0 = no tables at all): a test knob, read once
@@ -950,7 +960,7 @@ static LzmTableCache& lzm_tables() {
   return cache;
 }
 static u32x4* lzm_arena_base(int dev) {  // the static arena's address on this device (hipGetSymbolAddress once per device)
-  static std::atomic<u32x4*> base[64];
+  std::atomic<u32x4*>* const base = g_lzm_arena_base;
   u32x4* p = base[dev].load(std::memory_order_acquire);
   if (!p) {
     void* q = nullptr;
@@ -1009,11 +1019,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
     capturing = cs != hipStreamCaptureStatusNone;
   }
-  const uint32_t ws_first = wrec && wrec->magic == LzmWorkspace::kMagic && wrec->stream == (const void*)st && wrec->device == (uint32_t)dev ? wrec->n : 0u;
+  uint32_t ws_touched = 0;  // the workspace entries this launch has been given (hit or added): never dropped under it
   // one table of one plane: -> its address (nullptr: evaluate the weights in the kernel), building it first where nobody has
   auto table = [&](uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes, auto&& build) -> const u32x4* {
     if (wrec) {
-      const LzmTableCache::Hit h = wrec->get(wsp->bytes, st, dev, capturing, kind, k0, k1, k2, k3, bytes, ws_first);
+      const LzmTableCache::Hit h = wrec->get(wsp->bytes, st, dev, capturing, kind, k0, k1, k2, k3, bytes, &ws_touched);
       if (h.off16) {
         u32x4* const p = static_cast<u32x4*>(wsp->ptr) + h.off16;
         if (h.build) { (void)hipGetLastError(); build(p); }

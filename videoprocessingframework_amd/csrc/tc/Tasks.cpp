@@ -152,6 +152,17 @@ void hip_stream_sync(void* p) {
   (void)hipStreamSynchronize((hipStream_t)s->str);
 }
 
+// Before device memory that queued kernels may still read is freed: the stream is drained; a stream the caller has destroyed meanwhile
+// (the Python side owns it) cannot be asked — then the whole device is, and the failure is said out loud
+static void drain_before_free(StreamRef* s, const char* what) {
+  DeviceScope scope(s->ctx);
+  const hipError_t e = hipStreamSynchronize((hipStream_t)s->str);
+  if (e == hipSuccess) return;
+  (void)hipGetLastError();
+  std::cerr << what << ": hipStreamSynchronize failed (" << hipGetErrorName(e) << "); waiting for the device instead" << std::endl;
+  if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+}
+
 // every HIP failure is reported on stderr (the reference prints its CUDA/NPP error codes the same way)
 bool hip_ok(hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
@@ -481,7 +492,7 @@ struct ResizeSurface::Impl {
     ws_interp = interp; ws_sw = sw; ws_sh = sh;
     const uint64_t need = vpf_resize_workspace_bytes(fmt, interp, vpf_size{sw, sh}, vpf_size{w, h});
     if (need > ws.bytes || !need) {
-      if (ws_mem) hip_stream_sync(&sref);  // kernels queued with the old region's tables must have finished before it is freed (a change of input size: rare)
+      if (ws_mem) drain_before_free(&sref, "ResizeSurface workspace");  // kernels queued with the old region's tables must have finished before it is freed (a change of input size: rare)
       ws_mem.reset(need ? CudaBuffer::Make(1, (size_t)need, sref.ctx) : nullptr);
       ws = vpf_workspace{};
       if (ws_mem && ws_mem->GpuMem()) { ws.ptr = (void*)ws_mem->GpuMem(); ws.bytes = need; }
@@ -520,7 +531,7 @@ ResizeSurface::ResizeSurface(uint32_t w, uint32_t h, Pixel_Format f, HipContext 
   pImpl->out.reset(Surface::Make(f, w, h, ctx));
 }
 ResizeSurface::~ResizeSurface() {
-  if (pImpl && pImpl->ws_mem) hip_stream_sync(&pImpl->sref);  // queued resizes still read the workspace's tables
+  if (pImpl && pImpl->ws_mem) drain_before_free(&pImpl->sref, "~ResizeSurface");  // queued resizes still read the workspace's tables
 }
 ResizeSurface* ResizeSurface::Make(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) {
   return new ResizeSurface(w, h, f, ctx, str);

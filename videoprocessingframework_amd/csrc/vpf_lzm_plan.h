@@ -178,6 +178,10 @@ struct LzmSync {
   virtual void wait(const void* stream, void* ev) = 0;     // `stream` waits for it
   virtual void destroy(void* ev) = 0;
   virtual bool device_alive(int dev) = 0;                  // false once after the device was reset: the cache forgets the device's tables
+  // a stream an entry remembers from an EARLIER launch of somebody else, asked about at eviction: 0 = an event can be recorded on it |
+  // 1 = it is under capture (a record would become a node of that graph and the cross-stream wait could invalidate the capture: the entry
+  // is left alone) | 2 = the handle no longer names a stream (destroyed: nothing left to order behind)
+  virtual int stream_state(const void* stream) { (void)stream; return 0; }
 };
 class LzmTableCache {
  public:
@@ -211,7 +215,15 @@ class LzmTableCache {
       if (victim < 0) return Hit{0, false, -1};  // everything left is pinned by this very launch
       Ent& v = ents_[victim];
       // the space is rewritten by a build kernel queued on `stream`: behind everything queued so far on the streams that read the old
-      // table (an event recorded on each of them now), and behind its build
+      // table (an event recorded on each of them now), and behind its build.  The remembered handles are somebody else's and may have
+      // changed since: a stream under capture keeps its entry (not a victim for this launch), a destroyed one drops out
+      bool busy = false;
+      for (int i = 0; i < v.nusers; i++) {
+        const int state = v.users[i] == stream ? 0 : sync_->stream_state(v.users[i]);
+        if (state == 1) busy = true;
+        if (state == 2) { v.users[i--] = v.users[--v.nusers]; v.users[v.nusers] = nullptr; }
+      }
+      if (busy) { v.tick = tick_; continue; }
       for (int i = 0; i < v.nusers; i++) {
         if (v.users[i] == stream) continue;  // this stream's own earlier launches are in front of the build anyway
         void* ev = sync_->record(v.users[i], dev);
@@ -326,7 +338,10 @@ class LzmTableCache {
 // ---- the caller-owned workspace (vpf_workspace, include/vpf_hip.h): its `opaque` words hold this record.  Used on ONE stream at a time:
 // builds and launches are ordered by that stream alone.  A launch on another stream, a captured launch or a shape the record does not
 // hold rebuilds (when the space is short: everything is dropped and the region reused from its start — the new builds queue behind the
-// kernels that read the old tables).
+// kernels that read the old tables).  What a launch has already been GIVEN — an entry it hit as much as one it added — is never dropped
+// under it: `touched` is the launch's own mask of such entries (zero at its first lookup), and a table that finds the record full while the
+// mask is non-zero goes to the fallback arena instead (round 4 guarded added entries only: a hit followed by a miss on a full record handed
+// out the hit table's bytes a second time — ADVICE r4).
 struct LzmWorkspace {
   static constexpr uint32_t kMagic = 0x4c5a4d57u;  // "LZMW"
   static constexpr int kEntries = 8;               // three planes x {columns, rows} + two spare
@@ -335,20 +350,22 @@ struct LzmWorkspace {
   struct E { uint32_t kind, k0, k1, k2, k3, off16, len16, pad; } e[kEntries];
   // -> off16 (0: does not fit, use the fallback) and whether the caller must queue the build
   LzmTableCache::Hit get(uint64_t region_bytes, const void* st, int dev, bool capturing, uint32_t kind, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint64_t bytes,
-                         uint32_t pinned_from) {
+                         uint32_t* touched) {
     const uint32_t cap16 = (uint32_t)std::min<uint64_t>(region_bytes / 16, 0x7fffffffu);
-    if (magic != kMagic || device != (uint32_t)dev) { magic = kMagic; n = 0; used16 = 16; device = (uint32_t)dev; stream = st; }
-    if (stream != st) { n = 0; used16 = 16; stream = st; }  // another stream: nothing in here is ordered for it — start over
+    // (a record that starts over cannot hold anything this launch was given: the launcher reads stream / device before its first lookup)
+    if (magic != kMagic || device != (uint32_t)dev || n > (uint32_t)kEntries) { magic = kMagic; n = 0; used16 = 16; device = (uint32_t)dev; stream = st; *touched = 0; }
+    if (stream != st) { n = 0; used16 = 16; stream = st; *touched = 0; }  // another stream: nothing in here is ordered for it — start over
     for (uint32_t i = 0; i < n; i++)
-      if (e[i].kind == kind && e[i].k0 == k0 && e[i].k1 == k1 && e[i].k2 == k2 && e[i].k3 == k3) return LzmTableCache::Hit{e[i].off16, capturing, (int)i};
+      if (e[i].kind == kind && e[i].k0 == k0 && e[i].k1 == k1 && e[i].k2 == k2 && e[i].k3 == k3) { *touched |= 1u << i; return LzmTableCache::Hit{e[i].off16, capturing, (int)i}; }
     const uint32_t need16 = (uint32_t)std::min<uint64_t>((bytes + 255) / 256 * 16, 0xffffffffu);
     if (need16 > cap16 || cap16 < 16 || need16 > cap16 - 16) return LzmTableCache::Hit{0, false, -1};
     if (n == (uint32_t)kEntries || used16 + need16 > cap16) {
-      if (pinned_from < n) return LzmTableCache::Hit{0, false, -1};  // entries of this very launch would go: the fallback takes this one
+      if (*touched) return LzmTableCache::Hit{0, false, -1};  // tables of this very launch would go: the fallback takes this one
       n = 0; used16 = 16;
     }
     e[n] = E{kind, k0, k1, k2, k3, used16, need16, 0};
     used16 += need16;
+    *touched |= 1u << n;
     return LzmTableCache::Hit{e[n].off16, true, (int)n++};
   }
 };
