@@ -431,7 +431,9 @@ def main():
             torch.cuda.empty_cache()
 
     wl = RehearsalWorkload(rank) if a.rehearse_host else Workload(a.workload, dev, a.ring, a.variant, a.mode)
+    ident = sharding.rank_identity(None if a.rehearse_host else local)  # per-rank diagnostics (device, PCI address, NUMA node, clocks): the "ranks" array of the JSON line
     heated_ms = preheat(wl, 0.0 if a.rehearse_host else a.preheat_ms)
+    ident["sclk_mhz_start"] = sharding.current_sclk_mhz(ident["pci"])
     for _ in range(a.warmup):
         wl.step()
     blocks = []  # per repeat: (whole-job pixels, MAX over ranks of the own launch -> synchronize time, this rank's device seconds, every rank's device ms per step, MAX wall incl. the closing barrier)
@@ -439,9 +441,12 @@ def main():
         t_own, wall, ev = timed_block(wl, a.steps)
         px, tmax = sharding.aggregate(wl.px_per_step * a.steps, t_own, red_dev)  # sum of pixels, MAX time over ranks
         _, wmax = sharding.aggregate(0, wall, red_dev)
-        blocks.append((px, tmax, ev, [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)], wmax))
+        blocks.append((px, tmax, ev, [round(t / a.steps * 1e3, 4) for t in sharding.gather(ev, red_dev)], wmax, t_own))
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][1])
-    total_px, wall_max, ev, per_rank_ms, wall_with_barrier = blocks[order[len(order) // 2]]  # the median block (same index on every rank: the times are all-reduced)
+    total_px, wall_max, ev, per_rank_ms, wall_with_barrier, own = blocks[order[len(order) // 2]]  # the median block (same index on every rank: the times are all-reduced)
+    # every rank's own account of the median block, next to where it ran: a slow rank in a scaling run is then visible in the line itself
+    ident.update(sclk_mhz_end=sharding.current_sclk_mhz(ident["pci"]), own_ms_per_step=round(own / a.steps * 1e3, 4), event_ms_per_step=round(ev / a.steps * 1e3, 4))
+    ranks = sharding.gather_objects(ident)
 
     if rank == 0:
         n_launch = wl.launches_per_step * a.steps
@@ -471,6 +476,7 @@ def main():
             "dtype": "f32",  # u8 pixels in/out, fp32 FMA arithmetic, round-to-nearest-even saturating pack
             "data": "synthetic",
             "per_rank_ms_per_step": per_rank_ms,
+            "ranks": ranks,  # per rank: device, pci, numa_node, sclk_mhz_start / _end, own_ms_per_step (host clock, launch -> synchronize), event_ms_per_step (HIP events), cpus
             "barrier_ms": round(max(0.0, wall_with_barrier - wall_max) * 1e3, 4),  # the closing barrier's own cost over the timed block: outside `value`; ms_per_step x steps + barrier_ms = the block's wall time
             "repeats": len(blocks), "per_repeat_ms": [round(b[1] / a.steps * 1e3, 4) for b in blocks],  # ms_per_step is their median
             "preheat_ms": round(heated_ms, 1),

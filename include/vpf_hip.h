@@ -234,6 +234,8 @@ VPF_API void vpf_trace_pop(int opened);
  *   9        the any-size / any-alignment generic kernels everywhere (byte accesses, gather resize / remap)
  *   40       the narrower fast paths instead of the 16-px "r16" / tiled / quad kernels (A/B runs, test coverage)
  *   43       resize: the tiled separable kernel for bilinear down-scales as well (default: up-scales only)
+ *   47       fused convert + resize: the per-wave strips of rounds 2-4 instead of the workgroup-shared strip (A/B runs, test coverage)
+ *   48       fused convert + resize: the workgroup-shared strip also beyond ~2x down-scales, where the policy takes the per-tap kernel
  *   4, 8, 12, 30, 37, 44, 45, 46   one named NV12 / YUV420 -> RGB kernel of the default policy's set (k_yuv2rgb.hip launch_420)
  * Any other value is rejected: -1 is returned and nothing changes (the experimental kernels and bandwidth probes of round 1
  * are not in this library; they live in tools/lab).  Not part of the reference surface.  Returns the previous value. */

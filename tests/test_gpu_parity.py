@@ -383,7 +383,7 @@ def test_fused_convert_resize(capi, oracle):
             src = oracle.synth(getattr(oracle, sfmt), sw, sh, 1050)
             for dfmt in ("RGB", "BGR", "RGB_PLANAR"):
                 _, want = oracle.convert_resize(getattr(oracle, sfmt), getattr(oracle, dfmt), 1, 0, sw, sh, src, dw, dh)
-                for variant, align in ((0, 256), (40, 256), (9, 256), (0, 2)):  # fast paths, general LDS kernel, forced gather, unaligned (-> gather)
+                for variant, align in ((0, 256), (40, 256), (9, 256), (0, 2), (47, 256), (48, 256)):  # fast paths, general LDS kernel, forced gather, unaligned (-> gather), per-wave strips (rounds 2-4), workgroup strips beyond 2x
                     s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, dfmt), dw, dh), align)
                     prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
                     try:
@@ -412,6 +412,33 @@ def test_fused_convert_resize_batch(capi, oracle):
         _, want = oracle.resize(oracle.BGR, oracle.LINEAR, sw, sh, mid, dw, dh)
         assert intact
         assert_planes_equal(got, want, f"fused batch frame {i}")
+
+
+@pytest.mark.parametrize("variant", [0, 47, 48])
+def test_fused_strip_kernels_at_every_band_height(capi, oracle, variant):
+    """k_convert_strip_wg (round 5: one RGB strip per workgroup, conversions dealt out over all 256 lanes) with R = 16 / 8 / 4 / 2 rows per
+    wave — the launcher picks R from the strip's LDS bytes and the number of workgroups, so batches of mid-sized frames reach every
+    instantiation; ragged right / bottom edges, odd source row parity at the workgroup's first row, sources narrower than one 8-px
+    group.  47 = the per-wave strips it replaced, 48 = workgroup strips beyond 2x.  Every frame == convert-then-resize (the oracle)."""
+    cases = [("NV12", "RGB", 640, 360, 1280, 720, 12), ("YUV420", "RGB_PLANAR", 480, 270, 1000, 610, 9), ("NV12", "BGR", 1280, 720, 854, 480, 10),
+             ("YUV420", "RGB", 1920, 360, 1288, 239, 8), ("NV12", "RGB_PLANAR", 1280, 720, 1920, 1080, 6), ("NV12", "RGB", 1920, 1080, 800, 450, 3),
+             ("NV12", "RGB", 1920, 540, 1600, 450, 6), ("YUV420", "BGR", 16, 8, 300, 170, 5), ("NV12", "RGB", 8, 64, 9, 70, 4), ("NV12", "RGB", 648, 366, 431, 243, 33)]
+    prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+    try:
+        for sf, df, sw, sh, dw, dh, n in cases:
+            srcs = [oracle.synth(getattr(oracle, sf), sw, sh, 5100 + i) for i in range(min(n, 3))]
+            wants = [oracle.convert_resize(getattr(oracle, sf), getattr(oracle, df), 1, 0, sw, sh, s_, dw, dh)[1] for s_ in srcs]
+            S = [DevPlanes(srcs[i % len(srcs)]) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(getattr(oracle, df), dw, dh, fill=9)) for _ in range(n)]
+            capi.convert_resize_batch(capi.make_exec(stream_handle()), getattr(capi, sf), getattr(capi, df), 1, 0, sw, sh, dw, dh,
+                                      capi.make_batch([(s_.desc(), d_.desc()) for s_, d_ in zip(S, D)]))
+            torch.cuda.synchronize()
+            for i in sorted({0, 1, n // 2, n - 1}):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, wants[i % len(srcs)], f"fused strips v{variant} {sf}->{df} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+    finally:
+        capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
 
 
 def _maps(kind, w, h):
@@ -649,6 +676,7 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
         align = int(rng.choice([256, 256, 16, 4, 1]))
         variant = int(rng.choice([0, 0, 40, 43, 9]))
         if rng.integers(4) == 0:  # fused NV12 / YUV420 -> resize -> RGB family
+            variant = int(rng.choice([variant, variant, 47, 48]))  # (+ the per-wave strips of rounds 2-4 / workgroup strips beyond 2x)
             sw, sh = sw + (sw & 1), sh + (sh & 1)
             sf, df = str(rng.choice(["NV12", "YUV420"])), str(rng.choice(["RGB", "BGR", "RGB_PLANAR"]))
             src = oracle.synth(getattr(oracle, sf), sw, sh, int(rng.integers(1 << 30)))
@@ -831,7 +859,7 @@ def test_tuning_hook_rejects_values_outside_the_product(capi):
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v) == -1
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 0      # unchanged
     assert capi.set_tuning(7, 0) == -1                                    # unknown key
-    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46):
+    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46, 47, 48):
         capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v)
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == v
 
@@ -959,14 +987,16 @@ def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
 
 
-@pytest.mark.parametrize("band", [1, 2, 4, 8, 16, 0x104, 0x204, 0x304, 0x804])
+@pytest.mark.parametrize("band", [1, 2, 4, 8, 16, 0x104, 0x204, 0x304, 0x804, 0x10000, 0x10002, 0x10008, 0x10104, 0x10304])
 def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 16 / 8 / 4 / 2 for launches with >= 2048
     workgroups, 1 otherwise).  Every value writes the oracle's pixels: general and > 2x down-scales, shared and disjoint source rows,
     heights that are not a multiple of the band, one-row pictures, ragged widths, fx == 0 columns (even integer factor on x only), an
     up-scale forced onto the row-pair family (variant 40: repeated source rows), multi-plane formats, and a 33-frame batch.
     4 | nb << 8: the march form (nb 4-row bands per wave, the next band's rows in flight while this one is blended, the walk's lerps carried
-    from band to band) on the down-scales of wide 1-channel planes, the plain 4-row form everywhere else."""
+    from band to band) on the down-scales of wide 1-channel planes, the plain 4-row form everywhere else.
+    | 0x10000 (round 5): the PERSISTENT launch of the same band kernels — the resident workgroups pull (frame, plane, wave row, column chunk)
+    items from the stream's work counters (k_planes_mp_persist): more items than waves, fewer items than waves, one item."""
     cases = [("RGB", 640, 360, 427, 240, 0, 3), ("RGB", 1920, 96, 416, 37, 0, 2), ("NV12", 1280, 72, 854, 48, 0, 3), ("YUV420", 642, 90, 300, 31, 0, 2),
              ("RGB", 300, 5, 200, 1, 0, 2), ("Y", 997, 61, 333, 47, 0, 2), ("RGB", 512, 90, 128, 61, 0, 2), ("RGB", 200, 50, 333, 77, 40, 2),
              ("NV12", 200, 50, 320, 96, 40, 2), ("RGB", 640, 360, 224, 224, 0, 33), ("RGB", 1919, 64, 1280, 43, 0, 2),
@@ -997,6 +1027,7 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
         capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 32) == -1
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x208) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x904) == -1  # bands per wave: 4-row bands only, at most 8
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x20004) == -1                                                           # forms: 0 the grid, 1 the persistent launch
 
 
 @pytest.mark.parametrize("fmt", ["Y", "NV12"])
@@ -1015,6 +1046,57 @@ def test_bilinear_march_form_by_policy(capi, oracle, fmt):
         got, intact = D[i].download()
         assert intact
         assert_planes_equal(got, wants[i % 3], f"march by policy {fmt} frame {i}")
+
+
+@pytest.mark.parametrize("fmt,knob,sizes", [("Y", 0x10104, (1920, 1080, 1280, 720)), ("NV12", 0x10204, (1920, 1080, 1280, 720)), ("YUV420", 0x10004, (1280, 720, 854, 480)),
+                                            ("RGB", 0x10010, (640, 360, 1280, 720)), ("RGB", 0x10008, (1280, 720, 854, 480))])
+def test_persistent_band_launch_with_more_items_than_waves_on_two_streams(capi, oracle, fmt, knob, sizes):
+    """k_planes_mp_persist (round 5) where it matters: 32-frame dispatches whose wave items outnumber the resident waves several times (every
+    wave pulls many items; the XCDs finish their own eighth and help the others; the last ticket of each counter puts it back to zero for
+    the next launch), three dispatches in a row per stream, two streams at once (a slot of counters each: vpf_persist.h), then the same
+    streams again after a synchronisation.  Every frame equals the oracle; a hipGraph capture takes the plain grid (same pixels)."""
+    sw, sh, dw, dh = sizes
+    f, of = getattr(capi, fmt), getattr(oracle, fmt)
+    n = 32
+    srcs = [oracle.synth(of, sw, sh, 7900 + i) for i in range(2)]
+    wants = [oracle.resize(of, 1, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, knob) >= 0
+    try:
+        jobs = []
+        for rnd in range(2):
+            for si, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    S = [DevPlanes(srcs[(i + si) % 2]) for i in range(n)]
+                    ex = capi.make_exec(st.cuda_stream)
+                    for rep in range(3):
+                        D = [DevPlanes(oracle.alloc(of, dw, dh, fill=3)) for _ in range(n)]
+                        capi.resize_batch(ex, f, 1, sw, sh, dw, dh, capi.make_batch([(s_.desc(), d_.desc()) for s_, d_ in zip(S, D)]))
+                        jobs.append((si, S, D))
+            torch.cuda.synchronize()
+        st = streams[0]
+        with torch.cuda.stream(st):
+            S = [DevPlanes(srcs[i % 2]) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(of, dw, dh, fill=3)) for _ in range(n)]
+            b = capi.make_batch([(s_.desc(), d_.desc()) for s_, d_ in zip(S, D)])
+            ex = capi.make_exec(st.cuda_stream)
+            capi.resize_batch(ex, f, 1, sw, sh, dw, dh, b); st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                capi.resize_batch(ex, f, 1, sw, sh, dw, dh, b)
+            for d_ in D:
+                for t in d_.bufs:
+                    t.fill_(0xCD)
+            g.replay(); st.synchronize()
+            jobs.append((0, S, D))
+        torch.cuda.synchronize()
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
+    for ji, (si, S, D) in enumerate(jobs):
+        for i in (0, 1, 13, 30, 31):
+            got, intact = D[i].download()
+            assert intact
+            assert_planes_equal(got, wants[(i + si) % 2] if ji < len(jobs) - 1 else wants[i % 2], f"persistent {fmt} knob {knob:#x} job {ji} frame {i}")
 
 
 @pytest.mark.parametrize("fmt,interp,sizes", [("RGB", 1, (1920, 1080, 1280, 720)), ("RGB", 2, (1920, 1080, 1280, 720)), ("NV12", 1, (1920, 1080, 1280, 720)),

@@ -96,6 +96,39 @@ def test_bench_multi_rank_control_flow_rehearsal(launcher):
     assert abs(out["rehearsal_units_per_s"] - px / (out["ms_per_step"] * 5e-3)) / out["rehearsal_units_per_s"] < 0.01
 
 
+def test_bench_eight_rank_rehearsal_carries_per_rank_diagnostics():
+    """The first 8-GPU run must be diagnosable from its own output: bench.py's control flow with EIGHT gloo ranks — the
+    driver's launch line at the size of a full node — prints one JSON line whose `ranks` array says, per rank, which device it drove, its
+    PCI address and NUMA node, the shader clock before and after, its own host-clock time and its HIP-event time per step.  (Host rehearsal:
+    device / pci / clocks are null here; the fields and the reduction are what is checked.)"""
+    out = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                      "bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1", "--repeats", "3", "--rehearse-host"], timeout=600)
+    assert out["n_gpus"] == 8 and out["data"] == "rehearsal" and len(out["per_rank_ms_per_step"]) == 8
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and len({r["pid"] for r in ranks}) == 8
+    for r in ranks:
+        for key in ("device", "pci", "numa_node", "sclk_mhz_start", "sclk_mhz_end", "own_ms_per_step", "event_ms_per_step", "cpus", "local_rank"):
+            assert key in r, key
+        assert r["own_ms_per_step"] >= 2.0 * (1 + r["rank"]) * 0.95          # rank r's step sleeps 2 (1 + r) ms
+    slowest = max(r["own_ms_per_step"] for r in ranks)
+    assert abs(out["ms_per_step"] - slowest) / slowest < 0.02                  # the job's time IS the slowest rank's own time
+    px = 8 * 32 * 3840 * 2160 * 4
+    assert abs(out["rehearsal_units_per_s"] - px / (out["ms_per_step"] * 4e-3)) / out["rehearsal_units_per_s"] < 0.01
+
+
+def test_rank_identity_and_clock_from_a_fake_sysfs(tmp_path):
+    from videoprocessingframework_amd import sharding
+
+    d = tmp_path / "0000:c1:00.0"
+    d.mkdir()
+    (d / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 1270Mhz\n2: 2100Mhz *\n")
+    assert sharding.current_sclk_mhz("0000:c1:00.0", str(tmp_path)) == 2100
+    assert sharding.current_sclk_mhz("0000:c2:00.0", str(tmp_path)) is None and sharding.current_sclk_mhz(None) is None
+    ident = sharding.rank_identity(None)
+    assert ident["device"] is None and ident["pci"] is None and ident["cpus"] >= 1 and ident["rank"] == 0
+    assert sharding.gather_objects({"a": 1}) == [{"a": 1}]                    # no process group: the rank's own object
+
+
 def test_bench_refuses_mismatched_world_size():
     import subprocess
 

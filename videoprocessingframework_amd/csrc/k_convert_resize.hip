@@ -495,8 +495,141 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
 template <int SRC, int DST, int R>
 __global__ __launch_bounds__(256) void k_convert_strip(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
                                                        float scx, float scy, int vec_ok, uint32_t rowq) {
+  VPF_WAVE_TIMER(4);
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): bands above each other and chunks next to each other share one L2
   convert_strip_task<SRC, DST, R>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same, with the strip shared by the WORKGROUP (round 5).  In k_convert_strip every wave converts its own window with 8 pixels per lane
+// over the window's columns: 49 of 64 lanes at 1.5x (386 px), 17 of 64 at a 2x up-scale (130 px), each of them walking all the window's
+// rows — at 1080p -> 4K the conversions took as long as the blend and the kernel LOST to convert-then-resize (11.5 against 7.4 us per
+// frame).  Here the four waves of a workgroup own four bands above each other (4 R destination rows x 256 columns), the source
+// window of all of them is ONE strip, and its conversion is dealt out in UNITS of (chroma row, 8-pixel group) = 8 px x 2 luma rows over all
+// 256 lanes: every source row is converted once per workgroup (the rows two neighbouring bands share were converted twice), a chroma sample's
+// terms are evaluated once per strip, and the lanes are full whatever the window's width (2x up, R = 16: 306 units, 60 % of two trips;
+// 1.5x down, R = 4: 637 units, 83 % of three trips).  One s_barrier between the conversion and the blend.  Same conversions, same
+// rounding, same blend: the bytes of k_convert_strip, of convert-then-resize and of the oracle.
+// ------------------------------------------------------------------------------------------
+template <int SRC>
+VPF_DEV void convert_unit8(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t crow, uint32_t px0, bool row_a, bool row_b, uint8_t* wa /* strip byte of (row 2 crow, px0) */,
+                           uint32_t rowbytes, u32x2 ya, u32x2 yb, u32x2 cq, uint32_t vq) {
+  (void)f; (void)crow; (void)px0;
+  uint32_t uv[2];  // U V U V bytes of pixel pairs 0, 1 | 2, 3
+  if constexpr (SRC == FC_NV12) {
+    uv[0] = cq[0]; uv[1] = cq[1];
+  } else {
+    uv[0] = __builtin_amdgcn_perm(vq, cq[0], 0x05010400u); uv[1] = __builtin_amdgcn_perm(vq, cq[0], 0x07030602u);
+  }
+  Chroma k[4];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    k[2 * j] = chroma_terms(c, ubyte<0>(uv[j]), ubyte<1>(uv[j]));
+    k[2 * j + 1] = chroma_terms(c, ubyte<2>(uv[j]), ubyte<3>(uv[j]));
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; hf++) {
+    if (!(hf ? row_b : row_a)) continue;
+    const u32x2 yq = hf ? yb : ya;
+    uint32_t d[6];  // 8 px -> 24 bytes R G B R G B ..., vpf_convert's rounding (v_cvt_pk_u8_f32)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {  // (the pixel-pair form of convert_strip_task: same IEEE fma per component as convert4 -> same bits)
+      const uint32_t yd = yq[j];
+      const f32x2 cy2 = {c.cy, c.cy}, ya2 = {ubyte<0>(yd), ubyte<1>(yd)}, yb2 = {ubyte<2>(yd), ubyte<3>(yd)};
+      const Chroma &ka = k[2 * j], &kb = k[2 * j + 1];
+      const f32x2 ra = __builtin_elementwise_fma(ya2, cy2, f32x2{ka.rc, ka.rc}), ga = __builtin_elementwise_fma(ya2, cy2, f32x2{ka.gc, ka.gc}),
+                  ba = __builtin_elementwise_fma(ya2, cy2, f32x2{ka.bc, ka.bc});
+      const f32x2 rb = __builtin_elementwise_fma(yb2, cy2, f32x2{kb.rc, kb.rc}), gb = __builtin_elementwise_fma(yb2, cy2, f32x2{kb.gc, kb.gc}),
+                  bb = __builtin_elementwise_fma(yb2, cy2, f32x2{kb.bc, kb.bc});
+      d[3 * j] = pack4<1>(ra[0], ga[0], ba[0], ra[1]);
+      d[3 * j + 1] = pack4<1>(ga[1], ba[1], rb[0], gb[0]);
+      d[3 * j + 2] = pack4<1>(bb[0], rb[1], gb[1], bb[1]);
+    }
+    u32x2* w = reinterpret_cast<u32x2*>(wa + (hf ? rowbytes : 0u));
+    w[0] = u32x2{d[0], d[1]}; w[1] = u32x2{d[2], d[3]}; w[2] = u32x2{d[4], d[5]};
+  }
+}
+template <int SRC, int DST, int R>
+VPF_DEV void convert_strip_wg_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy,
+                                   int vec_ok, uint32_t rowq, uint32_t bx, uint32_t by) {
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, tid = threadIdx.x;
+  const uint32_t Y0 = by * (4 * R), xs = bx * 256;  // the grid covers the picture exactly: Y0 < dh, xs < dw
+  const uint32_t Y1 = (Y0 + 4 * R - 1 < dh - 1) ? Y0 + 4 * R - 1 : dh - 1, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
+  const uint32_t base_px = first & ~7u;
+  // the workgroup's source rows (the launcher sized the strip for them: vpf_band_rows_exact(4 R, ..))
+  const uint32_t R_lo = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(Y0, scy, sh).i0), R_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(Y1, scy, sh).i1);
+  uint8_t* const strip = reinterpret_cast<uint8_t*>(dyn_strip);
+  const uint32_t rowbytes = rowq * 16;
+  const uint32_t c_lo = R_lo >> 1, ncr = (R_hi >> 1) - c_lo + 1, ng = ((last - base_px) >> 3) + 1, units = ncr * ng;
+  const float rng = 1.0f / (float)ng;
+  // unit u -> (chroma row ci = u / ng, group g): (u + 0.5) / ng is at least 0.5 / ng from an integer, far more than the fp32 error for u < 2^14
+  struct Unit { uint32_t px0 = 0; bool act = false, ra = false, rb = false; uint8_t* w = nullptr; u32x2 ya = {0u, 0u}, yb = {0u, 0u}, cq = {0u, 0u}; uint32_t vq = 0, crow = 0; };
+  auto fetch = [&](uint32_t u, Unit& q) {
+    q.act = u < units;
+    if (!q.act) return;
+    const uint32_t ci = (uint32_t)(((float)u + 0.5f) * rng), g = u - ci * ng;
+    q.crow = c_lo + ci; q.px0 = base_px + 8 * g;
+    const uint32_t r0 = 2 * q.crow;
+    q.ra = r0 >= R_lo; q.rb = r0 + 1 <= R_hi;  // (r0 <= R_hi and r0 + 1 >= R_lo hold for every chroma row of the window)
+    if constexpr (SRC == FC_NV12) {
+      q.cq = ldg<false, u32x2>(f.s[1] + (size_t)q.crow * f.sp[1] + q.px0);
+    } else {
+      q.cq = u32x2{ldg<false, uint32_t>(f.s[1] + (size_t)q.crow * f.sp[1] + (q.px0 >> 1)), 0u};
+      q.vq = ldg<false, uint32_t>(f.s[2] + (size_t)q.crow * f.sp[2] + (q.px0 >> 1));
+    }
+    if (q.ra) q.ya = ldg<false, u32x2>(f.s[0] + (size_t)r0 * f.sp[0] + q.px0);
+    if (q.rb) q.yb = ldg<false, u32x2>(f.s[0] + (size_t)(r0 + 1) * f.sp[0] + q.px0);
+    // strip byte of (row r0, px0); r0 may be R_lo - 1 (that row is not written then: only row r0 + 1 is) — a signed offset
+    q.w = strip + ((int32_t)(r0 - R_lo) * (int32_t)rowbytes + (int32_t)(3 * (q.px0 - base_px)));
+  };
+  for (uint32_t u0 = tid; u0 < units; u0 += 512) {  // two units per lane in flight
+    Unit q0, q1;
+    fetch(u0, q0);
+    fetch(u0 + 256, q1);
+    __builtin_amdgcn_sched_barrier(0);  // both units' loads are requested before the first conversion
+    if (q0.act) convert_unit8<SRC>(f, c, q0.crow, q0.px0, q0.ra, q0.rb, q0.w, rowbytes, q0.ya, q0.yb, q0.cq, q0.vq);
+    if (q1.act) convert_unit8<SRC>(f, c, q1.crow, q1.px0, q1.ra, q1.rb, q1.w, rowbytes, q1.ya, q1.yb, q1.cq, q1.vq);
+  }
+  __syncthreads();
+  const uint32_t ya = Y0 + wv * R;
+  if (ya > Y1) return;
+  const uint32_t yb = (ya + R - 1 < Y1) ? ya + R - 1 : Y1;
+  const Tap row_taps = band_row_taps(ya, yb, scy, sh);  // every lane of the wave still active here
+  const uint32_t x0 = xs + lane * 4;
+  if (x0 >= dw) return;
+  const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
+  const ColTaps<3> T = make_col_taps<3>(3 * base_px, x0, dw, sw, scx);  // once for the R rows
+  band_blend_rows<3, R>(strip, rowbytes, R_lo, ya, yb, row_taps, T, [&](uint32_t y, const float* o) {  // o: pixel-major R G B, + 0.5 added
+    if constexpr (DST == FC_PLANAR) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
+        if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch], o[3 + ch], o[6 + ch], o[9 + ch]));
+        else for (uint32_t j = 0; j < nv; j++) out[j] = (uint8_t)(uint32_t)o[3 * j + ch];
+      }
+    } else {
+      constexpr int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
+      uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
+      if (vec_ok && nv == 4) {
+        const float t[12] = {o[a], o[1], o[b], o[3 + a], o[4], o[3 + b], o[6 + a], o[7], o[6 + b], o[9 + a], o[10], o[9 + b]};
+        uint32_t d0, d1, d2;
+        pack12_trunc(t, d0, d1, d2);
+        stg3<false>(out, d0, d1, d2);
+      } else {
+        for (uint32_t j = 0; j < nv; j++) {
+          out[3 * j] = (uint8_t)(uint32_t)o[3 * j + a]; out[3 * j + 1] = (uint8_t)(uint32_t)o[3 * j + 1]; out[3 * j + 2] = (uint8_t)(uint32_t)o[3 * j + b];
+        }
+      }
+    }
+  });
+}
+template <int SRC, int DST, int R>
+__global__ __launch_bounds__(256) void k_convert_strip_wg(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
+                                                          float scx, float scy, int vec_ok, uint32_t rowq) {
+  VPF_WAVE_TIMER(5);
+  const BlockId b = picture_order();
+  convert_strip_wg_task<SRC, DST, R>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
 }
 
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh,
@@ -553,6 +686,40 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       // conversions per destination pixel: scx x ((r - 1) scy + 2) / r source pixels against the four taps of the per-tap kernel —
       // measured break-even near 2x (4K -> 1600x900, 2.4x: 9.5 us here vs 5.2 us per-tap; 1080p -> 720p: 2.36 vs 3.21; 1080p -> 4K: 15.0 vs 23.6)
       const double conv_per_px = r ? (double)scx * ((r - 1) * (double)scy + 2.0) / r : 1e9;
+      // Round 5: the strip shared by the workgroup (k_convert_strip_wg: the source window of 4 R destination rows converted once, dealt
+      // out over all 256 lanes).  Band height: the largest of 16 (up-scales) / 8 / 4 / 2 whose strip leaves four workgroups per CU
+      // (<= 36 KiB) and whose launch still covers the chip.  VPF_TUNE_NV12_RGB_VARIANT = 47 keeps the per-wave strips (A/B runs, tests).
+      if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 47) {
+        static thread_local struct { uint32_t sh, dh, rows[4]; } wseen = {0, 0, {0, 0, 0, 0}};
+        if (!(wseen.sh == sh && wseen.dh == dh)) {
+          wseen.sh = sh; wseen.dh = dh;
+          for (int k = 0; k < 4; k++) wseen.rows[k] = vpf_band_rows_exact(4 * (2 << k), sh, dh, scy);  // the workgroup's 4 R rows: R = 2, 4, 8, 16
+        }
+        int rw = 0;
+        uint32_t wrows = 0;
+        for (int k = 3; k >= 0; k--) {
+          const int cand = 2 << k;
+          if (cand == 16 && scy > 1.0f) continue;
+          if ((uint64_t)wseen.rows[k] * rowbytes > 36u * 1024u) continue;
+          if (cand > 2 && (uint64_t)((dw + 255) / 256) * ((dh + 4 * cand - 1) / (4 * cand)) * n < (cand >= 8 ? 2048u : 512u)) continue;  // keep the chip covered
+          rw = cand; wrows = wseen.rows[k];
+          break;
+        }
+        // source pixels converted per destination pixel: rows of the strip x its width / (4 R x 256); the per-tap kernel converts four
+        const double wconv = rw ? (double)wrows * ((double)scx * 255.0 + 18.0) / (4.0 * rw * 256.0) : 1e9;
+        if (rw && wconv <= (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 48 ? 8.0 : 3.0)) {
+          const uint32_t ldsw = wrows * rowbytes;
+          dim3 wgrid((dw + 255) / 256, (dh + 4 * rw - 1) / (4 * rw), n);
+#define VPF_WG1(S, D, RR) VPF_LAUNCH((k_convert_strip_wg<S, D, RR>), wgrid, dim3(256), ldsw, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes / 16)
+#define VPF_WG(S, D) do { if (rw == 16) VPF_WG1(S, D, 16); else if (rw == 8) VPF_WG1(S, D, 8); else if (rw == 4) VPF_WG1(S, D, 4); else VPF_WG1(S, D, 2); } while (0)
+#define VPF_WGD(S) do { if (dst_fc == FC_RGB) VPF_WG(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_WG(S, FC_BGR); else VPF_WG(S, FC_PLANAR); } while (0)
+          if (src_fc == FC_NV12) VPF_WGD(FC_NV12); else VPF_WGD(FC_YUV420);
+#undef VPF_WGD
+#undef VPF_WG
+#undef VPF_WG1
+          return hipGetLastError();
+        }
+      }
       if (r && lds1 <= 64u * 1024u && conv_per_px <= 3.0) {
         dim3 sgrid((dw + 255) / 256, (dh + 4 * r - 1) / (4 * r), n);
 #define VPF_STRIP1(S, D, RR) VPF_LAUNCH((k_convert_strip<S, D, RR>), sgrid, dim3(256), lds1, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, (rowbytes / 16) | (srows << 16))
@@ -589,3 +756,4 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 }
 
 }  // namespace vpf
+VPF_WAVE_TIMES_EXPORT(vpf_lab_wave_times_fused)

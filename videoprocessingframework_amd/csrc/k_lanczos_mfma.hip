@@ -877,6 +877,7 @@ struct LzmTableArgs {
 };
 template <template <int> class TaskCH>
 __global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T, const LzmTableArgs W) {
+  VPF_WAVE_TIMER(3);
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): neighbouring strips and bands share one L2
   const uint32_t bx = b.x, by = b.y, bz = b.z;
   const FrameDesc& f = args.f[bz];
@@ -1096,3 +1097,4 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
 }
 
 }  // namespace vpf
+VPF_WAVE_TIMES_EXPORT(vpf_lab_wave_times_lanczos)

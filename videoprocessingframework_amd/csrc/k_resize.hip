@@ -24,6 +24,9 @@
 #include <cstring>
 
 #include "k_resize_common.h"
+#include "vpf_persist.h"
+
+#include <atomic>
 
 namespace vpf {
 
@@ -288,18 +291,22 @@ struct RowBandTask {
   static constexpr int kThreads = 256;
   static constexpr int kSlots = kBandSlots * 2 / IT < 2 * R + 1 ? kBandSlots * 2 / IT : 2 * R + 1;  // a band touches at most floor((R - 1) scy) + 3 source rows, scy <= 2
   static constexpr int kPx = band_px(CH, P1);
-  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by);
+  static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by) {
+    run_w(src, sp, dst, dp, G, bx, by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+  }
+  // one wave's share: column chunk bx, wave row wrow (the persistent launch hands these out one by one: k_planes_mp_persist)
+  static VPF_DEV void run_w(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t wrow);
 };
 template <int CH, int R, int IT, int P1, bool MULTI>
-VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
-                                         uint32_t bx, uint32_t by) {
+VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_w(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
+                                           uint32_t bx, uint32_t wrow) {
   constexpr int PX = kPx;
   constexpr uint32_t W = 64 * PX;  // destination columns per wave
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, rowq = G.a0, slots = G.a1;
   const uint32_t nb = (MULTI && G.a2) ? G.a2 : 1u;  // bands per wave (launcher): the wave walks down nb consecutive bands of its columns
   const float scx = G.scx, scy = G.scy;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  uint32_t ya = (by * 4 + wv) * (R * nb);
+  uint32_t ya = wrow * (R * nb);
   if (ya >= dh || bx * W >= dw) return;
   const uint32_t xs = bx * W, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
@@ -333,6 +340,7 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ 
   rows_of(ya);
   request();
   const ColTaps<CH, PX> T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);  // once for all rows of all bands (evaluated while the first band's rows are in flight)
+  VPF_WAVE_MARK(0);  // (lab builds: setup done)
   // With nb > 1 the source rows of band k + 1 are requested right after band k's have been written to the strips — the registers are free
   // again — and arrive while band k is blended: the wave hides its own memory latency, and its fixed part (task decode, column taps) is
   // paid once per nb bands.  Measured on 1- and 2-channel planes, whose waves are short (profiles/r04_bilinear_ablate.txt: staging, blend
@@ -340,6 +348,7 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ 
   BandWalk<CH, PX> walk;
   for (uint32_t k = 0; k < nb; k++) {
     commit();
+    VPF_WAVE_MARK(1);  // (lab builds: the first band's rows have arrived and sit in LDS)
     const Tap row_taps = band_row_taps(ya, yb, scy, sh);  // every lane active here
     const uint32_t ya_k = ya, yb_k = yb, r_lo_k = r_lo;
     ya += R;
@@ -350,6 +359,7 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run(const uint8_t* __restrict__ 
         store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
       });
     }
+    VPF_WAVE_MARK(2);  // (lab builds: the first band is blended and its stores are issued)
     if (!more) return;
     wave_lds_sync();  // the blend's LDS reads are done before the next band's rows overwrite the strips
   }
@@ -1279,6 +1289,68 @@ static void launch_planes_mp(hipStream_t st, dim3 grid, uint32_t lds, const Batc
   (void)hipGetLastError();
   hipLaunchKernelGGL((k_planes_mp<TaskCH>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
 }
+// ---- the persistent form of the same launch (k_resize_common.h: k_planes_mp_persist; vpf_persist.h): the resident set of workgroups pulls
+// wave items (frame, plane, wave row, column chunk) from the stream's work counters.  -> false when it does not apply (captured stream, no
+// counter slot free, too few items per wave to be worth it): the caller launches the plain grid.
+__device__ uint32_t g_persist_ctr[kPersistSlots * 8];
+static PersistSlotTable& persist_slots() { static PersistSlotTable t; return t; }
+static bool persist_stream_idle(int dev, const void* stream) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != dev) { (void)hipGetLastError(); return false; }  // (another device's stream: not asked from here)
+  const hipError_t e = hipStreamQuery((hipStream_t)stream);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e != hipErrorNotReady;  // drained — or no longer a stream
+}
+static uint32_t* persist_ctr_base(int dev) {
+  static std::atomic<uint32_t*> base[64];
+  uint32_t* p = base[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_persist_ctr)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    p = static_cast<uint32_t*>(q);
+    base[dev].store(p, std::memory_order_release);
+  }
+  return p;
+}
+template <template <int> class TaskCH>
+static uint32_t persist_resident_groups(int dev, uint32_t lds) {  // workgroups of this kernel the whole chip holds at `lds` bytes each
+  struct Seen { int dev; uint32_t lds, groups; };
+  static thread_local Seen seen[4];
+  static thread_local unsigned next = 0;
+  for (const Seen& e : seen) if (e.groups && e.dev == dev && e.lds == lds) return e.groups;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_planes_mp_persist<TaskCH>), (int)TaskCH<3>::kThreads, lds) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1) { (void)hipGetLastError(); return 0; }
+  const uint32_t groups = (uint32_t)per_cu * (uint32_t)cus;
+  seen[next++ & 3] = Seen{dev, lds, groups};
+  return groups;
+}
+template <template <int> class TaskCH>
+static bool launch_planes_mp_persist(hipStream_t st, uint32_t lds, const BatchArgs& a, const PlaneTable& t, uint32_t n, const uint32_t* nbx, const uint32_t* nwr, uint32_t min_items_per_wave) {
+  PersistArgs P{};
+  uint32_t per_frame = 0;
+  for (uint32_t p = 0; p < t.np; p++) { P.p0[p] = per_frame; P.nbx[p] = nbx[p]; per_frame += nbx[p] * nwr[p]; }
+  const uint64_t total = (uint64_t)per_frame * n;
+  if (!per_frame || total >= (1u << 22)) return false;
+  int dev = 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { (void)hipGetLastError(); return false; }
+  const uint32_t resident = persist_resident_groups<TaskCH>(dev, lds), wpg = TaskCH<3>::kThreads / 64u;
+  if (!resident || total < (uint64_t)resident * wpg * min_items_per_wave) return false;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (cs != hipStreamCaptureStatusNone) return false;
+  uint32_t* const ctr = persist_ctr_base(dev);
+  const int slot = ctr ? persist_slots().slot_of(dev, (const void*)st, persist_stream_idle) : -1;
+  if (slot < 0) return false;
+  P.ctr = ctr + 8 * slot;
+  P.per_frame = per_frame;
+  persist_shares((uint32_t)total, P.lo);
+  if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
+  (void)hipGetLastError();
+  const uint32_t groups = (uint32_t)std::min<uint64_t>(resident, (total + wpg - 1) / wpg);
+  hipLaunchKernelGGL((k_planes_mp_persist<TaskCH>), dim3(groups), dim3(TaskCH<3>::kThreads), lds, st, a, t, P);
+  return true;
+}
 template <template <int, int> class T2, int I>
 static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, const ResizeJob& j, const PlaneGeom& g) {
   if (j.ch == 1) launch_plane_batch<T2<1, I>>(st, grid, 0, a, j.k, g);
@@ -1372,7 +1444,7 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
 // lose with it and keep their forms.  VPF_TUNE_RESIZE_BAND = 4 | nb << 8 forces it where it applies.
 struct BandPlan { int rows; uint32_t slots; bool narrow; int p1; uint32_t rb; uint32_t nb; };
 static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
-  const int p1 = band_p1(njobs, jobs), knob = tuning(VPF_TUNE_RESIZE_BAND), forced_nb = knob >> 8;
+  const int p1 = band_p1(njobs, jobs), knob = tuning(VPF_TUNE_RESIZE_BAND) & 0xffff, forced_nb = knob >> 8;
   if (p1 == 8) {
     const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 8);
     const BandShape bs = band_rows(njobs, jobs, rb, n, 8);
@@ -1552,6 +1624,25 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; t.g[p].a2 = bs.nb; }  // one strip size for the launch (the widest plane's)
       it = (rb + 1023) / 1024;
       const uint32_t lds = band > 1 ? 4 * bs.slots * rb + 16 : 4 * 2 * rb + 16;
+      // the persistent form for the band kernels (VPF_TUNE_RESIZE_BAND | 0x10000: wherever it can run): wave items instead of a grid
+      const int pknob = tuning(VPF_TUNE_RESIZE_BAND) >> 16;
+      if (band > 1 && pknob == 1) {
+        uint32_t nbx[3] = {0, 0, 0}, nwr[3] = {0, 0, 0};
+        for (int p = 0; p < njobs; p++) {
+          const uint32_t wcols = 64u * band_px(jobs[p].ch, bs.p1);
+          nbx[p] = (jobs[p].dw + wcols - 1) / wcols; nwr[p] = (jobs[p].dh + band * band_nb - 1) / (band * band_nb);
+        }
+        bool done = false;
+        if (band == 4 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand4wm>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 16 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand16w>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 8 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand8w>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 16) done = launch_planes_mp_persist<RowBand16n>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 8 && bs.narrow) done = launch_planes_mp_persist<RowBand8n>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 8) done = launch_planes_mp_persist<RowBand8>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 4) done = launch_planes_mp_persist<RowBand4>(st, lds, a, t, n, nbx, nwr, 0);
+        else if (band == 2) done = launch_planes_mp_persist<RowBand2>(st, lds, a, t, n, nbx, nwr, 0);
+        if (done) return hipGetLastError();
+      }
       if (band == 4 && bs.p1 == 8) launch_planes_mp<RowBand4wm>(st, grid, lds, a, t);
       else       if (band == 16 && bs.p1 == 8) launch_planes_mp<RowBand16w>(st, grid, lds, a, t);
       else if (band == 8 && bs.p1 == 8) launch_planes_mp<RowBand8w>(st, grid, lds, a, t);
@@ -1659,3 +1750,4 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
 }
 
 }  // namespace vpf
+VPF_WAVE_TIMES_EXPORT(vpf_lab_wave_times_resize)

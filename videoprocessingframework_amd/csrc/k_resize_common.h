@@ -3,6 +3,7 @@
 // restates bit for bit (its lanczos_weights_fp32 / lanczos_weights_q14).
 #pragma once
 #include "k_bilinear_blend.h"
+#include "vpf_wave_times.h"
 
 namespace vpf {
 
@@ -43,6 +44,7 @@ VPF_DEV BlockId picture_order() {
 }
 template <class Task>
 __global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BatchArgs args, const int k, const PlaneGeom G) {
+  VPF_WAVE_TIMER(1);
   const BlockId b = picture_order();
   const FrameDesc& f = args.f[b.z];
   Task::run(f.s[k], f.sp[k], f.d[k], f.dp[k], G, b.x, b.y);
@@ -51,8 +53,14 @@ struct PlaneTable {
   PlaneGeom g[3];
   uint32_t by0[3], k[3], ch[3], np;
 };
+#ifdef VPF_WAVE_TIMES  // (lab builds: the timer's common exit costs the band kernels 30 VGPRs and with them the fourth wave per SIMD — held at the product's occupancy)
+#define VPF_WT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define VPF_WT_OCCUPANCY
+#endif
 template <template <int> class TaskCH>
-__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchArgs args, const PlaneTable T) {
+__global__ __launch_bounds__(TaskCH<3>::kThreads) VPF_WT_OCCUPANCY void k_planes_mp(const BatchArgs args, const PlaneTable T) {
+  VPF_WAVE_TIMER(2);
   const BlockId b = picture_order();
   const FrameDesc& f = args.f[b.z];
   const uint32_t by = b.y;
@@ -62,6 +70,60 @@ __global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp(const BatchAr
     case 1: TaskCH<1>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], b.x, lby); break;
     case 2: TaskCH<2>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], b.x, lby); break;
     default: TaskCH<3>::run(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], b.x, lby); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The launch that survives its tail (round 5).  A batched resize of small planes is 1.1-2.2 ROUNDS of workgroups: the last,
+// partial round occupies a fraction of the chip for a whole wave life, and the waves of a round start and end together.  Here the grid is
+// the RESIDENT set of workgroups and its waves pull wave-sized items (frame, plane, column chunk, run of bands) from work counters until
+// none is left — the dispatch ends within one item of its busiest wave, whatever the number of items.  One counter per XCD: XCD x works
+// through the x-th eighth of the picture-ordered item list (neighbours in the picture are neighbours in time on ONE L2, as picture_order()
+// arranges for the plain launch) and then helps the others.  Every wave ends with exactly one failing fetch per counter, so a launch over
+// n_x items and W waves draws n_x + W tickets from counter x: the wave that draws the last one puts the counter back to zero — the next
+// launch of the slot's stream finds it as the code object left it (vpf_persist.h: a slot of eight counters per stream).  A task takes part through
+//   static VPF_DEV void run_w(src, sp, dst, dp, G, bx, wrow)   — one wave's share: column chunk bx, wave row wrow (= by * 4 + wave of run())
+// ------------------------------------------------------------------------------------------
+struct PersistArgs {
+  uint32_t* ctr;      // the slot's eight counters (zero between launches)
+  uint32_t lo[9];     // XCD x owns items [lo[x], lo[x + 1])
+  uint32_t per_frame; // items per frame (all planes)
+  uint32_t p0[3];     // first item of plane p inside a frame
+  uint32_t nbx[3];    // column chunks of plane p
+};
+template <template <int> class TaskCH>
+__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp_persist(const BatchArgs args, const PlaneTable T, const PersistArgs P) {
+  VPF_WAVE_TIMER(6);
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const uint32_t lane = threadIdx.x & 63u, waves = gridDim.x * (TaskCH<3>::kThreads / 64u);
+  const float rpf = 1.0f / (float)P.per_frame;
+  for (uint32_t hop = 0; hop < 8; hop++) {
+    const uint32_t x = (xcc + hop) & 7u, lo = P.lo[x], nx = P.lo[x + 1] - lo;
+    for (;;) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(P.ctr + x, 1u);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nx) {
+        if (t == nx + waves - 1u && lane == 0) atomicExch(P.ctr + x, 0u);  // the counter's last ticket of this launch: nobody asks again
+        break;
+      }
+      const uint32_t it = lo + t;
+      // item -> (frame, plane, wave row, column chunk); (it + 0.5) / per_frame is >= 0.5 / per_frame away from an integer: exact in fp32 for it < 2^22
+      uint32_t z = (uint32_t)(((float)it + 0.5f) * rpf);
+      uint32_t r = it - z * P.per_frame;
+      if ((int32_t)r < 0) { z--; r += P.per_frame; } else if (r >= P.per_frame) { z++; r -= P.per_frame; }
+      const uint32_t pi = (uint32_t)(T.np > 1 && r >= P.p0[1]) + (uint32_t)(T.np > 2 && r >= P.p0[2]);
+      r -= P.p0[pi];
+      const uint32_t nbx = P.nbx[pi], wrow = r / nbx, bx = r - wrow * nbx, k = T.k[pi];
+      const FrameDesc& f = args.f[z];
+      switch (T.ch[pi]) {  // wave-uniform
+        case 1: TaskCH<1>::run_w(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, wrow); break;
+        case 2: TaskCH<2>::run_w(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, wrow); break;
+        default: TaskCH<3>::run_w(f.s[k], f.sp[k], f.d[k], f.dp[k], T.g[pi], bx, wrow); break;
+      }
+      wave_lds_sync();  // the item's LDS reads are done before the next item's rows overwrite the strips
+    }
   }
 }
 

@@ -218,7 +218,7 @@ vpf_status vpf_convert_batch(const vpf_exec* exec, int sf, int df, int cs, int c
     const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
     BatchArgs a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, ns, frames[base + i].dst, nd);
-    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
     hipError_t e;
     switch (fam) {
       case FAM_YUV2RGB:
@@ -288,7 +288,7 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
   if (guard.err != hipSuccess) return status_of(guard.err);
   hipStream_t st = static_cast<hipStream_t>(exec->stream);
   const int np = num_planes(fmt);
-  const bool forced_family = (tuning(VPF_TUNE_RESIZE_MFMA) & 0xffff) >= 2 || tuning(VPF_TUNE_RESIZE_BAND) >= 2;  // measurement runs: the batch kernels on one frame
+  const bool forced_family = (tuning(VPF_TUNE_RESIZE_MFMA) & 0xffff) >= 2 || (tuning(VPF_TUNE_RESIZE_BAND) & 0xffff) >= 2 || (tuning(VPF_TUNE_RESIZE_BAND) >> 16);  // measurement runs: the batch kernels on one frame
   if (n == 1 && nj == 1 && !forced_family) {  // one plane of one frame: the scalar-argument kernel entries (kernarg preload)
     const vpf_plane &s0 = frames[0].src[0], &d0 = frames[0].dst[0];
     const hipError_t e = f32 ? launch_resize_f32(st, jobs[0].ch, interp, ss.width, ss.height, static_cast<const uint8_t*>(s0.ptr), s0.pitch, ds.width, ds.height,
@@ -301,7 +301,7 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
     const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
     BatchArgs a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, np, frames[base + i].dst, np);
-    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
     const hipError_t e = launch_resize_jobs(st, f32, interp, nj, jobs, m, a);
     if (e != hipSuccess) return status_of(e);
   }
@@ -360,7 +360,7 @@ vpf_status vpf_remap_batch(const vpf_exec* exec, int fmt, vpf_size ss, const flo
     const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
     BatchArgs a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, 1, frames[base + i].dst, 1);
-    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
     const hipError_t e = launch_remap_batch(static_cast<hipStream_t>(exec->stream), ss.width, ss.height, xmap, xp, ymap, yp, ds.width, ds.height, m, a);
     if (e != hipSuccess) return status_of(e);
   }
@@ -397,7 +397,7 @@ vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int sf, int df, int cs
     const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
     BatchArgs a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, num_planes(sf), frames[base + i].dst, num_planes(df));
-    for (uint32_t i = m; i < (uint32_t)kMaxBatch; i++) a.f[i] = a.f[0];
+    for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
     const hipError_t e = launch_convert_resize(static_cast<hipStream_t>(exec->stream), yuv_src_class(sf), rgb_class(df), c,
                                                ss.width, ss.height, m, a, ds.width, ds.height);
     if (e != hipSuccess) return status_of(e);
@@ -454,13 +454,13 @@ int vpf_set_tuning(int key, int value) {
     return g_tune_mfma.exchange(value);
   }
   if (key == VPF_TUNE_RESIZE_BAND) {
-    const int rows = value & 0xff, nb = value >> 8;  // nb: bands per wave of the march form (4-row bands only)
-    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4);
+    const int rows = value & 0xff, nb = (value >> 8) & 0xff, form = value >> 16;  // nb: bands per wave of the march form (4-row bands only); form: | 0x10000 = the persistent launch
+    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4) && form <= 1;
     return ok ? g_tune_band.exchange(value) : -1;
   }
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
-    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: return g_tune_variant.exchange(value);
+    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: case 47: case 48: return g_tune_variant.exchange(value);
     default: return -1;  // unknown value: nothing changes
   }
 }

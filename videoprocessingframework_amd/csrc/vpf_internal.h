@@ -25,8 +25,11 @@ struct Rgb2YuvCoef {
 bool make_yuv2rgb(int color_space, int color_range, Yuv2RgbCoef* out);
 bool make_rgb2yuv(int color_range, Rgb2YuvCoef* out);
 
-// Up to 32 frames per dispatch travel in the kernarg segment (32 x 72 B; no device-side table to manage).
-constexpr int kMaxBatch = 32;
+// Up to 128 frames per dispatch travel in the kernarg segment (128 x 72 B = 9 KiB; no device-side table to manage).  32 until round 5: a batch of
+// small planes is 25-50 us of kernel, and every dispatch boundary costs ~3 us of idle chip plus a tail of partly empty CUs of about one wave
+// life (profiles/r05_wave_times.txt) — four times the frames per dispatch amortise both (the runtime takes kernel arguments of 32 KiB and more:
+// profiles/r05_probe_kernarg_size.txt; 9 KiB cost 0.3 us more host time per launch than 2 KiB).
+constexpr int kMaxBatch = 128;
 struct FrameDesc {
   const uint8_t* s[3];
   uint8_t* d[3];

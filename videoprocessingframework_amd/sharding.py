@@ -68,6 +68,16 @@ def gather(value_local: float, device: torch.device | None = None) -> List[float
     return [float(t.item()) for t in out]
 
 
+def gather_objects(obj) -> list:
+    """One picklable object per rank, in rank order (the per-rank diagnostics of bench.py's JSON line: device, PCI address, NUMA node, clocks).
+    Off the timed path; gloo and nccl (= RCCL: the objects travel as byte tensors on the rank's current device) alike."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def throughput(units_local: float, seconds_local: float, device: torch.device | None = None) -> float:
     u, t = aggregate(units_local, seconds_local, device)
     return u / t
@@ -109,6 +119,38 @@ def gpu_numa_cpus(pci_addr: str, sysfs_pci: str = "/sys/bus/pci/devices") -> Tup
     except (OSError, ValueError):
         cpus = []
     return (node if node >= 0 else None), cpus
+
+
+def current_sclk_mhz(pci_addr: Optional[str], sysfs_pci: str = "/sys/bus/pci/devices") -> Optional[int]:
+    """The shader clock the amdgpu driver reports as current for this device (the starred level of pp_dpm_sclk), None where sysfs does not
+    say (containers often hide it).  A rank that starts or ends a timed region on a lower clock than its neighbours explains a slow rank."""
+    if not pci_addr:
+        return None
+    try:
+        for line in open(os.path.join(sysfs_pci, pci_addr, "pp_dpm_sclk")).read().splitlines():
+            if line.rstrip().endswith("*"):
+                return int("".join(ch for ch in line.split(":", 1)[1] if ch.isdigit()))
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
+def rank_identity(device_index: Optional[int], sysfs_pci: str = "/sys/bus/pci/devices") -> Dict[str, object]:
+    """What a scaling run needs to be diagnosable from its own output: which device this rank drives, where it sits (PCI address, NUMA node)
+    and which CPUs the rank may use.  device_index None = a host-only rehearsal."""
+    rank, _, local = env_rank()
+    info: Dict[str, object] = {"rank": rank, "local_rank": local, "device": device_index, "pci": None, "numa_node": None, "name": None,
+                               "cpus": len(os.sched_getaffinity(0)), "pid": os.getpid()}
+    if device_index is None:
+        return info
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        info["name"] = p.name
+        info["pci"] = pci_address(int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(p.pci_device_id))
+        info["numa_node"] = gpu_numa_cpus(info["pci"], sysfs_pci)[0]
+    except Exception as e:  # noqa: BLE001
+        info["why"] = f"no PCI address: {e}"
+    return info
 
 
 def bind_to_gpu_numa(device_index: int, sysfs_pci: str = "/sys/bus/pci/devices") -> Dict[str, object]:
