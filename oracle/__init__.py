@@ -13,7 +13,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvpforacle.so")
+# `make sanitize` (tools/sanitize.sh): VPF_TEST_CFLAGS / VPF_TEST_BUILD_TAG build and load an instrumented copy next to the plain one
+_TAG = os.environ.get("VPF_TEST_BUILD_TAG", "")
+_LIB_PATH = os.path.join(_HERE, f"libvpforacle_{_TAG}.so" if _TAG else "libvpforacle.so")
 
 EXACT, FP32 = 0, 1
 
@@ -37,7 +39,7 @@ def build(force: bool = False) -> str:
         with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # pytest-xdist workers must not link the same file at the same time
             fcntl.flock(lock, fcntl.LOCK_EX)
             if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
-                subprocess.check_call(["make", "-C", _HERE, "libvpforacle.so"], stdout=subprocess.DEVNULL)
+                subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH), "EXTRA_CFLAGS=" + os.environ.get("VPF_TEST_CFLAGS", "")], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src/TC/TC_CORE/src"):
         ref = os.path.join(_HERE, "_ref")
         shim_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_shim.cpp", "ref_tc_shim.cpp", "Makefile"))

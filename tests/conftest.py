@@ -8,6 +8,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def native_test_build():
+    """(extra compiler flags, build directory) for the C / C++ harnesses the CPU tests compile (tests/c/*, oracle/): `make sanitize`
+    (tools/sanitize.sh) sets VPF_TEST_CFLAGS to the sanitizer flags and VPF_TEST_BUILD_TAG so that instrumented objects never mix with
+    the plain ones."""
+    import shlex
+
+    flags = shlex.split(os.environ.get("VPF_TEST_CFLAGS", ""))
+    tag = os.environ.get("VPF_TEST_BUILD_TAG", "")
+    out = os.path.join(ROOT, "tests", "_build", tag) if tag else os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    return flags, out
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -14,14 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def pst():
-    out = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(out, exist_ok=True)
+    from conftest import native_test_build
+    extra, out = native_test_build()
     so = os.path.join(out, "libpersist_capi.so")
     src = os.path.join(ROOT, "tests", "c", "persist_capi.cpp")
     hdr = os.path.join(ROOT, "videoprocessingframework_amd", "csrc")
     deps = [src, os.path.join(hdr, "vpf_persist.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Werror", "-I", hdr, src, "-o", so, "-pthread"], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Werror", *extra, "-I", hdr, src, "-o", so, "-pthread"], check=True)
     L = C.CDLL(so)
     L.pst_new.restype = C.c_void_p
     L.pst_free.argtypes = [C.c_void_p]

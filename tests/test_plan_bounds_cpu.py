@@ -17,8 +17,9 @@ F = np.float32
 
 @pytest.fixture(scope="module")
 def pb(tmp_path_factory):
+    from conftest import native_test_build
     so = str(tmp_path_factory.mktemp("pb") / "libplanbounds.so")
-    subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"),
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror", *native_test_build()[0], "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"),
                            os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so, "-lm"])
     L = C.CDLL(so)
     for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_band_rows_exact", [C.c_int, C.c_uint32, C.c_uint32]),

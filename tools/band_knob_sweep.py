@@ -18,20 +18,21 @@ CASES = [("Y", 1920, 1080, 1280, 720), ("NV12", 1920, 1080, 1280, 720), ("YUV420
 if os.environ.get("SWEEP_CASES"):
     CASES = [(c.split(":")[0],) + tuple(int(v) for v in c.split(":")[1].split("x")) + tuple(int(v) for v in c.split(":")[2].split("x")) for c in os.environ["SWEEP_CASES"].split(",")]
 PASSES = int(os.environ.get("SWEEP_PASSES", "3"))
+NB = int(os.environ.get("SWEEP_N", "32"))  # frames per dispatch
 
 
 def main():
     knobs = [int(k, 0) for k in sys.argv[1:]] or [0]
     ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
-    print(f"[knobs] interp {INTERP}, 32 frames per dispatch; cells: min / median of {PASSES} interleaved passes, us per frame")
+    print(f"[knobs] interp {INTERP}, {NB} frames per dispatch; cells: min / median of {PASSES} interleaved passes, us per frame")
     print("[knobs] " + " " * 12 + " | ".join(f"{c[0]:>6s} {c[1]}x{c[2]}->{c[3]}x{c[4]}" for c in CASES))
     res = {k: [] for k in knobs}
     for fname, sw, sh, dw, dh in CASES:
         fmt = getattr(capi, fname)
-        ring = max(32, min(128, int(600e6 // ((sw * sh + dw * dh) * 3)) // 32 * 32))
+        ring = max(NB, min(256, int(600e6 // ((sw * sh + dw * dh) * 3)) // NB * NB))
         S = [surf(fmt, sw, sh, True) for _ in range(ring)]
         D = [surf(fmt, dw, dh, False) for _ in range(ring)]
-        batches = [capi.make_batch([(s[1], d[1]) for s, d in list(zip(S, D))[i:i + 32]]) for i in range(0, ring, 32)]
+        batches = [capi.make_batch([(s[1], d[1]) for s, d in list(zip(S, D))[i:i + NB]]) for i in range(0, ring, NB)]
         cell = {k: [] for k in knobs}
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(PASSES + 1):  # the first pass warms up

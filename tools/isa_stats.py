@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Static ISA statistics of one translation unit's gfx950 kernels (no GPU needed): instruction mix per kernel, VGPR / SGPR / LDS use,
-occupancy-relevant numbers, and per-loop-body counts.  python tools/isa_stats.py csrc/k_resize.hip [name-substring ...]"""
+occupancy-relevant numbers, and per-loop-body counts.  python tools/isa_stats.py csrc/k_resize.hip [name-substring ...]
+python tools/isa_stats.py --spills csrc/k_lanczos_mfma.hip: one line per kernel (VGPRs, spilled VGPRs / SGPRs, scratch bytes) and exit status 1 when any
+kernel of the translation unit spills a VGPR or uses scratch (tests/test_isa_no_spills.py: VERDICT r4 item 5)."""
 import collections
 import os
 import re
@@ -31,7 +33,28 @@ def klass(i):
     return "other"
 
 
+def spills(src):
+    """[(kernel, vgprs, spilled vgprs, spilled sgprs, scratch bytes)] from the code object's metadata"""
+    s = asm_of(src)
+    out = []
+    for blk in s.split("  - .agpr_count:")[1:]:
+        g = lambda key: int(re.search(key + r":\s+(\d+)", blk).group(1))
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        out.append((subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name, g(r"\.vgpr_count"), g(r"\.vgpr_spill_count"),
+                    g(r"\.sgpr_spill_count"), g(r"\.private_segment_fixed_size")))
+    return out
+
+
 def main():
+    if sys.argv[1] == "--spills":
+        src = sys.argv[2]
+        if not os.path.isabs(src):
+            src = os.path.join(ROOT, "videoprocessingframework_amd", src) if not os.path.exists(src) else src
+        bad = 0
+        for name, vg, vs, ss, scr in spills(src):
+            print(f"{name[:110]:110s} vgpr {vg:3d} spilled {vs} (sgpr {ss}) scratch {scr} B")
+            bad += vs > 0 or scr > 0
+        sys.exit(1 if bad else 0)
     src = sys.argv[1]
     if not os.path.isabs(src):
         src = os.path.join(ROOT, "videoprocessingframework_amd", src) if not os.path.exists(src) else src

@@ -148,6 +148,19 @@ def main():
         verified += 1
     verified_all, _ = sharding.aggregate(verified, 0.0, red_dev)
     clips_per_rank = [sharding.assign_clips(a.clips, world, r) for r in range(world)]
+    # What one uploaded frame costs the HOST's memory system (round 5: the 8-GPU end-to-end rate is set by host DRAM, not by the GPUs).  A frame in
+    # page-locked memory is read once, by the DMA engine.  A pageable frame is read by the uploader's host copy, written into a pinned slot
+    # (non-temporal stores: no read-for-ownership) and read again by the DMA engine: three times its size.  Next to it, what one core of this
+    # box copies per second (one pass over 256 MiB, best of three): the scale for "how many ranks can one socket feed".
+    frame_bytes = w * h * 3 // 2
+    host_bytes = frame_bytes * (1 if a.source == "pinned" else 3)
+    probe_src, probe_dst = np.ones(1 << 28, np.uint8), np.empty(1 << 28, np.uint8)
+    copy_gbps = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        np.copyto(probe_dst, probe_src)
+        copy_gbps = max(copy_gbps, (1 << 28) / (time.perf_counter() - t0) / 1e9)
+    del probe_src, probe_dst
     if rank == 0:
         print(json.dumps({"runner": "shard_pipeline", "n_gpus": world, "clips": a.clips, "clips_per_rank": clips_per_rank,
                           "frames_total": a.clips * a.frames, "size": f"{w}x{h}", "verified_clips": int(verified_all),
@@ -155,6 +168,10 @@ def main():
                                     "(no libav in this image; tools/clip_pipeline.py runs a real decoder where libav exists)",
                           "threads": "one per clip" if a.threads else "one, round-robin", "numa": numa,
                           "bytes_per_s_end_to_end": round(rates["end_to_end"]["frames_per_s"] * w * h * 1.5 / 1e9, 2),
+                          "host_memory": {"source": a.source, "frame_bytes": frame_bytes, "host_dram_bytes_per_frame": host_bytes,
+                                          "host_dram_GBps_at_this_rate": round(rates["end_to_end"]["frames_per_s"] * host_bytes / 1e9, 1),
+                                          "one_core_copy_GBps": round(copy_gbps, 1),
+                                          "model": "pinned source: 1 x frame (DMA read); pageable: 3 x (host copy read + pinned-slot write + DMA read)"},
                           "end_to_end": rates["end_to_end"], "device_resident": rates["device_resident"],
                           "sharding": "clip s -> rank s mod N; no data-path collective"}), flush=True)
     if world > 1:

@@ -278,11 +278,15 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         uint32_t keep;
+        // (the table address is workgroup-uniform; spelled through readfirstlane so that the "s" operand is a scalar register pair whatever
+        // the register allocator made of the values it is computed from — a build with more live state had handed the asm a VGPR pair)
+        const uint64_t ta = reinterpret_cast<uint64_t>(reinterpret_cast<const uint8_t*>(t) + 4096 * h);
+        const uint64_t tsc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ta >> 32)) << 32 | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ta);  // (the builtin returns int: widened unsigned)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %2, %1\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024\n\t"
                      "global_load_lds_dwordx4 %2, %1 offset:2048\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072\n\t"
                      "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(reinterpret_cast<const uint8_t*>(t) + 4096 * h), "v"(voff), "s"(ldst + 4096u * h) : "memory");
+                     : "=&s"(keep) : "s"(tsc), "v"(voff), "s"(ldst + 4096u * h) : "memory");
       }
     } else {
       lzm_row_group(wm, lane, ya, yb, g, scy, sh, t_first, rts);
@@ -345,9 +349,13 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
   // ends with the plane's last row: a fetch costs no vector arithmetic at all (it was 8 instructions per tile), and the rows of the
   // picture's last, partial tile (sh % 16 != 0) that lie below the picture are out of the buffer's range — they read as zeros instead of
   // faulting, and carry no weight (the row weights of clamped taps sit on the last real row)
-  uint32_t voff[PF];
+  // Even PF: load k and load k + PF / 2 are the same unit of rows 8 apart — one vector offset serves both, the row step travels as the
+  // buffer load's SCALAR offset (round 5: PF / 2 VGPRs instead of PF; LzMfma4k8 sat at 256 VGPRs + one spilled)
+  constexpr int NV = LPR == 8 ? HALF : PF;
+  uint32_t voff[NV];
 #pragma unroll
-  for (int k = 0; k < PF; k++) voff[k] = mad24(k_row(k), sp, S0 + 16u * (k_unit(k) < nq ? k_unit(k) : nq - 1u));
+  for (int k = 0; k < NV; k++) voff[k] = mad24(k_row(k), sp, S0 + 16u * (k_unit(k) < nq ? k_unit(k) : nq - 1u));
+  const uint32_t sp8 = 8u * sp;  // scalar
   // Source tiles travel global memory -> registers -> LDS, TWO tiles ahead of the arithmetic (two register sets: the march is unrolled
   // four deep, so "which set" is a compile-time constant).  One tile ahead left the waves waiting for HBM: with two waves per SIMD a
   // tile's arithmetic lasts ~1 us, less than a loaded chip's memory latency (SQ_WAIT_ANY was 42 % of the wave cycles).
@@ -366,7 +374,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
     const uint32_t toff = (uint32_t)(T < t_last ? T : t_last) * 16u * sp;  // scalar
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + toff, 0, plane_bytes - toff, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < PF; k++) pf[SET][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k], 0, 0));
+    for (int k = 0; k < PF; k++) pf[SET][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k % NV], LPR == 8 && k >= HALF ? (int)sp8 : 0, 0));
   };
   v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs)
 #pragma unroll
