@@ -987,7 +987,7 @@ def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
 
 
-@pytest.mark.parametrize("band", [1, 2, 4, 8, 16, 0x104, 0x204, 0x304, 0x804, 0x10000, 0x10002, 0x10008, 0x10104, 0x10304])
+@pytest.mark.parametrize("band", [1, 2, 4, 8, 16, 0x104, 0x204, 0x304, 0x804, 0x10000, 0x10002, 0x10008, 0x10104, 0x10304, 0x20000, 0x20008, 0x20304])
 def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
     """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 16 / 8 / 4 / 2 for launches with >= 2048
     workgroups, 1 otherwise).  Every value writes the oracle's pixels: general and > 2x down-scales, shared and disjoint source rows,
@@ -1027,7 +1027,7 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
         capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 32) == -1
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x208) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x904) == -1  # bands per wave: 4-row bands only, at most 8
-    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x20004) == -1                                                           # forms: 0 the grid, 1 the persistent launch
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x40004) == -1                                                           # forms: | 0x10000 the persistent launch, | 0x20000 eight pixels per lane on every 1-channel plane
 
 
 @pytest.mark.parametrize("fmt", ["Y", "NV12"])

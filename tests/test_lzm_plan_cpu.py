@@ -95,26 +95,28 @@ def test_planner_stays_close_to_the_best_measured_shape(lzp):
     assert len(regrets) == 27 and float(np.mean(regrets)) <= 0.06, np.mean(regrets)
 
 
-def test_planner_at_128_frames_per_dispatch(lzp):
-    """Round 5 (kMaxBatch 32 -> 128): the cost model (rounds = a quarter of the rounded-up count + three quarters of the plain ratio) against the
-    n = 128 sweep (RGB / NV12 / YUV420 / Y x three size pairs): the pick within 16 % of the best measured shape, 5 % on average — the round-3
-    model, asked about 128 frames, lost 26 % on NV12 1080p -> 720p and 20 % on Y."""
+@pytest.mark.parametrize("n,mean_max,worst_max", [(64, 0.06, 0.15), (128, 0.05, 0.15)])
+def test_planner_beyond_32_frames_per_dispatch(lzp, n, mean_max, worst_max):
+    """Round 5 (up to 128 frames per dispatch): the cost model's large-launch branch (continuous rounds + a tail of one and a half wave lives)
+    against the sweeps at 64 and 128 frames (RGB / NV12 / YUV420 / Y x three size pairs each): the pick within 15 % of the best measured
+    shape, 5-6 % on average — the round-3 model, asked about such launches, put NV12 and Y 1080p -> 720p on whole-column 4-tile strips
+    (46 % / 27 % off the best)."""
     regrets = []
-    for line in open(os.path.join(ROOT, "profiles", "r05_lanczos_shape_sweep_n128.txt")):
+    for line in open(os.path.join(ROOT, "profiles", f"r05_lanczos_shape_sweep_n{n}.txt")):
         m = re.match(r"\[lzm-sweep\] (\w+)\s+(\d+)x(\d+)->(\d+)x(\d+) n=(\d+):", line)
         if not m:
             continue
-        fmt, (sw, sh, dw, dh, n) = m.group(1), (int(v) for v in m.groups()[1:])
+        fmt, (sw, sh, dw, dh, nn) = m.group(1), (int(v) for v in m.groups()[1:])
         res = {(int(a), int(b)): float(c) for a, b, c in re.findall(r"nt(\d) r(\d+)=([\d.]+)", line)}
-        p = plan(lzp, planes_of(fmt, sw, sh, dw, dh), n)
-        assert p["ok"] and n == 128
+        p = plan(lzp, planes_of(fmt, sw, sh, dw, dh), nn)
+        assert p["ok"] and nn == n
         rs = sorted(r for (nt, r) in res if nt == p["nt"])
         lo = max([r for r in rs if r <= p["r"]], default=rs[0])
         hi = min([r for r in rs if r >= p["r"]], default=rs[-1])
         t = res[(p["nt"], lo)] if lo == hi else np.interp(p["r"], [lo, hi], [res[(p["nt"], lo)], res[(p["nt"], hi)]])
         regrets.append(t / min(res.values()) - 1.0)
-        assert regrets[-1] <= 0.16, (fmt, sw, dw, p, t, min(res.values()))
-    assert len(regrets) == 12 and float(np.mean(regrets)) <= 0.05, np.mean(regrets)
+        assert regrets[-1] <= worst_max, (fmt, sw, dw, p, t, min(res.values()))
+    assert len(regrets) == 12 and float(np.mean(regrets)) <= mean_max, np.mean(regrets)
 
 
 def test_planner_limits_and_forced_shapes(lzp):

@@ -35,8 +35,8 @@ VPF_DEV void texel_rgb(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t x, uin
   rgb[2] = (float)sat_rne(__builtin_fmaf(yf, c.cy, k.bc));
 }
 
-template <int SRC, int DST>
-__global__ __launch_bounds__(256) void k_convert_resize(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw,
+template <int SRC, int DST, class BA = BatchArgs>  // BA: the frame table's size (<= 32 / <= 128 frames: vpf_internal.h)
+__global__ __launch_bounds__(256) void k_convert_resize(const BA args, const Yuv2RgbCoef c, uint32_t sw,
                                                         uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy,
                                                         int vec_ok) {
   const FrameDesc f = args.f[blockIdx.z];
@@ -273,8 +273,8 @@ VPF_DEV void convert_resize_lds_task(const FrameDesc& f, const Yuv2RgbCoef& c, u
     }
   }
 }
-template <int SRC, int DST, int IT>
-__global__ __launch_bounds__(256) void k_convert_resize_lds(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
+template <int SRC, int DST, int IT, class BA = BatchArgs>
+__global__ __launch_bounds__(256) void k_convert_resize_lds(const BA args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
                                                             uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok, uint32_t rowq) {
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h)
   convert_resize_lds_task<SRC, DST, IT>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
@@ -359,8 +359,8 @@ VPF_DEV void convert_half_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_
     }
   }
 }
-template <int DST, int SRC>
-__global__ __launch_bounds__(256) void k_convert_half(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t dh,
+template <int DST, int SRC, class BA = BatchArgs>
+__global__ __launch_bounds__(256) void k_convert_half(const BA args, const Yuv2RgbCoef c, uint32_t sw, uint32_t dh,
                                                       uint32_t chunks_x, uint32_t n_tasks) {
   convert_half_task<DST, SRC>(args.f[blockIdx.y], c, sw, dh, chunks_x, n_tasks);
 }
@@ -492,8 +492,8 @@ VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32
     }
   });
 }
-template <int SRC, int DST, int R>
-__global__ __launch_bounds__(256) void k_convert_strip(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
+template <int SRC, int DST, int R, class BA = BatchArgs>
+__global__ __launch_bounds__(256) void k_convert_strip(const BA args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
                                                        float scx, float scy, int vec_ok, uint32_t rowq) {
   VPF_WAVE_TIMER(4);
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): bands above each other and chunks next to each other share one L2
@@ -624,8 +624,8 @@ VPF_DEV void convert_strip_wg_task(const FrameDesc& f, const Yuv2RgbCoef& c, uin
     }
   });
 }
-template <int SRC, int DST, int R>
-__global__ __launch_bounds__(256) void k_convert_strip_wg(const BatchArgs args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
+template <int SRC, int DST, int R, class BA = BatchArgs>
+__global__ __launch_bounds__(256) void k_convert_strip_wg(const BA args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
                                                           float scx, float scy, int vec_ok, uint32_t rowq) {
   VPF_WAVE_TIMER(5);
   const BlockId b = picture_order();
@@ -633,9 +633,16 @@ __global__ __launch_bounds__(256) void k_convert_strip_wg(const BatchArgs args, 
 }
 
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh,
-                                 uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh) {
+                                 uint32_t n, const BatchArgsL& a, uint32_t dw, uint32_t dh) {
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
   int vec_ok = 1;
+  // up to 32 frames travel in the small frame table, more in the large one: two instantiations of every batch kernel (vpf_internal.h)
+  const bool small = n <= (uint32_t)kSmallBatch;
+  const BatchArgs as = small_batch(a, small ? n : 0u);
+#define VPF_UNPAREN(...) __VA_ARGS__
+#define VPF_LAUNCH_BA(K, TARGS, GRID, BLK, LDS, ST, ...) do { \
+    if (small) VPF_LAUNCH((K<VPF_UNPAREN TARGS, BatchArgs>), GRID, BLK, LDS, ST, as, __VA_ARGS__); \
+    else VPF_LAUNCH((K<VPF_UNPAREN TARGS, BatchArgsL>), GRID, BLK, LDS, ST, a, __VA_ARGS__); } while (0)
   const uint32_t rowb = lds_strip_bytes(1, sw, dw, a.f[0].s[0], a.f[0].sp[0], kFusedRowBytes);
   bool lds_ok = rowb != 0;
   for (uint32_t i = 0; i < n; i++) {
@@ -653,7 +660,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       const uint32_t chunks = (sw + 1023) / 1024, tasks = chunks * dh;
       dim3 hgrid((tasks + 3) / 4, n);
 #define VPF_HALF1(D, S) do { if (n == 1) VPF_LAUNCH((k_convert_half_one<D, S>), hgrid, dim3(256), 0, st, VPF_ONE_SRC_ARGS(a.f[0]), sw, dh, chunks, tasks, VPF_ONE_DST_ARGS(a.f[0]), c); \
-                            else VPF_LAUNCH((k_convert_half<D, S>), hgrid, dim3(256), 0, st, a, c, sw, dh, chunks, tasks); } while (0)
+                            else VPF_LAUNCH_BA(k_convert_half, (D, S), hgrid, dim3(256), 0, st, c, sw, dh, chunks, tasks); } while (0)
 #define VPF_HALF(S) do { if (dst_fc == FC_RGB) VPF_HALF1(FC_RGB, S); else if (dst_fc == FC_BGR) VPF_HALF1(FC_BGR, S); else VPF_HALF1(FC_PLANAR, S); } while (0)
       if (src_fc == FC_NV12) VPF_HALF(FC_NV12); else VPF_HALF(FC_YUV420);
 #undef VPF_HALF
@@ -710,7 +717,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
         if (rw && wconv <= (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 48 ? 8.0 : 3.0)) {
           const uint32_t ldsw = wrows * rowbytes;
           dim3 wgrid((dw + 255) / 256, (dh + 4 * rw - 1) / (4 * rw), n);
-#define VPF_WG1(S, D, RR) VPF_LAUNCH((k_convert_strip_wg<S, D, RR>), wgrid, dim3(256), ldsw, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes / 16)
+#define VPF_WG1(S, D, RR) VPF_LAUNCH_BA(k_convert_strip_wg, (S, D, RR), wgrid, dim3(256), ldsw, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes / 16)
 #define VPF_WG(S, D) do { if (rw == 16) VPF_WG1(S, D, 16); else if (rw == 8) VPF_WG1(S, D, 8); else if (rw == 4) VPF_WG1(S, D, 4); else VPF_WG1(S, D, 2); } while (0)
 #define VPF_WGD(S) do { if (dst_fc == FC_RGB) VPF_WG(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_WG(S, FC_BGR); else VPF_WG(S, FC_PLANAR); } while (0)
           if (src_fc == FC_NV12) VPF_WGD(FC_NV12); else VPF_WGD(FC_YUV420);
@@ -722,7 +729,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       }
       if (r && lds1 <= 64u * 1024u && conv_per_px <= 3.0) {
         dim3 sgrid((dw + 255) / 256, (dh + 4 * r - 1) / (4 * r), n);
-#define VPF_STRIP1(S, D, RR) VPF_LAUNCH((k_convert_strip<S, D, RR>), sgrid, dim3(256), lds1, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, (rowbytes / 16) | (srows << 16))
+#define VPF_STRIP1(S, D, RR) VPF_LAUNCH_BA(k_convert_strip, (S, D, RR), sgrid, dim3(256), lds1, st, c, sw, sh, dw, dh, scx, scy, vec_ok, (rowbytes / 16) | (srows << 16))
 #define VPF_STRIP(S, D) do { if (r == 8) VPF_STRIP1(S, D, 8); else if (r == 4) VPF_STRIP1(S, D, 4); else VPF_STRIP1(S, D, 2); } while (0)
 #define VPF_STRIPD(S) do { if (dst_fc == FC_RGB) VPF_STRIP(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_STRIP(S, FC_BGR); else VPF_STRIP(S, FC_PLANAR); } while (0)
         if (src_fc == FC_NV12) VPF_STRIPD(FC_NV12); else VPF_STRIPD(FC_YUV420);
@@ -737,9 +744,9 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
   const uint32_t lds = 4 * (src_fc == FC_NV12 ? 4 : 6) * rowb;
 #define VPF_GOL1(S, D, I) do { if (n == 1) VPF_LAUNCH((k_convert_resize_lds_one<S, D, I>), grid, dim3(256), lds, st, a.f[0].s[0], a.f[0].s[1], a.f[0].sp[0], a.f[0].sp[1], \
                                                       sw, sh, dw, dh, scx, scy, rowb / 16, vec_ok, a.f[0].s[2], a.f[0].sp[2], VPF_ONE_DST_ARGS(a.f[0]), c); \
-                               else VPF_LAUNCH((k_convert_resize_lds<S, D, I>), grid, dim3(256), lds, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); } while (0)
+                               else VPF_LAUNCH_BA(k_convert_resize_lds, (S, D, I), grid, dim3(256), lds, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); } while (0)
 #define VPF_GOL(S, D) do { if (rowb <= 1024) VPF_GOL1(S, D, 1); else VPF_GOL1(S, D, 2); } while (0)
-#define VPF_GO(S, D) VPF_LAUNCH((k_convert_resize<S, D>), grid, dim3(256), 0, st, a, c, sw, sh, dw, dh, scx, scy, vec_ok)
+#define VPF_GO(S, D) VPF_LAUNCH_BA(k_convert_resize, (S, D), grid, dim3(256), 0, st, c, sw, sh, dw, dh, scx, scy, vec_ok)
 #define VPF_PICK(S, D) do { if (lds_ok) VPF_GOL(S, D); else VPF_GO(S, D); } while (0)
   if (src_fc == FC_NV12) {
     if (dst_fc == FC_RGB) VPF_PICK(FC_NV12, FC_RGB); else if (dst_fc == FC_BGR) VPF_PICK(FC_NV12, FC_BGR); else VPF_PICK(FC_NV12, FC_PLANAR);
@@ -752,6 +759,8 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 #undef VPF_GO
 #undef VPF_GOL
 #undef VPF_GOL1
+#undef VPF_LAUNCH_BA
+#undef VPF_UNPAREN
   return hipGetLastError();
 }
 

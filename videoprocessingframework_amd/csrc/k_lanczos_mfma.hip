@@ -883,8 +883,8 @@ struct LzmTableArgs {
   const u32x4* ctab[3];
   const u32x4* rtab[3];
 };
-template <template <int> class TaskCH>
-__global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BatchArgs args, const PlaneTable T, const LzmTableArgs W) {
+template <template <int> class TaskCH, class BA = BatchArgs>  // BA: the frame table's size (<= 32 / <= 128 frames: vpf_internal.h)
+__global__ __launch_bounds__(256, TaskCH<3>::kGroupsPerCu) void k_lanczos_mfma(const BA args, const PlaneTable T, const LzmTableArgs W) {
   VPF_WAVE_TIMER(3);
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): neighbouring strips and bands share one L2
   const uint32_t bx = b.x, by = b.y, bz = b.z;
@@ -908,7 +908,8 @@ static bool lzm_big_lds_ok() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
   const uint64_t bit = 1ull << dev;
   if (done.load(std::memory_order_acquire) & bit) return !(failed.load(std::memory_order_acquire) & bit);
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_mfma<TaskCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLzmMaxLds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_mfma<TaskCH, BatchArgs>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLzmMaxLds);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_mfma<TaskCH, BatchArgsL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLzmMaxLds);  // (both frame-table sizes)
   if (e != hipSuccess) { (void)hipGetLastError(); failed.fetch_or(bit, std::memory_order_release); }
   done.fetch_or(bit, std::memory_order_release);
   return e == hipSuccess;
@@ -984,7 +985,7 @@ thread_local vpf_workspace* t_lzm_workspace = nullptr;
 void set_lanczos_workspace(vpf_workspace* ws) { t_lzm_workspace = ws; }
 uint64_t lanczos_table_bytes_bound(int ch, uint32_t dw, uint32_t dh) { return lzm_table_bytes_bound(ch, dw, dh); }
 
-bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
+bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a) {
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT), knob = tuning(VPF_TUNE_RESIZE_MFMA);
   const int forced = knob & 0xffff;           // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
   const bool tables = !(knob & 0x10000);      // | 0x10000: evaluate the weights in the kernel (the path a full arena takes)
@@ -1086,7 +1087,9 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   if (lds > 64u * 1024u && !(kc == 3 ? (lzm_pf_of(span, 3) == 8 ? lzm_big_lds_ok<LzMfma2k8>() : lzm_big_lds_ok<LzMfma2k6>()) : kc == 2 ? (lzm_pf_of(span, 2) == 8 ? lzm_big_lds_ok<LzMfma4k8>() : lzm_pf_of(span, 2) == 6 ? lzm_big_lds_ok<LzMfma4k6>() : lzm_big_lds_ok<LzMfma4k4>())
                              : nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
-                           hipLaunchKernelGGL((k_lanczos_mfma<K>), grid, dim3(256), lds, st, a, t, wt); unlock.launched = true; } while (0)
+                           if (n <= (uint32_t)kSmallBatch) hipLaunchKernelGGL((k_lanczos_mfma<K, BatchArgs>), grid, dim3(256), lds, st, small_batch(a, n), t, wt); \
+                           else hipLaunchKernelGGL((k_lanczos_mfma<K, BatchArgsL>), grid, dim3(256), lds, st, a, t, wt); \
+                           unlock.launched = true; } while (0)
   if (kc == 3 && lzm_pf_of(span, 3) == 8) VPF_LZM_GO(LzMfma2k8);
   else if (kc == 3) VPF_LZM_GO(LzMfma2k6);
   else if (kc == 2 && lzm_pf_of(span, 2) == 8) VPF_LZM_GO(LzMfma4k8);

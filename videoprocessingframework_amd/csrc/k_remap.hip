@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 8) void k_remap3_p4_b(const BatchArgs args, ui
   remap3_p4_task(f.s[0], f.sp[0], sw, sh, xmap, xp, ymap, yp, f.d[0], f.dp[0], dw, dh, vec_ok);
 }
 
-// one map applied to n <= kMaxBatch frames in one dispatch
+// one map applied to n <= kSmallBatch frames in one dispatch
 hipError_t launch_remap_batch(hipStream_t st, uint32_t sw, uint32_t sh, const float* xmap, uint32_t xp, const float* ymap, uint32_t yp, uint32_t dw,
                               uint32_t dh, uint32_t n, const BatchArgs& a) {
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);

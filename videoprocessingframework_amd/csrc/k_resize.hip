@@ -1087,8 +1087,8 @@ hipError_t launch_resize(hipStream_t st, int ch, int interp, uint32_t sw, uint32
     // the matrix-core kernel (k_lanczos_mfma.hip) wherever its windows fit; the tiled separable form for strong down-scales (beyond those
     // windows) — and, tried FIRST, for one small plane per dispatch (lanczos_single_prefers_tile below); the gather form for what is left
     auto mfma = [&]() -> bool {
-      BatchArgs a;
-      std::memset(&a, 0, sizeof(a));
+      BatchArgsL a;  // (host side only: one frame is launched with the small table)
+      std::memset(&a.f[0], 0, sizeof(a.f[0]));
       a.f[0].s[0] = src; a.f[0].sp[0] = sp; a.f[0].d[0] = dst; a.f[0].dp[0] = dp;
       const ResizeJob j{ch, 0, sw, sh, dw, dh};
       return launch_lanczos_mfma(st, 1, &j, 1, a);
@@ -1271,23 +1271,26 @@ hipError_t launch_resize_f32(hipStream_t st, int ch, int interp, uint32_t sw, ui
 // plane of the format lands in the same (tiled or row-pair) family they all go into ONE launch (k_planes_mp), otherwise each plane
 // gets one launch over all frames (k_plane_batch).  Same task bodies as the single-frame kernels -> identical pixels.
 // ------------------------------------------------------------------------------------------
-static bool planes_aligned(const BatchArgs& a, uint32_t n, int k, uintptr_t src_mask, uintptr_t dst_mask) {
+static bool planes_aligned(const BatchArgsL& a, uint32_t n, int k, uintptr_t src_mask, uintptr_t dst_mask) {
   for (uint32_t i = 0; i < n; i++)
     if ((((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & src_mask) || (((uintptr_t)a.f[i].d[k] | a.f[i].dp[k]) & dst_mask)) return false;
   return true;
 }
 // (the selection log / roctx mark carries __PRETTY_FUNCTION__: it names the task the generic entry was instantiated with)
+// (grid.z = the frames of the launch: up to 32 take the small frame table, more the large one — two instantiations of the same kernel)
 template <class Task>
-static void launch_plane_batch(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgs& a, int k, const PlaneGeom& g) {
+static void launch_plane_batch(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgsL& a, int k, const PlaneGeom& g) {
   if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
   (void)hipGetLastError();
-  hipLaunchKernelGGL((k_plane_batch<Task>), grid, dim3(Task::kThreads), lds, st, a, k, g);
+  if (grid.z <= (uint32_t)kSmallBatch) hipLaunchKernelGGL((k_plane_batch<Task, BatchArgs>), grid, dim3(Task::kThreads), lds, st, small_batch(a, grid.z), k, g);
+  else hipLaunchKernelGGL((k_plane_batch<Task, BatchArgsL>), grid, dim3(Task::kThreads), lds, st, a, k, g);
 }
 template <template <int> class TaskCH>
-static void launch_planes_mp(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgs& a, const PlaneTable& t) {
+static void launch_planes_mp(hipStream_t st, dim3 grid, uint32_t lds, const BatchArgsL& a, const PlaneTable& t) {
   if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
   (void)hipGetLastError();
-  hipLaunchKernelGGL((k_planes_mp<TaskCH>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
+  if (grid.z <= (uint32_t)kSmallBatch) hipLaunchKernelGGL((k_planes_mp<TaskCH, BatchArgs>), grid, dim3(TaskCH<3>::kThreads), lds, st, small_batch(a, grid.z), t);
+  else hipLaunchKernelGGL((k_planes_mp<TaskCH, BatchArgsL>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
 }
 // ---- the persistent form of the same launch (k_resize_common.h: k_planes_mp_persist; vpf_persist.h): the resident set of workgroups pulls
 // wave items (frame, plane, wave row, column chunk) from the stream's work counters.  -> false when it does not apply (captured stream, no
@@ -1319,14 +1322,14 @@ static uint32_t persist_resident_groups(int dev, uint32_t lds) {  // workgroups 
   static thread_local unsigned next = 0;
   for (const Seen& e : seen) if (e.groups && e.dev == dev && e.lds == lds) return e.groups;
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_planes_mp_persist<TaskCH>), (int)TaskCH<3>::kThreads, lds) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_planes_mp_persist<TaskCH, BatchArgs>), (int)TaskCH<3>::kThreads, lds) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1) { (void)hipGetLastError(); return 0; }
   const uint32_t groups = (uint32_t)per_cu * (uint32_t)cus;
   seen[next++ & 3] = Seen{dev, lds, groups};
   return groups;
 }
 template <template <int> class TaskCH>
-static bool launch_planes_mp_persist(hipStream_t st, uint32_t lds, const BatchArgs& a, const PlaneTable& t, uint32_t n, const uint32_t* nbx, const uint32_t* nwr, uint32_t min_items_per_wave) {
+static bool launch_planes_mp_persist(hipStream_t st, uint32_t lds, const BatchArgsL& a, const PlaneTable& t, uint32_t n, const uint32_t* nbx, const uint32_t* nwr, uint32_t min_items_per_wave) {
   PersistArgs P{};
   uint32_t per_frame = 0;
   for (uint32_t p = 0; p < t.np; p++) { P.p0[p] = per_frame; P.nbx[p] = nbx[p]; per_frame += nbx[p] * nwr[p]; }
@@ -1348,11 +1351,12 @@ static bool launch_planes_mp_persist(hipStream_t st, uint32_t lds, const BatchAr
   if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
   (void)hipGetLastError();
   const uint32_t groups = (uint32_t)std::min<uint64_t>(resident, (total + wpg - 1) / wpg);
-  hipLaunchKernelGGL((k_planes_mp_persist<TaskCH>), dim3(groups), dim3(TaskCH<3>::kThreads), lds, st, a, t, P);
+  if (n <= (uint32_t)kSmallBatch) hipLaunchKernelGGL((k_planes_mp_persist<TaskCH, BatchArgs>), dim3(groups), dim3(TaskCH<3>::kThreads), lds, st, small_batch(a, n), t, P);
+  else hipLaunchKernelGGL((k_planes_mp_persist<TaskCH, BatchArgsL>), dim3(groups), dim3(TaskCH<3>::kThreads), lds, st, a, t, P);
   return true;
 }
 template <template <int, int> class T2, int I>
-static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgs& a, const ResizeJob& j, const PlaneGeom& g) {
+static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgsL& a, const ResizeJob& j, const PlaneGeom& g) {
   if (j.ch == 1) launch_plane_batch<T2<1, I>>(st, grid, 0, a, j.k, g);
   else if (j.ch == 2) launch_plane_batch<T2<2, I>>(st, grid, 0, a, j.k, g);
   else launch_plane_batch<T2<3, I>>(st, grid, 0, a, j.k, g);
@@ -1392,15 +1396,16 @@ static uint32_t band_slots_exact(int r, int njobs, const ResizeJob* jobs, uint32
 // (1280 px: 3 chunks, 83 %; the 640-px chroma planes of a 720p YUV420 frame: 2 chunks, 62 % -> 4)
 static int band_p1(int njobs, const ResizeJob* jobs) {
   bool any = false;
+  const bool force8 = (tuning(VPF_TUNE_RESIZE_BAND) >> 17) & 1;  // | 0x20000: 8 pixels per lane on 1-channel planes however well 512-column chunks fill them (measurement knob)
   for (int p = 0; p < njobs; p++) {
     if (jobs[p].ch != 1) continue;
     any = true;
-    if ((double)jobs[p].dw < 0.8 * 512.0 * ((jobs[p].dw + 511) / 512)) return 4;
+    if (!force8 && (double)jobs[p].dw < 0.8 * 512.0 * ((jobs[p].dw + 511) / 512)) return 4;
   }
   return any ? 8 : 4;
 }
 // strip bytes of the widest plane for a band launch (RowBandTask: 64 * band_px(ch, p1) columns per wave); 0 when some plane has no LDS path
-static uint32_t band_strip_bytes(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a, int p1) {
+static uint32_t band_strip_bytes(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a, int p1) {
   uint32_t rbmax = 0;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
@@ -1443,7 +1448,7 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
 // planes of Y / NV12 (profiles/r04_bilinear_march.txt: Y 1080p -> 720p 0.85 -> 0.79 us, NV12 1.14 -> 1.06); 3-channel planes and up-scales
 // lose with it and keep their forms.  VPF_TUNE_RESIZE_BAND = 4 | nb << 8 forces it where it applies.
 struct BandPlan { int rows; uint32_t slots; bool narrow; int p1; uint32_t rb; uint32_t nb; };
-static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
+static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a) {
   const int p1 = band_p1(njobs, jobs), knob = tuning(VPF_TUNE_RESIZE_BAND) & 0xffff, forced_nb = knob >> 8;
   if (p1 == 8) {
     const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 8);
@@ -1469,7 +1474,7 @@ static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const Ba
   return {bs.rows, bs.slots, bs.narrow, 4, rb, 0};
 }
 
-hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a) {
+hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a) {
   enum Fam { FAM_GATHER, FAM_LZ_GATHER, FAM_LZ_MFMA, FAM_LZ_TILE, FAM_HALF, FAM_HALF3, FAM_TILE, FAM_ROWPAIR };
   bool lz_tile_ok[3] = {false, false, false};  // a Lanczos plane the tiled kernel may take when the matrix-core kernel does not
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT);
@@ -1625,7 +1630,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       it = (rb + 1023) / 1024;
       const uint32_t lds = band > 1 ? 4 * bs.slots * rb + 16 : 4 * 2 * rb + 16;
       // the persistent form for the band kernels (VPF_TUNE_RESIZE_BAND | 0x10000: wherever it can run): wave items instead of a grid
-      const int pknob = tuning(VPF_TUNE_RESIZE_BAND) >> 16;
+      const int pknob = (tuning(VPF_TUNE_RESIZE_BAND) >> 16) & 1;
       if (band > 1 && pknob == 1) {
         uint32_t nbx[3] = {0, 0, 0}, nwr[3] = {0, 0, 0};
         for (int p = 0; p < njobs; p++) {

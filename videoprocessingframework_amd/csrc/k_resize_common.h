@@ -42,8 +42,8 @@ VPF_DEV BlockId picture_order() {
   const uint32_t yz = m / gx;
   return BlockId{m - yz * gx, yz % gy, yz / gy};
 }
-template <class Task>
-__global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BatchArgs args, const int k, const PlaneGeom G) {
+template <class Task, class BA = BatchArgs>  // BA: the frame table's size (BatchArgs: <= 32 frames, BatchArgsL: <= 128; vpf_internal.h)
+__global__ __launch_bounds__(Task::kThreads) void k_plane_batch(const BA args, const int k, const PlaneGeom G) {
   VPF_WAVE_TIMER(1);
   const BlockId b = picture_order();
   const FrameDesc& f = args.f[b.z];
@@ -58,8 +58,8 @@ struct PlaneTable {
 #else
 #define VPF_WT_OCCUPANCY
 #endif
-template <template <int> class TaskCH>
-__global__ __launch_bounds__(TaskCH<3>::kThreads) VPF_WT_OCCUPANCY void k_planes_mp(const BatchArgs args, const PlaneTable T) {
+template <template <int> class TaskCH, class BA = BatchArgs>
+__global__ __launch_bounds__(TaskCH<3>::kThreads) VPF_WT_OCCUPANCY void k_planes_mp(const BA args, const PlaneTable T) {
   VPF_WAVE_TIMER(2);
   const BlockId b = picture_order();
   const FrameDesc& f = args.f[b.z];
@@ -91,8 +91,8 @@ struct PersistArgs {
   uint32_t p0[3];     // first item of plane p inside a frame
   uint32_t nbx[3];    // column chunks of plane p
 };
-template <template <int> class TaskCH>
-__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp_persist(const BatchArgs args, const PlaneTable T, const PersistArgs P) {
+template <template <int> class TaskCH, class BA = BatchArgs>
+__global__ __launch_bounds__(TaskCH<3>::kThreads) void k_planes_mp_persist(const BA args, const PlaneTable T, const PersistArgs P) {
   VPF_WAVE_TIMER(6);
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

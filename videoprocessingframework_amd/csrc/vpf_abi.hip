@@ -113,6 +113,21 @@ static uint32_t row_bytes(int f, int k, uint32_t w) {
     default: return 0;
   }
 }
+// Frames per dispatch of the resize / fused batch entries (round 5).  A dispatch costs ~3 us between its last wave and the next one's first
+// plus a tail of partly empty CUs of about one wave life: for SMALL planes (a 32-frame dispatch of Y 1080p -> 720p is 24 us of kernel) four
+// times the frames per dispatch are worth 8-18 %; for larger ones they are level or a loss (RGB 1080p -> 720p Lanczos 2.04 -> 2.31 us per
+// frame, RGB 720p -> 1080p bilinear 1.82 -> 2.14: dispatches of 60 us and more had little tail to amortise, and the launch planners are fitted
+// at 32 and at 128 frames only).  Measured over seven shapes x 32 / 64 / 96 / 128 frames (profiles/r05_frames_per_dispatch_curve.txt): the
+// gain sits with the shapes that move up to ~7 MB per frame (source + destination).
+static uint32_t frames_per_dispatch(uint64_t bytes_per_frame) { return bytes_per_frame <= 7000000ull ? (uint32_t)kMaxBatch : (uint32_t)kSmallBatch; }
+static uint64_t frame_bytes(int f, vpf_size s) {
+  uint64_t b = 0;
+  for (int k = 0; k < num_planes(f); k++) {
+    const bool half = k > 0 && (f == VPF_FMT_NV12 || f == VPF_FMT_YUV420 || f == VPF_FMT_YCBCR || f == VPF_FMT_P10 || f == VPF_FMT_P12);
+    b += (uint64_t)row_bytes(f, k, s.width) * (half ? (s.height + 1) / 2 : s.height);
+  }
+  return b;
+}
 // Pictures larger than 65536 in either dimension are refused: beyond that 12 * width (RGB_32F row bytes) and the kernels'
 // 32-bit in-row offsets could wrap, and no video surface is that large.
 static bool dims_ok(vpf_size s) { return s.width && s.height && s.width <= 65536u && s.height <= 65536u; }
@@ -214,11 +229,11 @@ vpf_status vpf_convert_batch(const vpf_exec* exec, int sf, int df, int cs, int c
   Rgb2YuvCoef rc;
   if (fam == FAM_YUV2RGB) make_yuv2rgb(cs, cr, &yc);
   if (fam == FAM_RGB2YUV) make_rgb2yuv(cr, &rc);
-  for (uint32_t base = 0; base < n; base += kMaxBatch) {
-    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
+  for (uint32_t base = 0; base < n; base += kSmallBatch) {
+    const uint32_t m = (n - base < (uint32_t)kSmallBatch) ? n - base : (uint32_t)kSmallBatch;
     BatchArgs a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, ns, frames[base + i].dst, nd);
-    for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
+    for (uint32_t i = m; i < (uint32_t)kSmallBatch; i++) a.f[i] = a.f[0];
     hipError_t e;
     switch (fam) {
       case FAM_YUV2RGB:
@@ -297,9 +312,10 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
                                              static_cast<uint8_t*>(d0.ptr), d0.pitch);
     return status_of(e);
   }
-  for (uint32_t base = 0; base < n; base += kMaxBatch) {
-    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
-    BatchArgs a;
+  const uint32_t per = frames_per_dispatch(frame_bytes(fmt, ss) + frame_bytes(fmt, ds));  // 128 for small planes, else 32 (the launchers take the small frame table for up to 32)
+  for (uint32_t base = 0; base < n; base += per) {
+    const uint32_t m = (n - base < per) ? n - base : per;
+    BatchArgsL a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, np, frames[base + i].dst, np);
     for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
     const hipError_t e = launch_resize_jobs(st, f32, interp, nj, jobs, m, a);
@@ -356,11 +372,11 @@ vpf_status vpf_remap_batch(const vpf_exec* exec, int fmt, vpf_size ss, const flo
     if (!planes_ok(fmt, ss.width, frames[i].src) || !planes_ok(fmt, ds.width, frames[i].dst)) return VPF_ERR_BAD_ARG;
   DeviceGuard guard(exec->device);
   if (guard.err != hipSuccess) return status_of(guard.err);
-  for (uint32_t base = 0; base < n; base += kMaxBatch) {
-    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
+  for (uint32_t base = 0; base < n; base += kSmallBatch) {
+    const uint32_t m = (n - base < (uint32_t)kSmallBatch) ? n - base : (uint32_t)kSmallBatch;
     BatchArgs a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, 1, frames[base + i].dst, 1);
-    for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
+    for (uint32_t i = m; i < (uint32_t)kSmallBatch; i++) a.f[i] = a.f[0];
     const hipError_t e = launch_remap_batch(static_cast<hipStream_t>(exec->stream), ss.width, ss.height, xmap, xp, ymap, yp, ds.width, ds.height, m, a);
     if (e != hipSuccess) return status_of(e);
   }
@@ -393,9 +409,10 @@ vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int sf, int df, int cs
   if (guard.err != hipSuccess) return status_of(guard.err);
   Yuv2RgbCoef c;
   make_yuv2rgb(cs, cr, &c);
-  for (uint32_t base = 0; base < n; base += kMaxBatch) {
-    const uint32_t m = (n - base < (uint32_t)kMaxBatch) ? n - base : (uint32_t)kMaxBatch;
-    BatchArgs a;
+  const uint32_t per = frames_per_dispatch(frame_bytes(sf, ss) + frame_bytes(df, ds));  // 128 for small frames (1080p -> 720p and smaller), else 32
+  for (uint32_t base = 0; base < n; base += per) {
+    const uint32_t m = (n - base < per) ? n - base : per;
+    BatchArgsL a;
     for (uint32_t i = 0; i < m; i++) fill_desc(a.f[i], frames[base + i].src, num_planes(sf), frames[base + i].dst, num_planes(df));
     for (uint32_t i = m; i < ((m + 7u) & ~7u); i++) a.f[i] = a.f[0];  // (entries beyond the batch are never read: blockIdx runs over m frames; a few copies keep the tail of the last cache line defined)
     const hipError_t e = launch_convert_resize(static_cast<hipStream_t>(exec->stream), yuv_src_class(sf), rgb_class(df), c,
@@ -455,7 +472,7 @@ int vpf_set_tuning(int key, int value) {
   }
   if (key == VPF_TUNE_RESIZE_BAND) {
     const int rows = value & 0xff, nb = (value >> 8) & 0xff, form = value >> 16;  // nb: bands per wave of the march form (4-row bands only); form: | 0x10000 = the persistent launch
-    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4) && form <= 1;
+    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4) && form <= 3;  // form: | 1 the persistent launch, | 2 eight pixels per lane on every 1-channel plane
     return ok ? g_tune_band.exchange(value) : -1;
   }
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;

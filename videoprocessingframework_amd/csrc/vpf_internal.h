@@ -1,5 +1,6 @@
 // vpf_internal.h — shared between the translation units of libvpfhip (gfx950 only).
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,10 +26,16 @@ struct Rgb2YuvCoef {
 bool make_yuv2rgb(int color_space, int color_range, Yuv2RgbCoef* out);
 bool make_rgb2yuv(int color_range, Rgb2YuvCoef* out);
 
-// Up to 128 frames per dispatch travel in the kernarg segment (128 x 72 B = 9 KiB; no device-side table to manage).  32 until round 5: a batch of
-// small planes is 25-50 us of kernel, and every dispatch boundary costs ~3 us of idle chip plus a tail of partly empty CUs of about one wave
-// life (profiles/r05_wave_times.txt) — four times the frames per dispatch amortise both (the runtime takes kernel arguments of 32 KiB and more:
-// profiles/r05_probe_kernarg_size.txt; 9 KiB cost 0.3 us more host time per launch than 2 KiB).
+// The frame table of a batched launch travels in the kernarg segment (no device-side table to manage).  Two sizes since round 5:
+//   BatchArgs   32 frames x 72 B = 2.3 KiB — every converter and remap kernel, and every resize / fused launch of up to 32 frames (one
+//               frame per dispatch included: the unmodified per-Execute() API);
+//   BatchArgsL  128 frames = 9 KiB — resize and fused launches of 33 .. 128 frames.  A batch of small planes is 25-50 us of kernel per 32
+//               frames; every dispatch boundary costs ~3 us of idle chip plus a tail of partly empty CUs of about one wave life
+//               (profiles/r05_wave_times.txt): four times the frames per dispatch amortise both.
+// The kernarg segment is write-combined host memory: a launch pays ~0.2 us of HOST time per KiB of argument (9 KiB: + 1.3-2 us per call,
+// profiles/r05_abi_launch_rate_9k_kernarg.txt) — nothing against a 128-frame dispatch, 40-70 % of a single frame's issue time.  Hence
+// two instantiations of the resize / fused batch kernels (template parameter BA) instead of one large table for everybody.
+constexpr int kSmallBatch = 32;
 constexpr int kMaxBatch = 128;
 struct FrameDesc {
   const uint8_t* s[3];
@@ -36,9 +43,18 @@ struct FrameDesc {
   uint32_t sp[3];
   uint32_t dp[3];
 };
-struct BatchArgs {
-  FrameDesc f[kMaxBatch];
+template <int CAP>
+struct BatchArgsT {
+  FrameDesc f[CAP];
 };
+using BatchArgs = BatchArgsT<kSmallBatch>;
+using BatchArgsL = BatchArgsT<kMaxBatch>;
+// the small table of a launch of n <= kSmallBatch frames (host side: the launchers pass BatchArgsL around and cut it down at the launch)
+inline BatchArgs small_batch(const BatchArgsL& a, uint32_t n) {
+  BatchArgs s;
+  std::memcpy(s.f, a.f, (size_t)(n < (uint32_t)kSmallBatch ? n : (uint32_t)kSmallBatch) * sizeof(FrameDesc));
+  return s;
+}
 // Single-frame kernel entries (one Execute() = one launch) take the frame as SCALAR arguments, source side and task
 // counts first: the library is built with -amdgpu-kernarg-preload-count=16, so the dispatcher hands those to the wave in
 // SGPRs and its first loads do not wait for a scalar-cache round trip to the kernarg segment (a by-value BatchArgs is
@@ -75,10 +91,10 @@ struct ResizeJob {
   uint32_t sw, sh, dw, dh;
 };
 // all planes of a format over n <= kMaxBatch same-shape frames in as few launches as possible (k_resize.hip)
-hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a);
+hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a);
 // 8-bit Lanczos-3 on the matrix cores (k_lanczos_mfma.hip): every plane in `jobs` over n frames in ONE dispatch; false when it does not apply
 // (window / ring bounds of vpf_plan_bounds.h, 16-B aligned rows) and nothing was launched
-bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgs& a);
+bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a);
 // the caller-owned table workspace of the vpf_resize_ws / vpf_resize_batch_ws call the current thread is inside (nullptr: none)
 void set_lanczos_workspace(vpf_workspace* ws);
 uint64_t lanczos_table_bytes_bound(int ch, uint32_t dw, uint32_t dh);  // upper bound of one plane's table bytes under any launch shape
@@ -88,7 +104,7 @@ hipError_t launch_remap(hipStream_t st, uint32_t sw, uint32_t sh, const uint8_t*
 hipError_t launch_remap_batch(hipStream_t st, uint32_t sw, uint32_t sh, const float* xmap, uint32_t xpitch, const float* ymap, uint32_t ypitch,
                               uint32_t dw, uint32_t dh, uint32_t n, const BatchArgs& a);
 hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Yuv2RgbCoef& c, uint32_t sw,
-                                 uint32_t sh, uint32_t n, const BatchArgs& a, uint32_t dw, uint32_t dh);
+                                 uint32_t sh, uint32_t n, const BatchArgsL& a, uint32_t dw, uint32_t dh);
 
 int tuning(int key);
 

@@ -138,17 +138,15 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
         work = std::max(work, (double)std::min(r, tiles) * w * vert);
       }
-      // Round 5 (kMaxBatch 32 -> 128).  Up to 32 frames per dispatch the model above stands as fitted (every round, the last partial one too,
-      // costs one wave time).  At 128 frames a launch is many rounds long and the rounds blur — workgroups start as others end —; what is
-      // left of the quantisation is the TAIL, about one more wave life at a partly empty chip, which favours shorter bands on small planes
-      // (Y 1080p -> 720p: bands of 9-15 tiles, not the whole column) and the wide strips (a 4-tile strip of a 1-channel plane costs 0.8 of
-      // an 8-tile one there, not 0.45): cost = (2.5 + work') (max(1, wgs / slots) + 1), fitted to profiles/r05_lanczos_shape_sweep_n128.txt
-      // (mean regret 3 %, worst 11 %; the round-3 model, asked about 128 frames, was 8.6 % / 27 % off).  Between 32 and 128 frames the two
-      // are blended linearly in the frame count (t = (n - 32) / 96): continuous at 32, where the tests pin the old fit.
-      const double t = n <= 32u ? 0.0 : std::min(1.0, (double)(n - 32u) / 96.0);
-      const double x = (double)wgs / slots;
-      double cost = (S + work) * std::ceil(x);
-      if (t > 0.0) {
+      // Round 5 (up to 128 frames per dispatch).  Up to 32 frames the model above stands as fitted (every round, the last partial one
+      // too, costs one wave time).  Beyond, a launch is many rounds long and the rounds blur — workgroups start as others end —; what is
+      // left of the quantisation is the TAIL, one to two more wave lives at a partly empty chip, which favours shorter bands on small
+      // planes (Y 1080p -> 720p: bands of 9-15 tiles, not the whole column) and charges the 4-tile strips of 1-channel planes 0.8 of an
+      // 8-tile strip instead of 0.45: cost = (4 + work') (max(1, wgs / slots) + 1.5), fitted to the sweeps at 64 and 128 frames
+      // (profiles/r05_lanczos_shape_sweep_n64.txt, _n128.txt: mean regret 4 % / 3 %, worst 12 % / 11 %; the round-3 model, asked about
+      // 64 / 128 frames, is 9 % / 9 % off on average and 46 % / 27 % at worst: whole-column 4-tile strips on NV12 and Y 1080p -> 720p).
+      double cost = (S + work) * std::ceil((double)wgs / slots);
+      if (n > 32u) {
         double work2 = 0.0;
         for (int p = 0; p < njobs; p++) {
           const uint32_t tiles = (jobs[p].dh + rt - 1) / rt;
@@ -157,9 +155,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
           const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
           work2 = std::max(work2, (double)std::min(r, tiles) * w * vert);
         }
-        const double big = (2.5 * (tables ? 1.0 : 3.0) + work2) * (std::max(1.0, x) + 1.0);
-        // (x 0.5: a one-round launch is charged two rounds by the second form and one by the first — the halves put them on one scale)
-        cost = (1.0 - t) * cost + t * big * 0.5;
+        cost = (4.0 * (tables ? 1.0 : 3.0) + work2) * (std::max(1.0, (double)wgs / slots) + 1.5);
       }
       if (!P.ok || cost < best) { best = cost; P = q; P.ok = true; P.band_tiles = r; }
     }
