@@ -248,7 +248,8 @@ VPF_API int vpf_set_tuning(int key, int value);
                                   evaluates its filter weights itself instead of loading the per-shape tables (the path taken when no table fits);
                                   | 0x20000: the two-role kernel form (pass 1 and pass 2 on different waves; measured slower on RGB, kept as a
                                   measurement knob); | 0x40000: one small plane per dispatch takes the matrix-core kernel too (the policy sends it to
-                                  the tile kernel, whose single-launch latency is lower); same pixels whatever the value */
+                                  the tile kernel, whose single-launch latency is lower); | 0x80000: up-scales march with the ring of four source tiles like
+                                  everything else (policy: a ring of two, one K chunk in pass 2); same pixels whatever the value */
 #define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4, 8 or 16; 4 | nb << 8 (nb = 1..8): the march form
                                   (nb 4-row bands per wave, 8 pixels per lane on 1-channel planes) where it applies; | 0x10000: the persistent launch of the band kernels
                                   (resident workgroups pulling wave items from per-XCD work counters: measured 10 x slower than the grid on this chip, a

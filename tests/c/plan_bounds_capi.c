@@ -12,3 +12,4 @@ uint32_t pb_lzm_span(int ch, uint32_t sw, uint32_t dw, int nt) { return vpf_boun
 uint32_t pb_lzm_span_win(int ch, uint32_t sw, uint32_t dw, int nt, uint32_t win) { return vpf_bound_lzm_span_win(ch, sw, dw, (float)sw / (float)dw, nt, win); }
 uint32_t pb_lzm_pitch(uint32_t span) { return vpf_bound_lzm_pitch(span); }
 int pb_lzm_rows_ok(uint32_t sh, uint32_t dh) { return vpf_bound_lzm_rows_ok(sh, dh, (float)sh / (float)dh); }
+int pb_lzm_rows_two(uint32_t sh, uint32_t dh) { return vpf_bound_lzm_rows_two(sh, dh, (float)sh / (float)dh); }

@@ -56,8 +56,9 @@ def mfma_i8(A, B, c):
 
 
 class Model:
-    def __init__(self, ch, sw, sh, dw, dh, taps_x, taps_y, nt=8, band_rows=32, pitch=None, garbage_seed=1, kc=1, rt=16):
+    def __init__(self, ch, sw, sh, dw, dh, taps_x, taps_y, nt=8, band_rows=32, pitch=None, garbage_seed=1, kc=1, rt=16, up2=False):
         self.ch, self.sw, self.sh, self.dw, self.dh, self.nt, self.band = ch, sw, sh, dw, dh, nt, band_rows
+        self.up2 = up2   # the ring of TWO (up-scales): every tile's taps lie in the source tiles (Tmax - 1, Tmax); one K chunk in pass 2
         self.rt = rt   # destination rows a 16-row tile carries: 16, or 8 (half tiles: rows 8 .. 15 repeat row 7 and are never stored)
         self.kc, self.win = kc, 64 * kc   # K chunks of a pass-1 window (2: the two-chunk windows of strong horizontal down-scales, 4-tile strips)
         self.i0x, self.qx = taps_x
@@ -120,9 +121,13 @@ class Model:
             Wm = np.zeros((4, 2, 2, 64, 16), np.int8)
             for l in range(64):
                 t, y = l >> 4, l & 15
+                tmax_t = taps[(l & ~15) | (rt - 1)][-1][0] >> 4   # the tile's last source tile: what the emit test looks at
                 for pos, w in taps[l]:
                     T, g, r = pos >> 4, (pos >> 2) & 3, pos & 3
                     p = (T - t_first) & 3
+                    if self.up2:   # the operand has ONE chunk: source tile Tmax - 1 in its first half, Tmax in its second
+                        p = T - (tmax_t - 1)
+                        assert p in (0, 1), (p, T, tmax_t)
                     slot = 16 * g + 8 * (p & 1) + 2 * r
                     qh, ql = split_i8(w)
                     assert not Wm[t, :, p >> 1, slot:slot + 2, y].any()
@@ -132,7 +137,7 @@ class Model:
                 tmin = taps[16 * t][0][0] >> 4
                 tmax = taps[16 * t + rt - 1][-1][0] >> 4
                 self.max_tile_span = max(self.max_tile_span, tmax - tmin)
-                assert tmax - tmin <= 3
+                assert tmax - tmin <= (1 if self.up2 else 3)
                 if t_done is None:
                     t_done = tmin - 1
                 while t_done < tmax:
@@ -140,7 +145,7 @@ class Model:
                     self.pass1(src, ring, B1, ws, S0, P, t_done, t_first)
                 # every source tile this destination tile needs is one of the last four produced
                 assert tmin >= t_done - 3
-                self.emit(dst, ring, Wm[t], ob0, ya + GR * G + rt * t, yb)
+                self.emit(dst, ring, Wm[t], ob0, ya + GR * G + rt * t, yb, (tmax - t_first - 1) & 1)
 
     def pass1(self, src, ring, B1, ws, S0, P, T, t_first):
         ch, nt, sw, sh = self.ch, self.nt, self.sw, self.sh
@@ -161,24 +166,32 @@ class Model:
             h2 = ((HI.astype(np.int64) << 8) + LO).astype(np.int64) & 0xffffffff
             zh = ((h2 >> 16) & 0xff).astype(np.uint8).view(np.int8)
             zl = (((h2 >> 8) & 0xff) ^ 0x80).astype(np.uint8).view(np.int8)
-            ring[0, j, (T - t_first) & 3], ring[1, j, (T - t_first) & 3] = zl, zh
+            if self.up2:
+                # the register file holds two overlapping chunks, chunk k = tiles (k, k + 1) in slots (2 (k & 1), 2 (k & 1) + 1): tile T is
+                # the first half of chunk T and the second half of chunk T - 1
+                rel = T - t_first
+                for s_, z in ((0, zl), (1, zh)):
+                    ring[s_, j, 2 * (rel & 1)] = z
+                    ring[s_, j, 2 * ((rel & 1) ^ 1) + 1] = z
+            else:
+                ring[0, j, (T - t_first) & 3], ring[1, j, (T - t_first) & 3] = zl, zh
 
-    def emit(self, dst, ring, W, ob0, y0, yb):
+    def emit(self, dst, ring, W, ob0, y0, yb, chunk=0):
         ch, nt = self.ch, self.nt
         dwb = self.dw * ch
         for j in range(nt):
             # chunk c: A2[n][k slot = 16 g + 8 (p & 1) + 2 r + s] = ring[s, j, p, row 4 g + r, n] for the two tiles p = 2 c, 2 c + 1
             X = np.zeros((16, 16), np.int32)
             Y = np.full((16, 16), (1 << 19) + (1 << 11), np.int32)
-            for c in range(2):
+            for c in ((chunk,) if self.up2 else range(2)):
                 A2 = np.zeros((16, 64), np.int8)
                 for g in range(4):
                     for pp in range(2):
                         for r in range(4):
                             for sb in range(2):
                                 A2[:, 16 * g + 8 * pp + 2 * r + sb] = ring[sb, j, 2 * c + pp, 4 * g + r, :]
-                X = X + mfma_i8(A2, W[0, c], 0)
-                Y = Y + mfma_i8(A2, W[1, c], 0)
+                X = X + mfma_i8(A2, W[0, 0 if self.up2 else c], 0)
+                Y = Y + mfma_i8(A2, W[1, 0 if self.up2 else c], 0)
             V = (X.astype(np.int64) << 8) + Y
             assert np.all(np.abs(V) < 2 ** 31)
             out = np.clip(V >> 12, 0, 255).astype(np.uint8)   # [n][y]

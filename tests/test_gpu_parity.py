@@ -1155,6 +1155,37 @@ def test_lanczos_mfma_kernel_shapes_write_the_oracle_pixels(capi, oracle, shape)
     assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, (3 << 8) | 2) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, -1) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, (8 << 8) | 65) == -1
 
 
+@pytest.mark.parametrize("knob", [0, (8 << 8) | 1, (8 << 8) | 5, (8 << 8) | 64, (4 << 8) | 2, (4 << 8) | 9, 0x10000, 0x10000 | (8 << 8) | 3, 0x10000 | (4 << 8) | 7,
+                                  0x80000, 0x80000 | (8 << 8) | 5, 0x80000 | 0x10000 | (4 << 8) | 2])
+def test_lanczos_upscales_with_the_ring_of_two(capi, oracle, knob):
+    """Up-scales whose 16-row destination tiles find their source rows in two consecutive 16-row source tiles march with a ring of TWO
+    (LanczosMfmaTask<.., UP2>: overlapping two-tile chunks in registers, one K chunk in pass 2, its own row-table layout), | 0x80000 with the
+    ring of four like everything else: the oracle's pixels either way, with tables and without (| 0x10000), 8- and 4-tile strips, bands of
+    one tile .. the whole column (several weight groups per band), heights that end inside a tile and inside a group, factors from 1.05 to
+    9 (the mildest ones fail the two-tile bound on some tiles and keep the ring of four: both kernels run in this test), formats whose
+    chroma planes have their own sizes, 33 frames per dispatch, a mixed launch (up-scale in y only)."""
+    cases = [("RGB", 320, 180, 640, 360, 3), ("RGB", 480, 270, 720, 405, 2), ("Y", 333, 217, 1000, 651, 2), ("NV12", 426, 240, 1280, 720, 2), ("YUV420", 320, 180, 854, 480, 2),
+             ("YUV444", 100, 60, 333, 201, 2), ("RGB", 200, 300, 420, 333, 2), ("RGB", 160, 90, 1440, 810, 2), ("Y", 640, 100, 1280, 131, 2), ("RGB", 320, 200, 336, 211, 2),
+             ("RGB", 64, 36, 96, 54, 33), ("Y", 50, 1000, 75, 1500, 2), ("RGB", 300, 40, 200, 97, 2), ("NV12", 640, 360, 1920, 1080, 2), ("RGB", 7, 5, 40, 33, 2)]
+    assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, knob) >= 0
+    try:
+        for fmt, sw, sh, dw, dh, n in cases:
+            f, of = getattr(capi, fmt), getattr(oracle, fmt)
+            srcs = [oracle.synth(of, sw, sh, 9100 + i) for i in range(min(n, 3))]
+            S = [DevPlanes(srcs[i % len(srcs)]) for i in range(n)]
+            D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+            capi.resize_batch(capi.make_exec(stream_handle()), f, 2, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+            torch.cuda.synchronize()
+            wants = [oracle.resize(of, 2, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+            for i in range(n):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, wants[i % len(srcs)], f"ring of two, knob {knob:#x} {fmt} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+    finally:
+        capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
+    assert capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0x100000) == -1
+
+
 @pytest.mark.parametrize("knob", [0, 0x10000, (4 << 8) | 1, 0x10000 | (4 << 8) | 3])
 def test_lanczos_two_chunk_windows_write_the_oracle_pixels(capi, oracle, knob):
     """Horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network): the taps of 16 destination bytes spread over more than 64
@@ -1434,7 +1465,7 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         band = int(rng.choice([0, 1, 2, 4, 8, 16, 0x104, 0x204, 0x304]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy); 4 | nb << 8: the march form
         prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
         capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
-        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5, 0x40000]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves); 0x40000: small single frames on the matrix cores too  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
+        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5, 0x40000, 0x80000, 0x80000 | (8 << 8) | 2]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves); 0x40000: small single frames on the matrix cores too; 0x80000: up-scales with the ring of four  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
         if march != 1 and not (march & 0x20000) and rng.integers(3) == 0:
             march |= 0x10000                                                                # ... with its weights evaluated in the kernel, not loaded from the shape's tables
         capi.set_tuning(capi.TUNE_RESIZE_MFMA, march)

@@ -6,7 +6,7 @@ import pytest
 from lanczos_mfma_model import Model
 
 
-def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1, rt=16):
+def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1, rt=16, up2=False):
     fmt = {1: oracle.Y, 3: oracle.RGB}.get(ch)
     rng = np.random.default_rng(seed)
     if ch == 2:   # a 2-channel plane = the chroma plane of an NV12 picture twice as large
@@ -17,7 +17,7 @@ def _run(oracle, ch, sw, sh, dw, dh, nt, band, seed=3, kc=1, rt=16):
         src = [rng.integers(0, 256, (sh, sw * ch), dtype=np.uint8)]
         _, want = oracle.resize(fmt, oracle.LANCZOS3, sw, sh, src, dw, dh, oracle.FP32)
         plane, want = src[0], want[0]
-    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band, kc=kc, rt=rt)
+    m = Model(ch, sw, sh, dw, dh, oracle.lanczos_taps(sw, dw), oracle.lanczos_taps(sh, dh), nt=nt, band_rows=band, kc=kc, rt=rt, up2=up2)
     got = m.run(plane)
     assert np.array_equal(got, want), f"ch{ch} {sw}x{sh}->{dw}x{dh} nt{nt} band{band}: {np.argwhere(got != want)[:5]}"
     return m
@@ -29,6 +29,16 @@ def test_model_equals_the_oracle(oracle, ch):
                                        (37, 29, 53, 71, 4, 64), (7, 5, 40, 33, 8, 16), (120, 90, 57, 43, 8, 32), (40, 200, 40, 97, 4, 96),
                                        (3, 3, 9, 9, 4, 16), (1, 1, 5, 4, 4, 16), (200, 17, 95, 40, 8, 16)):
         _run(oracle, ch, sw, sh, dw, dh, nt, band)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_model_with_the_ring_of_two(oracle, ch):
+    """up-scales whose destination tiles find their source rows in two consecutive source tiles (vpf_bound_lzm_rows_two): overlapping
+    two-tile chunks in the register file, one K chunk in pass 2 — same bytes"""
+    for (sw, sh, dw, dh, nt, band) in ((64, 36, 96, 54, 8, 16), (64, 54, 128, 108, 4, 48), (37, 29, 53, 71, 4, 64), (7, 5, 40, 33, 8, 16),
+                                       (3, 3, 9, 9, 4, 16), (1, 1, 5, 4, 4, 16), (48, 90, 72, 135, 8, 144), (20, 100, 30, 300, 4, 112)):
+        m = _run(oracle, ch, sw, sh, dw, dh, nt, band, up2=True)
+        assert m.max_tile_span <= 1
 
 
 @pytest.mark.parametrize("ch", [1, 2, 3])

@@ -25,7 +25,7 @@ def pb(tmp_path_factory):
     for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_band_rows_exact", [C.c_int, C.c_uint32, C.c_uint32]),
                        ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
                        ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]), ("pb_lzm_span_win", [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]),
-                       ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32])):
+                       ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32]), ("pb_lzm_rows_two", [C.c_uint32, C.c_uint32])):
         getattr(L, name).argtypes, getattr(L, name).restype = args, C.c_uint32
     L.pb_fused_rows_fit.argtypes, L.pb_fused_rows_fit.restype = [C.c_int, C.c_float, C.c_int], C.c_int
     return L
@@ -167,7 +167,7 @@ def test_lanczos_mfma_windows_ring_and_strip(pb, ch):
     fit (the check is exact up to the last pixel's unused channels); rows_ok means a 16-row destination tile finds its source rows in four
     consecutive 16-row source tiles.  And the headline ratios — exactly 2.0 with three channels among them — pass."""
     rng = np.random.default_rng(77 + ch)
-    n_ok = n_no = 0
+    n_ok = n_no = n_two = 0
     for (S, D) in size_pairs(rng, 500, 0.2, 3.2):
         dwb = D * ch
         b = np.arange(dwb)
@@ -195,7 +195,16 @@ def test_lanczos_mfma_windows_ring_and_strip(pb, ch):
             y1 = np.minimum(y0 + 15, D - 1)
             tmin, tmax = np.clip(i0[y0] - 2, 0, S - 1) >> 4, np.clip(i0[y1] + 3, 0, S - 1) >> 4
             assert (tmax - tmin <= 3).all(), (S, D)
-    assert n_ok > 100 and n_no > 20
+        if pb.pb_lzm_rows_two(S, D):   # the ring of two: exact, both ways
+            assert pb.pb_lzm_rows_ok(S, D) and (tmax - tmin <= 1).all(), (S, D)
+            n_two += 1
+        elif pb.pb_lzm_rows_ok(S, D):
+            assert (tmax - tmin > 1).any(), (S, D)
+    assert n_ok > 100 and n_no > 20 and n_two > 20
+    for (S, D) in ((1080, 2160), (720, 1080), (1280, 1920), (1920, 3840), (640, 960), (540, 1080)):   # the up-scales the benches quote
+        assert pb.pb_lzm_rows_two(S, D), (S, D)
+    for (S, D) in ((1080, 1080), (1080, 720), (1000, 1080)):
+        assert not pb.pb_lzm_rows_two(S, D), (S, D)
     for (S, D) in ((1920, 1280), (3840, 1920), (1280, 1920), (1920, 3840), (1080, 720), (2160, 1080), (720, 1080), (960, 640), (640, 960)):
         assert pb.pb_lzm_span(ch, S, D, 8) and pb.pb_lzm_span(ch, S, D, 4) and pb.pb_lzm_rows_ok(S, D), (S, D)
 

@@ -92,7 +92,13 @@ VPF_DEV uint32_t opaque(uint32_t v) {
 }
 // PF = staging loads a lane keeps in flight = ceil(16-B units per staged row / 4); KC = 64-B K chunks of a pass-1 window (2: the taps of a
 // tile's 16 bytes spread over up to 128 source bytes — horizontal factors of ~2.2 .. 6 — and pass 1 chains two MFMAs per product)
-template <int CH, int NT, int PF, int KC = 1>
+// UP2 = the ring of TWO, for up-scales (every destination tile finds its source rows in the source tiles (Tmax - 1, Tmax):
+// vpf_bound_lzm_rows_two): pass 2 is ONE K chunk — two MFMAs per N-tile instead of four.  The register file still holds two chunks, but
+// OVERLAPPING ones: chunk k = source tiles (k, k + 1); a tile's (zl, zh) pairs are written twice — first half of its own chunk, second half of
+// the one before (two v_mov per N-tile and source tile) — and a destination tile multiplies chunk Tmax - 1 by a one-chunk weight operand
+// (its own row-table layout: lzm_row_group).  A 2x up-scale emits two destination tiles per source tile: 10 MFMAs per N-tile and source
+// tile become 6 and the matrix pipe stops being what two waves per SIMD queue for
+template <int CH, int NT, int PF, int KC = 1, bool UP2 = false>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
   static constexpr int kGroupsPerCu = NT == 4 && KC == 1 ? 3 : 2;  // register budget: 168 / 256 VGPRs
@@ -193,9 +199,13 @@ VPF_DEV uint32_t lzm_group_row(uint32_t lane, uint32_t ya, uint32_t yb, uint32_t
   const uint32_t rt = 1u << rts, rr = (lane & 15u) < rt ? (lane & 15u) : rt - 1u, row = ya + (g << (rts + 2u)) + ((lane >> 4) << rts) + rr;
   return row < yb ? row : yb;
 }
-VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb, uint32_t g, float scy, uint32_t sh, int32_t t_first, uint32_t rts) {
+// up2 (the ring of two, rts == 4 only): ONE chunk per destination tile — the tile's last source tile Tmax (what the march's emit test reads:
+// the last tap of the tile's last row) sits in the chunk's second half, Tmax - 1 in its first; no tap lies elsewhere (host: vpf_bound_lzm_rows_two)
+VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb, uint32_t g, float scy, uint32_t sh, int32_t t_first, uint32_t rts, bool up2) {
   const uint32_t yrow = lzm_group_row(lane, ya, yb, g, rts);
   const MTap m = merge_taps(quantize_ltap(make_ltap(yrow, scy)), sh);
+  int32_t tmax = ltap_i0(lzm_group_row(lane | 15u, ya, yb, g, rts), scy) + 3;
+  tmax = (tmax < 0 ? 0 : (tmax > (int32_t)sh - 1 ? (int32_t)sh - 1 : tmax)) >> 4;
   u32x4* z = reinterpret_cast<u32x4*>(wm);
 #pragma unroll
   for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) z[i * 64 + lane] = u32x4{0, 0, 0, 0};
@@ -203,7 +213,7 @@ VPF_DEV void lzm_row_group(uint8_t* wm, uint32_t lane, uint32_t ya, uint32_t yb,
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     if (m.pos[k] < 0) continue;
-    const uint32_t pos = (uint32_t)m.pos[k], p = ((pos >> 4) - (uint32_t)t_first) & 3;
+    const uint32_t pos = (uint32_t)m.pos[k], p = up2 ? ((pos >> 4) + 1u - (uint32_t)tmax) & 1u : ((pos >> 4) - (uint32_t)t_first) & 3;
     int32_t hi, lo;
     split_i8(m.q[k], hi, lo);
     uint8_t* const a = cell + (p >> 1) * 1024 + ((pos >> 2) & 3) * 256 + 8 * (p & 1) + 2 * (pos & 3);
@@ -231,21 +241,21 @@ __global__ __launch_bounds__(64) void k_lzm_build_cols(uint32_t ch, uint32_t sw,
     out[(NT * KC + i) * 64 + lane] = __builtin_bit_cast(u32x4, b1l[i]);
   }
 }
-__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, uint32_t rts, u32x4* __restrict__ tab) {
+__global__ __launch_bounds__(64) void k_lzm_build_rows(uint32_t sh, uint32_t dh, float scy, uint32_t R, uint32_t rts, uint32_t up2, u32x4* __restrict__ tab) {
   __shared__ u32x4 wm[kLzmWmBytes / 16];
   const uint32_t lane = threadIdx.x, g = blockIdx.x, ya = blockIdx.y * R;
   if (ya >= dh) return;
   const uint32_t yb = ya + R - 1 < dh - 1 ? ya + R - 1 : dh - 1;
   if (g > (yb - ya) >> (rts + 2u)) return;
-  lzm_row_group(reinterpret_cast<uint8_t*>(wm), lane, ya, yb, g, scy, sh, lzm_band_first_tile(ya, scy, sh), rts);
+  lzm_row_group(reinterpret_cast<uint8_t*>(wm), lane, ya, yb, g, scy, sh, lzm_band_first_tile(ya, scy, sh), rts, up2 != 0);
   wave_lds_sync();
   u32x4* const out = tab + (size_t)(blockIdx.y * gridDim.x + g) * (kLzmWmBytes / 16);
 #pragma unroll
   for (int i = 0; i < (int)(kLzmWmBytes / 1024); i++) out[i * 64 + lane] = wm[i * 64 + lane];
 }
 
-template <int CH, int NT, int PF, int KC>
-VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
+template <int CH, int NT, int PF, int KC, bool UP2>
+VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp,
                                               const PlaneGeom& G, uint32_t bx, uint32_t by, const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab) {
   const uint32_t sw = G.sw, sh = G.sh, dw = G.dw, dh = G.dh, R = G.a1;
   const uint32_t rts = G.a3, rt = 1u << rts;  // destination rows per 16-row tile: 16, or 8 (half tiles: vertical factors of ~2.9 .. 6, see lzm_group_row)
@@ -289,7 +299,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
                      : "=&s"(keep) : "s"(tsc), "v"(voff), "s"(ldst + 4096u * h) : "memory");
       }
     } else {
-      lzm_row_group(wm, lane, ya, yb, g, scy, sh, t_first, rts);
+      lzm_row_group(wm, lane, ya, yb, g, scy, sh, t_first, rts, UP2);
     }
   };
   // the wave that brought group g in by DMA: everything it has in flight must have landed before it enters the barrier in front of g's use
@@ -376,7 +386,18 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
 #pragma unroll
     for (int k = 0; k < PF; k++) pf[SET][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k % NV], LPR == 8 && k >= HALF ? (int)sp8 : 0, 0));
   };
-  v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs)
+  v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs); UP2: chunk k & 1 = tiles (k, k + 1)
+  static_assert(!UP2 || KC == 1, "the ring of two: one-chunk windows only");
+  // where pass 1 of the tile in slot SLOT puts its two dwords
+  auto ring_put = [&](int j, auto slot_tag, int32_t v0, int32_t v1) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    if constexpr (UP2) {
+      ring[j][SLOT & 1][0] = v0; ring[j][SLOT & 1][1] = v1;              // first half of its own chunk
+      ring[j][(SLOT & 1) ^ 1][2] = v0; ring[j][(SLOT & 1) ^ 1][3] = v1;  // second half of the chunk before
+    } else {
+      ring[j][SLOT >> 1][2 * (SLOT & 1)] = v0; ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = v1;
+    }
+  };
 #pragma unroll
   for (int j = 0; j < NT; j++) { ring[j][0] = v4i{0, 0, 0, 0}; ring[j][1] = v4i{0, 0, 0, 0}; }
   const v4i c128 = {128, 128, 128, 128};
@@ -432,8 +453,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
         }
         // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
         // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
-        ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
-        ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
+        ring_put(j, slot_tag, (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u), (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u));
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -470,8 +490,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
           lo[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[j + 1][0], b1l[j + 1], c128, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        ring[j][SLOT >> 1][2 * (SLOT & 1)] = (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u);
-        ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u);
+        ring_put(j, slot_tag, (int32_t)(__builtin_amdgcn_perm(h[1], h[0], 0x06050201u) ^ 0x00800080u), (int32_t)(__builtin_amdgcn_perm(h[3], h[2], 0x06050201u) ^ 0x00800080u));
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < NT) {
 #pragma unroll
@@ -496,8 +515,11 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
   const uint32_t ob = ob0 + 16u * (lane & (NT - 1));                   // first destination byte of the unit this lane stores
   const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
   const uint32_t obase = mad24(lane >> LOGNT, dp, ob);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
-  auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
-    const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16), by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
+  auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0, auto chunk_tag) {
+    constexpr int C2 = decltype(chunk_tag)::value;  // UP2: the chunk that holds (Tmax - 1, Tmax)
+    const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16);
+    v4i by1 = by0;
+    if constexpr (!UP2) by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
     // qh moves from the zl slot to the zh slot, the zl slots become 0: a left shift by 8 inside every 16-bit half (one v_pk_lshlrev_b16 per dword)
     typedef short v8s __attribute__((ext_vector_type(8)));
     const v4i bx0 = __builtin_bit_cast(v4i, __builtin_bit_cast(v8s, by0) << 8), bx1 = __builtin_bit_cast(v4i, __builtin_bit_cast(v8s, by1) << 8);
@@ -507,6 +529,27 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
     // three MFMA slots after Y was issued, its pack runs in tile j + 1's first two slots — so no VALU instruction waits out the matrix
     // pipe's result latency in s_nops
     v4i x[2], y[2];
+    uint32_t pa = 0, pb = 0, w[4] = {0, 0, 0, 0};
+    if constexpr (UP2) {
+      // one chunk: X and Y of tile j + 1 go out around the pack of tile j - 1 and the combine of tile j
+      x[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][C2], bx0, czero, 0, 0, 0);
+      y[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][C2], by0, cy, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const bool more = j + 1 < NT;
+        if (more) { x[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][C2], bx0, czero, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+        if (j > 0) {
+          shift12_sat_pack4_a(w[0], w[1], w[2], pa, pb);
+          *reinterpret_cast<uint32_t*>(owr + 16u * (j - 1)) = shift12_sat_pack4_b(pa, pb, w[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) { y[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[j + 1][C2], by0, cy, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int r = 0; r < 4; r++) w[r] = ((uint32_t)x[j & 1][r] << 8) + (uint32_t)y[j & 1][r];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     {
       v4i t = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][0], bx0, czero, 0, 0, 0);
       v4i u = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][0], by0, cy, 0, 0, 0);
@@ -514,7 +557,6 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
       y[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[0][1], by1, u, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    uint32_t pa = 0, pb = 0, w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const bool more = j + 1 < NT;
@@ -534,6 +576,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
       w[2] = ((uint32_t)x[j & 1][2] << 8) + (uint32_t)y[j & 1][2];
       w[3] = ((uint32_t)x[j & 1][3] << 8) + (uint32_t)y[j & 1][3];
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     shift12_sat_pack4_a(w[0], w[1], w[2], pa, pb);
     *reinterpret_cast<uint32_t*>(owr + 16u * (NT - 1)) = shift12_sat_pack4_b(pa, pb, w[3]);
@@ -577,7 +620,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC>::run(const uint8_t* __restrict__ sr
   for (;;) {                                                                                                        \
     const uint32_t tl = ((y_next - ya) >> rts) & 3u;                                                                \
     if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + rt - 1) >= T) break;                                            \
-    emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next);                                                               \
+    emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next, std::integral_constant<int, (((S) & 1) ^ 1)>{});               \
     y_next += rt;                                                                                                   \
     if (y_next > yb) return;                                                                                        \
     if (tl == 3) { next_group(grp); grp++; tmax_l = group_tmax(grp); }                                              \
@@ -868,6 +911,8 @@ template <int CH> struct LzMfma8n : LanczosMfmaTask<CH, 8, 2> {};  // ... of up 
 template <int CH> struct LzMfma8w : LanczosMfmaTask<CH, 8, 5> {};  // ... of up to 320 B (2x down-scales)
 template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
 template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
+template <int CH> struct LzMfma8u : LanczosMfmaTask<CH, 8, 2, 1, true> {};  // the ring of two (up-scales): one K chunk in pass 2
+template <int CH> struct LzMfma4u : LanczosMfmaTask<CH, 4, 2, 1, true> {};
 template <int CH> struct LzMfma4k4 : LanczosMfmaTask<CH, 4, 4, 2> {};  // two-chunk windows (strong horizontal down-scales): staged rows of up to 256 B
 template <int CH> struct LzMfma4k6 : LanczosMfmaTask<CH, 4, 6, 2> {};  // ... 384 B
 template <int CH> struct LzMfma4k8 : LanczosMfmaTask<CH, 4, 8, 2> {};  // ... 512 B
@@ -1010,6 +1055,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const uint32_t rts = (uint32_t)plan.rts;  // log2 of the destination rows per tile: 4, or 3 (half tiles)
   if (pair && rts != 4) return false;
   const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
+  const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
+  // the ring of two (LanczosMfmaTask<.., UP2>): up-scales — narrow strips, and every plane's destination tiles within two source tiles
+  // (| 0x80000: never, the measurement and test knob)
+  bool up2 = narrow && kc == 1 && rts == 4 && !pair && !(knob & 0x80000);
+  for (int p = 0; p < njobs && up2; p++) up2 = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh).rows_two;
   PlaneTable t{};
   LzmTableArgs wt{};
   t.np = (uint32_t)njobs;
@@ -1060,8 +1110,8 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
         else if (kc == 3) hipLaunchKernelGGL((k_lzm_build_cols<2, 3>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
         else hipLaunchKernelGGL((k_lzm_build_cols<4, 1>), dim3(strips), dim3(64), 0, st, (uint32_t)j.ch, j.sw, j.dw, scx, out);
       });
-      wt.rtab[p] = table(1, j.sh, j.dh, rows, rts, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
-        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, rts, out);
+      wt.rtab[p] = table(1, j.sh, j.dh, rows, rts | (uint32_t)up2 << 8, (uint64_t)bands * gpb * kLzmWmBytes, [&](u32x4* out) {
+        hipLaunchKernelGGL(k_lzm_build_rows, dim3(gpb, bands), dim3(64), 0, st, j.sh, j.dh, scy, rows, rts, (uint32_t)up2, out);
       });
     }
     t.g[p] = PlaneGeom{j.sw, j.sh, j.dw, j.dh, scx, scy, 0, pitch, rows, wave_lds, rts};
@@ -1083,7 +1133,6 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const dim3 grid(gx, gy, n);
   const uint32_t lds = pair ? lzm_pair_group_lds(lzm_pf_of(span)) : plan.group_lds;
   if (pair) for (int p = 0; p < njobs; p++) if (!wt.ctab[p] || !wt.rtab[p]) return false;  // the two-role form reads both tables
-  const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
   if (lds > 64u * 1024u && !(kc == 3 ? (lzm_pf_of(span, 3) == 8 ? lzm_big_lds_ok<LzMfma2k8>() : lzm_big_lds_ok<LzMfma2k6>()) : kc == 2 ? (lzm_pf_of(span, 2) == 8 ? lzm_big_lds_ok<LzMfma4k8>() : lzm_pf_of(span, 2) == 6 ? lzm_big_lds_ok<LzMfma4k6>() : lzm_big_lds_ok<LzMfma4k4>())
                              : nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;
 #define VPF_LZM_GO(K) do { if (log_level() >= 2 || trace_on()) note_kernel("k_lanczos_mfma<" #K ">"); (void)hipGetLastError(); \
@@ -1098,6 +1147,8 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   else if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);
   else if (pair && nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzPairW);
   else if (pair && nt == 8) VPF_LZM_GO(LzPair);
+  else if (nt == 8 && up2) VPF_LZM_GO(LzMfma8u);
+  else if (up2) VPF_LZM_GO(LzMfma4u);
   else if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);
   else if (nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzMfma8w);
   else if (nt == 8) VPF_LZM_GO(LzMfma8);

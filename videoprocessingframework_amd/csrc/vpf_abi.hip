@@ -465,8 +465,8 @@ int vpf_set_tuning(int key, int value) {
     return g_tune_tile.exchange(value);
   }
   if (key == VPF_TUNE_RESIZE_MFMA) {
-    const int shape = value & 0xffff, nt = shape >> 8, tiles = shape & 0xff;  // | 0x10000: no weight tables; | 0x20000: the two-role kernel form
-    if (value < 0 || (value & ~0x7ffff)) return -1;
+    const int shape = value & 0xffff, nt = shape >> 8, tiles = shape & 0xff;  // | 0x10000: no weight tables; | 0x20000: the two-role kernel form; | 0x40000: small single planes too; | 0x80000: no ring of two
+    if (value < 0 || (value & ~0xfffff)) return -1;
     if (shape != 0 && shape != 1 && ((nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
     return g_tune_mfma.exchange(value);
   }

@@ -39,15 +39,16 @@ constexpr uint32_t kLzmMaxLds = 80u * 1024u;  // two workgroups per CU share its
 // A per-frame caller asks the same question every call: a small per-thread cache answers it.
 // span4k2: 4-tile strips with 128-B windows (two K chunks in pass 1); rows_ok: 0 no | 4 a 16-row destination tile finds its source rows in the
 // ring's four source tiles | 3 only a HALF tile (8 rows) does: vertical factors of ~2.9 .. 6 (the log2 of the rows a tile carries)
-struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2, span2k3; int rows_ok; };  // span2k3: 2-tile strips, 192-B windows
+struct LzmShape { int ch; uint32_t sw, sh, dw, dh; uint32_t span4, span8, span4k2, span2k3; int rows_ok; bool rows_two; };  // span2k3: 2-tile strips, 192-B windows; rows_two: the ring of two holds every tile's source rows
 inline LzmShape lzm_shape(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
   thread_local LzmShape cache[8] = {};
   thread_local uint32_t next = 0;
   for (const LzmShape& c : cache)
     if (c.ch == ch && c.sw == sw && c.sh == sh && c.dw == dw && c.dh == dh) return c;
   const float scx = (float)sw / (float)dw, scy = (float)sh / (float)dh;
-  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, 0, 0};
+  LzmShape s{ch, sw, sh, dw, dh, 0, 0, 0, 0, 0, false};
   s.rows_ok = vpf_bound_lzm_rows_ok(sh, dh, scy) ? 4 : vpf_bound_lzm_rows_ok_rt(sh, dh, scy, 8u) ? 3 : 0;
+  s.rows_two = s.rows_ok == 4 && sh < dh && vpf_bound_lzm_rows_two(sh, dh, scy);
   if (s.rows_ok) {
     s.span4 = vpf_bound_lzm_span(ch, sw, dw, scx, 4); s.span8 = vpf_bound_lzm_span(ch, sw, dw, scx, 8);
     if (!s.span4) s.span4k2 = vpf_bound_lzm_span_win(ch, sw, dw, scx, 4, 128u);  // (asked for only where the 64-B windows do not hold the taps)
@@ -178,7 +179,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
 // Offsets are in 16-B units from the region's base; 0 = "no table: evaluate the weights in the kernel".
 struct LzmKey {
   int dev;
-  uint32_t kind, k0, k1, k2, k3;  // kind 0: columns (ch, sw, dw, nt) | 1: rows (sh, dh, band rows, 0)
+  uint32_t kind, k0, k1, k2, k3;  // kind 0: columns (ch, sw, dw, nt | chunks << 8) | 1: rows (sh, dh, band rows, log2 tile rows | ring of two << 8)
   bool operator==(const LzmKey& o) const { return dev == o.dev && kind == o.kind && k0 == o.k0 && k1 == o.k1 && k2 == o.k2 && k3 == o.k3; }
 };
 struct LzmKeyHash {

@@ -88,14 +88,17 @@ static inline uint32_t vpf_bound_lzm_span_win(int ch, uint32_t sw, uint32_t dw, 
 }
 static inline uint32_t vpf_bound_lzm_span(int ch, uint32_t sw, uint32_t dw, float scx, int nt) { return vpf_bound_lzm_span_win(ch, sw, dw, scx, nt, 64u); }
 static inline uint32_t vpf_bound_lzm_pitch(uint32_t span) { return ((span + 31u) & ~63u) + 32u; }
-/* every 16-row destination tile (tiles start at multiples of 16: bands are whole tiles) spans at most four 16-row source tiles */
-static inline int vpf_bound_lzm_rows_ok_rt(uint32_t sh, uint32_t dh, float scy, uint32_t rt /* destination rows a tile carries: 16, or 8 (half tiles) */) {
+/* every 16-row destination tile (tiles start at multiples of 16: bands are whole tiles) spans at most `tiles` 16-row source tiles: four (the
+ * ring), or two — the ring of two of the up-scales, vertical factors up to ~0.7 (16 destination rows + 5 rows of taps on <= 17 source rows), walked like everything here */
+static inline int vpf_bound_lzm_rows_within(uint32_t sh, uint32_t dh, float scy, uint32_t rt /* destination rows a tile carries: 16, or 8 (half tiles) */, uint32_t tiles) {
   for (uint32_t y0 = 0; y0 < dh; y0 += rt) {
     const uint32_t y1 = y0 + rt - 1u < dh - 1u ? y0 + rt - 1u : dh - 1u;
-    if ((vpf_lz_clamp(vpf_lz_i0(y1, scy) + 3, sh) >> 4) - (vpf_lz_clamp(vpf_lz_i0(y0, scy) - 2, sh) >> 4) > 3u) return 0;
+    if ((vpf_lz_clamp(vpf_lz_i0(y1, scy) + 3, sh) >> 4) - (vpf_lz_clamp(vpf_lz_i0(y0, scy) - 2, sh) >> 4) > tiles - 1u) return 0;
   }
   return 1;
 }
+static inline int vpf_bound_lzm_rows_ok_rt(uint32_t sh, uint32_t dh, float scy, uint32_t rt) { return vpf_bound_lzm_rows_within(sh, dh, scy, rt, 4u); }
 static inline int vpf_bound_lzm_rows_ok(uint32_t sh, uint32_t dh, float scy) { return vpf_bound_lzm_rows_ok_rt(sh, dh, scy, 16u); }
+static inline int vpf_bound_lzm_rows_two(uint32_t sh, uint32_t dh, float scy) { return vpf_bound_lzm_rows_within(sh, dh, scy, 16u, 2u); }
 
 #endif /* VPF_PLAN_BOUNDS_H_ */
