@@ -36,12 +36,12 @@ struct Cache {
 }  // namespace
 
 extern "C" {
-// planes: njobs x {ch, sw, sh, dw, dh}; out: {ok, nt, band_tiles, span, pitch, wave_lds, group_lds, kc, rts}
+// planes: njobs x {ch, sw, sh, dw, dh}; tables: bit 0 weight tables, bit 1 never the ring of two; out: {ok, nt, band_tiles, span, pitch, wave_lds, group_lds, kc, rts, up2}
 void lzp_plan(int njobs, const uint32_t* planes, uint32_t n, int forced, int tables, uint32_t* out) {
   vpf::LzmPlaneIn in[3];
   for (int p = 0; p < njobs && p < 3; p++) in[p] = vpf::LzmPlaneIn{(int)planes[5 * p], planes[5 * p + 1], planes[5 * p + 2], planes[5 * p + 3], planes[5 * p + 4]};
-  const vpf::LzmPlan q = vpf::lzm_plan(njobs, in, n, forced, tables != 0);
-  out[0] = q.ok; out[1] = (uint32_t)q.nt; out[2] = q.band_tiles; out[3] = q.span; out[4] = q.pitch; out[5] = q.wave_lds; out[6] = q.group_lds; out[7] = (uint32_t)q.kc; out[8] = (uint32_t)q.rts;
+  const vpf::LzmPlan q = vpf::lzm_plan(njobs, in, n, forced, (tables & 1) != 0, !(tables & 2));
+  out[0] = q.ok; out[1] = (uint32_t)q.nt; out[2] = q.band_tiles; out[3] = q.span; out[4] = q.pitch; out[5] = q.wave_lds; out[6] = q.group_lds; out[7] = (uint32_t)q.kc; out[8] = (uint32_t)q.rts; out[9] = q.up2;
 }
 void* lzp_cache_new(uint64_t arena_bytes) { return new Cache(arena_bytes); }
 void lzp_cache_free(void* c) { delete static_cast<Cache*>(c); }

@@ -51,11 +51,11 @@ def lzp():
     return L
 
 
-def plan(L, planes, n, forced=0, tables=True):
+def plan(L, planes, n, forced=0, tables=True, up2=True):
     a = (C.c_uint32 * (5 * len(planes)))(*[v for p in planes for v in p])
-    out = (C.c_uint32 * 9)()
-    L.lzp_plan(len(planes), a, n, forced, int(tables), out)
-    return dict(ok=bool(out[0]), nt=out[1], r=out[2], span=out[3], pitch=out[4], wave_lds=out[5], group_lds=out[6], kc=out[7], rts=out[8])
+    out = (C.c_uint32 * 10)()
+    L.lzp_plan(len(planes), a, n, forced, int(tables) | (0 if up2 else 2), out)
+    return dict(ok=bool(out[0]), nt=out[1], r=out[2], span=out[3], pitch=out[4], wave_lds=out[5], group_lds=out[6], kc=out[7], rts=out[8], up2=bool(out[9]))
 
 
 def planes_of(fmt, sw, sh, dw, dh):
@@ -68,20 +68,34 @@ def planes_of(fmt, sw, sh, dw, dh):
     return [(1, sw, sh, dw, dh), (1, sw // 2, sh // 2, dw // 2, dh // 2), (1, sw // 2, sh // 2, dw // 2, dh // 2)]
 
 
-def sweep_cases():
-    for n in (32, 8, 1):
-        path = os.path.join(ROOT, "profiles", f"r03_lanczos_shape_sweep_n{n}.txt")
-        for line in open(path):
-            m = re.match(r"\[lzm-sweep\] (\w+)\s+(\d+)x(\d+)->(\d+)x(\d+) n=(\d+):", line)
+def sweep_lines(name):
+    for line in open(os.path.join(ROOT, "profiles", name)):
+        m = re.match(r"\[lzm-sweep\] (\w+)\s+(\d+)x(\d+)->(\d+)x(\d+) n=(\d+):", line)
+        if m:
             fmt, (sw, sh, dw, dh, nn) = m.group(1), (int(v) for v in m.groups()[1:])
-            res = {(int(a), int(b)): float(c) for a, b, c in re.findall(r"nt(\d) r(\d+)=([\d.]+)", line)}
-            yield fmt, sw, sh, dw, dh, nn, res
+            yield fmt, sw, sh, dw, dh, nn, {(int(a), int(b)): float(c) for a, b, c in re.findall(r"nt(\d) r(\d+)=([\d.]+)", line)}
+
+
+def sweep_cases():
+    """the round-3 sweeps, without their up-scale lines: those kernels were replaced in round 5 (the ring of two; test_planner_on_up_scales)"""
+    for n in (32, 8, 1):
+        for c in sweep_lines(f"r03_lanczos_shape_sweep_n{n}.txt"):
+            if c[1] > c[3]:
+                yield c
+
+
+def pick_time(p, res):
+    """the planner's pick read off a sweep at the measured band heights either side of it (outside them: the nearest one)"""
+    rs = sorted(r for (nt, r) in res if nt == p["nt"])
+    lo = max([r for r in rs if r <= p["r"]], default=rs[0])
+    hi = min([r for r in rs if r >= p["r"]], default=rs[-1])
+    return res[(p["nt"], lo)] if lo == hi else float(np.interp(p["r"], [lo, hi], [res[(p["nt"], lo)], res[(p["nt"], hi)]]))
 
 
 def test_planner_stays_close_to_the_best_measured_shape(lzp):
-    """For every case of the three sweeps (RGB / NV12 / YUV420 x three size pairs x 32 / 8 / 1 frames per dispatch) the planner's pick — read off the
-    sweep at the measured band heights either side of it — is within 20 % of the best measured shape, 6 % on average.  A change of the cost
-    model that loses more than that shows up here, without a GPU."""
+    """For every down-scale case of the three sweeps (RGB / NV12 / YUV420 x two size pairs x 32 / 8 / 1 frames per dispatch) the planner's pick — read
+    off the sweep at the measured band heights either side of it — is within 20 % of the best measured shape, 6 % on average.  A change of the
+    cost model that loses more than that shows up here, without a GPU."""
     regrets = []
     for fmt, sw, sh, dw, dh, n, res in sweep_cases():
         p = plan(lzp, planes_of(fmt, sw, sh, dw, dh), n)
@@ -92,7 +106,32 @@ def test_planner_stays_close_to_the_best_measured_shape(lzp):
         t = res[(p["nt"], lo)] if lo == hi else np.interp(p["r"], [lo, hi], [res[(p["nt"], lo)], res[(p["nt"], hi)]])
         regrets.append(t / min(res.values()) - 1.0)
         assert regrets[-1] <= 0.20, (fmt, sw, dw, n, p, t, min(res.values()))
-    assert len(regrets) == 27 and float(np.mean(regrets)) <= 0.06, np.mean(regrets)
+    assert len(regrets) == 18 and float(np.mean(regrets)) <= 0.06, np.mean(regrets)
+
+
+def test_planner_on_up_scales(lzp):
+    """The ring-of-two kernels (round 5) against their own sweeps (profiles/r05_lanczos_shape_sweep_up_n*.txt: RGB / NV12 / YUV420 / Y x three
+    up-scales, 1 .. 128 frames per dispatch): 2 x up-scales take 8-tile strips (three workgroups per CU), 1.5 x ones 4-tile strips (an 8-tile
+    strip is wider than the narrow kernels' 128 staged bytes there: it would run the ring of four) — within 15 % of the best measured shape
+    everywhere, 4 % on average; and the planner says which kernel it planned for."""
+    regrets = []
+    for n in (32, 8, 1, 64, 128):
+        for fmt, sw, sh, dw, dh, nn, res in sweep_lines(f"r05_lanczos_shape_sweep_up_n{n}.txt"):
+            if fmt == "RGB" and nn > 32 and 3 * (sw * sh + dw * dh) > 7_000_000:
+                continue   # (frames of that size are dispatched 32 at a time by the ABI: not a launch of nn frames)
+            p = plan(lzp, planes_of(fmt, sw, sh, dw, dh), nn)
+            assert p["ok"] and p["up2"], (fmt, sw, dw, nn, p)
+            regrets.append(pick_time(p, res) / min(res.values()) - 1.0)
+            assert regrets[-1] <= 0.15, (fmt, sw, dw, nn, p, min(res.values()))
+    assert len(regrets) == 56 and float(np.mean(regrets)) <= 0.04, (len(regrets), np.mean(regrets))
+    # which candidates are the ring of two: 2 x -> both strip widths; 1.5 x packed RGB -> the 4-tile strips only; down-scales, and the knob -> none
+    assert plan(lzp, planes_of("RGB", 1920, 1080, 3840, 2160), 32)["nt"] == 8
+    assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32)["nt"] == 4
+    assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32, forced=8 << 8)["up2"] is False
+    assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32, forced=4 << 8)["up2"] is True
+    assert plan(lzp, planes_of("RGB", 1920, 1080, 1280, 720), 32)["up2"] is False
+    assert plan(lzp, planes_of("RGB", 1920, 1080, 3840, 2160), 32, up2=False)["up2"] is False
+    assert plan(lzp, [(3, 1920, 1080, 3840, 1000)], 32)["up2"] is False   # (an up-scale in x only)
 
 
 @pytest.mark.parametrize("n,mean_max,worst_max", [(64, 0.06, 0.15), (128, 0.05, 0.15)])
@@ -102,12 +141,9 @@ def test_planner_beyond_32_frames_per_dispatch(lzp, n, mean_max, worst_max):
     shape, 5-6 % on average — the round-3 model, asked about such launches, put NV12 and Y 1080p -> 720p on whole-column 4-tile strips
     (46 % / 27 % off the best)."""
     regrets = []
-    for line in open(os.path.join(ROOT, "profiles", f"r05_lanczos_shape_sweep_n{n}.txt")):
-        m = re.match(r"\[lzm-sweep\] (\w+)\s+(\d+)x(\d+)->(\d+)x(\d+) n=(\d+):", line)
-        if not m:
-            continue
-        fmt, (sw, sh, dw, dh, nn) = m.group(1), (int(v) for v in m.groups()[1:])
-        res = {(int(a), int(b)): float(c) for a, b, c in re.findall(r"nt(\d) r(\d+)=([\d.]+)", line)}
+    for fmt, sw, sh, dw, dh, nn, res in sweep_lines(f"r05_lanczos_shape_sweep_n{n}.txt"):
+        if sw < dw:
+            continue   # (the up-scale lines were measured with the kernels the ring of two replaced: test_planner_on_up_scales)
         p = plan(lzp, planes_of(fmt, sw, sh, dw, dh), nn)
         assert p["ok"] and nn == n
         rs = sorted(r for (nt, r) in res if nt == p["nt"])
@@ -116,7 +152,7 @@ def test_planner_beyond_32_frames_per_dispatch(lzp, n, mean_max, worst_max):
         t = res[(p["nt"], lo)] if lo == hi else np.interp(p["r"], [lo, hi], [res[(p["nt"], lo)], res[(p["nt"], hi)]])
         regrets.append(t / min(res.values()) - 1.0)
         assert regrets[-1] <= worst_max, (fmt, sw, dw, p, t, min(res.values()))
-    assert len(regrets) == 12 and float(np.mean(regrets)) <= mean_max, np.mean(regrets)
+    assert len(regrets) == 8 and float(np.mean(regrets)) <= mean_max, np.mean(regrets)
 
 
 def test_planner_limits_and_forced_shapes(lzp):

@@ -1,0 +1,97 @@
+"""Fit of the launch planner's constants for the ring-of-two up-scale kernels (vpf_lzm_plan.h) to the sweeps
+profiles/r05_lanczos_shape_sweep_up_n*.txt: a python restatement of the cost model with the constants as parameters, grid search for the
+lowest mean regret (the planner's pick read off the sweep against the best measured shape).  CPU only."""
+import ctypes as C, itertools, math, os, re, subprocess, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_so = os.path.join(tempfile.mkdtemp(), "libpb.so")
+subprocess.check_call(["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "videoprocessingframework_amd", "csrc"), os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", _so, "-lm"])
+PB = C.CDLL(_so)
+PB.pb_lzm_span.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int]; PB.pb_lzm_span.restype = C.c_uint32
+PB.pb_lzm_rows_two.argtypes = [C.c_uint32, C.c_uint32]
+
+
+def is_up2(planes, nt):
+    """the launcher's rule: narrow strips (every plane's span <= 128 B) and every plane's tiles within two source tiles"""
+    return all(0 < PB.pb_lzm_span(ch, sw, dw, nt) <= 128 and sh < dh and PB.pb_lzm_rows_two(sh, dh) for ch, sw, sh, dw, dh in planes)
+
+
+def planes_of(fmt, sw, sh, dw, dh):
+    if fmt == "RGB": return [(3, sw, sh, dw, dh)]
+    if fmt == "Y": return [(1, sw, sh, dw, dh)]
+    if fmt == "NV12": return [(1, sw, sh, dw, dh), (2, sw // 2, sh // 2, dw // 2, dh // 2)]
+    return [(1, sw, sh, dw, dh)] + [(1, sw // 2, sh // 2, dw // 2, dh // 2)] * 2
+
+
+def cases(ns):
+    for n in ns:
+        for line in open(os.path.join(ROOT, "profiles", f"r05_lanczos_shape_sweep_up_n{n}.txt")):
+            m = re.match(r"\[lzm-sweep\] (\w+)\s+(\d+)x(\d+)->(\d+)x(\d+) n=(\d+):", line)
+            fmt, (sw, sh, dw, dh, nn) = m.group(1), (int(v) for v in m.groups()[1:])
+            res = {(int(a), int(b)): float(c) for a, b, c in re.findall(r"nt(\d) r(\d+)=([\d.]+)", line)}
+            if fmt == "RGB" and nn > 32 and sw * sh * 3 + dw * dh * 3 > 7_000_000:
+                continue  # (dispatched 32 at a time by the ABI: not a launch of nn frames)
+            yield fmt, sw, sh, dw, dh, nn, res
+
+
+def pick(planes, n, P):
+    best = None
+    for nt in (8, 4):
+        up2 = is_up2(planes, nt)
+        slots = (P["slots8"] if nt == 8 else P["slots4"]) if up2 else (512 if nt == 8 else 768)
+        tmax = max((p[4] + 15) // 16 for p in planes)
+        for r in range(min(2, tmax), min(tmax, 64) + 1):
+            wgs, work = 0, 0.0
+            for ch, sw, sh, dw, dh in planes:
+                tiles = (dh + 15) // 16
+                gxp = ((dw * ch + 16 * nt - 1) // (16 * nt) + 3) // 4
+                wgs += gxp * ((tiles + r - 1) // r) * n
+                scy = sh / dh
+                if up2:
+                    w = P["w8"] if nt == 8 else P["w4"][ch]
+                else:
+                    w = 1.0 if nt == 8 else ({1: 0.45, 2: 0.9, 3: 0.8} if n <= 32 else {1: 0.8, 2: 0.9, 3: 1.0})[ch]
+                vert = (0.5 + 0.5 * scy / 1.5) if nt == 8 else (0.3 + 0.7 * scy / 1.5)
+                work = max(work, min(r, tiles) * w * vert)
+            if n <= 32:
+                cost = (P["S"] + work) * math.ceil(wgs / slots)
+            else:
+                cost = (P["S2"] + work) * (max(1.0, wgs / slots) + P["tail"])
+            if best is None or cost < best[0]:
+                best = (cost, nt, r)
+    return best[1], best[2]
+
+
+def regret(P, ns, verbose=False):
+    out = []
+    for fmt, sw, sh, dw, dh, n, res in cases(ns):
+        nt, r = pick(planes_of(fmt, sw, sh, dw, dh), n, P)
+        rs = sorted(rr for (t, rr) in res if t == nt)
+        lo = max([x for x in rs if x <= r], default=rs[0]); hi = min([x for x in rs if x >= r], default=rs[-1])
+        t = res[(nt, lo)] if lo == hi else float(np.interp(r, [lo, hi], [res[(nt, lo)], res[(nt, hi)]]))
+        out.append(t / min(res.values()) - 1.0)
+        if verbose:
+            b = min(res, key=res.get)
+            print(f"  {fmt:6s} {sw}x{sh}->{dw}x{dh} n={n}: pick nt{nt} r{r} {t:.2f}  best nt{b[0]} r{b[1]} {res[b]:.2f}  regret {out[-1]:.3f}")
+    return float(np.mean(out)), float(np.max(out))
+
+
+if __name__ == "__main__":
+    small = (32, 8, 1)
+    best = None
+    for s8, s4, S, w8, a, b, c in itertools.product((768,), (768, 1024), (2.0,), (0.7, 0.8, 0.9, 1.0), (0.35, 0.45, 0.55, 0.65), (0.5, 0.7, 0.9), (0.5, 0.6, 0.7, 0.8, 0.9)):
+        P = dict(slots8=s8, slots4=s4, S=S, S2=4.0, tail=1.5, w8=w8, w4={1: a, 2: b, 3: c})
+        m, w = regret(P, small)
+        if best is None or m < best[0]:
+            best = (m, w, P)
+    print("n <= 32:", best)
+    regret(best[2], small, True)
+    P0 = best[2]
+    best2 = None
+    for S2, tail, w8, a, b, c in itertools.product((4.0,), (1.5,), (0.7, 0.8, 0.9, 1.0), (0.5, 0.6, 0.8, 1.0), (0.5, 0.7, 0.9, 1.1), (0.6, 0.8, 1.0)):
+        P = dict(P0, S2=S2, tail=tail, w8=w8, w4={1: a, 2: b, 3: c})
+        m, w = regret(P, (64, 128))
+        if best2 is None or m < best2[0]:
+            best2 = (m, w, P)
+    print("n > 32:", best2)
+    regret(best2[2], (64, 128), True)

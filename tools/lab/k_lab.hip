@@ -485,11 +485,11 @@ __attribute__((visibility("default"))) int vpf_lab_is_conversion(int variant) {
 __attribute__((visibility("default"))) int vpf_lab_nv12_rgb(const vpf_exec* exec, int variant, int dst_fmt, int cs, int cr, vpf_size size, uint32_t n,
                                                            const vpf_frame_io* frames) {
   Yuv2RgbCoef c;
-  if (!exec || !frames || !n || n > (uint32_t)kMaxBatch || !size.width || !size.height || !coef_yuv2rgb(cs, cr, &c)) return 2;
+  if (!exec || !frames || !n || n > (uint32_t)kSmallBatch || !size.width || !size.height || !coef_yuv2rgb(cs, cr, &c)) return 2;
   BatchArgs a;
   std::memset(&a, 0, sizeof(a));
   const int nd = dst_fmt == VPF_FMT_RGB_PLANAR ? 3 : 1;
-  for (uint32_t i = 0; i < (uint32_t)kMaxBatch; i++) {
+  for (uint32_t i = 0; i < (uint32_t)kSmallBatch; i++) {
     const vpf_frame_io& f = frames[i < n ? i : 0];
     for (int k = 0; k < 2; k++) { if (!f.src[k].ptr) return 2; a.f[i].s[k] = (const uint8_t*)f.src[k].ptr; a.f[i].sp[k] = f.src[k].pitch; }
     for (int k = 0; k < nd; k++) { if (!f.dst[k].ptr) return 2; a.f[i].d[k] = (uint8_t*)f.dst[k].ptr; a.f[i].dp[k] = f.dst[k].pitch; }

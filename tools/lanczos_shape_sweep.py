@@ -1,6 +1,6 @@
 """Sweep of the matrix-core Lanczos kernel's launch shape (VPF_TUNE_RESIZE_MFMA = N-tiles per wave << 8 | 16-row tiles per band) over the
 batched cases the planner has to get right: us per frame for every (format, size pair, nt, tiles per band), 32 frames per dispatch.
-python tools/lanczos_shape_sweep.py [frames [passes]]"""
+python tools/lanczos_shape_sweep.py [frames [passes]]   (SWEEP_SIZES="1280x720:1920x1080,..." overrides the size pairs, SWEEP_Y=1 sweeps a 1-channel plane)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +14,11 @@ ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 PASSES = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 FMTS = ((capi.RGB, "RGB"), (capi.NV12, "NV12"), (capi.YUV420, "YUV420")) if not os.environ.get("SWEEP_Y") else ((capi.Y, "Y"),)  # SWEEP_Y=1: one 1-channel plane
+SIZES = ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080), (1280, 720, 1920, 1080))
+if os.environ.get("SWEEP_SIZES"):
+    SIZES = tuple(tuple(int(v) for v in c.replace(":", "x").split("x")) for c in os.environ["SWEEP_SIZES"].split(","))
 for fmt, fname in FMTS:
-    for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (3840, 2160, 1920, 1080), (1280, 720, 1920, 1080)):
+    for (sw, sh, dw, dh) in SIZES:
         ring = max(N, min(128, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // N * N))
         S = [surf(fmt, sw, sh, True) for _ in range(ring)]
         D = [surf(fmt, dw, dh, False) for _ in range(ring)]

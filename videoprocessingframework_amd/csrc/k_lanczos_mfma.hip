@@ -93,15 +93,15 @@ VPF_DEV uint32_t opaque(uint32_t v) {
 // PF = staging loads a lane keeps in flight = ceil(16-B units per staged row / 4); KC = 64-B K chunks of a pass-1 window (2: the taps of a
 // tile's 16 bytes spread over up to 128 source bytes — horizontal factors of ~2.2 .. 6 — and pass 1 chains two MFMAs per product)
 // UP2 = the ring of TWO, for up-scales (every destination tile finds its source rows in the source tiles (Tmax - 1, Tmax):
-// vpf_bound_lzm_rows_two): pass 2 is ONE K chunk — two MFMAs per N-tile instead of four.  The register file still holds two chunks, but
-// OVERLAPPING ones: chunk k = source tiles (k, k + 1); a tile's (zl, zh) pairs are written twice — first half of its own chunk, second half of
-// the one before (two v_mov per N-tile and source tile) — and a destination tile multiplies chunk Tmax - 1 by a one-chunk weight operand
-// (its own row-table layout: lzm_row_group).  A 2x up-scale emits two destination tiles per source tile: 10 MFMAs per N-tile and source
-// tile become 6 and the matrix pipe stops being what two waves per SIMD queue for
+// vpf_bound_lzm_rows_two): pass 2 is ONE K chunk — two MFMAs per N-tile instead of four — and the register file holds ONE chunk per N-tile,
+// (previous tile, this tile): pass 1 moves the second half down (two v_mov per N-tile and source tile) and writes the new tile's (zl, zh)
+// pairs into the second; a destination tile multiplies it by a one-chunk weight operand (its own row-table layout: lzm_row_group).  A 2x
+// up-scale emits two destination tiles per source tile: 10 MFMAs per N-tile and source tile become 6 — the matrix pipe stops being what
+// the waves of a SIMD queue for — and 32 VGPRs of ring are gone: three workgroups per CU instead of two
 template <int CH, int NT, int PF, int KC = 1, bool UP2 = false>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
-  static constexpr int kGroupsPerCu = NT == 4 && KC == 1 ? 3 : 2;  // register budget: 168 / 256 VGPRs
+  static constexpr int kGroupsPerCu = (NT == 4 && KC == 1) || UP2 ? 3 : 2;  // register budget: 168 / 256 VGPRs
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
                           const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab);  // the shape's column / row weight tables (nullptr: evaluate in place)
 };
@@ -378,7 +378,9 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   const uint32_t plane_bytes = sh * sp;  // < 2^32: launcher
   // (every fetch issues exactly PF loads, predicated on nothing — units past the strip are clamped duplicates, tiles past the band's last
   // re-read the last — so that the compiler can count: the wait in front of a commit is vmcnt(PF), not vmcnt(0))
-  u32x4 pf[2][PF];
+  // (the ring of two — three waves per SIMD, 168 registers — keeps ONE tile in flight: the third wave covers what the second set did)
+  constexpr int PD = UP2 ? 1 : 2;
+  u32x4 pf[PD][PF];
   auto fetch = [&](int32_t T, auto set_tag) {
     constexpr int SET = decltype(set_tag)::value;
     const uint32_t toff = (uint32_t)(T < t_last ? T : t_last) * 16u * sp;  // scalar
@@ -386,26 +388,39 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
 #pragma unroll
     for (int k = 0; k < PF; k++) pf[SET][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[k % NV], LPR == 8 && k >= HALF ? (int)sp8 : 0, 0));
   };
-  v4i ring[NT][2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs); UP2: chunk k & 1 = tiles (k, k + 1)
+  v4i ring[NT][UP2 ? 1 : 2];  // per N-tile: two K chunks x (two source tiles x two dwords of (zl, zh) byte pairs); UP2: one chunk, (previous tile, this tile)
   static_assert(!UP2 || KC == 1, "the ring of two: one-chunk windows only");
   // where pass 1 of the tile in slot SLOT puts its two dwords
   auto ring_put = [&](int j, auto slot_tag, int32_t v0, int32_t v1) {
     constexpr int SLOT = decltype(slot_tag)::value;
     if constexpr (UP2) {
-      ring[j][SLOT & 1][0] = v0; ring[j][SLOT & 1][1] = v1;              // first half of its own chunk
-      ring[j][(SLOT & 1) ^ 1][2] = v0; ring[j][(SLOT & 1) ^ 1][3] = v1;  // second half of the chunk before
+      ring[j][0][0] = ring[j][0][2]; ring[j][0][1] = ring[j][0][3];
+      ring[j][0][2] = v0; ring[j][0][3] = v1;
     } else {
       ring[j][SLOT >> 1][2 * (SLOT & 1)] = v0; ring[j][SLOT >> 1][2 * (SLOT & 1) + 1] = v1;
     }
   };
 #pragma unroll
-  for (int j = 0; j < NT; j++) { ring[j][0] = v4i{0, 0, 0, 0}; ring[j][1] = v4i{0, 0, 0, 0}; }
+  for (int j = 0; j < NT; j++) {
+    ring[j][0] = v4i{0, 0, 0, 0};
+    if constexpr (!UP2) ring[j][1] = v4i{0, 0, 0, 0};
+  }
   const v4i c128 = {128, 128, 128, 128};
   // A operand of pass 1: lane (i, g) -> row i, bytes 16 g .. of tile j's window (one address register per tile: the kernel is issue-bound,
   // an add per read is 7 % of pass 1)
-  const uint8_t* aptr[NT];
+  // (the ring of two: one register + the tile's scalar window offset, added at the read — seven registers for one VALU instruction per read)
+  const uint8_t* aptr[UP2 ? 1 : NT];
 #pragma unroll
-  for (int j = 0; j < NT; j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
+  for (int j = 0; j < (UP2 ? 1 : NT); j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
+  auto a_of = [&](int j) -> const uint8_t* {
+    if constexpr (UP2) {
+      uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(aptr[0]);
+      asm volatile("" : "+v"(a));  // (not to be hoisted out of the march into eight registers again)
+      return reinterpret_cast<const uint8_t*>(dyn_strip) + (a - (uint32_t)reinterpret_cast<uintptr_t>(dyn_strip)) + (wrel[j] - wrel[0]);
+    } else {
+      return aptr[j];
+    }
+  };
   uint8_t* const sdst = stage + (LPR == 8 ? (lane >> 3) : (lane >> 2)) * P + 16u * (lane & (LPR - 1));  // + 8 P per row half, + 16 LPR per unit column: immediates
 
   // pass 1 of source tile T into ring slot SLOT = (T - t_first) & 3 (a compile-time constant: the march below is unrolled four deep so
@@ -415,16 +430,18 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
 #pragma unroll
     for (int k = 0; k < PF; k++)
       *reinterpret_cast<u32x4*>(sdst + (LPR == 8 ? (uint32_t)(k / HALF) * 8u * P : 0u) + (uint32_t)(k % HALF) * (16u * LPR)) =
-          pf[SLOT & 1][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-    fetch(T + 2, std::integral_constant<int, SLOT & 1>{});
+          pf[SLOT & (PD - 1)][k] ^ u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    fetch(T + PD, std::integral_constant<int, SLOT & (PD - 1)>{});
     wave_lds_sync();
     if constexpr (KC == 1) {
       // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
       // flight and the wave waits four times per tile); the other four are requested one by one into the registers the MFMAs free
-      v4i av[4];
+      constexpr int AD = UP2 ? 2 : 4;  // A operands in flight (the ring of two runs three waves per SIMD: its register budget is 168)
+      v4i av[AD];
 #pragma unroll
-      for (int j = 0; j < 4; j++) av[j] = *reinterpret_cast<const v4i*>(aptr[j]);
-      asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));  // (an empty asm that "uses" them all: nothing may sink below it)
+      for (int j = 0; j < AD; j++) av[j] = *reinterpret_cast<const v4i*>(a_of(j));
+      if constexpr (AD == 4) asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+      else asm volatile("" : "+v"(av[0]), "+v"(av[1]));  // (an empty asm that "uses" them all: nothing may sink below it)
       // software pipeline over the N-tiles, interleaved at instruction level: the matrix pipe takes a new MFMA every 16 cycles and a wave issues
       // in order, so two MFMAs back to back park the wave for 12 cycles and the eight VALU instructions behind them then run with the pipe
       // idle.  Order per tile: HI of tile j + 1 | the four shift-adds of tile j (16 cycles: the pipe's own time) | LO of tile j + 1 | the two
@@ -437,7 +454,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
 #pragma unroll
       for (int j = 0; j < NT; j++) {
         if (j + 1 < NT) {
-          hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1h[j + 1], c128, 0, 0, 0);
+          hi[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & (AD - 1)], b1h[j + 1], c128, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t h[4];
@@ -445,11 +462,11 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
         for (int r = 0; r < 4; r++) h[r] = ((uint32_t)hi[j & 1][r] << 8) + (uint32_t)lo[j & 1][r];
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < NT) {
-          lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & 3], b1l[j + 1], c128, 0, 0, 0);
+          lo[(j + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[(j + 1) & (AD - 1)], b1l[j + 1], c128, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (j + 4 < NT) {
-          av[j & 3] = *reinterpret_cast<const v4i*>(aptr[j + 4]);
+        if (j + AD < NT) {
+          av[j & (AD - 1)] = *reinterpret_cast<const v4i*>(a_of(j + AD));
         }
         // bits 8 .. 23 of h'' = z + 128 (z = Hr - 8192): one v_perm_b32 per row pair packs two of them, the xor turns each low byte into the
         // signed zl (z = 256 zh + zl) — the ring holds (zl, zh) byte pairs, which is the K-slot order of pass 2's operands
@@ -465,7 +482,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
 #pragma unroll
       for (int j = 0; j < NT; j++)
 #pragma unroll
-        for (int c = 0; c < KC; c++) ac[j][c] = *reinterpret_cast<const v4i*>(aptr[j] + 64 * c);
+        for (int c = 0; c < KC; c++) ac[j][c] = *reinterpret_cast<const v4i*>(a_of(j) + 64 * c);
       v4i hi[2], lo[2];
       hi[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[0][0], b1h[0], c128, 0, 0, 0);
       lo[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[0][0], b1l[0], c128, 0, 0, 0);
@@ -515,8 +532,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   const uint32_t ob = ob0 + 16u * (lane & (NT - 1));                   // first destination byte of the unit this lane stores
   const bool ofull = ob + 16u <= dwb, opart = !ofull && ob < dwb;
   const uint32_t obase = mad24(lane >> LOGNT, dp, ob);  // 32-bit offsets on the plane's scalar base (planes stay below 4 GiB: host)
-  auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0, auto chunk_tag) {
-    constexpr int C2 = decltype(chunk_tag)::value;  // UP2: the chunk that holds (Tmax - 1, Tmax)
+  auto emit = [&](const uint8_t* wm, uint32_t t, uint32_t y0) {
+    constexpr int C2 = 0;
     const v4i by0 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 0) * 64 + lane) * 16);
     v4i by1 = by0;
     if constexpr (!UP2) by1 = *reinterpret_cast<const v4i*>(wm + ((t * 2 + 1) * 64 + lane) * 16);
@@ -610,7 +627,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   int32_t tmax_l = group_tmax(0);
   int32_t T = t_first;
   fetch(T, std::integral_constant<int, 0>{});
-  fetch(T + 1, std::integral_constant<int, 1>{});
+  if constexpr (PD == 2) fetch(T + 1, std::integral_constant<int, 1>{});
   group_ready(0); group_ready(1);
   __syncthreads();  // groups 0 and 1 are in LDS
   // one step: the next source tile, then every destination tile whose last source tile it was
@@ -620,7 +637,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   for (;;) {                                                                                                        \
     const uint32_t tl = ((y_next - ya) >> rts) & 3u;                                                                \
     if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + rt - 1) >= T) break;                                            \
-    emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next, std::integral_constant<int, (((S) & 1) ^ 1)>{});               \
+    emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next);                                                               \
     y_next += rt;                                                                                                   \
     if (y_next > yb) return;                                                                                        \
     if (tl == 3) { next_group(grp); grp++; tmax_l = group_tmax(grp); }                                              \
@@ -1049,17 +1066,15 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   }
   LzmPlaneIn in[3];
   for (int p = 0; p < njobs; p++) in[p] = LzmPlaneIn{jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh};
-  const LzmPlan plan = lzm_plan(njobs, in, n, pair ? ((8 << 8) | (forced & 0xff)) : forced, tables);  // launch shape by the cost model of vpf_lzm_plan.h
+  // launch shape by the cost model of vpf_lzm_plan.h (| 0x80000: never the ring of two, the measurement and test knob)
+  const LzmPlan plan = lzm_plan(njobs, in, n, pair ? ((8 << 8) | (forced & 0xff)) : forced, tables, !pair && !(knob & 0x80000));
   if (!plan.ok) return false;
   const int nt = plan.nt, kc = plan.kc;
   const uint32_t rts = (uint32_t)plan.rts;  // log2 of the destination rows per tile: 4, or 3 (half tiles)
   if (pair && rts != 4) return false;
   const uint32_t band_tiles = plan.band_tiles, span = plan.span, pitch = plan.pitch, wave_lds = plan.wave_lds;
   const bool narrow = span <= 2u * 64u;  // two staging loads per lane and tile cover the strip
-  // the ring of two (LanczosMfmaTask<.., UP2>): up-scales — narrow strips, and every plane's destination tiles within two source tiles
-  // (| 0x80000: never, the measurement and test knob)
-  bool up2 = narrow && kc == 1 && rts == 4 && !pair && !(knob & 0x80000);
-  for (int p = 0; p < njobs && up2; p++) up2 = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh).rows_two;
+  const bool up2 = plan.up2;  // the ring of two (LanczosMfmaTask<.., UP2>): narrow strips, every plane's destination tiles within two source tiles
   PlaneTable t{};
   LzmTableArgs wt{};
   t.np = (uint32_t)njobs;
@@ -1131,7 +1146,18 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
     }
   } unlock{arena_locked, st, dev, capturing, arena_ids, n_arena};
   const dim3 grid(gx, gy, n);
-  const uint32_t lds = pair ? lzm_pair_group_lds(lzm_pf_of(span)) : plan.group_lds;
+  // a wave's LDS = the staged tile + the out tile, or — larger for the narrow strips — the scratch the column weights are composed in: not
+  // needed when every plane's column table is there (a 4-tile up-scale strip: 48 -> 31 KiB per workgroup, a fourth workgroup per CU)
+  uint32_t lds = pair ? lzm_pair_group_lds(lzm_pf_of(span)) : plan.group_lds;
+  if (!pair && tables) {
+    bool all = true;
+    for (int p = 0; p < njobs; p++) all = all && wt.ctab[p] != nullptr;
+    const uint32_t run = 16u * pitch + 16u * lzm_out_pitch(nt);
+    if (all && run < wave_lds) {
+      for (int p = 0; p < njobs; p++) t.g[p].a2 = run;
+      lds = 4u * run + 2u * kLzmWmBytes;
+    }
+  }
   if (pair) for (int p = 0; p < njobs; p++) if (!wt.ctab[p] || !wt.rtab[p]) return false;  // the two-role form reads both tables
   if (lds > 64u * 1024u && !(kc == 3 ? (lzm_pf_of(span, 3) == 8 ? lzm_big_lds_ok<LzMfma2k8>() : lzm_big_lds_ok<LzMfma2k6>()) : kc == 2 ? (lzm_pf_of(span, 2) == 8 ? lzm_big_lds_ok<LzMfma4k8>() : lzm_pf_of(span, 2) == 6 ? lzm_big_lds_ok<LzMfma4k6>() : lzm_big_lds_ok<LzMfma4k4>())
                              : nt == 8 ? (span > 4u * 64u ? lzm_big_lds_ok<LzMfma8w>() : lzm_big_lds_ok<LzMfma8>()) : lzm_big_lds_ok<LzMfma4>())) return false;

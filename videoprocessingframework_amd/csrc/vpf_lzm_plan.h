@@ -82,10 +82,12 @@ struct LzmPlan {
                         // horizontal factors of ~2.2 .. 6 (1080p -> 416 x 416 in front of a network); 3 (2-tile strips) up to 192 bytes: factors up to
                         // ~10 (1080p -> 224 x 224).  Each taken only when nothing cheaper fits
   int rts;              // log2 of the destination rows a 16-row tile carries: 4, or 3 (half tiles) where some plane's vertical factor needs it
+  bool up2;             // the ring of two (LanczosMfmaTask<.., UP2>): up-scales whose strips are narrow (<= 128 staged bytes per row) and whose
+                        // destination tiles all lie within two source tiles — one K chunk in pass 2, three (8-tile strips) or four workgroups per CU
 };
 // forced: 0 policy | (nt << 8 | band tiles): measurement and test knob (either part may be 0 = policy)
-inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int forced, bool tables) {
-  LzmPlan P{false, 0, 0, 0, 0, 0, 0, 1, 4};
+inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int forced, bool tables, bool allow_up2 = true) {
+  LzmPlan P{false, 0, 0, 0, 0, 0, 0, 1, 4, false};
   int rts = 4;  // one tile height for the launch: the smallest any plane needs
   for (int p = 0; p < njobs; p++) {
     const int ok = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh).rows_ok;
@@ -121,9 +123,16 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
       if (packed3) continue;
     }
     if (forced > 1 && (forced >> 8) != 0 && (forced >> 8) != cand && !(kc == 3 && (forced >> 8) == 4)) continue;  // (forced 4-tile strips that do not fit: the 2-tile form may still take the launch)
-    LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc, rts};
+    LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc, rts, false};
     if (!fits(cand, kc, q)) continue;
-    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = cand == 8 || kc >= 2 ? 512.0 : 768.0;
+    // The ring of two (round 5): a candidate whose strips are narrow on an up-scale runs a different kernel — fewer instructions per tile
+    // (w 0.8 of an 8-tile strip's; 4-tile strips 0.65 / 0.5 / 0.7 by channel count, beyond 32 frames 0.7 and 0.5 / 0.7 / 0.8) and more
+    // resident workgroups (768, and 1024 for 4-tile strips whose tables exist: the LDS they are evaluated in is not reserved then).
+    // Fitted to profiles/r05_lanczos_shape_sweep_up_n*.txt (tools/lab/fit_lzm_up2.py: mean regret 2.3 % up to 32 frames, 2.5 % beyond;
+    // worst 12 % / 9 %).  1.5 x up-scales get 4-tile strips this way (an 8-tile strip is wider than 128 B there: ring of four), 2 x ones 8-tile strips
+    q.up2 = allow_up2 && kc == 1 && rts == 4 && q.span <= 128u;
+    for (int p = 0; p < njobs && q.up2; p++) q.up2 = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh).rows_two;
+    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = q.up2 ? (cand == 8 || !tables ? 768.0 : 1024.0) : cand == 8 || kc >= 2 ? 512.0 : 768.0;
     uint32_t tmax = 0;
     for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + rt - 1) / rt);
     const bool free_r = !(forced > 1 && (forced & 0xff));
@@ -135,7 +144,8 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         const uint32_t tiles = (jobs[p].dh + rt - 1) / rt, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
         wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
         const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-        const double w = cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
+        const double w = q.up2 ? (cand == 8 ? 0.8 : jobs[p].ch == 3 ? 0.7 : jobs[p].ch == 2 ? 0.5 : 0.65)
+                                 : cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
         const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
         work = std::max(work, (double)std::min(r, tiles) * w * vert);
       }
@@ -152,7 +162,8 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         for (int p = 0; p < njobs; p++) {
           const uint32_t tiles = (jobs[p].dh + rt - 1) / rt;
           const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-          const double w = cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 1.0 : jobs[p].ch == 2 ? 0.9 : 0.8;
+          const double w = q.up2 ? (cand == 8 ? 0.7 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.7 : 0.5)
+                                   : cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 1.0 : jobs[p].ch == 2 ? 0.9 : 0.8;
           const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
           work2 = std::max(work2, (double)std::min(r, tiles) * w * vert);
         }
