@@ -101,7 +101,10 @@ VPF_DEV uint32_t opaque(uint32_t v) {
 template <int CH, int NT, int PF, int KC = 1, bool UP2 = false>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
-  static constexpr int kGroupsPerCu = (NT == 4 && KC == 1) || UP2 ? 3 : 2;  // register budget: 168 / 256 VGPRs
+  // the register diet (one tile in flight, one A-operand address, two A operands ahead): with the ring of two it is worth a workgroup per CU (the
+  // 8-tile form: 166 VGPRs, three; the 4-tile form: 116, four).  Tried on the ring-of-four 4-tile strips too: 147 -> 145, still three — not taken
+  static constexpr bool kLean = UP2;
+  static constexpr int kGroupsPerCu = (NT == 4 && KC == 1) || UP2 ? 3 : 2;  // register budget: 168 / 256 VGPRs (the 4-tile ring of two fits four: its LDS decides)
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
                           const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab);  // the shape's column / row weight tables (nullptr: evaluate in place)
 };
@@ -379,7 +382,8 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   // (every fetch issues exactly PF loads, predicated on nothing — units past the strip are clamped duplicates, tiles past the band's last
   // re-read the last — so that the compiler can count: the wait in front of a commit is vmcnt(PF), not vmcnt(0))
   // (the ring of two — three waves per SIMD, 168 registers — keeps ONE tile in flight: the third wave covers what the second set did)
-  constexpr int PD = UP2 ? 1 : 2;
+  constexpr bool LEAN = LanczosMfmaTask<CH, NT, PF, KC, UP2>::kLean;
+  constexpr int PD = LEAN ? 1 : 2;
   u32x4 pf[PD][PF];
   auto fetch = [&](int32_t T, auto set_tag) {
     constexpr int SET = decltype(set_tag)::value;
@@ -409,11 +413,11 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   // A operand of pass 1: lane (i, g) -> row i, bytes 16 g .. of tile j's window (one address register per tile: the kernel is issue-bound,
   // an add per read is 7 % of pass 1)
   // (the ring of two: one register + the tile's scalar window offset, added at the read — seven registers for one VALU instruction per read)
-  const uint8_t* aptr[UP2 ? 1 : NT];
+  const uint8_t* aptr[LEAN ? 1 : NT];
 #pragma unroll
-  for (int j = 0; j < (UP2 ? 1 : NT); j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
+  for (int j = 0; j < (LEAN ? 1 : NT); j++) aptr[j] = stage + (lane & 15) * P + 16u * (lane >> 4) + wrel[j];
   auto a_of = [&](int j) -> const uint8_t* {
-    if constexpr (UP2) {
+    if constexpr (LEAN) {
       uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(aptr[0]);
       asm volatile("" : "+v"(a));  // (not to be hoisted out of the march into eight registers again)
       return reinterpret_cast<const uint8_t*>(dyn_strip) + (a - (uint32_t)reinterpret_cast<uintptr_t>(dyn_strip)) + (wrel[j] - wrel[0]);
@@ -436,7 +440,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
     if constexpr (KC == 1) {
       // the A operands of the first four N-tiles are requested together, before the first is used (left alone the compiler keeps two reads in
       // flight and the wave waits four times per tile); the other four are requested one by one into the registers the MFMAs free
-      constexpr int AD = UP2 ? 2 : 4;  // A operands in flight (the ring of two runs three waves per SIMD: its register budget is 168)
+      constexpr int AD = LEAN ? 2 : 4;  // A operands in flight (the ring of two runs three waves per SIMD: its register budget is 168)
       v4i av[AD];
 #pragma unroll
       for (int j = 0; j < AD; j++) av[j] = *reinterpret_cast<const v4i*>(a_of(j));
