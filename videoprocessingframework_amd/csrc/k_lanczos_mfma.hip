@@ -634,14 +634,17 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
   if constexpr (PD == 2) fetch(T + 1, std::integral_constant<int, 1>{});
   group_ready(0); group_ready(1);
   __syncthreads();  // groups 0 and 1 are in LDS
+  VPF_WAVE_MARK(0);  // (lab builds: setup done — row groups in LDS, column operands and the first two source tiles requested)
   // one step: the next source tile, then every destination tile whose last source tile it was
 #define VPF_LZM_STEP(S)                                                                                              \
   pass1(T, std::integral_constant<int, S>{});                                                                       \
+  if (T == t_first) VPF_WAVE_MARK(1); /* the first source tile has arrived and is through pass 1 */                 \
   T++;                                                                                                              \
   for (;;) {                                                                                                        \
     const uint32_t tl = ((y_next - ya) >> rts) & 3u;                                                                \
     if (__builtin_amdgcn_readlane(tmax_l, 16 * tl + rt - 1) >= T) break;                                            \
     emit(wmb + (grp & 1u) * kLzmWmBytes, tl, y_next);                                                               \
+    if (y_next == ya) VPF_WAVE_MARK(2); /* the first destination tile is stored */                                  \
     y_next += rt;                                                                                                   \
     if (y_next > yb) return;                                                                                        \
     if (tl == 3) { next_group(grp); grp++; tmax_l = group_tmax(grp); }                                              \
