@@ -73,3 +73,7 @@ if __name__ == "__main__":
             best = (m, w, P)
     print("refit:", best, " up with it", regret(best[2], up))
     regret(best[2], down, True)
+    print("one constant at a time (the 1-channel 4-tile strip's work factor):")
+    for a in (0.45, 0.5, 0.55, 0.6, 0.65, 0.7):
+        P = dict(cur, w4={1: a, 2: 0.9, 3: 0.8})
+        print(f"  w4[1] = {a}: down {regret(P, down)}  up {regret(P, up)}")
