@@ -1,12 +1,14 @@
 """band_knob_sweep.py KNOB [KNOB ...]: us/frame of the batched BILINEAR resize (32 frames per dispatch, rings past the Infinity Cache) under
 VPF_TUNE_RESIZE_BAND values (hex ok: rows | nb << 8 | 0x10000 = the persistent launch), passes interleaved over the knobs, minimum and median
 of the passes per cell.  SWEEP_CASES="Y:1920x1080:1280x720,NV12:..." overrides the cases; SWEEP_INTERP=2 sweeps VPF_TUNE_RESIZE_MFMA on the
-Lanczos kernels instead."""
+Lanczos kernels instead; SWEEP_LIB=path runs another build of the kernel library."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from videoprocessingframework_amd import capi
+if os.environ.get("SWEEP_LIB"):  # another build of the kernel library (same-box A/B of two builds: run alternately)
+    capi.LIB_PATH = os.path.abspath(os.environ["SWEEP_LIB"])
 argv, sys.argv = sys.argv, sys.argv[:1]
 from resize_batch_bench import surf  # noqa: E402
 sys.argv = argv
