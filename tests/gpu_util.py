@@ -36,6 +36,14 @@ class DevPlanes:
     def desc(self):
         return [(b.data_ptr() + self.offset, pitch) for b, pitch in zip(self.bufs, self.pitches)]
 
+    def upload(self, host_planes):
+        """new pixels into the SAME device buffers (a captured graph keeps their addresses)"""
+        for b, pitch, p in zip(self.bufs, self.pitches, host_planes):
+            rows, rb = p.shape[0], p.shape[1] * p.dtype.itemsize
+            h = np.full((rows * pitch + self.offset + 64,), PAD, dtype=np.uint8)
+            h[self.offset:self.offset + rows * pitch].reshape(rows, pitch)[:, :rb] = p.view(np.uint8).reshape(rows, rb)
+            b.copy_(torch.from_numpy(h))
+
     def download(self):
         """-> (list of tight numpy planes, padding_intact: bool)"""
         out, intact = [], True

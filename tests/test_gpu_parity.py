@@ -615,6 +615,39 @@ def test_batch_entries_are_hip_graph_capturable(capi, oracle):
                 assert_planes_equal(got, want, f"graph replay, remap_batch frame {i}")
 
 
+@pytest.mark.parametrize("fmt", ["RGB", "NV12"])
+def test_lanczos_upscale_is_hip_graph_capturable_with_cold_tables(capi, oracle, fmt):
+    """A Lanczos up-scale (the ring-of-two kernels and their own row-table layout) of a shape nobody has resized before, captured WITHOUT a warm-up:
+    the table builds are nodes of the graph (a capturing stream always queues its own), the replay — twice, sources changed in between — writes
+    the oracle's pixels."""
+    w, h, dw, dh, n = (214, 118, 428, 236, 3) if fmt == "RGB" else (222, 126, 444, 252, 3)
+    f, of = getattr(capi, fmt), getattr(oracle, fmt)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        srcs = [oracle.synth(of, w, h, 4200 + i) for i in range(n)]
+        S = [DevPlanes(p) for p in srcs]
+        D = [DevPlanes(oracle.alloc(of, dw, dh)) for _ in range(n)]
+        ex = capi.make_exec(st.cuda_stream)
+        b = capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)])
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            capi.resize_batch(ex, f, 2, w, h, dw, dh, b)
+        for rep in range(2):
+            if rep:   # new pixels in the same buffers
+                srcs = [oracle.synth(of, w, h, 4300 + i) for i in range(n)]
+                for s_, p in zip(S, srcs):
+                    s_.upload(p)
+            for d in D:
+                for t in d.bufs:
+                    t.fill_(0xCD)
+            g.replay(); st.synchronize()
+            for i in range(n):
+                got, intact = D[i].download()
+                assert intact
+                assert_planes_equal(got, oracle.resize(of, 2, w, h, srcs[i], dw, dh, oracle.FP32)[1], f"graph replay {rep}, lanczos up-scale {fmt} frame {i}")
+
+
 # ---------------------------------------------------------------------------------------------
 # randomised shape / pitch / alignment fuzz (deterministic seeds): every converter family, bit-exact
 # ---------------------------------------------------------------------------------------------
