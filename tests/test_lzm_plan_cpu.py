@@ -125,10 +125,10 @@ def test_planner_against_the_round_5_down_scale_sweeps(lzp):
 
 
 def test_planner_on_up_scales(lzp):
-    """The ring-of-two kernels (round 5) against their own sweeps (profiles/r05_lanczos_shape_sweep_up_n*.txt: RGB / NV12 / YUV420 / Y x three
-    up-scales, 1 .. 128 frames per dispatch): 2 x up-scales take 8-tile strips (three workgroups per CU), 1.5 x ones 4-tile strips (an 8-tile
-    strip is wider than the narrow kernels' 128 staged bytes there: it would run the ring of four) — within 15 % of the best measured shape
-    everywhere, 4 % on average; and the planner says which kernel it planned for."""
+    """The ring-of-two kernels (round 5) against their own sweeps (profiles/r05_lanczos_shape_sweep_up_n*.txt: RGB / NV12 / YUV420 / Y x five
+    up-scales at 32 / 8 / 1 frames per dispatch, four at 64 / 128): 2 x up-scales take 8-tile strips (three workgroups per CU), 1.5 x ones
+    4-tile strips — except large launches of them (1440p -> 4K x 32), which take the WIDE 8-tile strips (LzMfma8uw, rows of up to 256 B) —
+    within 15 % of the best measured shape everywhere, 4 % on average; and the planner says which kernel it planned for."""
     regrets = []
     for n in (32, 8, 1, 64, 128):
         for fmt, sw, sh, dw, dh, nn, res in sweep_lines(f"r05_lanczos_shape_sweep_up_n{n}.txt"):
@@ -138,11 +138,14 @@ def test_planner_on_up_scales(lzp):
             assert p["ok"] and p["up2"], (fmt, sw, dw, nn, p)
             regrets.append(pick_time(p, res) / min(res.values()) - 1.0)
             assert regrets[-1] <= 0.15, (fmt, sw, dw, nn, p, min(res.values()))
-    assert len(regrets) == 56 and float(np.mean(regrets)) <= 0.04, (len(regrets), np.mean(regrets))
+    assert len(regrets) == 86 and float(np.mean(regrets)) <= 0.04, (len(regrets), np.mean(regrets))
     # which candidates are the ring of two: 2 x -> both strip widths; 1.5 x packed RGB -> the 4-tile strips only; down-scales, and the knob -> none
     assert plan(lzp, planes_of("RGB", 1920, 1080, 3840, 2160), 32)["nt"] == 8
     assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32)["nt"] == 4
-    assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32, forced=8 << 8)["up2"] is False
+    assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32, forced=8 << 8)["up2"] is False   # (wide 8-tile strips: large launches only)
+    big = plan(lzp, planes_of("RGB", 2560, 1440, 3840, 2160), 32)
+    assert big["nt"] == 8 and big["up2"] and 128 < big["span"] <= 256
+    assert plan(lzp, planes_of("RGB", 2560, 1440, 3840, 2160), 8)["nt"] == 4
     assert plan(lzp, planes_of("RGB", 1280, 720, 1920, 1080), 32, forced=4 << 8)["up2"] is True
     assert plan(lzp, planes_of("RGB", 1920, 1080, 1280, 720), 32)["up2"] is False
     assert plan(lzp, planes_of("RGB", 1920, 1080, 3840, 2160), 32, up2=False)["up2"] is False

@@ -12,8 +12,14 @@ PB.pb_lzm_rows_two.argtypes = [C.c_uint32, C.c_uint32]
 
 
 def is_up2(planes, nt):
-    """the launcher's rule: narrow strips (every plane's span <= 128 B) and every plane's tiles within two source tiles"""
-    return all(0 < PB.pb_lzm_span(ch, sw, dw, nt) <= 128 and sh < dh and PB.pb_lzm_rows_two(sh, dh) for ch, sw, sh, dw, dh in planes)
+    """the planner's rule: every plane's tiles within two source tiles and the strips narrow (the launch's span <= 128 B: 1), or — 8-tile
+    strips only — up to 256 B (2: LzMfma8uw, two workgroups per CU); else 0"""
+    if not all(sh < dh and PB.pb_lzm_rows_two(sh, dh) for ch, sw, sh, dw, dh in planes):
+        return 0
+    spans = [PB.pb_lzm_span(ch, sw, dw, nt) for ch, sw, sh, dw, dh in planes]
+    if not all(spans):
+        return 0
+    return 1 if max(spans) <= 128 else 2 if nt == 8 and max(spans) <= 256 else 0
 
 
 def planes_of(fmt, sw, sh, dw, dh):
@@ -38,7 +44,11 @@ def pick(planes, n, P):
     best = None
     for nt in (8, 4):
         up2 = is_up2(planes, nt)
-        slots = (P["slots8"] if nt == 8 else P["slots4"]) if up2 else (512 if nt == 8 else 768)
+        if up2 == 2:  # the wide 8-tile strips pay on LARGE launches only: gate on the launch's volume (strip groups x tiles x frames / resident workgroups)
+            vol = sum(((p[3] * p[0] + 127) // 128 + 3) // 4 * ((p[4] + 15) // 16) for p in planes) * n / 512.0
+            if vol < P.get("gate", 0):
+                up2 = 0
+        slots = (512 if up2 == 2 else P["slots8"] if nt == 8 else P["slots4"]) if up2 else (512 if nt == 8 else 768)
         tmax = max((p[4] + 15) // 16 for p in planes)
         for r in range(min(2, tmax), min(tmax, 64) + 1):
             wgs, work = 0, 0.0
@@ -48,7 +58,7 @@ def pick(planes, n, P):
                 wgs += gxp * ((tiles + r - 1) // r) * n
                 scy = sh / dh
                 if up2:
-                    w = P["w8"] if nt == 8 else P["w4"][ch]
+                    w = P["w8w"][ch] if up2 == 2 else P["w8"] if nt == 8 else P["w4"][ch]
                 else:
                     w = 1.0 if nt == 8 else ({1: 0.45, 2: 0.9, 3: 0.8} if n <= 32 else {1: 0.8, 2: 0.9, 3: 1.0})[ch]
                 vert = (0.5 + 0.5 * scy / 1.5) if nt == 8 else (0.3 + 0.7 * scy / 1.5)
@@ -79,8 +89,9 @@ def regret(P, ns, verbose=False):
 if __name__ == "__main__":
     small = (32, 8, 1)
     best = None
-    for s8, s4, S, w8, a, b, c in itertools.product((768,), (768, 1024), (2.0,), (0.7, 0.8, 0.9, 1.0), (0.35, 0.45, 0.55, 0.65), (0.5, 0.7, 0.9), (0.5, 0.6, 0.7, 0.8, 0.9)):
-        P = dict(slots8=s8, slots4=s4, S=S, S2=4.0, tail=1.5, w8=w8, w4={1: a, 2: b, 3: c})
+    for s8, s4, S, w8, w8w, a, b, c in itertools.product((768,), (1024,), (2.0,), (0.8, 0.9), (0.45, 0.5, 0.55, 0.6), (0.65, 0.75), (0.5, 0.7), (0.7, 0.8)):
+      for w1, w2, gate in itertools.product((0.7, 0.9), (0.6, 0.8), (0, 60, 100, 150)):
+        P = dict(slots8=s8, slots4=s4, S=S, S2=4.0, tail=1.5, w8=w8, w8w={1: w1, 2: w2, 3: w8w}, w4={1: a, 2: b, 3: c}, gate=gate)
         m, w = regret(P, small)
         if best is None or m < best[0]:
             best = (m, w, P)
@@ -88,8 +99,9 @@ if __name__ == "__main__":
     regret(best[2], small, True)
     P0 = best[2]
     best2 = None
-    for S2, tail, w8, a, b, c in itertools.product((4.0,), (1.5,), (0.7, 0.8, 0.9, 1.0), (0.5, 0.6, 0.8, 1.0), (0.5, 0.7, 0.9, 1.1), (0.6, 0.8, 1.0)):
-        P = dict(P0, S2=S2, tail=tail, w8=w8, w4={1: a, 2: b, 3: c})
+    for S2, tail, w8, w8w, a, b, c in itertools.product((4.0,), (1.5,), (0.7, 0.8), (0.5, 0.6, 0.7, 0.8), (0.5, 0.6, 0.8), (0.5, 0.7, 0.9), (0.6, 0.8, 1.0)):
+      for w1, w2 in itertools.product((0.7, 0.9, 1.1), (0.6, 0.8, 1.0)):
+        P = dict(P0, S2=S2, tail=tail, w8=w8, w8w={1: w1, 2: w2, 3: w8w}, w4={1: a, 2: b, 3: c})
         m, w = regret(P, (64, 128))
         if best2 is None or m < best2[0]:
             best2 = (m, w, P)

@@ -103,8 +103,8 @@ struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
   // the register diet (one tile in flight, one A-operand address, two A operands ahead): with the ring of two it is worth a workgroup per CU (the
   // 8-tile form: 166 VGPRs, three; the 4-tile form: 116, four).  Tried on the ring-of-four 4-tile strips too: 147 -> 145, still three — not taken
-  static constexpr bool kLean = UP2;
-  static constexpr int kGroupsPerCu = (NT == 4 && KC == 1) || UP2 ? 3 : 2;  // register budget: 168 / 256 VGPRs (the 4-tile ring of two fits four: its LDS decides)
+  static constexpr bool kLean = UP2 && PF == 2;  // (the wide ring-of-two strips — 8 tiles at 1.5 x, rows of up to 256 B — keep the full prefetch at two workgroups per CU)
+  static constexpr int kGroupsPerCu = (NT == 4 && KC == 1) || (UP2 && PF == 2) ? 3 : 2;  // register budget: 168 / 256 VGPRs (the 4-tile ring of two fits four: its LDS decides)
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
                           const u32x4* __restrict__ ctab, const u32x4* __restrict__ rtab);  // the shape's column / row weight tables (nullptr: evaluate in place)
 };
@@ -937,6 +937,7 @@ template <int CH> struct LzMfma4 : LanczosMfmaTask<CH, 4, 4> {};
 template <int CH> struct LzMfma4n : LanczosMfmaTask<CH, 4, 2> {};
 template <int CH> struct LzMfma8u : LanczosMfmaTask<CH, 8, 2, 1, true> {};  // the ring of two (up-scales): one K chunk in pass 2
 template <int CH> struct LzMfma4u : LanczosMfmaTask<CH, 4, 2, 1, true> {};
+template <int CH> struct LzMfma8uw : LanczosMfmaTask<CH, 8, 4, 1, true> {};  // ... on 8-tile strips of 1.5 x up-scales (rows of up to 256 B)
 template <int CH> struct LzMfma4k4 : LanczosMfmaTask<CH, 4, 4, 2> {};  // two-chunk windows (strong horizontal down-scales): staged rows of up to 256 B
 template <int CH> struct LzMfma4k6 : LanczosMfmaTask<CH, 4, 6, 2> {};  // ... 384 B
 template <int CH> struct LzMfma4k8 : LanczosMfmaTask<CH, 4, 8, 2> {};  // ... 512 B
@@ -1180,6 +1181,7 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   else if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);
   else if (pair && nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzPairW);
   else if (pair && nt == 8) VPF_LZM_GO(LzPair);
+  else if (nt == 8 && up2 && !narrow) VPF_LZM_GO(LzMfma8uw);
   else if (nt == 8 && up2) VPF_LZM_GO(LzMfma8u);
   else if (up2) VPF_LZM_GO(LzMfma4u);
   else if (nt == 8 && narrow) VPF_LZM_GO(LzMfma8n);

@@ -126,13 +126,24 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
     LzmPlan q{false, cand, 0, 0, 0, 0, 0, kc, rts, false};
     if (!fits(cand, kc, q)) continue;
     // The ring of two (round 5): a candidate whose strips are narrow on an up-scale runs a different kernel — fewer instructions per tile
-    // (w 0.8 of an 8-tile strip's; 4-tile strips 0.65 / 0.5 / 0.7 by channel count, beyond 32 frames 0.7 and 0.5 / 0.7 / 0.8) and more
+    // (w 0.9 of an 8-tile strip's; 4-tile strips 0.75 / 0.5 / 0.7 by channel count, beyond 32 frames 0.7 and 0.5 / 0.7 / 0.8) and more
     // resident workgroups (768, and 1024 for 4-tile strips whose tables exist: the LDS they are evaluated in is not reserved then).
-    // Fitted to profiles/r05_lanczos_shape_sweep_up_n*.txt (tools/lab/fit_lzm_up2.py: mean regret 2.3 % up to 32 frames, 2.5 % beyond;
-    // worst 12 % / 9 %).  1.5 x up-scales get 4-tile strips this way (an 8-tile strip is wider than 128 B there: ring of four), 2 x ones 8-tile strips
-    q.up2 = allow_up2 && kc == 1 && rts == 4 && q.span <= 128u;
+    // At 1.5 x an 8-tile strip stages up to 256 B per row: the WIDE form (LzMfma8uw: two workgroups per CU, 512 slots, w 0.7 / 0.6 / 0.45 by
+    // channel count, 0.7 / 0.6 / 0.5 beyond 32 frames) pays on large launches of packed RGB (1440p -> 4K x 32: 9.0 us against 10.6 with
+    // 4-tile strips) and loses on small ones (720p -> 1080p: 2.46 against 2.33): it is a candidate only when the launch's volume — strip
+    // groups x tiles x frames over the 512 slots — is at least 150 (1080p -> 1620p x 32, volume 108, still prefers 4-tile strips: 5.07
+    // against 5.74 us; profiles/r05_lanczos_wide_ring_of_two_ab_n32.txt).  Fitted to profiles/r05_lanczos_shape_sweep_up_n*.txt
+    // (tools/lab/fit_lzm_up2.py: 92 cases, mean regret 2.4 % up to 32 frames, 2.8 % beyond; worst 13 % / 10 %)
+    q.up2 = allow_up2 && kc == 1 && rts == 4 && (q.span <= 128u || (cand == 8 && q.span <= 256u));
     for (int p = 0; p < njobs && q.up2; p++) q.up2 = lzm_shape(jobs[p].ch, jobs[p].sw, jobs[p].sh, jobs[p].dw, jobs[p].dh).rows_two;
-    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = q.up2 ? (cand == 8 || !tables ? 768.0 : 1024.0) : cand == 8 || kc >= 2 ? 512.0 : 768.0;
+    const bool wide = q.up2 && q.span > 128u;
+    if (wide) {
+      double vol = 0.0;
+      for (int p = 0; p < njobs; p++) vol += (double)(((jobs[p].dw * jobs[p].ch + 127u) / 128u + 3u) / 4u) * (double)((jobs[p].dh + 15u) / 16u);
+      if (vol * n / 512.0 < 150.0) q.up2 = false;  // (the candidate stays, as the ring-of-four 8-tile strip it was)
+    }
+    const double S = 2.0 * (tables ? 1.0 : 3.0), slots = q.up2 ? (q.span > 128u ? 512.0 : cand == 8 || !tables ? 768.0 : 1024.0) : cand == 8 || kc >= 2 ? 512.0 : 768.0;
+    const bool widen = q.up2 && q.span > 128u;
     uint32_t tmax = 0;
     for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + rt - 1) / rt);
     const bool free_r = !(forced > 1 && (forced & 0xff));
@@ -144,7 +155,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         const uint32_t tiles = (jobs[p].dh + rt - 1) / rt, gxp = ((jobs[p].dw * jobs[p].ch + 16u * cand - 1) / (16u * cand) + 3) / 4;
         wgs += (uint64_t)gxp * ((tiles + r - 1) / r) * n;
         const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-        const double w = q.up2 ? (cand == 8 ? 0.8 : jobs[p].ch == 3 ? 0.7 : jobs[p].ch == 2 ? 0.5 : 0.65)
+        const double w = widen ? (jobs[p].ch == 3 ? 0.45 : jobs[p].ch == 2 ? 0.6 : 0.7) : q.up2 ? (cand == 8 ? 0.9 : jobs[p].ch == 3 ? 0.7 : jobs[p].ch == 2 ? 0.5 : 0.75)
                                  : cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.9 : 0.45;
         const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
         work = std::max(work, (double)std::min(r, tiles) * w * vert);
@@ -162,7 +173,7 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
         for (int p = 0; p < njobs; p++) {
           const uint32_t tiles = (jobs[p].dh + rt - 1) / rt;
           const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
-          const double w = q.up2 ? (cand == 8 ? 0.7 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.7 : 0.5)
+          const double w = widen ? (jobs[p].ch == 3 ? 0.5 : jobs[p].ch == 2 ? 0.6 : 0.7) : q.up2 ? (cand == 8 ? 0.7 : jobs[p].ch == 3 ? 0.8 : jobs[p].ch == 2 ? 0.7 : 0.5)
                                    : cand == 8 || kc >= 2 ? 1.0 : jobs[p].ch == 3 ? 1.0 : jobs[p].ch == 2 ? 0.9 : 0.8;
           const double vert = cand == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
           work2 = std::max(work2, (double)std::min(r, tiles) * w * vert);
