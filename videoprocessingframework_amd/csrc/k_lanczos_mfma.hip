@@ -102,7 +102,7 @@ template <int CH, int NT, int PF, int KC = 1, bool UP2 = false>
 struct LanczosMfmaTask {
   static constexpr int kThreads = 256;
   // the register diet (one tile in flight, one A-operand address, two A operands ahead): with the ring of two it is worth a workgroup per CU (the
-  // 8-tile form: 166 VGPRs, three; the 4-tile form: 116, four).  Tried on the ring-of-four 4-tile strips too: 147 -> 145, still three — not taken
+  // 8-tile form: 166 VGPRs, three; the 4-tile form: 116, four).  Tried on the ring-of-four 4-tile strips too: 164 -> 145, still three — not taken
   static constexpr bool kLean = UP2 && PF == 2;  // (the wide ring-of-two strips — 8 tiles at 1.5 x, rows of up to 256 B — keep the full prefetch at two workgroups per CU)
   static constexpr int kGroupsPerCu = (NT == 4 && KC == 1) || (UP2 && PF == 2) ? 3 : 2;  // register budget: 168 / 256 VGPRs (the 4-tile ring of two fits four: its LDS decides)
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by,
