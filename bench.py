@@ -217,6 +217,44 @@ def preheat(wl, ms: float):
     return (time.perf_counter() - t0) * 1e3
 
 
+def sustained(fn, preheat_ms: float = 300.0, block_ms: float = 60.0, blocks: int = 5, pci=None):
+    """THE timing protocol of every secondary table (round 6; VERDICT r5 item 2: two tools disagreed by 17 % on one kernel because one timed 0.65 ms
+    after a single warm call and the other a few steps after ten idle seconds).  `fn` = one host call sequence (one step).  >= `preheat_ms` of the
+    SAME calls untimed, then `blocks` blocks of >= `block_ms` each (HIP events on the current stream around the block, back to back: >= 300 ms
+    timed in total), the MEDIAN block reported; the shader clock (sysfs pp_dpm_sclk, the starred level) read while the first and while the last
+    timed block is still running on the GPU.  -> dict(us = microseconds per fn(), blocks_us, reps, sclk_mhz = (first, last), preheat_ms, timed_ms)."""
+    fn(); torch.cuda.synchronize()
+    t0, calls = time.perf_counter(), 0
+    while True:
+        for _ in range(4):
+            fn()
+        calls += 4
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) * 1e3
+        if el >= preheat_ms:
+            break
+    per_call_ms = el / calls
+    reps = max(3, int(np.ceil(block_ms / max(per_call_ms, 1e-6))))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+    sclk = [None, None]
+    ev[0].record()
+    for b in range(blocks):
+        for _ in range(reps):
+            fn()
+        ev[b + 1].record()
+        if b == 0 or b == blocks - 1:  # the host runs ahead of the queue: the GPU is inside this block's work now
+            sclk[0 if b == 0 else 1] = sharding.current_sclk_mhz(pci)
+    torch.cuda.synchronize()
+    per = sorted(ev[b].elapsed_time(ev[b + 1]) * 1e3 / reps for b in range(blocks))
+    return {"us": per[len(per) // 2], "blocks_us": [round(x, 3) for x in per], "reps": reps, "sclk_mhz": tuple(sclk), "preheat_ms": round(el, 1),
+            "timed_ms": round(sum(per) * reps / 1e3, 1)}
+
+
+def device_pci(index: int = 0):
+    """PCI address of a device for `sustained(pci=...)` (None where it cannot be told: the clock columns then read None)"""
+    return sharding.rank_identity(index).get("pci")
+
+
 def timed(wl, steps: int, warmup: int, dist_on: bool):
     """one warm-up + one timed block (the sweeps' form) -> (own host seconds, device seconds)"""
     for _ in range(warmup):
@@ -315,6 +353,7 @@ def other_configs(dev, main_wl):
     """Short (a few steps each, median of three blocks) measurements of BASELINE.json's other configs and of the per-Execute() dispatch mode, so
     the one JSON line also carries them.  Same ring discipline (device-resident, > Infinity Cache); informational only."""
     res = {}
+    pci = device_pci(dev.index or 0)
     del main_wl.keep[:]
     torch.cuda.empty_cache()
     for key, name, ring, mode, steps in (
@@ -325,11 +364,12 @@ def other_configs(dev, main_wl):
             ("1080p_rgb_to_720p_bilinear_batched", "rgb_resize_1080p_720p_bilinear", 64, "batch", 10),   # vpf_resize_batch, north_star's filter
             ("1080p_rgb_to_720p_lanczos3_batched", "rgb_resize_1080p_720p_lanczos", 64, "batch", 10)):   # vpf_resize_batch, the reference resizer's filter
         wl = Workload(name, dev, ring, 0, mode)
-        ev = sorted(timed(wl, steps, 2, False)[1] for _ in range(3))[1]  # median of three short blocks (one block moves by several percent with the clocks)
-        res[key] = {"Gpix_s_src": round(wl.px_per_step * steps / ev / 1e9, 1),
-                    "algorithmic_GB_s": round(wl.bytes_per_step * steps / ev / 1e9, 0),
-                    "frac_of_8TB_s": round(wl.bytes_per_step * steps / ev / 1e9 / HBM_PEAK_GBS, 3),
-                    "us_per_frame": round(ev / steps / ring * 1e6, 2)}
+        m = sustained(wl.step, pci=pci)  # the one protocol of every secondary number: 300 ms pre-heat of this very step, median of five >= 60 ms blocks, clocks beside it
+        ev = m["us"] * 1e-6  # seconds per step
+        res[key] = {"Gpix_s_src": round(wl.px_per_step / ev / 1e9, 1),
+                    "algorithmic_GB_s": round(wl.bytes_per_step / ev / 1e9, 0),
+                    "frac_of_8TB_s": round(wl.bytes_per_step / ev / 1e9 / HBM_PEAK_GBS, 3),
+                    "us_per_frame": round(m["us"] / ring, 3), "sclk_mhz": m["sclk_mhz"], "timed_ms": m["timed_ms"], "reps_per_block": m["reps"]}
         del wl
         torch.cuda.empty_cache()
     return res

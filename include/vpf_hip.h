@@ -137,7 +137,7 @@ typedef struct vpf_frame_io {
 } vpf_frame_io;
 
 /* The same conversion over `n` independent frames of identical size/format, dispatched as few
- * launches as possible (one per 128 frames; 32 until round 5).  `frames` is a HOST array, consumed before return.
+ * launches as possible (one per 32 frames).  `frames` is a HOST array, consumed before return.
  * Exists because a 4K frame is ~5 us of HBM time, the same order as a kernel boundary. */
 VPF_API vpf_status vpf_convert_batch(const vpf_exec* exec, int src_fmt, int dst_fmt,
                                      int color_space, int color_range, vpf_size size, uint32_t n,
@@ -154,9 +154,10 @@ VPF_API int vpf_convert_supported(int src_fmt, int dst_fmt, int color_space, int
 VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_size src_size,
                               const vpf_plane src[3], vpf_size dst_size, const vpf_plane dst[3]);
 
-/* The same resize over `n` independent same-shape frames, every plane of every frame in as few dispatches as possible (one per 32
- * frames when all planes take the same kernel family — always the case for NV12 / YUV420 / planar surfaces allocated by this
- * library).  A 720p plane is 2-3 us of GPU work, the same order as a kernel boundary: per-frame, per-plane dispatch leaves the chip
+/* The same resize over `n` independent same-shape frames, every plane of every frame in as few dispatches as possible (one per 128
+ * frames when a frame moves at most 7 000 000 bytes, source + destination — Y / NV12 / YUV420 at 1080p -> 720p and smaller —, else one
+ * per 32 frames; when all planes take the same kernel family — always the case for NV12 / YUV420 / planar surfaces allocated by this
+ * library — one dispatch carries every plane).  A 720p plane is 2-3 us of GPU work, the same order as a kernel boundary: per-frame, per-plane dispatch leaves the chip
  * idle most of the time.  `frames` is a HOST array consumed before return.  vpf_resize is this call with n = 1. */
 VPF_API vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size src_size, vpf_size dst_size, uint32_t n,
                                     const vpf_frame_io* frames);
@@ -196,7 +197,7 @@ VPF_API vpf_status vpf_remap(const vpf_exec* exec, int fmt, vpf_size src_size, c
                              const float* xmap, uint32_t xmap_pitch, const float* ymap,
                              uint32_t ymap_pitch, vpf_size dst_size, const vpf_plane* dst);
 
-/* One pair of maps applied to `n` independent same-shape frames in one dispatch per 128 frames (a camera-undistortion map is the
+/* One pair of maps applied to `n` independent same-shape frames in one dispatch per 32 frames (a camera-undistortion map is the
  * same for every frame of a stream; frames after the first find the maps in the Infinity Cache).  frames[i].src[0] / dst[0] only. */
 VPF_API vpf_status vpf_remap_batch(const vpf_exec* exec, int fmt, vpf_size src_size, const float* xmap, uint32_t xmap_pitch, const float* ymap,
                                    uint32_t ymap_pitch, vpf_size dst_size, uint32_t n, const vpf_frame_io* frames);
@@ -209,8 +210,9 @@ VPF_API vpf_status vpf_convert_resize(const vpf_exec* exec, int src_fmt, int dst
                                       const vpf_plane src[3], vpf_size dst_size,
                                       const vpf_plane dst[3]);
 
-/* The same over `n` independent same-shape frames in as few dispatches as possible (one per 128 frames; 32 until round 5): a 720p
- * output is ~2 us of HBM time, far below a kernel boundary, so per-frame dispatch leaves the GPU mostly idle. */
+/* The same over `n` independent same-shape frames in as few dispatches as possible (one per 128 frames when a frame moves at most
+ * 7 000 000 bytes, source + destination — up to 1080p -> 720p —, else one per 32 frames): a 720p output is ~2 us of HBM time, far below
+ * a kernel boundary, so per-frame dispatch leaves the GPU mostly idle. */
 VPF_API vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int src_fmt, int dst_fmt, int color_space,
                                             int color_range, vpf_size src_size, vpf_size dst_size, uint32_t n,
                                             const vpf_frame_io* frames);
@@ -253,7 +255,9 @@ VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4, 8 or 16; 4 | nb << 8 (nb = 1..8): the march form
                                   (nb 4-row bands per wave, 8 pixels per lane on 1-channel planes) where it applies; | 0x10000: the persistent launch of the band kernels
                                   (resident workgroups pulling wave items from per-XCD work counters: measured 10 x slower than the grid on this chip, a
-                                  measurement knob; never taken by policy, never under stream capture); same pixels whatever the value */
+                                  measurement knob; never taken by policy, never under stream capture); | 0x20000: 8 pixels per lane on every 1-channel
+                                  plane of a band launch however well 512-column chunks fill its rows (policy: only at >= 80 % fill); same pixels
+                                  whatever the value */
 
 #ifdef __cplusplus
 }

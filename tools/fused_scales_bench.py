@@ -1,7 +1,8 @@
 """Fused NV12 -> bilinear -> RGB (vpf_convert_resize_batch) at several scale factors, NEXT TO the pair it fuses measured in the same run
 (vpf_convert_batch NV12 -> RGB into an intermediate ring, then vpf_resize_batch bilinear): the fused entry must never lose to the pair
-(VERDICT r4, item 3).  32 frames per dispatch (FUSED_N to change), rings of frames past the 256 MiB Infinity Cache, median of three passes —
-the method of tools/resize_batch_bench.py.
+(VERDICT r4, item 3).  32 frames per dispatch (FUSED_N to change), rings of frames past the 256 MiB Infinity Cache, timed by bench.sustained
+(round 6: 300 ms pre-heat of the same calls, median of five >= 60 ms blocks, shader clock beside every number) — the method of
+tools/resize_batch_bench.py.
 
 Fractions are ALGORITHMIC bytes per time against 8 TB/s, counted like bench.py counts them: the source rows the taps really touch (a 3x
 down-scale reads one luma row in three: counting the whole source gave "1.30 of 8 TB/s" until round 4 — a fraction above 1 means the byte
@@ -15,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from videoprocessingframework_amd import capi
-from resize_batch_bench import timed
+from resize_batch_bench import timed, clk, PROTOCOL
 
 dev = torch.device("cuda", 0)
 ex = capi.make_exec(torch.cuda.current_stream().cuda_stream)
@@ -52,7 +53,7 @@ def main():
             us = timed(lambda: [capi.convert_resize_batch(ex, capi.NV12, capi.RGB, capi.BT_709, capi.MPEG, sw, sh, dw, dh, b) for b in batches], 5) / ring
             capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0)
             best = us if best is None or (v == 0) else best
-            line += f"  fused[v{v}] {us:6.2f} us/frame = {nbytes / us / 8e6:.2f} of 8 TB/s |"
+            line += f"  fused[v{v}] {us:6.2f} us/frame = {nbytes / us / 8e6:.2f} of 8 TB/s [{clk()}] |"
         if PAIR:
             mid = [torch.empty((sh, mp), dtype=torch.uint8, device=dev) for _ in range(ring)]  # the 3 B/px intermediate the fused entry exists to avoid
             io1 = [([(s.data_ptr(), sp), (s.data_ptr() + sh * sp, sp)], [(m.data_ptr(), mp)]) for s, m in zip(src, mid)]
@@ -65,10 +66,11 @@ def main():
                     capi.convert_batch(ex, capi.NV12, capi.RGB, capi.BT_709, capi.MPEG, sw, sh, x)
                     capi.resize_batch(ex, capi.RGB, capi.INTERP_LINEAR, sw, sh, dw, dh, y)
             up = timed(pair, 5) / ring
+            cpair = clk()
             uc = timed(lambda: [capi.convert_batch(ex, capi.NV12, capi.RGB, capi.BT_709, capi.MPEG, sw, sh, x) for x in b1], 5) / ring
-            line += f"  convert then resize {up:6.2f} us/frame (convert alone {uc:.2f}) = {nbytes / up / 8e6:.2f} | fused / pair = {best / up:.2f}" + ("  LOSES" if best > up else "")
+            line += f"  convert then resize {up:6.2f} us/frame (convert alone {uc:.2f}) = {nbytes / up / 8e6:.2f} [{cpair}] | fused / pair = {best / up:.2f}" + ("  LOSES" if best > up else "")
             del mid, b1, b2
-        print(line + f"  ({N} frames per dispatch, ring {ring})", flush=True)
+        print(line + f"  ({N} frames per dispatch, ring {ring}, {PROTOCOL} protocol)", flush=True)
         del src, dst, batches
         torch.cuda.empty_cache()
 

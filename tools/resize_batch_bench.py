@@ -1,6 +1,8 @@
 """vpf_resize_batch / vpf_remap_batch vs one dispatch per frame (and per plane): us per frame and fraction of the 8 TB/s HBM roofline on
 ALGORITHMIC bytes (whole source frame read once + destination written once; a down-scale that skips source rows reads less).
-Rings are sized past the 256 MiB Infinity Cache.  Every number is the median of VPF_BENCH_PASSES (3) timed passes.  python tools/resize_batch_bench.py"""
+Rings are sized past the 256 MiB Infinity Cache.  Every number follows bench.sustained (round 6: 300 ms pre-heat of the same call, median of five >= 60 ms
+blocks, the shader clock printed beside it); VPF_BENCH_PROTOCOL=burst = rounds 2-5's timing (median of VPF_BENCH_PASSES x 5 calls after one warm
+call), kept to reconcile old tables.  python tools/resize_batch_bench.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,10 +40,15 @@ def surf(fmt, w, h, rand):
     raise ValueError(fmt)
 
 
-PASSES = int(os.environ.get("VPF_BENCH_PASSES", "3"))  # timed passes per number; the MEDIAN is reported (one pass moves by several percent with the clocks)
+PASSES = int(os.environ.get("VPF_BENCH_PASSES", "3"))  # burst protocol only: timed passes per number, the MEDIAN is reported
+PROTOCOL = os.environ.get("VPF_BENCH_PROTOCOL", "sustained")  # "sustained" (round 6, every committed table): bench.sustained — 300 ms pre-heat of the SAME call, median of five
+                                                              # >= 60 ms blocks, shader clock read beside it; "burst": rounds 2-5's few-call timing, kept for the reconciliation only
+import bench  # noqa: E402  (repo root: the one protocol lives next to the headline benchmark)
+PCI = bench.device_pci(0)
+LAST = {}  # the last measurement's clocks, for the line being printed
 
 
-def timed(fn, reps, passes=None):
+def timed_burst(fn, reps, passes=None):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = []
@@ -52,6 +59,21 @@ def timed(fn, reps, passes=None):
         e1.record(); torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) * 1e3 / reps)
     return sorted(out)[len(out) // 2]
+
+
+def timed(fn, reps, passes=None):
+    """microseconds per fn() under the protocol in force (`reps` / `passes` only matter to the burst form)"""
+    if PROTOCOL == "burst":
+        LAST["sclk"] = (bench.sharding.current_sclk_mhz(PCI),) * 2
+        return timed_burst(fn, reps, passes)
+    m = bench.sustained(fn, pci=PCI)
+    LAST["sclk"] = m["sclk_mhz"]
+    return m["us"]
+
+
+def clk():
+    a, b = LAST.get("sclk", (None, None))
+    return f"sclk {a}/{b} MHz"
 
 
 def main():
@@ -74,6 +96,7 @@ def main():
                     tb = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in batches], 5) / ring
                 else:
                     tb = timed(lambda: capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, batch), 5) / ring
+                ctb = clk()
                 ts = timed(lambda: [capi.resize(ex, fmt, interp, sw, sh, s, dw, dh, d) for s, d in planes], 3) / ring
                 extra = ""
                 if os.environ.get("VPF_BENCH_ONE"):  # batches of ONE frame: the multi-plane / band kernels at single-frame launch sizes
@@ -81,7 +104,7 @@ def main():
                     t1 = timed(lambda: [capi.resize_batch(ex, fmt, interp, sw, sh, dw, dh, b) for b in ones], 3) / ring
                     extra = f" | batches of one {t1:6.2f} us/frame ({nbytes / t1 / 8e6:.2f})"
                 print(f"[resize_batch] {fname:6s} {sw}x{sh}->{dw}x{dh} {NAMES[interp]:8s}: batched {tb:6.2f} us/frame = {nbytes / tb / 1e6:5.2f} TB/s ({nbytes / tb / 8e6:.2f} of 8 TB/s)"
-                      f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f}){extra}  ring {ring}", flush=True)
+                      f" | one dispatch per frame {ts:6.2f} us/frame ({nbytes / ts / 8e6:.2f}){extra}  ring {ring}  [{PROTOCOL}: batched {ctb}, per frame {clk()}]", flush=True)
             del S, D, batch, planes
             torch.cuda.empty_cache()
 
@@ -96,10 +119,11 @@ def main():
         D = [surf(capi.RGB, w, h, False) for _ in range(ring)]
         batch = capi.make_batch([(s[1], d[1]) for s, d in zip(S, D)])
         tb = timed(lambda: capi.remap_batch(ex, capi.RGB, w, h, xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, batch), 5) / ring
+        ctb = clk()
         ts = timed(lambda: [capi.remap(ex, capi.RGB, w, h, s[1][0], xm.data_ptr(), 4 * w, ym.data_ptr(), 4 * w, w, h, d[1][0]) for s, d in zip(S, D)], 3) / ring
         nb = 14 * w * h  # 8 B of maps + 3 B of source + 3 B written per pixel
         print(f"[remap_batch] RGB {w}x{h} barrel map: batched {tb:6.2f} us/frame = {nb / tb / 1e6:5.2f} TB/s ({nb / tb / 8e6:.2f} of 8 TB/s on 14 B/px)"
-              f" | one dispatch per frame {ts:6.2f} us/frame ({nb / ts / 8e6:.2f})", flush=True)
+              f" | one dispatch per frame {ts:6.2f} us/frame ({nb / ts / 8e6:.2f})  [{PROTOCOL}: batched {ctb}, per frame {clk()}]", flush=True)
         del S, D, batch
         torch.cuda.empty_cache()
 

@@ -1051,7 +1051,7 @@ static bool launch_resize_tile(hipStream_t st, int ch, uint32_t sw, uint32_t sh,
 // all of them.  Same bytes either way (both kernels are the integer definition of the filter).  VPF_TUNE_RESIZE_MFMA | 0x40000, or a forced
 // launch shape: always the matrix-core kernel.
 static bool lanczos_single_prefers_tile(int ch, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
-  if (tuning(VPF_TUNE_RESIZE_MFMA) & 0x7ffff) return false;
+  if (tuning(VPF_TUNE_RESIZE_MFMA) & 0xfffff) return false;
   const uint64_t src_b = (uint64_t)sw * sh * (uint32_t)ch, dst_b = (uint64_t)dw * dh * (uint32_t)ch;
   return src_b + 6u * dst_b <= (ch == 1 ? 28000000ull : ch == 2 ? 40000000ull : 51000000ull);
 }
@@ -1556,7 +1556,7 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
     // rule), the tile kernel — whose time follows the destination — leaves such a frame after 6-7 (profiles/r04_lanczos_single_multiplane.txt:
     // YUV420 1080p -> 224 x 224 5.9 against 7.9 us, NV12 1080p -> 416 x 416 6.8 against 9.0; 1080p -> 720p stays on the matrix cores, 7.5
     // against 8.3).  Only where ONE tile launch takes every plane (the chroma plane of NV12 at 8 x falls out of its windows).
-    if (all_mfma && n == 1 && njobs > 1 && !(tuning(VPF_TUNE_RESIZE_MFMA) & 0x7ffff)) {
+    if (all_mfma && n == 1 && njobs > 1 && !(tuning(VPF_TUNE_RESIZE_MFMA) & 0xfffff)) {
       uint64_t dst_b = 0;
       bool tile_ok = true;
       for (int p = 0; p < njobs; p++) { dst_b += (uint64_t)jobs[p].dw * jobs[p].dh * (uint32_t)jobs[p].ch; tile_ok = tile_ok && lz_tile_ok[p]; }

@@ -153,7 +153,12 @@ void hip_stream_sync(void* p) {
 }
 
 // Before device memory that queued kernels may still read is freed: the stream is drained; a stream the caller has destroyed meanwhile
-// (the Python side owns it) cannot be asked — then the whole device is, and the failure is said out loud
+// (the Python side owns it) cannot be asked — then the whole device is, and the failure is said out loud.
+// This leans on the HIP runtime validating stream handles (a destroyed handle returns hipErrorContextIsDestroyed / InvalidHandle /
+// InvalidValue instead of being dereferenced): if the address has meanwhile been RECYCLED for a new stream, the synchronize succeeds on that
+// stream — benign (a wait on somebody else's work, and the allocation's own users were drained when their stream was destroyed:
+// hipStreamDestroy completes queued work first), but then nothing is printed.  LzmHipSync::stream_state and persist_stream_idle rely on the
+// same validation.
 static void drain_before_free(StreamRef* s, const char* what) {
   DeviceScope scope(s->ctx);
   const hipError_t e = hipStreamSynchronize((hipStream_t)s->str);
