@@ -5,6 +5,8 @@ uint32_t pb_strip_bytes(int ch, uint32_t sw, uint32_t dw, uint32_t cap, uint32_t
 uint32_t pb_band_slots(int r, float scy) { return vpf_bound_band_slots(r, scy); }
 uint32_t pb_band_rows_exact(int r, uint32_t sh, uint32_t dh) { return vpf_band_rows_exact(r, sh, dh, (float)sh / (float)dh); }
 uint32_t pb_fused_rowbytes(float scx) { return vpf_bound_fused_rowbytes(scx); }
+uint32_t pb_strip_bytes_px4(uint32_t sw, uint32_t dw, uint32_t cap, uint32_t cols) { return vpf_bound_strip_bytes_px4(sw, dw, cap, cols); }
+uint32_t pb_fused_rowbytes4(float scx) { return vpf_bound_fused_rowbytes4(scx); }
 int pb_fused_rows_fit(int r, float scy, int strip_rows) { return vpf_bound_fused_rows_fit(r, scy, strip_rows); }
 uint32_t pb_tile_rows(uint32_t ty, float scy, int taps) { return vpf_bound_tile_rows(ty, scy, taps); }
 uint32_t pb_tile_rowq(float scx, int taps, int ch, int elem) { return vpf_bound_tile_rowq(scx, taps, ch, elem); }

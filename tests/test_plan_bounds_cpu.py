@@ -23,7 +23,7 @@ def pb(tmp_path_factory):
                            os.path.join(ROOT, "tests", "c", "plan_bounds_capi.c"), "-o", so, "-lm"])
     L = C.CDLL(so)
     for name, args in (("pb_strip_bytes", [C.c_int] + [C.c_uint32] * 4), ("pb_band_slots", [C.c_int, C.c_float]), ("pb_band_rows_exact", [C.c_int, C.c_uint32, C.c_uint32]),
-                       ("pb_fused_rowbytes", [C.c_float]), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
+                       ("pb_fused_rowbytes", [C.c_float]), ("pb_fused_rowbytes4", [C.c_float]), ("pb_strip_bytes_px4", [C.c_uint32] * 4), ("pb_tile_rows", [C.c_uint32, C.c_float, C.c_int]),
                        ("pb_tile_rowq", [C.c_float, C.c_int, C.c_int, C.c_int]), ("pb_lzm_span", [C.c_int, C.c_uint32, C.c_uint32, C.c_int]), ("pb_lzm_span_win", [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]),
                        ("pb_lzm_pitch", [C.c_uint32]), ("pb_lzm_rows_ok", [C.c_uint32, C.c_uint32]), ("pb_lzm_rows_two", [C.c_uint32, C.c_uint32])):
         getattr(L, name).argtypes, getattr(L, name).restype = args, C.c_uint32
@@ -122,6 +122,46 @@ def test_fused_strip_rows_hold_the_converted_window(pb):
         x = np.arange(dw)
         a = 3 * (lin_taps(x, sw, dw)[0] - base_px[x // 256])
         assert int(((a & ~3) + 12).max()) <= rowbytes, (sw, dw)
+
+
+def test_band_px4_strips_hold_the_widened_span(pb):
+    """RowBandTask<3, ..> since round 6: a strip row holds R G B x dwords of source pixels [first & ~3, last + 1] in whole units of four (Span4:
+    12 source bytes -> 16 LDS bytes per lane); a pixel's taps are the dword at 4 (i0 - base_px) and the next one"""
+    rng = np.random.default_rng(15)
+    for sw, dw in size_pairs(rng, 1500, 0.2, 4.0):
+        rb = pb.pb_strip_bytes_px4(sw, dw, 4096, 256)
+        if rb == 0:
+            continue
+        assert rb % 16 == 0
+        xs = np.arange(0, dw, 256)
+        xe = np.minimum(xs + 255, dw - 1)
+        first, last = lin_taps(xs, sw, dw)[0], lin_taps(xe, sw, dw)[1]
+        base_px = first & ~3
+        nu = (last + 2 - base_px + 3) // 4
+        assert int((16 * nu).max()) <= rb, (sw, dw)                                     # what the staging loop writes
+        x = np.arange(dw)
+        a = 4 * (lin_taps(x, sw, dw)[0] - base_px[x // 256])
+        assert int((a + 8).max()) <= 16 * int(nu.max()) and int((a + 8 - 16 * nu[x // 256]).max()) <= 0, (sw, dw)   # both tap dwords lie in staged units
+
+
+def test_fused_px4_strip_rows_hold_the_converted_window(pb):
+    """convert_strip_wg_task since round 6: a strip row holds R G B x dwords of source pixels [first & ~7, ...) in groups of 8 up to the last tap;
+    a pixel's taps are the dword at 4 (i0 - base_px) and the NEXT dword (also where i1 == i0: weight 0, but the dword is read)"""
+    rng = np.random.default_rng(14)
+    for sw, dw in size_pairs(rng, 1500, 0.2, 3.0):
+        if sw % 8:
+            continue
+        rowbytes = pb.pb_fused_rowbytes4(F(F(sw) / F(dw)))
+        assert rowbytes % 16 == 0
+        xs = np.arange(0, dw, 256)
+        xe = np.minimum(xs + 255, dw - 1)
+        first, last = lin_taps(xs, sw, dw)[0], lin_taps(xe, sw, dw)[1]
+        base_px = first & ~7
+        conv_end = base_px + (last - base_px) // 8 * 8 + 8                             # conversion runs in groups of 8 pixels through `last`
+        assert int((4 * (conv_end - base_px)).max()) <= rowbytes, (sw, dw)
+        x = np.arange(dw)
+        a = 4 * (lin_taps(x, sw, dw)[0] - base_px[x // 256])
+        assert int((a + 8).max()) <= rowbytes, (sw, dw)
 
 
 @pytest.mark.parametrize("taps", [2, 6])

@@ -62,6 +62,35 @@ struct Span {
       if (lane + 64 * k < nq) lds[lane + 64 * k] = v[k];
   }
 };
+// The px4 form of Span (CH = 3 strips widened to R G B x, see ColTapsX below): a unit is FOUR pixels = 12 source bytes (three dwords, 4-B aligned:
+// rows are 16-B aligned and a unit starts at 12 x its index) written as 16 LDS bytes.  `lim` = bytes of the row that may be read (the row
+// bytes rounded up to 16: what the 16-B units of Span touch too); dwords beyond it stay unread — they can only belong to the pixel after the
+// picture's right edge, whose dword is read by the tap window with weight exactly 0.
+template <int MAXIT>
+struct Span4 {
+  uint32_t v[MAXIT][3];
+  VPF_DEV void load(const uint8_t* row, uint32_t base, uint32_t nu, uint32_t lane, uint32_t lim) {
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++) {
+      const uint32_t u = lane + 64 * k, off = base + 12 * u;
+      if (u < nu) {
+        if (off + 12 <= lim) {
+          const uint32_t* q = reinterpret_cast<const uint32_t*>(row + off);
+          v[k][0] = q[0]; v[k][1] = q[1]; v[k][2] = q[2];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3; j++) v[k][j] = off + 4 * j + 4 <= lim ? *reinterpret_cast<const uint32_t*>(row + off + 4 * j) : 0u;
+        }
+      }
+    }
+  }
+  VPF_DEV void store(u32x4* lds, uint32_t nu, uint32_t lane) const {
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++)
+      if (lane + 64 * k < nu)
+        lds[lane + 64 * k] = u32x4{v[k][0], __builtin_amdgcn_alignbyte(v[k][1], v[k][0], 3), __builtin_amdgcn_alignbyte(v[k][2], v[k][1], 2), v[k][2] >> 8};
+  }
+};
 VPF_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -264,6 +293,47 @@ VPF_DEV void band_hlerp4(const uint8_t* r, const ColTaps<CH, PX>& T, f32x2* H) {
     }
   }
 }
+// ---- "px4" strips (round 6): packed RGB widened to FOUR bytes per pixel (R G B x) on its way into LDS.  A tap is then one aligned dword and both
+// taps of a pixel one ds_read2_b32: against the packed strip's 12-B window a horizontal lerp of four pixels loses 8 v_alignbyte_b32, 8 v_and_b32
+// and the address adds that feed them (22 of its 58 VALU instructions) and half its LDS reads, for a third more LDS per row.  The fused kernel
+// writes its converted pixels that way (same cvt count: three bytes per pixel either way); the row-band resize widens 12 source bytes to 16 when
+// it stages them (two v_alignbyte_b32 + one shift per four SOURCE pixels, once).  Same bytes into the same fp32 operations: same pixels.
+struct ColTapsX {
+  uint32_t a[4];  // byte offset of tap 0 from the strips' first byte (= 4 x pixels from the strip's first pixel); tap 1 is the next dword whatever i1
+                  // says: where i1 == i0 (the picture's right edge) its weight is exactly 0 and fma(0, finite, p) == p
+  float f[4];
+};
+VPF_DEV ColTapsX make_col_taps_x(uint32_t base_px, uint32_t x0, uint32_t dw, uint32_t sw, float scx) {
+  ColTapsX T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const Tap t = make_tap<VPF_INTERP_LINEAR>((x0 + k < dw) ? x0 + k : dw - 1, scx, sw);
+    T.a[k] = 4u * (t.i0 - base_px); T.f[k] = t.f;
+  }
+  return T;
+}
+VPF_DEV void band_hlerp(const uint8_t* r, const ColTapsX& T, f32x2* H) {
+  uint32_t d0[4], d1[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(r + T.a[k]);
+    d0[k] = q[0]; d1[k] = q[1];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const f32x2 fx2 = {T.f[2 * j], T.f[2 * j + 1]};
+    const uint32_t a0 = d0[2 * j], a1 = d1[2 * j], b0 = d0[2 * j + 1], b1 = d1[2 * j + 1];
+    const f32x2 r0 = {ubyte<0>(a0), ubyte<0>(b0)}, r1 = {ubyte<0>(a1), ubyte<0>(b1)};
+    const f32x2 g0 = {ubyte<1>(a0), ubyte<1>(b0)}, g1 = {ubyte<1>(a1), ubyte<1>(b1)};
+    const f32x2 c0 = {ubyte<2>(a0), ubyte<2>(b0)}, c1 = {ubyte<2>(a1), ubyte<2>(b1)};
+    H[j * 3 + 0] = __builtin_elementwise_fma(fx2, r1 - r0, r0);
+    H[j * 3 + 1] = __builtin_elementwise_fma(fx2, g1 - g0, g0);
+    H[j * 3 + 2] = __builtin_elementwise_fma(fx2, c1 - c0, c0);
+  }
+}
+template <int CH, int PX>
+VPF_DEV void band_hlerp(const uint8_t* r, const ColTaps<CH, PX>& T, f32x2* H) { band_hlerp4<CH, PX>(r, T, H); }
+
 // The row taps (i0, i1, fy) of a band's destination rows ya..yb, row i on lane i: one make_tap for the whole band instead of one per row on
 // every lane (~12 VALU instructions per row).  Call it while ALL lanes of the wave are active (before the columns beyond the picture's
 // right edge leave): band_blend_rows reads lanes 0..R-1 with v_readlane.  The empty asm pins the computation to this place — without it the
@@ -288,8 +358,8 @@ struct BandWalk {
   f32x2 Ha[NP], Hb[NP];
   uint32_t ida = 0xffffffffu, idb = 0xffffffffu;
 };
-template <int CH, int R, int PX = 4, class Put>
-VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const ColTaps<CH, PX>& T, BandWalk<CH, PX>& w,
+template <int CH, int R, int PX = 4, class TAPS, class Put>  // TAPS: ColTaps<CH, PX>, or ColTapsX (px4 strips: CH = 3, PX = 4)
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const TAPS& T, BandWalk<CH, PX>& w,
                              Put&& put) {
   static_assert(R <= 64, "one lane per row of the band");
   constexpr int NP = PX / 2 * CH;
@@ -303,7 +373,7 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
 #pragma unroll
         for (int q = 0; q < NP; q++) w.Ha[q] = w.Hb[q];
       } else {
-        band_hlerp4<CH, PX>(strips + (size_t)(i0 - r_lo) * rowbytes, T, w.Ha);
+        band_hlerp(strips + (size_t)(i0 - r_lo) * rowbytes, T, w.Ha);
       }
       w.ida = i0;
     }
@@ -312,7 +382,7 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
 #pragma unroll
         for (int q = 0; q < NP; q++) w.Hb[q] = w.Ha[q];
       } else {
-        band_hlerp4<CH, PX>(strips + (size_t)(i1 - r_lo) * rowbytes, T, w.Hb);
+        band_hlerp(strips + (size_t)(i1 - r_lo) * rowbytes, T, w.Hb);
       }
       w.idb = i1;
     }
@@ -330,8 +400,8 @@ VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t 
     put(ya + i, o);
   }
 }
-template <int CH, int R, int PX = 4, class Put>
-VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const ColTaps<CH, PX>& T, Put&& put) {
+template <int CH, int R, int PX = 4, class TAPS, class Put>
+VPF_DEV void band_blend_rows(const uint8_t* strips, uint32_t rowbytes, uint32_t r_lo, uint32_t ya, uint32_t yb, const Tap& rows, const TAPS& T, Put&& put) {
   BandWalk<CH, PX> w;
   band_blend_rows<CH, R, PX>(strips, rowbytes, r_lo, ya, yb, rows, T, w, static_cast<Put&&>(put));
 }

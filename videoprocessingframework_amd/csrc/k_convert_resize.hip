@@ -531,7 +531,7 @@ VPF_DEV void convert_unit8(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t cr
   for (int hf = 0; hf < 2; hf++) {
     if (!(hf ? row_b : row_a)) continue;
     const u32x2 yq = hf ? yb : ya;
-    uint32_t d[6];  // 8 px -> 24 bytes R G B R G B ..., vpf_convert's rounding (v_cvt_pk_u8_f32)
+    uint32_t d[8];  // 8 px -> 8 dwords R G B x (px4 strips, k_bilinear_blend.h), vpf_convert's rounding (v_cvt_pk_u8_f32): three cvt per pixel as for packed bytes
 #pragma unroll
     for (int j = 0; j < 2; j++) {  // (the pixel-pair form of convert_strip_task: same IEEE fma per component as convert4 -> same bits)
       const uint32_t yd = yq[j];
@@ -541,12 +541,13 @@ VPF_DEV void convert_unit8(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t cr
                   ba = __builtin_elementwise_fma(ya2, cy2, f32x2{ka.bc, ka.bc});
       const f32x2 rb = __builtin_elementwise_fma(yb2, cy2, f32x2{kb.rc, kb.rc}), gb = __builtin_elementwise_fma(yb2, cy2, f32x2{kb.gc, kb.gc}),
                   bb = __builtin_elementwise_fma(yb2, cy2, f32x2{kb.bc, kb.bc});
-      d[3 * j] = pack4<1>(ra[0], ga[0], ba[0], ra[1]);
-      d[3 * j + 1] = pack4<1>(ga[1], ba[1], rb[0], gb[0]);
-      d[3 * j + 2] = pack4<1>(bb[0], rb[1], gb[1], bb[1]);
+      d[4 * j] = pack3(ra[0], ga[0], ba[0]);
+      d[4 * j + 1] = pack3(ra[1], ga[1], ba[1]);
+      d[4 * j + 2] = pack3(rb[0], gb[0], bb[0]);
+      d[4 * j + 3] = pack3(rb[1], gb[1], bb[1]);
     }
-    u32x2* w = reinterpret_cast<u32x2*>(wa + (hf ? rowbytes : 0u));
-    w[0] = u32x2{d[0], d[1]}; w[1] = u32x2{d[2], d[3]}; w[2] = u32x2{d[4], d[5]};
+    u32x4* w = reinterpret_cast<u32x4*>(wa + (hf ? rowbytes : 0u));
+    w[0] = u32x4{d[0], d[1], d[2], d[3]}; w[1] = u32x4{d[4], d[5], d[6], d[7]};
   }
 }
 template <int SRC, int DST, int R>
@@ -581,7 +582,7 @@ VPF_DEV void convert_strip_wg_task(const FrameDesc& f, const Yuv2RgbCoef& c, uin
     if (q.ra) q.ya = ldg<false, u32x2>(f.s[0] + (size_t)r0 * f.sp[0] + q.px0);
     if (q.rb) q.yb = ldg<false, u32x2>(f.s[0] + (size_t)(r0 + 1) * f.sp[0] + q.px0);
     // strip byte of (row r0, px0); r0 may be R_lo - 1 (that row is not written then: only row r0 + 1 is) — a signed offset
-    q.w = strip + ((int32_t)(r0 - R_lo) * (int32_t)rowbytes + (int32_t)(3 * (q.px0 - base_px)));
+    q.w = strip + ((int32_t)(r0 - R_lo) * (int32_t)rowbytes + (int32_t)(4 * (q.px0 - base_px)));
   };
   for (uint32_t u0 = tid; u0 < units; u0 += 512) {  // two units per lane in flight
     Unit q0, q1;
@@ -599,7 +600,7 @@ VPF_DEV void convert_strip_wg_task(const FrameDesc& f, const Yuv2RgbCoef& c, uin
   const uint32_t x0 = xs + lane * 4;
   if (x0 >= dw) return;
   const uint32_t nv = dw - x0 < 4 ? dw - x0 : 4;
-  const ColTaps<3> T = make_col_taps<3>(3 * base_px, x0, dw, sw, scx);  // once for the R rows
+  const ColTapsX T = make_col_taps_x(base_px, x0, dw, sw, scx);  // once for the R rows (px4 strip: a tap is one aligned dword)
   band_blend_rows<3, R>(strip, rowbytes, R_lo, ya, yb, row_taps, T, [&](uint32_t y, const float* o) {  // o: pixel-major R G B, + 0.5 added
     if constexpr (DST == FC_PLANAR) {
 #pragma unroll
@@ -695,7 +696,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       const double conv_per_px = r ? (double)scx * ((r - 1) * (double)scy + 2.0) / r : 1e9;
       // Round 5: the strip shared by the workgroup (k_convert_strip_wg: the source window of 4 R destination rows converted once, dealt
       // out over all 256 lanes).  Band height: the largest of 16 (up-scales) / 8 / 4 / 2 whose strip leaves four workgroups per CU
-      // (<= 36 KiB) and whose launch still covers the chip.  VPF_TUNE_NV12_RGB_VARIANT = 47 keeps the per-wave strips (A/B runs, tests).
+      // (<= 40 KiB of the CU's 160: round 6's four-byte pixels make 1080p -> 720p at R = 4 a 39.5-KiB strip) and whose launch still covers the chip.  VPF_TUNE_NV12_RGB_VARIANT = 47 keeps the per-wave strips (A/B runs, tests).
       if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 47) {
         static thread_local struct { uint32_t sh, dh, rows[4]; } wseen = {0, 0, {0, 0, 0, 0}};
         if (!(wseen.sh == sh && wseen.dh == dh)) {
@@ -704,10 +705,11 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
         }
         int rw = 0;
         uint32_t wrows = 0;
+        const uint32_t rowbytes4 = vpf_bound_fused_rowbytes4(scx);  // the workgroup's strip holds four bytes per pixel (R G B x)
         for (int k = 3; k >= 0; k--) {
           const int cand = 2 << k;
           if (cand == 16 && scy > 1.0f) continue;
-          if ((uint64_t)wseen.rows[k] * rowbytes > 36u * 1024u) continue;
+          if ((uint64_t)wseen.rows[k] * rowbytes4 > 40u * 1024u) continue;
           if (cand > 2 && (uint64_t)((dw + 255) / 256) * ((dh + 4 * cand - 1) / (4 * cand)) * n < (cand >= 8 ? 2048u : 512u)) continue;  // keep the chip covered
           rw = cand; wrows = wseen.rows[k];
           break;
@@ -715,9 +717,9 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
         // source pixels converted per destination pixel: rows of the strip x its width / (4 R x 256); the per-tap kernel converts four
         const double wconv = rw ? (double)wrows * ((double)scx * 255.0 + 18.0) / (4.0 * rw * 256.0) : 1e9;
         if (rw && wconv <= (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 48 ? 8.0 : 3.0)) {
-          const uint32_t ldsw = wrows * rowbytes;
+          const uint32_t ldsw = wrows * rowbytes4;
           dim3 wgrid((dw + 255) / 256, (dh + 4 * rw - 1) / (4 * rw), n);
-#define VPF_WG1(S, D, RR) VPF_LAUNCH_BA(k_convert_strip_wg, (S, D, RR), wgrid, dim3(256), ldsw, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes / 16)
+#define VPF_WG1(S, D, RR) VPF_LAUNCH_BA(k_convert_strip_wg, (S, D, RR), wgrid, dim3(256), ldsw, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes4 / 16)
 #define VPF_WG(S, D) do { if (rw == 16) VPF_WG1(S, D, 16); else if (rw == 8) VPF_WG1(S, D, 8); else if (rw == 4) VPF_WG1(S, D, 4); else VPF_WG1(S, D, 2); } while (0)
 #define VPF_WGD(S) do { if (dst_fc == FC_RGB) VPF_WG(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_WG(S, FC_BGR); else VPF_WG(S, FC_PLANAR); } while (0)
           if (src_fc == FC_NV12) VPF_WGD(FC_NV12); else VPF_WGD(FC_YUV420);

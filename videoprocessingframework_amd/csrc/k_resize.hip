@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
 #include "k_resize_common.h"
 #include "vpf_persist.h"
 
@@ -291,6 +293,7 @@ struct RowBandTask {
   static constexpr int kThreads = 256;
   static constexpr int kSlots = kBandSlots * 2 / IT < 2 * R + 1 ? kBandSlots * 2 / IT : 2 * R + 1;  // a band touches at most floor((R - 1) scy) + 3 source rows, scy <= 2
   static constexpr int kPx = band_px(CH, P1);
+  static constexpr bool kPx4 = CH == 3 && R == 16 && IT == 1;  // strips hold four bytes per pixel (band_rows sizes them: vpf_bound_strip_bytes_px4)
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by) {
     run_w(src, sp, dst, dp, G, bx, by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
   }
@@ -310,7 +313,13 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_w(const uint8_t* __restrict_
   if (ya >= dh || bx * W >= dw) return;
   const uint32_t xs = bx * W, xe = (xs + W - 1 < dw - 1) ? xs + W - 1 : dw - 1;
   const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
-  const uint32_t base = (CH * first) & ~15u, nq = (CH * (last + 1) - base + 15) / 16;
+  // packed RGB in 16-row bands (up-scales: a source pixel is tapped ~4 times per row it is staged): "px4" strips (k_bilinear_blend.h) — pixels
+  // [first & ~3, last + 1] widened to R G B x in units of four; else the packed bytes in 16-B units.  (Down-scales tap a staged pixel ~1.3
+  // times and pay a third more LDS per row — 1080p -> 720p: four workgroups per CU instead of five, 1.71 -> 2.33 us; profiles/r06_c_*.)
+  constexpr bool X4 = kPx4;
+  const uint32_t base_px = first & ~3u;
+  const uint32_t base = X4 ? 3u * base_px : (CH * first) & ~15u, nq = X4 ? (last + 2 - base_px + 3) / 4 : (CH * (last + 1) - base + 15) / 16;
+  const uint32_t lim = (CH * sw + 15u) & ~15u;  // bytes of a source row that may be read
   u32x4* const strips = dyn_strip + (size_t)wv * slots * rowq;
   // the source rows [i0(first row), i1(last row)] of one band (the launcher guarantees r_hi - r_lo < slots <= kSlots) ...
   uint32_t yb, r_lo, r_hi;
@@ -320,11 +329,14 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_w(const uint8_t* __restrict_
     r_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(yb, scy, sh).i1);
   };
   // ... requested (all loads in flight together) ...
-  Span<IT> rows[kSlots];
+  typename std::conditional<X4, Span4<IT>, Span<IT>>::type rows[kSlots];
   auto request = [&]() {
 #pragma unroll
     for (int k = 0; k < kSlots; k++)
-      if (r_lo + k <= r_hi) rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane);
+      if (r_lo + k <= r_hi) {
+        if constexpr (X4) rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane, lim);
+        else rows[k].load(src + (size_t)(r_lo + k) * sp, base, nq, lane);
+      }
   };
   // ... and written to the wave's strips
   auto commit = [&]() {
@@ -339,7 +351,10 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_w(const uint8_t* __restrict_
   const uint32_t nv = !draws ? 0u : dw - x0 < (uint32_t)PX ? dw - x0 : (uint32_t)PX;
   rows_of(ya);
   request();
-  const ColTaps<CH, PX> T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);  // once for all rows of all bands (evaluated while the first band's rows are in flight)
+  // once for all rows of all bands (evaluated while the first band's rows are in flight)
+  typename std::conditional<X4, ColTapsX, ColTaps<CH, PX>>::type T;
+  if constexpr (X4) T = make_col_taps_x(base_px, x0, dw, sw, scx);
+  else T = make_col_taps<CH, PX>(base, x0, dw, sw, scx);
   VPF_WAVE_MARK(0);  // (lab builds: setup done)
   // With nb > 1 the source rows of band k + 1 are requested right after band k's have been written to the strips — the registers are free
   // again — and arrive while band k is blended: the wave hides its own memory latency, and its fixed part (task decode, column taps) is
@@ -1369,7 +1384,7 @@ static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgsL& a, con
 // source rows (a contiguous band would read rows nobody blends) and odd integer factors on both axes move bytes (RowPairTask's
 // centre-sample shortcut): both keep one row per wave.  VPF_TUNE_RESIZE_BAND forces a value where it applies.
 constexpr uint32_t kBandMinGroups = 2048;
-struct BandShape { int rows; uint32_t slots; bool narrow; };
+struct BandShape { int rows; uint32_t slots; bool narrow; uint32_t rb; };  // rb: strip bytes of the chosen form (16-row bands of packed RGB: four bytes per pixel)
 static uint32_t band_slots(int r, float scy) { return vpf_bound_band_slots(r, scy); }  // (vpf_plan_bounds.h: checked on the CPU against the tap arithmetic)
 // The strips a launch ALLOCATES: the rows its bands really touch (vpf_band_rows_exact: a walk over the bands with make_tap's arithmetic),
 // never more than the closed-form bound that chose the band height.  1080p -> 720p with 4-row bands: 6 strips instead of 8, five
@@ -1419,26 +1434,34 @@ static uint32_t band_strip_bytes(int njobs, const ResizeJob* jobs, uint32_t n, c
 }
 static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32_t n, int p1 = 4) {
   const int forced = tuning(VPF_TUNE_RESIZE_BAND) & 0xff;  // (bits 8..: bands per wave of the march form, plan_band)
-  if (forced == 1 || rb == 0 || rb > 2048) return {1, 0, false};
+  if (forced == 1 || rb == 0 || rb > 2048) return {1, 0, false, rb};
+  const uint32_t rb_packed = rb;
   float scy = 0.f;
   for (int p = 0; p < njobs; p++) {
     const ResizeJob& j = jobs[p];
-    if (j.sw % j.dw == 0 && j.sh % j.dh == 0 && ((j.sw / j.dw) & 1) && ((j.sh / j.dh) & 1)) return {1, 0, false};
+    if (j.sw % j.dw == 0 && j.sh % j.dh == 0 && ((j.sw / j.dw) & 1) && ((j.sh / j.dh) & 1)) return {1, 0, false, rb};
     const float s = (float)j.sh / (float)j.dh;
     scy = s > scy ? s : scy;
   }
-  if (scy > 2.0f) return {1, 0, false};
+  if (scy > 2.0f) return {1, 0, false, rb};
   for (int r = 16; r >= 2; r >>= 1) {
     if (forced && forced != r) continue;
+    rb = rb_packed;
+    if (r == 16)  // RowBandTask<3, 16, 1>::kPx4: its strips hold packed RGB four bytes per pixel
+      for (int p = 0; p < njobs; p++)
+        if (jobs[p].ch == 3) {
+          const uint32_t rb4 = vpf_bound_strip_bytes_px4(jobs[p].sw, jobs[p].dw, 1024u, 256u);
+          rb = !rb4 ? 4096u : rb4 > rb ? rb4 : rb;
+        }
     const bool narrow = r >= 8 && rb <= 1024;  // the IT = 1 instantiations (8 and 16 rows)
     if (r == 16 && !narrow) continue;
     const uint32_t slots = band_slots(r, scy);
     if (slots > (uint32_t)(narrow ? 2 * kBandSlots : kBandSlots) || 4u * slots * rb + 16u > 64u * 1024u) continue;
     uint64_t groups = 0;
     for (int p = 0; p < njobs; p++) groups += (uint64_t)((jobs[p].dw + 64u * band_px(jobs[p].ch, p1) - 1) / (64u * band_px(jobs[p].ch, p1))) * ((jobs[p].dh + 4 * r - 1) / (4 * r)) * n;
-    if (forced || groups >= kBandMinGroups) return {r, band_slots_exact(r, njobs, jobs, slots), narrow};
+    if (forced || groups >= kBandMinGroups) return {r, band_slots_exact(r, njobs, jobs, slots), narrow, rb};
   }
-  return {1, 0, false};
+  return {1, 0, false, rb_packed};
 }
 // the whole decision: 8 pixels per lane on the 1-channel planes only with the 16-slot (narrow-strip) instantiations that exist for it.
 // Where that form would run 8-row bands on a DOWN-scale (every plane's vertical factor in [1, 2]) the launch takes the MARCH form instead
@@ -1467,11 +1490,11 @@ static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const Ba
       const uint32_t slots = band_slots_exact(4, njobs, jobs, band_slots(4, scy));
       if (nb >= (forced_nb ? 1u : 2u) && slots <= 9u && 4u * slots * rb + 16u <= 64u * 1024u) return {4, slots, true, 8, rb, nb};
     }
-    if (bs.rows >= 8 && bs.narrow) return {bs.rows, bs.slots, true, 8, rb, 0};
+    if (bs.rows >= 8 && bs.narrow) return {bs.rows, bs.slots, true, 8, bs.rb, 0};
   }
   const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 4);
   const BandShape bs = band_rows(njobs, jobs, rb, n, 4);
-  return {bs.rows, bs.slots, bs.narrow, 4, rb, 0};
+  return {bs.rows, bs.slots, bs.narrow, 4, bs.rb, 0};
 }
 
 hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a) {

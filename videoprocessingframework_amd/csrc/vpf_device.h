@@ -42,6 +42,12 @@ VPF_DEV uint32_t pack4(float a, float b, float c, float d) {
     return sat_rne_explicit(a) | (sat_rne_explicit(b) << 8) | (sat_rne_explicit(c) << 16) | (sat_rne_explicit(d) << 24);
   }
 }
+// three channel values -> bytes 0..2 of a dword (byte 3 = 0): one pixel of a "px4" LDS strip (k_bilinear_blend.h), vpf_convert's rounding
+VPF_DEV uint32_t pack3(float a, float b, float c) {
+  uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0u);
+  o = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, o);
+  return __builtin_amdgcn_cvt_pk_u8_f32(c, 2, o);
+}
 // four values already carrying +0.5: saturate + truncate (round half up), for resize / remap / RGB -> YUV.
 // v_cvt_pk_u8_f32 follows the fp32 rounding field of the MODE register (measured: tools/lab/probes/probe_rtz_pack.hip, profiles/
 // r03_probe_rtz_pack.txt — 0 of 4 M groups differ from med3 + v_cvt_u32_f32, values from -1e30 to 1e30 included), so under round-toward-zero

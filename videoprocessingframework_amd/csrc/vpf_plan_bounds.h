@@ -19,6 +19,17 @@ static inline uint32_t vpf_bound_strip_bytes(int ch, uint32_t sw, uint32_t dw, u
   return ((uint32_t)need + 255u) & ~255u;
 }
 
+/* the row-band kernels' strips of packed RGB widened to four bytes per pixel (k_bilinear_blend.h "px4", round 6): pixels [first & ~3, last + 1]
+ * in whole units of four — (cols - 1) * scale + 3 pixels of taps + 3 of alignment + 1 for the second tap's dword at the right edge + 3 of unit
+ * rounding, 4 B each — rounded up to 64 B (LDS rows are what decides how many workgroups a CU holds: 256-B rounding would cost 1080p -> 720p
+ * one of its four); 0 when above `cap` */
+static inline uint32_t vpf_bound_strip_bytes_px4(uint32_t sw, uint32_t dw, uint32_t cap, uint32_t cols) {
+  const double scale = (double)sw / (double)dw;
+  const double need = ((double)(cols - 1) * scale + 11.0) * 4.0;
+  if (need > (double)cap) return 0;
+  return ((uint32_t)need + 63u) & ~63u;
+}
+
 /* source rows a band of `r` destination rows can touch (bilinear): i1(last row) - i0(first row) + 1 <= floor((r - 1) scy) + 3 (+ fp32 slack) */
 static inline uint32_t vpf_bound_band_slots(int r, float scy) {
   return (uint32_t)((double)(r - 1) * (double)scy + 0.01) + 3u;
@@ -48,6 +59,11 @@ static inline uint32_t vpf_band_rows_exact(int r, uint32_t sh, uint32_t dh, floa
  * 8-pixel conversion groups on both sides + the tap window's over-read), and whether `r` destination rows fit `strip_rows` source rows */
 static inline uint32_t vpf_bound_fused_rowbytes(float scx) {
   return (((uint32_t)(255.0 * (double)scx) + 2 + 8 + 8) * 3 + 16 + 15) & ~15u;
+}
+/* the same strip with FOUR bytes per pixel (R G B x: k_bilinear_blend.h "px4"; the workgroup-shared strips of round 6): the same pixel span +
+ * one pixel for the second tap's dword at the right edge */
+static inline uint32_t vpf_bound_fused_rowbytes4(float scx) {
+  return (((uint32_t)(255.0 * (double)scx) + 2 + 8 + 8 + 1) * 4 + 15) & ~15u;
 }
 static inline int vpf_bound_fused_rows_fit(int r, float scy, int strip_rows) {  /* rows touched <= (r - 1) scy + 3 (+ fp32 slack) */
   return (double)scy * (double)(r - 1) + 3.01 <= (double)strip_rows;
