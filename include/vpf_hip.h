@@ -236,11 +236,14 @@ VPF_API void vpf_trace_pop(int opened);
  *   9        the any-size / any-alignment generic kernels everywhere (byte accesses, gather resize / remap)
  *   40       the narrower fast paths instead of the 16-px "r16" / tiled / quad kernels (A/B runs, test coverage)
  *   43       resize: the tiled separable kernel for bilinear down-scales as well (default: up-scales only)
- *   47       fused convert + resize: the per-wave strips of rounds 2-4 instead of the workgroup-shared strip (A/B runs, test coverage)
  *   48       fused convert + resize: the workgroup-shared strip also beyond ~2x down-scales, where the policy takes the per-tap kernel
  *   4, 8, 12, 30, 37, 44, 45, 46   one named NV12 / YUV420 -> RGB kernel of the default policy's set (k_yuv2rgb.hip launch_420)
- * Any other value is rejected: -1 is returned and nothing changes (the experimental kernels and bandwidth probes of round 1
- * are not in this library; they live in tools/lab).  Not part of the reference surface.  Returns the previous value. */
+ * Any other value is rejected: -1 is returned and nothing changes.  This library holds the kernels some policy path can select, nothing
+ * else: the experimental kernels and bandwidth probes of round 1 live in tools/lab/libvpfhip_lab.so, and the kernel FORMS that were
+ * measured and lost — the fused kernel's per-wave strips (variant 47), the two-role Lanczos form (VPF_TUNE_RESIZE_MFMA | 0x20000), the
+ * persistent launch of the band kernels (VPF_TUNE_RESIZE_BAND | 0x10000 [| 0x40000 | 0x80000]) — in tools/lab/libvpfhip_forms.so, a build of
+ * these same sources with -DVPF_LAB_FORMS that accepts those values (tools/lab/build_lab.py).  Not part of the reference surface.
+ * Returns the previous value. */
 VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_NV12_RGB_VARIANT 1
 #define VPF_TUNE_RESIZE_TILE 2 /* shape of the tiled resize kernels for measurement sweeps: 0 = policy, else rows-per-tile | waves-per-workgroup << 8
@@ -248,14 +251,11 @@ VPF_API int vpf_set_tuning(int key, int value);
 #define VPF_TUNE_RESIZE_MFMA 5 /* 8-bit Lanczos-3 on the matrix cores (k_lanczos_mfma.hip): 0 = policy, 1 = never (the tiled / gather kernels take Lanczos), else
                                   N-tiles per wave (0 = policy, 4 or 8) << 8 | destination 16-row tiles per band (0 = policy, 1..64); | 0x10000: the kernel
                                   evaluates its filter weights itself instead of loading the per-shape tables (the path taken when no table fits);
-                                  | 0x20000: the two-role kernel form (pass 1 and pass 2 on different waves; measured slower on RGB, kept as a
-                                  measurement knob); | 0x40000: one small plane per dispatch takes the matrix-core kernel too (the policy sends it to
+                                  | 0x40000: one small plane per dispatch takes the matrix-core kernel too (the policy sends it to
                                   the tile kernel, whose single-launch latency is lower); | 0x80000: up-scales march with the ring of four source tiles like
                                   everything else (policy: a ring of two, one K chunk in pass 2); same pixels whatever the value */
 #define VPF_TUNE_RESIZE_BAND 3 /* destination rows per wave of the row-pair bilinear kernels: 0 = policy, 1, 2, 4, 8 or 16; 4 | nb << 8 (nb = 1..8): the march form
-                                  (nb 4-row bands per wave, 8 pixels per lane on 1-channel planes) where it applies; | 0x10000: the persistent launch of the band kernels
-                                  (resident workgroups pulling wave items from per-XCD work counters: measured 10 x slower than the grid on this chip, a
-                                  measurement knob; never taken by policy, never under stream capture); | 0x20000: 8 pixels per lane on every 1-channel
+                                  (nb 4-row bands per wave, 8 pixels per lane on 1-channel planes) where it applies; | 0x20000: 8 pixels per lane on every 1-channel
                                   plane of a band launch however well 512-column chunks fill its rows (policy: only at >= 80 % fill); same pixels
                                   whatever the value */
 

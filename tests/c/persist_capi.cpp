@@ -19,6 +19,10 @@ int pst_slot(void* p, int dev, uint64_t stream) {
   Table* T = static_cast<Table*>(p);
   return T->t.slot_of(dev, reinterpret_cast<const void*>(stream), [T](int, const void* s) { return T->busy.count((uint64_t)(uintptr_t)s) == 0; });
 }
+int pst_take(void* p, int dev, uint64_t stream, int* set) {
+  Table* T = static_cast<Table*>(p);
+  return T->t.take(dev, reinterpret_cast<const void*>(stream), [T](int, const void* s) { return T->busy.count((uint64_t)(uintptr_t)s) == 0; }, set);
+}
 int pst_used(void* p) { return static_cast<Table*>(p)->t.used(); }
 void pst_shares(uint32_t total, uint32_t* lo) { vpf::persist_shares(total, lo); }
 }

@@ -45,6 +45,30 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def capi_forms():
+    """The same ctypes binding over tools/lab/libvpfhip_forms.so: libvpfhip's sources compiled with -DVPF_LAB_FORMS (tools/lab/build_lab.py), i.e.
+    WITH the kernel forms no policy selects — the persistent band launch, the two-role Lanczos form, the fused kernel's per-wave strips — and the
+    knob values that force them.  The product library contains none of them (tests/test_product_kernels_cpu.py)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools", "lab"))
+    import build_lab
+
+    so = build_lab.FORMS_OUT
+    if not os.path.exists(so):
+        so = build_lab.build_forms()
+    import videoprocessingframework_amd  # noqa: F401  (the package the copy's relative imports resolve in)
+    spec = importlib.util.spec_from_file_location("videoprocessingframework_amd._capi_forms", os.path.join(root, "videoprocessingframework_amd", "capi.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    m.LIB_PATH = so
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="session")
 def capi():
     from videoprocessingframework_amd import capi as c
 

@@ -92,7 +92,7 @@ FUSED_SHAPES = [(320, 180, 214, 120), (160, 90, 320, 180), (256, 64, 128, 32), (
 
 
 @pytest.mark.parametrize("sf,df", [("NV12", "RGB"), ("YUV420", "BGR"), ("NV12", "RGB_PLANAR")])
-def test_convert_resize_batch_beyond_32_frames(capi, oracle, sf, df):
+def test_convert_resize_batch_beyond_32_frames(capi, capi_forms, oracle, sf, df):
     osf, odf = getattr(oracle, sf), getattr(oracle, df)
     for si, (sw, sh, dw, dh) in enumerate(FUSED_SHAPES):
         srcs = [oracle.synth(osf, sw, sh, 7500 + 10 * si + i) for i in range(NSRC)]
@@ -101,12 +101,13 @@ def test_convert_resize_batch_beyond_32_frames(capi, oracle, sf, df):
         for variant in ((0, 47, 48) if si < 2 else (0,)):
             for n in (NS if (si < 2 and variant == 0) else (128, 129)):
                 D = [DevPlanes(oracle.alloc(odf, dw, dh, fill=0x5A)) for _ in range(n)]
-                prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+                lib = capi_forms if variant == 47 else capi  # (47, the per-wave strips of rounds 2-4: the lab build of the library)
+                prev = lib.set_tuning(lib.TUNE_NV12_RGB_VARIANT, variant)
                 try:
-                    capi.convert_resize_batch(capi.make_exec(stream_handle()), getattr(capi, sf), getattr(capi, df), 1, 0, sw, sh, dw, dh,
-                                              capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S[:n], D)]))
+                    lib.convert_resize_batch(lib.make_exec(stream_handle()), getattr(lib, sf), getattr(lib, df), 1, 0, sw, sh, dw, dh,
+                                             lib.make_batch([(s.desc(), d.desc()) for s, d in zip(S[:n], D)]))
                 finally:
-                    capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+                    lib.set_tuning(lib.TUNE_NV12_RGB_VARIANT, prev)
                 torch.cuda.synchronize()
                 for i in range(n):
                     got, intact = D[i].download()

@@ -415,11 +415,14 @@ def test_fused_convert_resize_batch(capi, oracle):
 
 
 @pytest.mark.parametrize("variant", [0, 47, 48])
-def test_fused_strip_kernels_at_every_band_height(capi, oracle, variant):
+def test_fused_strip_kernels_at_every_band_height(capi, capi_forms, oracle, variant):
     """k_convert_strip_wg (round 5: one RGB strip per workgroup, conversions dealt out over all 256 lanes) with R = 16 / 8 / 4 / 2 rows per
     wave — the launcher picks R from the strip's LDS bytes and the number of workgroups, so batches of mid-sized frames reach every
     instantiation; ragged right / bottom edges, odd source row parity at the workgroup's first row, sources narrower than one 8-px
     group.  47 = the per-wave strips it replaced, 48 = workgroup strips beyond 2x.  Every frame == convert-then-resize (the oracle)."""
+    if variant == 47:  # the per-wave strips live in the lab build of the library (tools/lab/libvpfhip_forms.so); the product refuses the value
+        assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 47) == -1
+        capi = capi_forms
     cases = [("NV12", "RGB", 640, 360, 1280, 720, 12), ("YUV420", "RGB_PLANAR", 480, 270, 1000, 610, 9), ("NV12", "BGR", 1280, 720, 854, 480, 10),
              ("YUV420", "RGB", 1920, 360, 1288, 239, 8), ("NV12", "RGB_PLANAR", 1280, 720, 1920, 1080, 6), ("NV12", "RGB", 1920, 1080, 800, 450, 3),
              ("NV12", "RGB", 1920, 540, 1600, 450, 6), ("YUV420", "BGR", 16, 8, 300, 170, 5), ("NV12", "RGB", 8, 64, 9, 70, 4), ("NV12", "RGB", 648, 366, 431, 243, 33)]
@@ -692,7 +695,7 @@ def test_fuzz_shapes_pitches_alignments(capi, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", _FUZZ_SEEDS)
-def test_fuzz_resize_and_fused(capi, oracle, seed):
+def test_fuzz_resize_and_fused(capi, capi_forms, oracle, seed):
     """random (format, filter, source size, destination size, alignment, kernel family): the tiled / row-pair / gather
     resize kernels and the LDS / gather fused kernels against the oracle, bit for bit"""
     rng = np.random.default_rng(9000 + seed)
@@ -716,11 +719,12 @@ def test_fuzz_resize_and_fused(capi, oracle, seed):
             _, want = oracle.convert_resize(getattr(oracle, sf), getattr(oracle, df), 1, 0, sw, sh, src, dw, dh)
             _, exact = oracle.convert_resize(getattr(oracle, sf), getattr(oracle, df), 1, 0, sw, sh, src, dw, dh, oracle.EXACT)
             s, d = DevPlanes(src, align), DevPlanes(oracle.alloc(getattr(oracle, df), dw, dh), align)
-            prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
+            lib = capi_forms if variant == 47 else capi  # (the per-wave strips: the lab build of the library)
+            prev = lib.set_tuning(lib.TUNE_NV12_RGB_VARIANT, variant)
             try:
-                capi.convert_resize(capi.make_exec(stream_handle()), getattr(capi, sf), getattr(capi, df), 1, 0, sw, sh, s.desc(), dw, dh, d.desc())
+                lib.convert_resize(lib.make_exec(stream_handle()), getattr(lib, sf), getattr(lib, df), 1, 0, sw, sh, s.desc(), dw, dh, d.desc())
             finally:
-                capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
+                lib.set_tuning(lib.TUNE_NV12_RGB_VARIANT, prev)
             what = f"fused {sf}->{df}"
         else:
             fmt = str(rng.choice(["RGB", "BGR", "Y", "NV12", "YUV420", "RGB_PLANAR"]))
@@ -892,9 +896,12 @@ def test_tuning_hook_rejects_values_outside_the_product(capi):
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v) == -1
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 0      # unchanged
     assert capi.set_tuning(7, 0) == -1                                    # unknown key
-    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46, 47, 48):
+    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46, 48):
         capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v)
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == v
+    # forms no policy selects are not in the product (lab build: tools/lab/libvpfhip_forms.so): their knob values change nothing here
+    assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 47) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x10000) == -1 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0x20000) == -1
+    assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 0 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0) == 0 and capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0) == 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1021,7 +1028,7 @@ def test_lanczos_tile_kernel_writes_the_oracle_pixels(capi, oracle, shape):
 
 
 @pytest.mark.parametrize("band", [1, 2, 4, 8, 16, 0x104, 0x204, 0x304, 0x804, 0x10000, 0x10002, 0x10008, 0x10104, 0x10304, 0x20000, 0x20008, 0x20304])
-def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
+def test_row_band_kernels_write_the_row_pair_pixels(capi, capi_forms, oracle, band):
     """VPF_TUNE_RESIZE_BAND = destination rows per wave of the bilinear row-pair kernels (policy: 16 / 8 / 4 / 2 for launches with >= 2048
     workgroups, 1 otherwise).  Every value writes the oracle's pixels: general and > 2x down-scales, shared and disjoint source rows,
     heights that are not a multiple of the band, one-row pictures, ragged widths, fx == 0 columns (even integer factor on x only), an
@@ -1038,6 +1045,8 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
              ("Y", 1920, 300, 1280, 200, 0, 3), ("NV12", 1920, 270, 1280, 180, 0, 2), ("Y", 1030, 131, 1025, 67, 0, 2), ("NV12", 1600, 98, 1100, 66, 0, 2),  # ... down-scales: the march form
              ("Y", 1100, 77, 1100, 77, 0, 2), ("YUV444", 1536, 50, 1024, 34, 0, 2), ("Y", 2000, 9, 1999, 5, 0, 2),
              ("RGB", 1, 1, 9, 7, 0, 2), ("RGB", 2, 3, 300, 5, 0, 2), ("Y", 3, 2, 5, 70, 0, 2), ("NV12", 4, 4, 18, 10, 0, 2), ("RGB", 5, 2, 3, 1, 0, 2)]  # tiny pictures
+    if band & 0x10000:  # the persistent launch lives in the lab build of the library
+        capi = capi_forms
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, band) >= 0
     try:
         for fmt, sw, sh, dw, dh, variant, n in cases:
@@ -1060,7 +1069,7 @@ def test_row_band_kernels_write_the_row_pair_pixels(capi, oracle, band):
         capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 3) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 32) == -1
     assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x208) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x904) == -1  # bands per wave: 4-row bands only, at most 8
-    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x40004) == -1                                                           # forms: | 0x10000 the persistent launch, | 0x20000 eight pixels per lane on every 1-channel plane
+    assert capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x100004) == -1 and capi.set_tuning(capi.TUNE_RESIZE_BAND, 0x40004) == -1                                                     # forms: | 0x10000 the persistent launch, | 0x20000 eight pixels per lane on every 1-channel plane
 
 
 @pytest.mark.parametrize("fmt", ["Y", "NV12"])
@@ -1083,11 +1092,13 @@ def test_bilinear_march_form_by_policy(capi, oracle, fmt):
 
 @pytest.mark.parametrize("fmt,knob,sizes", [("Y", 0x10104, (1920, 1080, 1280, 720)), ("NV12", 0x10204, (1920, 1080, 1280, 720)), ("YUV420", 0x10004, (1280, 720, 854, 480)),
                                             ("RGB", 0x10010, (640, 360, 1280, 720)), ("RGB", 0x10008, (1280, 720, 854, 480))])
-def test_persistent_band_launch_with_more_items_than_waves_on_two_streams(capi, oracle, fmt, knob, sizes):
+def test_persistent_band_launch_with_more_items_than_waves_on_two_streams(capi_forms, oracle, fmt, knob, sizes):
     """k_planes_mp_persist (round 5) where it matters: 32-frame dispatches whose wave items outnumber the resident waves several times (every
     wave pulls many items; the XCDs finish their own eighth and help the others; the last ticket of each counter puts it back to zero for
     the next launch), three dispatches in a row per stream, two streams at once (a slot of counters each: vpf_persist.h), then the same
-    streams again after a synchronisation.  Every frame equals the oracle; a hipGraph capture takes the plain grid (same pixels)."""
+    streams again after a synchronisation.  Every frame equals the oracle; a hipGraph capture takes the plain grid (same pixels).
+    Round 6: the second form (chunks, a static first chunk, prefetched tickets, two counter sets per stream taking turns) — in the lab build."""
+    capi = capi_forms
     sw, sh, dw, dh = sizes
     f, of = getattr(capi, fmt), getattr(oracle, fmt)
     n = 32
@@ -1471,7 +1482,7 @@ def test_lanczos_weight_table_arena_full(tmp_path):
 
 
 @pytest.mark.parametrize("seed", _FUZZ_SEEDS)
-def test_fuzz_resize_batch(capi, oracle, seed):
+def test_fuzz_resize_batch(capi, capi_forms, oracle, seed):
     """random format (multi-plane formats exercise the one-launch-for-all-planes kernels, odd sizes give the chroma planes their own
     scale factors), filter, size pair (incl. exact 2x, odd integer factors, up-scales), frame count, alignment and kernel family: every
     frame of the batch equals the oracle"""
@@ -1493,32 +1504,38 @@ def test_fuzz_resize_batch(capi, oracle, seed):
         else:              # general down-scale
             sw, sh = int(rng.integers(32, 900)), int(rng.integers(10, 200))
             dw, dh = max(2, int(sw / rng.uniform(1.0, 6.5))), max(2, int(sh / rng.uniform(1.0, 6.5)))   # (2.2 .. 6: two-chunk windows / half tiles of the matrix-core Lanczos kernel)
-        n = int(rng.choice([1, 2, 3, 5]))
+        n = int(rng.choice([1, 2, 3, 5, 40, 130], p=[0.3, 0.25, 0.2, 0.15, 0.05, 0.05]))  # 40: one dispatch through the 128-frame table; 130: 128 + 2
+        if n >= 40 and sw * sh > 24000:  # (many frames: small ones)
+            k = (sw * sh / 24000.0) ** 0.5
+            sw, sh, dw, dh = max(2, int(sw / k)) & ~1, max(2, int(sh / k)) & ~1, max(2, int(dw / k)) & ~1, max(2, int(dh / k)) & ~1
         align, variant = int(rng.choice([256, 256, 16, 4, 1])), int(rng.choice([0, 0, 0, 40, 43, 9]))
-        f, of = getattr(capi, fmt), getattr(oracle, fmt)
-        srcs = [oracle.synth(of, sw, sh, int(rng.integers(1 << 30))) for _ in range(n)]
-        S = [DevPlanes(p, align) for p in srcs]
+        of = getattr(oracle, fmt)
+        nsrc = min(n, 3)
+        srcs = [oracle.synth(of, sw, sh, int(rng.integers(1 << 30))) for _ in range(nsrc)]
+        S = [DevPlanes(srcs[i % nsrc], align) for i in range(n)]
         D = [DevPlanes(oracle.alloc(of, dw, dh), align) for _ in range(n)]
         band = int(rng.choice([0, 1, 2, 4, 8, 16, 0x104, 0x204, 0x304]))  # rows per wave of the row-pair kernels (small batches would never leave 1 by policy); 4 | nb << 8: the march form
-        prev = capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, variant)
-        capi.set_tuning(capi.TUNE_RESIZE_BAND, band)
-        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5, 0x40000, 0x80000, 0x80000 | (8 << 8) | 2]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves); 0x40000: small single frames on the matrix cores too; 0x80000: up-scales with the ring of four  # shape of the matrix-core Lanczos kernel (N-tiles per wave << 8 | tiles per band; 1 = gather form)
+        march = int(rng.choice([0, 1, (4 << 8) | 1, (8 << 8) | 1, (8 << 8) | 2, 3, 64, 0x20000, 0x20000 | 2, 0x20000 | 5, 0x40000, 0x80000, 0x80000 | (8 << 8) | 2]))  # 0x20000: the two-role form (pass 1 / pass 2 on different waves; lab build of the library); 0x40000: small single frames too; 0x80000: no ring of two
         if march != 1 and not (march & 0x20000) and rng.integers(3) == 0:
             march |= 0x10000                                                                # ... with its weights evaluated in the kernel, not loaded from the shape's tables
-        capi.set_tuning(capi.TUNE_RESIZE_MFMA, march)
+        lib = capi_forms if march & 0x20000 else capi
+        f = getattr(lib, fmt)
+        prev = lib.set_tuning(lib.TUNE_NV12_RGB_VARIANT, variant)
+        lib.set_tuning(lib.TUNE_RESIZE_BAND, band)
+        assert lib.set_tuning(lib.TUNE_RESIZE_MFMA, march) >= 0
         try:
-            capi.resize_batch(capi.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+            lib.resize_batch(lib.make_exec(stream_handle()), f, interp, sw, sh, dw, dh, lib.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
         finally:
-            capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, prev)
-            capi.set_tuning(capi.TUNE_RESIZE_BAND, 0)
-            capi.set_tuning(capi.TUNE_RESIZE_MFMA, 0)
+            lib.set_tuning(lib.TUNE_NV12_RGB_VARIANT, prev)
+            lib.set_tuning(lib.TUNE_RESIZE_BAND, 0)
+            lib.set_tuning(lib.TUNE_RESIZE_MFMA, 0)
         torch.cuda.synchronize()
+        wants = [oracle.resize(of, interp, sw, sh, p, dw, dh, oracle.FP32)[1] for p in srcs]
+        exacts = [oracle.resize(of, interp, sw, sh, p, dw, dh, oracle.EXACT)[1] for p in srcs] if interp != capi.INTERP_NEAREST else None  # (nearest: a coordinate tie moves a whole pixel, see test_fuzz_resize_and_fused)
         for i in range(n):
             got, intact = D[i].download()
             assert intact
-            _, want = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.FP32)
-            assert_planes_equal(got, want, f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} mfma{march:#x} frame {i}")
-            if interp != capi.INTERP_NEAREST:  # (nearest: a coordinate tie moves a whole pixel, see test_fuzz_resize_and_fused)
-                _, exact = oracle.resize(of, interp, sw, sh, srcs[i], dw, dh, oracle.EXACT)
-                assert max(int(np.abs(g.astype(int) - e.astype(int)).max()) for g, e in zip(got, exact)) <= 1, \
+            assert_planes_equal(got, wants[i % nsrc], f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} n{n} a{align} v{variant} band{band} mfma{march:#x} frame {i}")
+            if exacts is not None:
+                assert max(int(np.abs(g.astype(int) - e.astype(int)).max()) for g, e in zip(got, exacts[i % nsrc])) <= 1, \
                     f"fuzz resize_batch {fmt} interp {interp} {sw}x{sh}->{dw}x{dh} frame {i}: HIP vs EXACT > 1 LSB"

@@ -86,7 +86,7 @@ def test_bench_multi_rank_control_flow_rehearsal(launcher):
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["data"] == "rehearsal" and out["value"] is None and out["roofline"] is None
     per_rank = out["per_rank_ms_per_step"]
-    assert len(per_rank) == 2 and per_rank[1] > 1.5 * per_rank[0]           # rank 1's step sleeps twice as long
+    assert len(per_rank) == 2 and per_rank[1] > 1.25 * per_rank[0]          # rank 1's step sleeps twice as long (a loaded host stretches both sleeps by the same absolute amount)
     assert out["ms_per_step"] >= per_rank[1] * 0.99                          # MAX over ranks, not the mean ...
     # ... of each rank's OWN launch -> synchronize time: the closing barrier's cost is reported beside it, not inside it.  Rank 1's step
     # takes 4 ms against rank 0's 2, so the slow rank's own time is the job's time to within scheduling noise, and the barrier figure

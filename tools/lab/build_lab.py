@@ -29,5 +29,40 @@ def build(force=False):
     return OUT
 
 
+# ---- the kernel FORMS no policy selects: libvpfhip.so's own sources compiled once more with -DVPF_LAB_FORMS —
+#   the persistent launch of the band kernels (k_planes_mp_persist; VPF_TUNE_RESIZE_BAND | 0x10000 [| 0x40000 | 0x80000]),
+#   the two-role Lanczos form (LanczosPairTask; VPF_TUNE_RESIZE_MFMA | 0x20000),
+#   the fused kernel's per-wave strips of rounds 2-4 (k_convert_strip; VPF_TUNE_NV12_RGB_VARIANT = 47).
+# The product library contains none of them and refuses those knob values; tests/conftest.py's `capi_forms` and the sweep tools
+# (SWEEP_LIB=tools/lab/libvpfhip_forms.so) load this build.  Same C ABI, same pixels.
+FORMS_OUT = os.path.join(HERE, "libvpfhip_forms.so")
+FORMS_TUS = ["vpf_abi.hip", "k_resize.hip", "k_lanczos_mfma.hip", "k_convert_resize.hip"]  # the translation units VPF_LAB_FORMS changes
+
+
+def build_forms(force=False):
+    sys.path.insert(0, ROOT)
+    from videoprocessingframework_amd import _build
+    import concurrent.futures as cf
+    _build.build_kernels()  # the other translation units' objects are the product's
+    obj_dir = os.path.join(HERE, "build_forms")
+    os.makedirs(obj_dir, exist_ok=True)
+    hdrs = _build._headers()
+    jobs, objs = [], []
+    for tu in _build.KERNEL_TUS:
+        if tu not in FORMS_TUS:
+            objs.append(os.path.join(_build.OBJ, tu.replace(".hip", ".o")))
+            continue
+        src, obj = os.path.join(CSRC, tu), os.path.join(obj_dir, tu.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _build._newer(obj, [src] + hdrs):
+            jobs.append([_build.HIPCC, *_build.HIP_FLAGS, "-DVPF_LAB_FORMS", "-c", src, "-o", obj])
+    with cf.ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(_build._run, jobs))
+    if force or jobs or _build._newer(FORMS_OUT, objs):
+        _build._run([_build.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", FORMS_OUT, *objs])
+    return FORMS_OUT
+
+
 if __name__ == "__main__":
     print(build("--force" in sys.argv))
+    print(build_forms("--force" in sys.argv))

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void k_convert_half_one(VPF_ONE_SRC_PARAMS, ui
 // (whose centre-sample shortcut is HBM-bound already), exact 2x keeps k_convert_half.
 // ------------------------------------------------------------------------------------------
 constexpr int kStripRows = 8;  // source rows a wave's strip can hold
+#ifdef VPF_LAB_FORMS  // superseded by k_convert_strip_wg (round 5): built into tools/lab/libvpfhip_forms.so only (VPF_TUNE_NV12_RGB_VARIANT = 47)
 template <int SRC, int DST, int R>
 VPF_DEV void convert_strip_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx, float scy,
                                 int vec_ok, uint32_t rowq_rows, uint32_t bx, uint32_t by) {
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256) void k_convert_strip(const BA args, const Yuv2
   const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h): bands above each other and chunks next to each other share one L2
   convert_strip_task<SRC, DST, R>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
 }
+#endif  // VPF_LAB_FORMS
 
 // ------------------------------------------------------------------------------------------
 // The same, with the strip shared by the WORKGROUP (round 5).  In k_convert_strip every wave converts its own window with 8 pixels per lane
@@ -678,6 +680,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
     for (uint32_t i = 0; i < n && ok8; i++)
       for (int k = 0; k < (src_fc == FC_NV12 ? 2 : 3); k++) ok8 = ok8 && !(((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & 7);
     if (ok8) {
+#ifdef VPF_LAB_FORMS  // the per-wave strips of rounds 2-4 (k_convert_strip): variant 47, and where the workgroup strips do not apply
       const uint32_t rowbytes = vpf_bound_fused_rowbytes(scx);  // a wave's source span + alignment + tap-window slack (vpf_plan_bounds.h)
       int r = 0;
       if (vpf_bound_fused_rows_fit(8, scy, kStripRows)) r = 8;  // rows a wave's R destination rows can touch: <= (R - 1) scy + 3 (+ fp32 slack)
@@ -694,10 +697,14 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
       // conversions per destination pixel: scx x ((r - 1) scy + 2) / r source pixels against the four taps of the per-tap kernel —
       // measured break-even near 2x (4K -> 1600x900, 2.4x: 9.5 us here vs 5.2 us per-tap; 1080p -> 720p: 2.36 vs 3.21; 1080p -> 4K: 15.0 vs 23.6)
       const double conv_per_px = r ? (double)scx * ((r - 1) * (double)scy + 2.0) / r : 1e9;
+#endif  // VPF_LAB_FORMS
       // Round 5: the strip shared by the workgroup (k_convert_strip_wg: the source window of 4 R destination rows converted once, dealt
       // out over all 256 lanes).  Band height: the largest of 16 (up-scales) / 8 / 4 / 2 whose strip leaves four workgroups per CU
-      // (<= 40 KiB of the CU's 160: round 6's four-byte pixels make 1080p -> 720p at R = 4 a 39.5-KiB strip) and whose launch still covers the chip.  VPF_TUNE_NV12_RGB_VARIANT = 47 keeps the per-wave strips (A/B runs, tests).
-      if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 47) {
+      // (<= 40 KiB of the CU's 160: round 6's four-byte pixels make 1080p -> 720p at R = 4 a 39.5-KiB strip) and whose launch still covers the chip.  (Lab builds: VPF_TUNE_NV12_RGB_VARIANT = 47 keeps the per-wave strips.)
+#ifdef VPF_LAB_FORMS
+      if (tuning(VPF_TUNE_NV12_RGB_VARIANT) != 47)
+#endif
+      {
         static thread_local struct { uint32_t sh, dh, rows[4]; } wseen = {0, 0, {0, 0, 0, 0}};
         if (!(wseen.sh == sh && wseen.dh == dh)) {
           wseen.sh = sh; wseen.dh = dh;
@@ -715,8 +722,21 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
           break;
         }
         // source pixels converted per destination pixel: rows of the strip x its width / (4 R x 256); the per-tap kernel converts four
-        const double wconv = rw ? (double)wrows * ((double)scx * 255.0 + 18.0) / (4.0 * rw * 256.0) : 1e9;
-        if (rw && wconv <= (tuning(VPF_TUNE_NV12_RGB_VARIANT) == 48 ? 8.0 : 3.0)) {
+        auto wconv_of = [&](int cand, uint32_t rows) { return cand ? (double)rows * ((double)scx * 255.0 + 18.0) / (4.0 * cand * 256.0) : 1e9; };
+        const double wmax = tuning(VPF_TUNE_NV12_RGB_VARIANT) == 48 ? 8.0 : 3.0;
+        // Second pass (round 6: the four-byte pixels pushed factors of 1.55-1.9 and small single frames out of the first): 4- or 2-row bands
+        // with a strip of up to 53 KiB (three workgroups per CU) however few workgroups the launch has — the shapes the per-wave strips of
+        // rounds 2-4 (lab builds: k_convert_strip) used to take, with the rows neighbouring bands share converted once.
+        if (!rw || wconv_of(rw, wrows) > wmax) {
+          rw = 0;
+          for (int k = 1; k >= 0; k--) {
+            const int cand = 2 << k;
+            if ((uint64_t)wseen.rows[k] * rowbytes4 > 53u * 1024u || (dh < 64 && cand > 2)) continue;
+            if (wconv_of(cand, wseen.rows[k]) <= wmax) { rw = cand; wrows = wseen.rows[k]; break; }
+          }
+        }
+        const double wconv = wconv_of(rw, wrows);
+        if (rw && wconv <= wmax) {
           const uint32_t ldsw = wrows * rowbytes4;
           dim3 wgrid((dw + 255) / 256, (dh + 4 * rw - 1) / (4 * rw), n);
 #define VPF_WG1(S, D, RR) VPF_LAUNCH_BA(k_convert_strip_wg, (S, D, RR), wgrid, dim3(256), ldsw, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowbytes4 / 16)
@@ -729,6 +749,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
           return hipGetLastError();
         }
       }
+#ifdef VPF_LAB_FORMS
       if (r && lds1 <= 64u * 1024u && conv_per_px <= 3.0) {
         dim3 sgrid((dw + 255) / 256, (dh + 4 * r - 1) / (4 * r), n);
 #define VPF_STRIP1(S, D, RR) VPF_LAUNCH_BA(k_convert_strip, (S, D, RR), sgrid, dim3(256), lds1, st, c, sw, sh, dw, dh, scx, scy, vec_ok, (rowbytes / 16) | (srows << 16))
@@ -740,6 +761,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 #undef VPF_STRIP1
         return hipGetLastError();
       }
+#endif  // VPF_LAB_FORMS
     }
   }
   dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);

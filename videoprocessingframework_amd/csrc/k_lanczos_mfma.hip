@@ -655,6 +655,7 @@ VPF_DEV void LanczosMfmaTask<CH, NT, PF, KC, UP2>::run(const uint8_t* __restrict
 #undef VPF_LZM_STEP
 }
 
+#ifdef VPF_LAB_FORMS  // measured and not selected by any policy: built into tools/lab/libvpfhip_forms.so only (knob VPF_TUNE_RESIZE_MFMA | 0x20000)
 // ------------------------------------------------------------------------------------------------------------------------------------
 // The same filter with the two passes on DIFFERENT waves (round 4).  LanczosMfmaTask keeps the column operands (64 VGPRs), the ring (64) and
 // the prefetch sets in one wave: 230-250 registers, two waves per SIMD — and two in-order waves leave the SIMD's issue port 40 % idle
@@ -929,6 +930,7 @@ VPF_DEV void LanczosPairTask<CH, PF>::run(const uint8_t* __restrict__ src, uint3
     consume(k, std::integral_constant<int, 3>{}); ++k;
   }
 }
+#endif  // VPF_LAB_FORMS
 
 template <int CH> struct LzMfma8 : LanczosMfmaTask<CH, 8, 4> {};   // strips of 8 tiles, staged rows of up to 256 B
 template <int CH> struct LzMfma8n : LanczosMfmaTask<CH, 8, 2> {};  // ... of up to 128 B (up-scales)
@@ -943,9 +945,11 @@ template <int CH> struct LzMfma4k6 : LanczosMfmaTask<CH, 4, 6, 2> {};  // ... 38
 template <int CH> struct LzMfma4k8 : LanczosMfmaTask<CH, 4, 8, 2> {};  // ... 512 B
 template <int CH> struct LzMfma2k6 : LanczosMfmaTask<CH, 2, 6, 3> {};  // three-chunk windows, 2-tile strips (factors up to ~10): staged rows of up to 384 B
 template <int CH> struct LzMfma2k8 : LanczosMfmaTask<CH, 2, 8, 3> {};  // ... 512 B
+#ifdef VPF_LAB_FORMS
 template <int CH> struct LzPair : LanczosPairTask<CH, 4> {};    // the two-role form: two 8-tile strips per workgroup, three workgroups per CU
 template <int CH> struct LzPairN : LanczosPairTask<CH, 2> {};
 template <int CH> struct LzPairW : LanczosPairTask<CH, 5> {};
+#endif
 
 // all planes of up to 32 frames in one dispatch (the k_planes_mp scheme of k_resize_common.h, with this family's register budget:
 // two workgroups per CU, and the planes' weight tables)
@@ -1059,7 +1063,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   const int tune = tuning(VPF_TUNE_NV12_RGB_VARIANT), knob = tuning(VPF_TUNE_RESIZE_MFMA);
   const int forced = knob & 0xffff;           // 0 policy | 1 off | (nt << 8 | band rows / 16): measurement and test knob
   const bool tables = !(knob & 0x10000);      // | 0x10000: evaluate the weights in the kernel (the path a full arena takes)
+#ifdef VPF_LAB_FORMS
   const bool pair = (knob & 0x20000) != 0;    // | 0x20000: the two-role form (LanczosPairTask): 8-tile strips only
+#else
+  constexpr bool pair = false;                // (the two-role form lives in the lab build: tools/lab/libvpfhip_forms.so)
+#endif
   if (tune == 9 || tune == 40 || forced == 1) return false;
   if (njobs < 1 || njobs > 3 || !n || n > (uint32_t)kMaxBatch) return false;
   for (int p = 0; p < njobs; p++) {
@@ -1178,9 +1186,11 @@ bool launch_lanczos_mfma(hipStream_t st, int njobs, const ResizeJob* jobs, uint3
   else if (kc == 2 && lzm_pf_of(span, 2) == 8) VPF_LZM_GO(LzMfma4k8);
   else if (kc == 2 && lzm_pf_of(span, 2) == 6) VPF_LZM_GO(LzMfma4k6);
   else if (kc == 2) VPF_LZM_GO(LzMfma4k4);
+#ifdef VPF_LAB_FORMS
   else if (pair && nt == 8 && narrow) VPF_LZM_GO(LzPairN);
   else if (pair && nt == 8 && span > 4u * 64u) VPF_LZM_GO(LzPairW);
   else if (pair && nt == 8) VPF_LZM_GO(LzPair);
+#endif
   else if (nt == 8 && up2 && !narrow) VPF_LZM_GO(LzMfma8uw);
   else if (nt == 8 && up2) VPF_LZM_GO(LzMfma8u);
   else if (up2) VPF_LZM_GO(LzMfma4u);

@@ -26,7 +26,9 @@
 #include <type_traits>
 
 #include "k_resize_common.h"
+#ifdef VPF_LAB_FORMS
 #include "vpf_persist.h"
+#endif
 
 #include <atomic>
 
@@ -297,8 +299,13 @@ struct RowBandTask {
   static VPF_DEV void run(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t by) {
     run_w(src, sp, dst, dp, G, bx, by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
   }
-  // one wave's share: column chunk bx, wave row wrow (the persistent launch hands these out one by one: k_planes_mp_persist)
+  // one wave's share: column chunk bx, wave row wrow
   static VPF_DEV void run_w(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G, uint32_t bx, uint32_t wrow);
+#ifdef VPF_LAB_FORMS
+  // the persistent launch (k_planes_mp_persist, k_resize_common.h): chunk after chunk while the stream hands out chunks of CH-channel planes
+  template <class Stream>
+  static VPF_DEV void run_chunks(BandChunk& c, Stream& ts, const PlaneTable& PT);
+#endif
 };
 template <int CH, int R, int IT, int P1, bool MULTI>
 VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_w(const uint8_t* __restrict__ src, uint32_t sp, uint8_t* __restrict__ dst, uint32_t dp, const PlaneGeom& G,
@@ -379,6 +386,110 @@ VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_w(const uint8_t* __restrict_
     wave_lds_sync();  // the blend's LDS reads are done before the next band's rows overwrite the strips
   }
 }
+
+#ifdef VPF_LAB_FORMS
+// The same walk for the persistent launch: a wave works through CHUNKS (runs of bands of one column chunk) that a ChunkStream hands out.  Inside
+// a chunk it is the march form; at a chunk's last band the NEXT chunk — any frame, plane (of the same channel count) or column — is fetched from
+// the stream and ITS first rows are requested before this band is blended and stored; the column taps and the walk are rebuilt after the blend.
+template <int CH, int R, int IT, int P1, bool MULTI>
+template <class Stream>
+VPF_DEV void RowBandTask<CH, R, IT, P1, MULTI>::run_chunks(BandChunk& c, Stream& ts, const PlaneTable& PT) {
+  constexpr int PX = kPx;
+  constexpr uint32_t W = 64 * PX;
+  constexpr bool X4 = kPx4;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t rowq = PT.g[c.pi].a0, slots = PT.g[c.pi].a1;  // one strip size for the launch
+  u32x4* const strips = dyn_strip + (size_t)wv * slots * rowq;
+  // the staging side: the chunk whose source rows are being requested ...
+  const uint8_t* s_src = nullptr;
+  uint32_t s_sp = 0, s_sh = 0, s_dh = 0, s_base = 0, s_nq = 0, s_lim = 0, s_bpx = 0;
+  float s_scy = 0.f;
+  uint32_t ya = 0, y_end = 0, yb = 0, r_lo = 0, r_hi = 0;
+  auto stage_of = [&](const BandChunk& k) {
+    const PlaneGeom& g = PT.g[k.pi];
+    const uint32_t xs = k.bx * W, xe = (xs + W - 1 < g.dw - 1) ? xs + W - 1 : g.dw - 1;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(xs, g.scx, g.sw).i0), last = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(xe, g.scx, g.sw).i1);
+    s_bpx = first & ~3u;
+    s_base = X4 ? 3u * s_bpx : (CH * first) & ~15u;
+    s_nq = X4 ? (last + 2 - s_bpx + 3) / 4 : (CH * (last + 1) - s_base + 15) / 16;
+    s_lim = (CH * g.sw + 15u) & ~15u;
+    s_src = k.src; s_sp = k.sp; s_sh = g.sh; s_dh = g.dh; s_scy = g.scy;
+    ya = k.band0 * R;
+    y_end = (k.band0 + k.nb) * R < g.dh ? (k.band0 + k.nb) * R : g.dh;
+  };
+  auto rows_of = [&](uint32_t y0) {
+    yb = (y0 + R - 1 < s_dh - 1) ? y0 + R - 1 : s_dh - 1;
+    r_lo = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(y0, s_scy, s_sh).i0);
+    r_hi = __builtin_amdgcn_readfirstlane(make_tap<VPF_INTERP_LINEAR>(yb, s_scy, s_sh).i1);
+  };
+  typename std::conditional<X4, Span4<IT>, Span<IT>>::type rows[kSlots];
+  auto request = [&]() {
+#pragma unroll
+    for (int k = 0; k < kSlots; k++)
+      if (r_lo + k <= r_hi) {
+        if constexpr (X4) rows[k].load(s_src + (size_t)(r_lo + k) * s_sp, s_base, s_nq, lane, s_lim);
+        else rows[k].load(s_src + (size_t)(r_lo + k) * s_sp, s_base, s_nq, lane);
+      }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < kSlots; k++)
+      if (r_lo + k <= r_hi) rows[k].store(strips + (size_t)k * rowq, s_nq, lane);
+    wave_lds_sync();
+  };
+  // ... and the drawing side: the chunk whose bands are being blended
+  uint8_t* d_dst = nullptr;
+  uint32_t d_dp = 0, d_x0 = 0, d_nv = 0;
+  bool d_draws = false, d_vec4 = false;
+  typename std::conditional<X4, ColTapsX, ColTaps<CH, PX>>::type T;
+  auto draw_of = [&](const BandChunk& k) {  // (after stage_of(k): s_base / s_bpx are k's)
+    const PlaneGeom& g = PT.g[k.pi];
+    d_x0 = k.bx * W + lane * PX;
+    d_draws = d_x0 < g.dw;
+    d_vec4 = g.vec_ok && d_x0 + PX <= g.dw;
+    d_nv = !d_draws ? 0u : g.dw - d_x0 < (uint32_t)PX ? g.dw - d_x0 : (uint32_t)PX;
+    d_dst = k.dst; d_dp = k.dp;
+    if constexpr (X4) T = make_col_taps_x(s_bpx, d_x0, g.dw, g.sw, g.scx);
+    else T = make_col_taps<CH, PX>(s_base, d_x0, g.dw, g.sw, g.scx);
+  };
+  stage_of(c);
+  rows_of(ya);
+  request();
+  draw_of(c);
+  BandWalk<CH, PX> walk;
+  for (;;) {
+    commit();
+    const Tap row_taps = band_row_taps(ya, yb, s_scy, s_sh);  // every lane active here
+    const uint32_t ya_k = ya, yb_k = yb, r_lo_k = r_lo;
+    ya += R;
+    const bool same = ya < y_end;
+    BandChunk nx{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+    bool cross = false;
+    if (same) {
+      rows_of(ya);
+      request();
+    } else {
+      nx = ts.next();
+      cross = nx.nb != 0 && PT.ch[nx.pi] == (uint32_t)CH;
+      if (cross) { stage_of(nx); rows_of(ya); request(); }
+    }
+    if (d_draws) {
+      uint8_t* const dst = d_dst;
+      const uint32_t dp = d_dp, x0 = d_x0, nv = d_nv;
+      const bool vec4 = d_vec4;
+      band_blend_rows<CH, R, PX>(reinterpret_cast<const uint8_t*>(strips), rowq * 16, r_lo_k, ya_k, yb_k, row_taps, T, walk, [&](uint32_t y, const float* o) {
+        store_blend4<CH, PX>(dst + (size_t)y * dp + (size_t)CH * x0, o, vec4, nv);
+      });
+    }
+    if (!same) {
+      if (!cross) { c = nx; return; }  // (the caller's wave_lds_sync stands between this blend and the next task's strips)
+      draw_of(nx);
+      walk = BandWalk<CH, PX>();
+    }
+    wave_lds_sync();  // the blend's LDS reads are done before the next band's rows overwrite the strips
+  }
+}
+#endif  // VPF_LAB_FORMS
 
 // ------------------------------------------------------------------------------------------
 // Tiled, separable BILINEAR resize for up-scales (8-bit Lanczos-3 lives in k_lanczos_mfma.hip; k_resize_lanczos / k_resize remain the
@@ -1307,10 +1418,11 @@ static void launch_planes_mp(hipStream_t st, dim3 grid, uint32_t lds, const Batc
   if (grid.z <= (uint32_t)kSmallBatch) hipLaunchKernelGGL((k_planes_mp<TaskCH, BatchArgs>), grid, dim3(TaskCH<3>::kThreads), lds, st, small_batch(a, grid.z), t);
   else hipLaunchKernelGGL((k_planes_mp<TaskCH, BatchArgsL>), grid, dim3(TaskCH<3>::kThreads), lds, st, a, t);
 }
+#ifdef VPF_LAB_FORMS
 // ---- the persistent form of the same launch (k_resize_common.h: k_planes_mp_persist; vpf_persist.h): the resident set of workgroups pulls
 // wave items (frame, plane, wave row, column chunk) from the stream's work counters.  -> false when it does not apply (captured stream, no
 // counter slot free, too few items per wave to be worth it): the caller launches the plain grid.
-__device__ uint32_t g_persist_ctr[kPersistSlots * 8];
+__device__ uint32_t g_persist_ctr[kPersistSlots * 16];  // two sets of eight per slot (vpf_persist.h)
 static PersistSlotTable& persist_slots() { static PersistSlotTable t; return t; }
 static bool persist_stream_idle(int dev, const void* stream) {
   int cur = -1;
@@ -1344,32 +1456,39 @@ static uint32_t persist_resident_groups(int dev, uint32_t lds) {  // workgroups 
   return groups;
 }
 template <template <int> class TaskCH>
-static bool launch_planes_mp_persist(hipStream_t st, uint32_t lds, const BatchArgsL& a, const PlaneTable& t, uint32_t n, const uint32_t* nbx, const uint32_t* nwr, uint32_t min_items_per_wave) {
+static bool launch_planes_mp_persist(hipStream_t st, uint32_t lds, const BatchArgsL& a, const PlaneTable& t, uint32_t n, const uint32_t* nbx, const uint32_t* nbands, uint32_t chunk, uint32_t hops) {
   PersistArgs P{};
   uint32_t per_frame = 0;
-  for (uint32_t p = 0; p < t.np; p++) { P.p0[p] = per_frame; P.nbx[p] = nbx[p]; per_frame += nbx[p] * nwr[p]; }
+  if (!chunk) return false;
+  for (uint32_t p = 0; p < t.np; p++) { P.p0[p] = per_frame; P.nbx[p] = nbx[p]; P.nbands[p] = nbands[p]; per_frame += nbx[p] * ((nbands[p] + chunk - 1) / chunk); }
   const uint64_t total = (uint64_t)per_frame * n;
   if (!per_frame || total >= (1u << 22)) return false;
+  if (st == hipStreamPerThread) return false;  // one handle, a different stream in every thread: not a key for a slot of counters
   int dev = 0;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { (void)hipGetLastError(); return false; }
   const uint32_t resident = persist_resident_groups<TaskCH>(dev, lds), wpg = TaskCH<3>::kThreads / 64u;
-  if (!resident || total < (uint64_t)resident * wpg * min_items_per_wave) return false;
+  if (!resident) return false;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (cs != hipStreamCaptureStatusNone) return false;
   uint32_t* const ctr = persist_ctr_base(dev);
-  const int slot = ctr ? persist_slots().slot_of(dev, (const void*)st, persist_stream_idle) : -1;
+  int set = 0;
+  const int slot = ctr ? persist_slots().take(dev, (const void*)st, persist_stream_idle, &set) : -1;
   if (slot < 0) return false;
-  P.ctr = ctr + 8 * slot;
+  P.ctr = ctr + 16 * slot + 8 * set;
+  P.ctr_other = ctr + 16 * slot + 8 * (set ^ 1);
   P.per_frame = per_frame;
+  P.chunk = chunk;
+  P.hops = hops > 8 ? 8 : hops;
   persist_shares((uint32_t)total, P.lo);
   if (log_level() >= 2 || trace_on()) note_kernel(__PRETTY_FUNCTION__);
   (void)hipGetLastError();
-  const uint32_t groups = (uint32_t)std::min<uint64_t>(resident, (total + wpg - 1) / wpg);
+  const uint32_t groups = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(resident, (total + wpg - 1) / wpg));  // >= 8: every XCD's share has a wave that draws from it
   if (n <= (uint32_t)kSmallBatch) hipLaunchKernelGGL((k_planes_mp_persist<TaskCH, BatchArgs>), dim3(groups), dim3(TaskCH<3>::kThreads), lds, st, small_batch(a, n), t, P);
   else hipLaunchKernelGGL((k_planes_mp_persist<TaskCH, BatchArgsL>), dim3(groups), dim3(TaskCH<3>::kThreads), lds, st, a, t, P);
   return true;
 }
+#endif  // VPF_LAB_FORMS
 template <template <int, int> class T2, int I>
 static void launch_gather_ch(hipStream_t st, dim3 grid, const BatchArgsL& a, const ResizeJob& j, const PlaneGeom& g) {
   if (j.ch == 1) launch_plane_batch<T2<1, I>>(st, grid, 0, a, j.k, g);
@@ -1472,7 +1591,7 @@ static BandShape band_rows(int njobs, const ResizeJob* jobs, uint32_t rb, uint32
 // lose with it and keep their forms.  VPF_TUNE_RESIZE_BAND = 4 | nb << 8 forces it where it applies.
 struct BandPlan { int rows; uint32_t slots; bool narrow; int p1; uint32_t rb; uint32_t nb; };
 static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const BatchArgsL& a) {
-  const int p1 = band_p1(njobs, jobs), knob = tuning(VPF_TUNE_RESIZE_BAND) & 0xffff, forced_nb = knob >> 8;
+  const int p1 = band_p1(njobs, jobs), knob = tuning(VPF_TUNE_RESIZE_BAND) & 0xffff, forced_nb = (knob & 0xff) == 4 ? knob >> 8 : 0;  // (other row counts: the field is the persistent launch's chunk)
   if (p1 == 8) {
     const uint32_t rb = band_strip_bytes(njobs, jobs, n, a, 8);
     const BandShape bs = band_rows(njobs, jobs, rb, n, 8);
@@ -1483,7 +1602,7 @@ static BandPlan plan_band(int njobs, const ResizeJob* jobs, uint32_t n, const Ba
       down = s >= 1.0f && s <= 2.0f;
       scy = s > scy ? s : scy;
     }
-    if (down && (forced_nb ? bs.rows == 4 : (knob == 0 && bs.rows == 8 && bs.narrow))) {
+    if (down && (forced_nb ? bs.rows == 4 : ((knob & 0xff) == 0 && bs.rows == 8 && bs.narrow))) {
       uint64_t groups = 0;
       for (int p = 0; p < njobs; p++) groups += (uint64_t)((jobs[p].dw + 64u * band_px(jobs[p].ch, 8) - 1) / (64u * band_px(jobs[p].ch, 8))) * ((jobs[p].dh + 15) / 16) * n;
       const uint32_t nb = forced_nb ? (uint32_t)forced_nb : (uint32_t)std::min<uint64_t>(3, groups / kBandMinGroups);
@@ -1652,25 +1771,30 @@ hipError_t launch_resize_jobs(hipStream_t st, bool f32, int interp, int njobs, c
       for (int p = 0; p < njobs; p++) { t.g[p].a0 = rb / 16; t.g[p].a1 = bs.slots; t.g[p].a2 = bs.nb; }  // one strip size for the launch (the widest plane's)
       it = (rb + 1023) / 1024;
       const uint32_t lds = band > 1 ? 4 * bs.slots * rb + 16 : 4 * 2 * rb + 16;
-      // the persistent form for the band kernels (VPF_TUNE_RESIZE_BAND | 0x10000: wherever it can run): wave items instead of a grid
+#ifdef VPF_LAB_FORMS
+      // the persistent form for the band kernels (lab builds, VPF_TUNE_RESIZE_BAND | 0x10000): chunks of bands instead of a grid
       const int pknob = (tuning(VPF_TUNE_RESIZE_BAND) >> 16) & 1;
       if (band > 1 && pknob == 1) {
-        uint32_t nbx[3] = {0, 0, 0}, nwr[3] = {0, 0, 0};
+        // chunks of `chunk` bands (knob bits 8..15; default 2), one counter per XCD; | 0x40000: a wave whose counter has run dry visits the other seven
+        uint32_t nbx[3] = {0, 0, 0}, nbands[3] = {0, 0, 0};
         for (int p = 0; p < njobs; p++) {
           const uint32_t wcols = 64u * band_px(jobs[p].ch, bs.p1);
-          nbx[p] = (jobs[p].dw + wcols - 1) / wcols; nwr[p] = (jobs[p].dh + band * band_nb - 1) / (band * band_nb);
+          nbx[p] = (jobs[p].dw + wcols - 1) / wcols; nbands[p] = (jobs[p].dh + band - 1) / band;
         }
+        const uint32_t chunk = ((tuning(VPF_TUNE_RESIZE_BAND) >> 8) & 0xff) ? (uint32_t)((tuning(VPF_TUNE_RESIZE_BAND) >> 8) & 0xff) : 2u;
+        const uint32_t hops = ((tuning(VPF_TUNE_RESIZE_BAND) >> 19) & 1) ? 0u : ((tuning(VPF_TUNE_RESIZE_BAND) >> 18) & 1) ? 8u : 1u;  // | 0x80000 (measurement): no counters, a wave strides through its XCD's share
         bool done = false;
-        if (band == 4 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand4wm>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 16 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand16w>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 8 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand8w>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 16) done = launch_planes_mp_persist<RowBand16n>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 8 && bs.narrow) done = launch_planes_mp_persist<RowBand8n>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 8) done = launch_planes_mp_persist<RowBand8>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 4) done = launch_planes_mp_persist<RowBand4>(st, lds, a, t, n, nbx, nwr, 0);
-        else if (band == 2) done = launch_planes_mp_persist<RowBand2>(st, lds, a, t, n, nbx, nwr, 0);
+        if (band == 4 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand4wm>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 16 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand16w>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 8 && bs.p1 == 8) done = launch_planes_mp_persist<RowBand8w>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 16) done = launch_planes_mp_persist<RowBand16n>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 8 && bs.narrow) done = launch_planes_mp_persist<RowBand8n>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 8) done = launch_planes_mp_persist<RowBand8>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 4) done = launch_planes_mp_persist<RowBand4>(st, lds, a, t, n, nbx, nbands, chunk, hops);
+        else if (band == 2) done = launch_planes_mp_persist<RowBand2>(st, lds, a, t, n, nbx, nbands, chunk, hops);
         if (done) return hipGetLastError();
       }
+#endif  // VPF_LAB_FORMS
       if (band == 4 && bs.p1 == 8) launch_planes_mp<RowBand4wm>(st, grid, lds, a, t);
       else       if (band == 16 && bs.p1 == 8) launch_planes_mp<RowBand16w>(st, grid, lds, a, t);
       else if (band == 8 && bs.p1 == 8) launch_planes_mp<RowBand8w>(st, grid, lds, a, t);

@@ -467,17 +467,27 @@ int vpf_set_tuning(int key, int value) {
   if (key == VPF_TUNE_RESIZE_MFMA) {
     const int shape = value & 0xffff, nt = shape >> 8, tiles = shape & 0xff;  // | 0x10000: no weight tables; | 0x20000: the two-role kernel form; | 0x40000: small single planes too; | 0x80000: no ring of two
     if (value < 0 || (value & ~0xfffff)) return -1;
+#ifndef VPF_LAB_FORMS
+    if (value & 0x20000) return -1;  // the two-role form lives in the lab build (tools/lab/libvpfhip_forms.so)
+#endif
     if (shape != 0 && shape != 1 && ((nt != 0 && nt != 4 && nt != 8) || tiles > 64 || (nt == 0 && tiles < 2))) return -1;
     return g_tune_mfma.exchange(value);
   }
   if (key == VPF_TUNE_RESIZE_BAND) {
-    const int rows = value & 0xff, nb = (value >> 8) & 0xff, form = value >> 16;  // nb: bands per wave of the march form (4-row bands only); form: | 0x10000 = the persistent launch
-    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4) && form <= 3;  // form: | 1 the persistent launch, | 2 eight pixels per lane on every 1-channel plane
+    const int rows = value & 0xff, nb = (value >> 8) & 0xff, form = value >> 16;  // nb: bands per wave of the march form (4-row bands only) / bands per chunk of the persistent launch
+    // form: | 1 the persistent launch, | 2 eight pixels per lane on every 1-channel plane, | 4 persistent waves visit every XCD's counter
+    const bool ok = value >= 0 && (rows == 0 || rows == 1 || rows == 2 || rows == 4 || rows == 8 || rows == 16) && nb <= 8 && (nb == 0 || rows == 4 || (form & 1)) && form <= 15 && (!(form & 12) || (form & 1));  // | 8 (measurement) persistent waves stride through their share, no counters
+#ifndef VPF_LAB_FORMS
+    if (form & 13) return -1;  // the persistent launch and its knobs live in the lab build (tools/lab/libvpfhip_forms.so)
+#endif
     return ok ? g_tune_band.exchange(value) : -1;
   }
   if (key != VPF_TUNE_NV12_RGB_VARIANT) return -1;
   switch (value) {  // the kernels libvpfhip contains: every one writes the same pixels (include/vpf_hip.h)
-    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: case 47: case 48: return g_tune_variant.exchange(value);
+#ifdef VPF_LAB_FORMS
+    case 47:  // the per-wave strips of the fused kernel (rounds 2-4): lab build only
+#endif
+    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: case 48: return g_tune_variant.exchange(value);
     default: return -1;  // unknown value: nothing changes
   }
 }

@@ -2,9 +2,11 @@
 // counters a launch uses, how many workgroups stay resident, and how the item list is cut into the XCDs' shares.  No HIP in the slot
 // table itself (tests/test_persist_cpu.py compiles it with g++); the launchers pass the two stream questions in as callbacks.
 //
-// Counters: a block of eight per SLOT in static device memory, zero when the code object is loaded and zero again after every launch (the
-// wave that draws a counter's last ticket puts it back) — nothing for the host to track, nothing a device reset can leave stale.  Two
-// launches may share a slot only if they cannot run at the same time: a slot belongs to ONE stream (launches of a stream run in order).
+// Counters: TWO sets of eight per SLOT in static device memory, all zero when the code object is loaded.  A launch draws from one set and puts
+// the OTHER back to zero; the slot's next launch draws from that other set (take() hands out the sets in turn).  Two launches may share a
+// slot only if they cannot run at the same time: a slot belongs to ONE stream (launches of a stream run in order), so the set a launch
+// zeroes is the one the launch before it has finished with.  (Round 5's single set was put back by "the wave that draws the last ticket",
+// which needed every wave to fail exactly once on every counter: 8 x 4 096 atomics at the end of each launch.)
 // A stream meets the table once and keeps its slot; when the table is full, a slot whose stream is idle (or gone) is handed on; when none
 // is, the launch simply is not persistent.  Captured launches are never persistent (a graph replays on any stream at any time).
 #pragma once
@@ -18,6 +20,17 @@ constexpr int kPersistSlots = 64;
 class PersistSlotTable {
  public:
   // stream_idle(stream) -> true when nothing is queued or running on it any more (or the handle no longer names a stream)
+  // the slot of (dev, stream) and, in *set, which of its two counter sets this launch draws from (the other one is the one it zeroes)
+  template <class Idle>
+  int take(int dev, const void* stream, Idle&& stream_idle, int* set) {
+    const int s = slot_of(dev, stream, stream_idle);
+    if (s >= 0) {
+      std::lock_guard<std::mutex> g(mu_);
+      *set = e_[s].set;
+      e_[s].set ^= 1;
+    }
+    return s;
+  }
   template <class Idle>
   int slot_of(int dev, const void* stream, Idle&& stream_idle) {
     std::lock_guard<std::mutex> g(mu_);
@@ -33,7 +46,7 @@ class PersistSlotTable {
       if (oldest < 0 || !stream_idle(e_[oldest].dev, e_[oldest].stream)) return -1;
       free_slot = oldest;
     }
-    e_[free_slot] = Ent{true, dev, stream, tick_};
+    e_[free_slot] = Ent{true, dev, stream, tick_, e_[free_slot].set};  // (the sets keep their turn when a slot changes hands: its last launch zeroed the one that is next)
     return free_slot;
   }
   int used() {
@@ -44,7 +57,7 @@ class PersistSlotTable {
   }
 
  private:
-  struct Ent { bool used; int dev; const void* stream; uint64_t tick; };
+  struct Ent { bool used; int dev; const void* stream; uint64_t tick; int set; };
   std::mutex mu_;
   Ent e_[kPersistSlots] = {};
   uint64_t tick_ = 0;
