@@ -215,15 +215,45 @@ public:
   }
 };
 
+// The numpy array that OWNS a frame's memory (the end of the .base chain), if the frame is a plain view of it: the object HostPinCache may
+// key a page-locked registration on — its death (a weak-reference callback) is when the memory can go away.  nullptr: nobody to vouch for the
+// memory (a bytes / bytearray / mmap / foreign buffer at the root, an array that does not own its data): the upload stages a copy as before.
+static PyObject* frame_owner(const py::array& f) {
+  py::handle o = f;
+  for (int depth = 0; depth < 8; depth++) {
+    if (!py::isinstance<py::array>(o)) return nullptr;
+    py::object base = py::reinterpret_borrow<py::array>(o).base();
+    if (!base || base.is_none()) return py::reinterpret_borrow<py::array>(o).owndata() ? o.ptr() : nullptr;
+    o = base;  // (borrowed: the chain is kept alive by `f` for the duration of the call)
+    if (py::isinstance<py::capsule>(o)) return nullptr;  // AllocPinned(): page-locked already
+  }
+  return nullptr;
+}
+static void vouch_for_frame(const py::array& f, const void* data, size_t bytes, int device) {
+  PyObject* owner = frame_owner(f);
+  if (!owner) return;
+  const uint64_t id = (uint64_t)(uintptr_t)owner;
+  if (HostPinCache::note_use(data, bytes, id, device) != HostPinCache::kFirstSight) return;
+  // the owner's first buffer: from now on its death unregisters whatever was page-locked on its behalf (before numpy frees the memory:
+  // weak-reference callbacks run before tp_dealloc releases the data)
+  py::weakref(py::handle(owner), py::cpp_function([id](py::handle wr) {
+                HostPinCache::owner_gone(id);
+                wr.dec_ref();
+              })).release();
+}
+
 class PyFrameUploader {
   std::unique_ptr<CudaUploadFrame> up_;
   Pixel_Format fmt_;
+  int dev_ = 0;
 
 public:
   PyFrameUploader(uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str) : fmt_(f) {
     up_.reset(CudaUploadFrame::Make(str, ctx, w, h, f));
+    dev_ = DeviceOfContext(ctx);  // (-1: whatever device is current)
   }
   Pixel_Format GetFormat() const { return fmt_; }
+  int Device() const { return dev_; }
   void SetAsync(bool on) { up_->SetAsync(on); }
   bool GetAsync() const { return up_->GetAsync(); }
   std::shared_ptr<Surface> Upload(void* data, size_t bytes) {
@@ -572,11 +602,11 @@ PYBIND11_MODULE(_PyNvCodec, m) {
            "page-locked source frame must stay untouched until that stream is synchronised).  Default False = wait for the copy, like the reference. "
            "VPF_HIP_UPLOAD_ASYNC=1 makes True the default")
       .def("GetAsync", &PyFrameUploader::GetAsync)
-      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size()); },
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { vouch_for_frame(f, f.data(), (size_t)f.size(), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size()); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
-      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { vouch_for_frame(f, f.data(), (size_t)f.size() * sizeof(float), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
-      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint16_t>& f) { return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(uint16_t)); },
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint16_t>& f) { vouch_for_frame(f, f.data(), (size_t)f.size() * sizeof(uint16_t), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(uint16_t)); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>());
 
   py::class_<PySurfaceDownloader>(m, "PySurfaceDownloader")
@@ -644,6 +674,14 @@ PYBIND11_MODULE(_PyNvCodec, m) {
           return py::array_t<uint8_t>({(py::ssize_t)nbytes}, {(py::ssize_t)1}, b->GetDataAs<uint8_t>(), owner);
         },
         py::arg("nbytes"), "additive: page-locked host buffer as a numpy uint8 array (decode straight into it)");
+  m.def("PinCacheStats", []() {
+    const HostPinCache::Stats t = HostPinCache::stats();
+    py::dict d;
+    d["registered"] = t.registered; d["bytes"] = t.bytes; d["in_place"] = t.hits; d["staged"] = t.staged; d["evictions"] = t.evictions; d["failures"] = t.failures;
+    return d;
+  }, "additive: the cache of page-locked caller frame buffers (Tasks.hpp HostPinCache): buffers registered now, their bytes, uploads DMA'd in place / "
+     "staged through a copy since start, registrations given up, registrations that failed");
+  m.def("PinCacheDrop", []() { HostPinCache::drop_all(); }, "additive: unregister every page-locked caller buffer");
   m.def("_UseHostAllocator", [](bool on) {
     static const DeviceAllocator host = {host_alloc, host_free, nullptr};
     SetDeviceAllocator(on ? &host : nullptr);

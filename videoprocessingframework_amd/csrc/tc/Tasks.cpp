@@ -14,6 +14,7 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <vector>
@@ -663,6 +664,107 @@ TaskExecStatus RemapSurface::RunBatch(Surface* const* ins, Surface* const* outs,
     return TASK_EXEC_FAIL;
   }
   return TASK_EXEC_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------ HostPinCache (Tasks.hpp)
+namespace {
+struct PinEnt {
+  uintptr_t p; size_t n; uint64_t owner; uint64_t tick; int dev; bool registered, failed;
+};
+struct PinState {
+  std::mutex mu;
+  std::vector<PinEnt> e;
+  uint64_t tick = 0;
+  HostPinCache::Stats st{};
+  size_t cap_bytes = [] {
+    const char* v = std::getenv("VPF_HIP_PIN_CACHE_MB");
+    return (size_t)(v ? std::strtoull(v, nullptr, 10) : 1024ull) << 20;
+  }();
+};
+PinState& pins() { static PinState* s = new PinState; return *s; }  // (leaked on purpose: weak-reference callbacks may run during interpreter shutdown)
+constexpr size_t kPinMaxEntries = 64, kPinMinBytes = 256u << 10;
+// a DMA that an asynchronous upload queued from this range may still be running: the device it was used on is drained first
+void pin_release(PinState& S, PinEnt& x) {
+  if (!x.registered) return;
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess) {
+    if (x.dev >= 0 && x.dev != cur) (void)hipSetDevice(x.dev);
+    (void)hipDeviceSynchronize();
+    if (x.dev >= 0 && x.dev != cur) (void)hipSetDevice(cur);
+  }
+  if (hipHostUnregister(reinterpret_cast<void*>(x.p)) != hipSuccess) (void)hipGetLastError();
+  x.registered = false;
+  S.st.registered--; S.st.bytes -= x.n; S.st.evictions++;
+}
+}  // namespace
+HostPinCache::Use HostPinCache::note_use(const void* ptr, size_t bytes, uint64_t owner, int device) {
+  PinState& S = pins();
+  if (!S.cap_bytes || !ptr || bytes < kPinMinBytes || bytes > S.cap_bytes) return kStaged;
+  const uintptr_t p = reinterpret_cast<uintptr_t>(ptr);
+  std::lock_guard<std::mutex> g(S.mu);
+  S.tick++;
+  bool owner_known = false;
+  PinEnt* hit = nullptr;
+  for (size_t i = 0; i < S.e.size();) {
+    PinEnt& x = S.e[i];
+    owner_known = owner_known || x.owner == owner;
+    if (x.p == p && x.n == bytes && x.owner == owner) { hit = &x; i++; continue; }
+    if (x.p < p + bytes && p < x.p + x.n) {  // overlaps under another owner / other bounds: whatever was there is gone
+      pin_release(S, x);
+      S.e.erase(S.e.begin() + (ptrdiff_t)i);
+      hit = nullptr;  // (erase moved the elements: look the hit up again below)
+      for (PinEnt& y : S.e) if (y.p == p && y.n == bytes && y.owner == owner) hit = &y;
+      continue;
+    }
+    i++;
+  }
+  if (hit) {
+    hit->tick = S.tick; hit->dev = device;
+    if (hit->registered) { S.st.hits++; return kInPlace; }
+    if (hit->failed) { S.st.staged++; return kStaged; }
+    // second sight: register, making room first (least recently used registered entries leave)
+    while (S.st.bytes + bytes > S.cap_bytes) {
+      PinEnt* lru = nullptr;
+      for (PinEnt& x : S.e) if (x.registered && (!lru || x.tick < lru->tick)) lru = &x;
+      if (!lru) break;
+      pin_release(S, *lru);
+    }
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable) == hipSuccess) {
+      hit->registered = true;
+      S.st.registered++; S.st.bytes += bytes; S.st.hits++;
+      return kInPlace;
+    }
+    (void)hipGetLastError();
+    hit->failed = true; S.st.failures++; S.st.staged++;
+    return kStaged;
+  }
+  if (S.e.size() >= kPinMaxEntries) {  // the least recently used entry leaves
+    size_t lru = 0;
+    for (size_t i = 1; i < S.e.size(); i++) if (S.e[i].tick < S.e[lru].tick) lru = i;
+    pin_release(S, S.e[lru]);
+    S.e.erase(S.e.begin() + (ptrdiff_t)lru);
+  }
+  S.e.push_back(PinEnt{p, bytes, owner, S.tick, device, false, false});
+  S.st.staged++;
+  return owner_known ? kStaged : kFirstSight;
+}
+void HostPinCache::owner_gone(uint64_t owner) {
+  PinState& S = pins();
+  std::lock_guard<std::mutex> g(S.mu);
+  for (size_t i = 0; i < S.e.size();) {
+    if (S.e[i].owner == owner) { pin_release(S, S.e[i]); S.e.erase(S.e.begin() + (ptrdiff_t)i); } else i++;
+  }
+}
+void HostPinCache::drop_all() {
+  PinState& S = pins();
+  std::lock_guard<std::mutex> g(S.mu);
+  for (PinEnt& x : S.e) pin_release(S, x);
+  S.e.clear();
+}
+HostPinCache::Stats HostPinCache::stats() {
+  PinState& S = pins();
+  std::lock_guard<std::mutex> g(S.mu);
+  return S.st;
 }
 
 // ------------------------------------------------------------------------------------------ CudaUploadFrame

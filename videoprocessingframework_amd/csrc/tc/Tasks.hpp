@@ -97,6 +97,25 @@ private:
   RemapSurface(const float* x_map, const float* y_map, uint32_t w, uint32_t h, Pixel_Format f, HipContext ctx, HipStream str);
 };
 
+// Page-locking of CALLER frame buffers that are seen again and again (round 6).  A frame in pageable memory costs the host three times its
+// bytes of DRAM traffic per upload (host copy read, pinned-slot write, DMA read) and a core's time for the copy; a decoder's frame pool is a
+// small fixed set of buffers, so the second time a buffer shows up it is registered (hipHostRegister) and from then on DMA'd from where it
+// lies, like an AllocPinned() buffer.  The cache cannot know when a caller frees memory, so it only takes buffers somebody VOUCHES for:
+// `owner` names whatever keeps the memory alive (the Python binding passes the numpy array that owns the data and calls owner_gone() from a
+// weak-reference callback when that array dies; a C++ caller passes any id and calls owner_gone() before it frees).  A range that overlaps a
+// registered one under another owner or other bounds evicts it first: a freed-and-reallocated buffer at an old address is a NEW buffer.
+// Least recently used entries leave when the cache is full (VPF_HIP_PIN_CACHE_MB, default 1024; 0 switches it off; at most 64 buffers).
+// One-shot buffers keep the staged copy.  Process-wide, thread-safe.
+class HostPinCache {
+public:
+  enum Use { kStaged = 0, kInPlace = 1, kFirstSight = 2 };  // kFirstSight: `owner` has no buffer here yet (the binding installs its weak reference now)
+  static Use note_use(const void* p, size_t bytes, uint64_t owner, int device);
+  static void owner_gone(uint64_t owner);
+  static void drop_all();
+  struct Stats { uint64_t registered, bytes, hits, staged, evictions, failures; };
+  static Stats stats();
+};
+
 // host frame (planes concatenated at tight width) -> device Surface
 class CudaUploadFrame final : public Task {
 public:
