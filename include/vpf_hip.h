@@ -237,6 +237,8 @@ VPF_API void vpf_trace_pop(int opened);
  *   40       the narrower fast paths instead of the 16-px "r16" / tiled / quad kernels (A/B runs, test coverage)
  *   43       resize: the tiled separable kernel for bilinear down-scales as well (default: up-scales only)
  *   48       fused convert + resize: the workgroup-shared strip also beyond ~2x down-scales, where the policy takes the per-tap kernel
+ *   49       fused convert + resize: the per-tap kernel's row-band form (four rows per wave) at every general factor and launch size
+ *            (policy: beyond ~2x, on launches of >= 2048 workgroups)
  *   4, 8, 12, 30, 37, 44, 45, 46   one named NV12 / YUV420 -> RGB kernel of the default policy's set (k_yuv2rgb.hip launch_420)
  * Any other value is rejected: -1 is returned and nothing changes.  This library holds the kernels some policy path can select, nothing
  * else: the experimental kernels and bandwidth probes of round 1 live in tools/lab/libvpfhip_lab.so, and the kernel FORMS that were

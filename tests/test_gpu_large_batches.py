@@ -98,7 +98,7 @@ def test_convert_resize_batch_beyond_32_frames(capi, capi_forms, oracle, sf, df)
         srcs = [oracle.synth(osf, sw, sh, 7500 + 10 * si + i) for i in range(NSRC)]
         wants = [oracle.convert_resize(osf, odf, 1, 0, sw, sh, s, dw, dh)[1] for s in srcs]
         S = [DevPlanes(srcs[i % NSRC]) for i in range(max(NS))]
-        for variant in ((0, 47, 48) if si < 2 else (0,)):
+        for variant in ((0, 47, 48, 49) if si < 2 else (0, 49) if si == 4 else (0,)):
             for n in (NS if (si < 2 and variant == 0) else (128, 129)):
                 D = [DevPlanes(oracle.alloc(odf, dw, dh, fill=0x5A)) for _ in range(n)]
                 lib = capi_forms if variant == 47 else capi  # (47, the per-wave strips of rounds 2-4: the lab build of the library)

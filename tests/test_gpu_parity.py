@@ -414,7 +414,25 @@ def test_fused_convert_resize_batch(capi, oracle):
         assert_planes_equal(got, want, f"fused batch frame {i}")
 
 
-@pytest.mark.parametrize("variant", [0, 47, 48])
+@pytest.mark.parametrize("sf,df,sw,sh,dw,dh,n", [("NV12", "RGB", 1920, 1080, 800, 450, 32), ("YUV420", "RGB_PLANAR", 1280, 720, 500, 300, 64), ("NV12", "BGR", 1920, 1080, 803, 401, 33)])
+def test_fused_row_band_by_policy(capi, oracle, sf, df, sw, sh, dw, dh, n):
+    """factors beyond ~2x on launches that cover the chip: the POLICY takes the per-tap kernel's row-band form (k_convert_resize_band, round 6: four
+    rows per wave, column taps once, the next row's strips in flight, pairs across the two source rows).  Every frame == convert-then-resize
+    (the oracle), through the 32- and the 128-frame table, ragged right edge and bottom band included."""
+    osf, odf = getattr(oracle, sf), getattr(oracle, df)
+    srcs = [oracle.synth(osf, sw, sh, 8800 + i) for i in range(3)]
+    wants = [oracle.convert_resize(osf, odf, 1, 0, sw, sh, s, dw, dh)[1] for s in srcs]
+    S = [DevPlanes(srcs[i % 3]) for i in range(n)]
+    D = [DevPlanes(oracle.alloc(odf, dw, dh, fill=0x5A)) for _ in range(n)]
+    capi.convert_resize_batch(capi.make_exec(stream_handle()), getattr(capi, sf), getattr(capi, df), 1, 0, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(S, D)]))
+    torch.cuda.synchronize()
+    for i in range(n):
+        got, intact = D[i].download()
+        assert intact
+        assert_planes_equal(got, wants[i % 3], f"fused row band {sf}->{df} {sw}x{sh}->{dw}x{dh} frame {i} of {n}")
+
+
+@pytest.mark.parametrize("variant", [0, 47, 48, 49])  # 49: the per-tap kernel's row-band form (round 6) on the same shapes
 def test_fused_strip_kernels_at_every_band_height(capi, capi_forms, oracle, variant):
     """k_convert_strip_wg (round 5: one RGB strip per workgroup, conversions dealt out over all 256 lanes) with R = 16 / 8 / 4 / 2 rows per
     wave — the launcher picks R from the strip's LDS bytes and the number of workgroups, so batches of mid-sized frames reach every
@@ -712,7 +730,7 @@ def test_fuzz_resize_and_fused(capi, capi_forms, oracle, seed):
         align = int(rng.choice([256, 256, 16, 4, 1]))
         variant = int(rng.choice([0, 0, 40, 43, 9]))
         if rng.integers(4) == 0:  # fused NV12 / YUV420 -> resize -> RGB family
-            variant = int(rng.choice([variant, variant, 47, 48]))  # (+ the per-wave strips of rounds 2-4 / workgroup strips beyond 2x)
+            variant = int(rng.choice([variant, variant, 47, 48, 49]))  # (+ the per-wave strips of rounds 2-4 / workgroup strips beyond 2x / the per-tap kernel's row-band form)
             sw, sh = sw + (sw & 1), sh + (sh & 1)
             sf, df = str(rng.choice(["NV12", "YUV420"])), str(rng.choice(["RGB", "BGR", "RGB_PLANAR"]))
             src = oracle.synth(getattr(oracle, sf), sw, sh, int(rng.integers(1 << 30)))
@@ -896,7 +914,7 @@ def test_tuning_hook_rejects_values_outside_the_product(capi):
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v) == -1
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == 0      # unchanged
     assert capi.set_tuning(7, 0) == -1                                    # unknown key
-    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46, 48):
+    for v in (4, 8, 9, 12, 30, 37, 40, 43, 44, 45, 46, 48, 49):
         capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, v)
         assert capi.set_tuning(capi.TUNE_NV12_RGB_VARIANT, 0) == v
     # forms no policy selects are not in the product (lab build: tools/lab/libvpfhip_forms.so): their knob values change nothing here

@@ -289,6 +289,159 @@ __global__ __launch_bounds__(256) void k_convert_resize_lds_one(const uint8_t* s
 
 
 // ------------------------------------------------------------------------------------------
+// The per-tap kernel as a ROW BAND (round 6): factors beyond ~2x (4K -> 1600 x 900, 1080p -> 800 x 450: every destination row has source rows
+// of its own, four conversions per destination pixel whatever the kernel) spent a quarter of their ~100 VALU instructions per pixel on work
+// that does not depend on the row — make_tap and the tap offsets of the four columns of a lane (17 per pixel) — and on a horizontal lerp
+// evaluated row by row in scalar fp32.  Here a wave walks down R destination rows of its 256 columns: the column taps are computed once, the
+// NEXT row's four (six) source strips are requested before this row is converted (the wave hides its own memory latency and pays its fixed
+// part once per R rows), and everything runs on PAIRS ACROSS THE TWO SOURCE ROWS ({upper row, lower row} of one tap: v_pk_fma_f32), so the
+// horizontal lerp of both rows is one v_pk_add_f32 + one v_pk_fma_f32 per channel.  Every component goes through the operations of
+// convert_resize_lds_task in its order (fma(0, finite, p) == p covers the right picture edge): the same bytes.  No zero-weight shortcuts:
+// odd integer factors keep convert_resize_lds_task, whose shortcuts skip whole rows and taps.
+// ------------------------------------------------------------------------------------------
+template <int SRC, int DST, int IT, int R>
+VPF_DEV void convert_resize_band_task(const FrameDesc& f, const Yuv2RgbCoef& c, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, float scx,
+                                      float scy, int vec_ok, uint32_t rowq, uint32_t bx, uint32_t by) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t y0 = (by * 4 + wv) * R;
+  if (y0 >= dh || bx * 256 >= dw) return;
+  const uint32_t xs = bx * 256, xe = (xs + 255 < dw - 1) ? xs + 255 : dw - 1;
+  const uint32_t first = make_tap<VPF_INTERP_LINEAR>(xs, scx, sw).i0, last = make_tap<VPF_INTERP_LINEAR>(xe, scx, sw).i1;
+  const uint32_t ybase = first & ~15u, ynq = (last + 1 - ybase + 15) / 16;
+  uint32_t cbase, cnq;
+  if constexpr (SRC == FC_NV12) {
+    cbase = (2 * (first >> 1)) & ~15u; cnq = (2 * (last >> 1) + 2 - cbase + 15) / 16;
+  } else {
+    cbase = (first >> 1) & ~15u; cnq = ((last >> 1) + 1 - cbase + 15) / 16;
+  }
+  constexpr int NS = (SRC == FC_NV12) ? 4 : 6;
+  u32x4* const wstrip = dyn_strip + wv * NS * rowq;
+  auto strip_at = [&](int k) { return reinterpret_cast<const uint8_t*>(wstrip + k * rowq); };
+  // ---- the column side, once for the R rows
+  const uint32_t x0 = xs + lane * 4;
+  const bool draws = x0 < dw;
+  const uint32_t nv = !draws ? 0u : dw - x0 < 4 ? dw - x0 : 4;
+  uint32_t l0[4], l1[4], a0[4], a1[4];
+  float fx[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const Tap tx = make_tap<VPF_INTERP_LINEAR>((x0 + k < dw) ? x0 + k : dw - 1, scx, sw);
+    l0[k] = tx.i0 - ybase; l1[k] = tx.i1 - ybase; fx[k] = tx.f;
+    a0[k] = (SRC == FC_NV12 ? (tx.i0 & ~1u) : (tx.i0 >> 1)) - cbase; a1[k] = (SRC == FC_NV12 ? (tx.i1 & ~1u) : (tx.i1 >> 1)) - cbase;
+  }
+  // ---- the row side: strips of one destination row requested (all loads in flight together), then written to LDS
+  Span<IT> sp_[NS];
+  uint32_t r_i0 = 0, r_i1 = 0;
+  float r_f = 0.f;
+  bool row1 = false, one_crow = true;
+  auto request = [&](uint32_t y) {
+    const Tap ty = make_tap<VPF_INTERP_LINEAR>(y, scy, sh);
+    r_i0 = __builtin_amdgcn_readfirstlane(ty.i0); r_i1 = __builtin_amdgcn_readfirstlane(ty.i1);
+    r_f = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ty.f)));
+    row1 = r_f != 0.f;
+    one_crow = !row1 || (r_i0 >> 1) == (r_i1 >> 1);
+    sp_[0].load(f.s[0] + (size_t)r_i0 * f.sp[0], ybase, ynq, lane);
+    if (row1) sp_[1].load(f.s[0] + (size_t)r_i1 * f.sp[0], ybase, ynq, lane);
+    sp_[2].load(f.s[1] + (size_t)(r_i0 >> 1) * f.sp[1], cbase, cnq, lane);
+    if (!one_crow) sp_[3].load(f.s[1] + (size_t)(r_i1 >> 1) * f.sp[1], cbase, cnq, lane);
+    if constexpr (SRC != FC_NV12) {
+      sp_[4].load(f.s[2] + (size_t)(r_i0 >> 1) * f.sp[2], cbase, cnq, lane);
+      if (!one_crow) sp_[5].load(f.s[2] + (size_t)(r_i1 >> 1) * f.sp[2], cbase, cnq, lane);
+    }
+  };
+  auto commit = [&]() {
+    sp_[0].store(wstrip, ynq, lane);
+    if (row1) sp_[1].store(wstrip + rowq, ynq, lane);
+    sp_[2].store(wstrip + 2 * rowq, cnq, lane);
+    if (!one_crow) sp_[3].store(wstrip + 3 * rowq, cnq, lane);
+    if constexpr (SRC != FC_NV12) {
+      sp_[4].store(wstrip + 4 * rowq, cnq, lane);
+      if (!one_crow) sp_[5].store(wstrip + 5 * rowq, cnq, lane);
+    }
+    wave_lds_sync();
+  };
+  const f32x2 cy2 = {c.cy, c.cy}, rv2 = {c.rv, c.rv}, gu2 = {c.gu, c.gu}, gv2 = {c.gv, c.gv}, bu2 = {c.bu, c.bu};
+  const f32x2 br2 = {c.br, c.br}, bg2 = {c.bg, c.bg}, bb2 = {c.bb, c.bb};
+  auto rnd = [](f32x2 t) { return f32x2{(float)sat_rne(t[0]), (float)sat_rne(t[1])}; };
+  request(y0);
+#pragma unroll 1
+  for (uint32_t r = 0; r < (uint32_t)R; r++) {
+    const uint32_t y = y0 + r;
+    commit();
+    const bool row1_k = row1, one_crow_k = one_crow;
+    const float fy = r_f;
+    const bool more = r + 1 < (uint32_t)R && y + 1 < dh;
+    if (more) request(y + 1);  // in flight while this row is converted
+    if (draws) {
+      const int lr = row1_k ? 1 : 0, cr = one_crow_k ? 0 : 1;  // the strip that stands for the lower source row (the upper one itself where there is none: weight 0 / never blended)
+      const uint8_t* const y_up = strip_at(0);
+      const uint8_t* const y_lo = strip_at(lr);
+      float o[3][4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // chroma terms of tap t on {upper, lower} source row
+        f32x2 rc[2], gc[2], bc[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const uint32_t a = t ? a1[k] : a0[k];
+          f32x2 u, v;
+          if constexpr (SRC == FC_NV12) {
+            const uint32_t du = *reinterpret_cast<const uint16_t*>(strip_at(2) + a), dl = *reinterpret_cast<const uint16_t*>(strip_at(2 + cr) + a);
+            u = f32x2{ubyte<0>(du), ubyte<0>(dl)}; v = f32x2{ubyte<1>(du), ubyte<1>(dl)};
+          } else {
+            u = f32x2{(float)strip_at(2)[a], (float)strip_at(2 + cr)[a]}; v = f32x2{(float)strip_at(4)[a], (float)strip_at(4 + cr)[a]};
+          }
+          rc[t] = __builtin_elementwise_fma(v, rv2, br2);
+          gc[t] = __builtin_elementwise_fma(u, gu2, __builtin_elementwise_fma(v, gv2, bg2));
+          bc[t] = __builtin_elementwise_fma(u, bu2, bb2);
+        }
+        const f32x2 yv0 = {(float)y_up[l0[k]], (float)y_lo[l0[k]]}, yv1 = {(float)y_up[l1[k]], (float)y_lo[l1[k]]};
+        const f32x2 fx2 = {fx[k], fx[k]};
+        const f32x2 r0 = rnd(__builtin_elementwise_fma(yv0, cy2, rc[0])), r1 = rnd(__builtin_elementwise_fma(yv1, cy2, rc[1]));
+        const f32x2 g0 = rnd(__builtin_elementwise_fma(yv0, cy2, gc[0])), g1 = rnd(__builtin_elementwise_fma(yv1, cy2, gc[1]));
+        const f32x2 b0 = rnd(__builtin_elementwise_fma(yv0, cy2, bc[0])), b1 = rnd(__builtin_elementwise_fma(yv1, cy2, bc[1]));
+        const f32x2 hr = __builtin_elementwise_fma(fx2, r1 - r0, r0), hg = __builtin_elementwise_fma(fx2, g1 - g0, g0), hb = __builtin_elementwise_fma(fx2, b1 - b0, b0);  // {top, bot}
+        if (row1_k) {
+          o[0][k] = __builtin_fmaf(fy, hr[1] - hr[0], hr[0]) + 0.5f; o[1][k] = __builtin_fmaf(fy, hg[1] - hg[0], hg[0]) + 0.5f; o[2][k] = __builtin_fmaf(fy, hb[1] - hb[0], hb[0]) + 0.5f;
+        } else {
+          o[0][k] = hr[0] + 0.5f; o[1][k] = hg[0] + 0.5f; o[2][k] = hb[0] + 0.5f;
+        }
+      }
+      if constexpr (DST == FC_PLANAR) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          uint8_t* out = f.d[ch] + (size_t)y * f.dp[ch] + x0;
+          if (vec_ok && nv == 4) stg<false, uint32_t>(out, pack4_trunc(o[ch][0], o[ch][1], o[ch][2], o[ch][3]));
+          else for (uint32_t i = 0; i < nv; i++) out[i] = (uint8_t)(uint32_t)(o[ch][i]);
+        }
+      } else {
+        constexpr int a = (DST == FC_BGR) ? 2 : 0, b = (DST == FC_BGR) ? 0 : 2;
+        uint8_t* out = f.d[0] + (size_t)y * f.dp[0] + 3 * (size_t)x0;
+        if (vec_ok && nv == 4) {
+          const float t[12] = {o[a][0], o[1][0], o[b][0], o[a][1], o[1][1], o[b][1], o[a][2], o[1][2], o[b][2], o[a][3], o[1][3], o[b][3]};
+          uint32_t d0, d1, d2;
+          pack12_trunc(t, d0, d1, d2);
+          stg3<false>(out, d0, d1, d2);
+        } else {
+          for (uint32_t i = 0; i < nv; i++) {
+            out[3 * i] = (uint8_t)(uint32_t)(o[a][i]); out[3 * i + 1] = (uint8_t)(uint32_t)(o[1][i]); out[3 * i + 2] = (uint8_t)(uint32_t)(o[b][i]);
+          }
+        }
+      }
+    }
+    if (!more) break;
+    wave_lds_sync();  // this row's LDS reads are done before the next row's strips overwrite them
+  }
+}
+template <int SRC, int DST, int IT, int R, class BA = BatchArgs>
+__global__ __launch_bounds__(256) void k_convert_resize_band(const BA args, const Yuv2RgbCoef c, uint32_t sw, uint32_t sh,
+                                                             uint32_t dw, uint32_t dh, float scx, float scy, int vec_ok, uint32_t rowq) {
+  const BlockId b = picture_order();  // XCD-aware numbering (k_resize_common.h)
+  convert_resize_band_task<SRC, DST, IT, R>(args.f[b.z], c, sw, sh, dw, dh, scx, scy, vec_ok, rowq, b.x, b.y);
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact 2x down-scale (4K -> 1080p, 1080p -> 540p ...): s = (d + 0.5) * 2 - 0.5 = 2d + 0.5 exactly, so every destination
 // pixel is the bilerp with fx = fy = 0.5 of the 2 x 2 block (2x..2x+1, 2y..2y+1), which shares ONE chroma sample.  That
 // structure needs no tap arithmetic, no LDS gathers and one chroma evaluation per destination pixel: a lane converts
@@ -676,7 +829,7 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
   {
     const bool odd_x = sw % dw == 0 && ((sw / dw) & 1), odd_y = sh % dh == 0 && ((sh / dh) & 1);
     bool ok8 = (src_fc == FC_NV12 || src_fc == FC_YUV420) && sw % 8 == 0 && !odd_x && !odd_y && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 40 &&
-               tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && sw < (1u << 22) && sh < (1u << 22);
+               tuning(VPF_TUNE_NV12_RGB_VARIANT) != 9 && tuning(VPF_TUNE_NV12_RGB_VARIANT) != 49 && sw < (1u << 22) && sh < (1u << 22);
     for (uint32_t i = 0; i < n && ok8; i++)
       for (int k = 0; k < (src_fc == FC_NV12 ? 2 : 3); k++) ok8 = ok8 && !(((uintptr_t)a.f[i].s[k] | a.f[i].sp[k]) & 7);
     if (ok8) {
@@ -764,8 +917,26 @@ hipError_t launch_convert_resize(hipStream_t st, int src_fc, int dst_fc, const Y
 #endif  // VPF_LAB_FORMS
     }
   }
-  dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);
   const uint32_t lds = 4 * (src_fc == FC_NV12 ? 4 : 6) * rowb;
+  // factors beyond ~2x on a launch that covers the chip with four rows per wave: the per-tap kernel as a row band (k_convert_resize_band);
+  // odd integer factors keep the row-at-a-time kernel below and its zero-weight shortcuts.  VPF_TUNE_NV12_RGB_VARIANT = 40 / 9 keep it too.
+  {
+    const bool odd_x = sw % dw == 0 && ((sw / dw) & 1), odd_y = sh % dh == 0 && ((sh / dh) & 1);
+    const int v = tuning(VPF_TUNE_NV12_RGB_VARIANT);
+    if ((src_fc == FC_NV12 || src_fc == FC_YUV420) && lds_ok && !odd_x && !odd_y && v != 40 && v != 9 && sw < (1u << 22) && sh < (1u << 22) &&
+        ((uint64_t)((dw + 255) / 256) * ((dh + 15) / 16) * n >= 2048u || v == 49)) {  // 49: whatever the launch size (tests, A/B runs)
+      dim3 bgrid((dw + 255) / 256, (dh + 15) / 16, n);
+#define VPF_BAND1(S, D, I) VPF_LAUNCH_BA(k_convert_resize_band, (S, D, I, 4), bgrid, dim3(256), lds, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16)
+#define VPF_BAND(S, D) do { if (rowb <= 1024) VPF_BAND1(S, D, 1); else VPF_BAND1(S, D, 2); } while (0)
+#define VPF_BANDD(S) do { if (dst_fc == FC_RGB) VPF_BAND(S, FC_RGB); else if (dst_fc == FC_BGR) VPF_BAND(S, FC_BGR); else VPF_BAND(S, FC_PLANAR); } while (0)
+      if (src_fc == FC_NV12) VPF_BANDD(FC_NV12); else VPF_BANDD(FC_YUV420);
+#undef VPF_BANDD
+#undef VPF_BAND
+#undef VPF_BAND1
+      return hipGetLastError();
+    }
+  }
+  dim3 grid(((dw + 3) / 4 + 63) / 64, (dh + 3) / 4, n);
 #define VPF_GOL1(S, D, I) do { if (n == 1) VPF_LAUNCH((k_convert_resize_lds_one<S, D, I>), grid, dim3(256), lds, st, a.f[0].s[0], a.f[0].s[1], a.f[0].sp[0], a.f[0].sp[1], \
                                                       sw, sh, dw, dh, scx, scy, rowb / 16, vec_ok, a.f[0].s[2], a.f[0].sp[2], VPF_ONE_DST_ARGS(a.f[0]), c); \
                                else VPF_LAUNCH_BA(k_convert_resize_lds, (S, D, I), grid, dim3(256), lds, st, c, sw, sh, dw, dh, scx, scy, vec_ok, rowb / 16); } while (0)

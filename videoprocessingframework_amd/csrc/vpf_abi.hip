@@ -487,7 +487,7 @@ int vpf_set_tuning(int key, int value) {
 #ifdef VPF_LAB_FORMS
     case 47:  // the per-wave strips of the fused kernel (rounds 2-4): lab build only
 #endif
-    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: case 48: return g_tune_variant.exchange(value);
+    case 0: case 4: case 8: case 9: case 12: case 30: case 37: case 40: case 43: case 44: case 45: case 46: case 48: case 49: return g_tune_variant.exchange(value);
     default: return -1;  // unknown value: nothing changes
   }
 }
