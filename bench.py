@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from videoprocessingframework_amd import capi, sharding  # noqa: E402  (capi raises if libvpfhip.so is missing: no fallback)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"  # newest PMC traffic summary of the headline kernel under profiles/
 
 
 def _pitched(rows, row_bytes, dev, gen=None, align=256):

@@ -52,4 +52,6 @@ def test_shard_pipeline_two_ranks_share_one_gpu():
                     "--width", "1920", "--height", "1080")
     assert out["n_gpus"] == 2 and out["clips"] == 4 and out["clips_per_rank"] == [[0, 2], [1, 3]]
     assert out["frames_total"] == 24 and out["verified_clips"] == 4
-    assert out["end_to_end"]["value"] > 0 and out["device_resident"]["value"] > out["end_to_end"]["value"]
+    # (both rates of a 6-frame run are launch-overhead numbers; that the device-resident one is the larger holds on an idle box only — the suite
+    # runs this next to three other workers — so only their presence is asserted; tools/shard_pipeline.py's own runs measure them)
+    assert out["end_to_end"]["value"] > 0 and out["device_resident"]["value"] > 0

@@ -126,20 +126,42 @@ def test_least_recently_used_buffers_leave_a_full_cache():
     assert int(nvc.PinCacheStats()["registered"]) == 0
 
 
-def test_async_uploads_from_registered_buffers():
-    """SetAsync(True): the copy is only queued when the call returns — a registration must not be pulled from under it (unregistering drains the device)"""
+def test_async_uploads_keep_the_staged_copy():
+    """SetAsync(True): the call returns with the copy only QUEUED and its contract lets the caller reuse an ordinary frame at once — so such uploads are
+    never read in place: not registered on their own, and copied out first when a blocking uploader had the buffer page-locked earlier"""
     nvc.PinCacheDrop()
+    rng = np.random.default_rng(8)
+    frame = rng.integers(0, 256, N, dtype=np.uint8)
+    blocking = nvc.PyFrameUploader(W, H, PF.NV12, 0)
+    for _ in range(2):
+        assert np.array_equal(download(blocking.UploadSingleFrame(frame)), frame)
+    assert int(nvc.PinCacheStats()["registered"]) == 1                                # page-locked by the blocking uploader
     up = nvc.PyFrameUploader(W, H, PF.NV12, 0)
     up.SetAsync(True)
-    rng = np.random.default_rng(8)
-    frames = [rng.integers(0, 256, N, dtype=np.uint8) for _ in range(3)]
-    surfs = []
-    for rnd in range(3):
-        for f in frames:
-            surfs.append((up.UploadSingleFrame(f).Clone(0), f))
+    s0 = nvc.PinCacheStats()
+    wants, surfs = [], []
+    for k in range(6):
+        frame[:] = rng.integers(0, 256, N, dtype=np.uint8)
+        wants.append(frame.copy())
+        surfs.append(up.UploadSingleFrame(frame).Clone(0))                            # ... and the frame is overwritten right away, next iteration
     torch.cuda.synchronize()
-    for s, f in surfs[-3:]:
-        assert np.array_equal(download(s), f)
-    del frames, surfs, s, f
+    for k in range(6):
+        assert np.array_equal(download(surfs[k]), wants[k]), k                        # every upload saw ITS bytes: they were copied out before the call returned
+    d = delta(s0)
+    assert d["in_place"] == 0 and d["registered"] == 0
+    fresh = [rng.integers(0, 256, N, dtype=np.uint8) for _ in range(2)]
+    for rnd in range(3):
+        for f in fresh:
+            up.UploadSingleFrame(f)
+    torch.cuda.synchronize()
+    assert delta(s0)["registered"] == 0                                               # asynchronous uploads do not register buffers
+    up.SetAsync(True, in_place=True)                                                  # ... unless the caller promises to leave frames alone until they are consumed
+    for rnd in range(3):
+        for f in fresh:
+            last = up.UploadSingleFrame(f).Clone(0)
+    torch.cuda.synchronize()
+    assert delta(s0)["registered"] == 2 and delta(s0)["in_place"] >= 4 and np.array_equal(download(last), fresh[-1])
+    del last
+    del frame, fresh, f, surfs
     gc.collect()
     assert int(nvc.PinCacheStats()["registered"]) == 0

@@ -39,7 +39,7 @@ import PyNvCodec as nvc  # noqa: E402
 def _async(up):
     """the pipeline's uploaders return once their copy is queued (additive SetAsync; the default waits for the copy like the reference): every
     consumer here runs on the uploader's own stream, and the stand-in decoder never rewrites a frame the stream has not consumed"""
-    up.SetAsync(True)
+    up.SetAsync(True, in_place=True)  # (pageable frames that come back are page-locked and read where they lie: the stand-in decoder keeps the promise)
     return up
 
 

@@ -254,8 +254,9 @@ public:
   }
   Pixel_Format GetFormat() const { return fmt_; }
   int Device() const { return dev_; }
-  void SetAsync(bool on) { up_->SetAsync(on); }
+  void SetAsync(bool on, bool in_place) { up_->SetAsync(on); up_->SetAsyncInPlace(on && in_place); }
   bool GetAsync() const { return up_->GetAsync(); }
+  bool Vouches() const { return !up_->GetAsync() || up_->GetAsyncInPlace(); }  // uploads that may read a caller frame in place: blocking ones, asynchronous ones on the caller's promise
   std::shared_ptr<Surface> Upload(void* data, size_t bytes) {
     py::gil_scoped_release nogil;  // the reference releases the GIL around uploads too (PyFrameUploader.cpp:118-160)
     std::unique_ptr<Buffer> raw(Buffer::Make(bytes, data));
@@ -597,16 +598,17 @@ PYBIND11_MODULE(_PyNvCodec, m) {
       .def(py::init([](uint32_t w, uint32_t h, Pixel_Format f, size_t ctx, size_t str) { return new PyFrameUploader(w, h, f, (HipContext)ctx, (HipStream)str); }),
            py::arg("width"), py::arg("height"), py::arg("format"), py::arg("context"), py::arg("stream"))
       .def("Format", &PyFrameUploader::GetFormat)
-      .def("SetAsync", &PyFrameUploader::SetAsync, py::arg("on"),
+      .def("SetAsync", &PyFrameUploader::SetAsync, py::arg("on"), py::arg("in_place") = false,
            "additive: True = UploadSingleFrame returns once the copy is queued (the surface is valid in stream order on the uploader's stream; a "
            "page-locked source frame must stay untouched until that stream is synchronised).  Default False = wait for the copy, like the reference. "
-           "VPF_HIP_UPLOAD_ASYNC=1 makes True the default")
+           "VPF_HIP_UPLOAD_ASYNC=1 makes True the default.  in_place=True: ordinary numpy frames that come back may be page-locked and read where they "
+           "lie as well (the caller promises for them what it promises for AllocPinned() frames); default: they are copied out before the call returns")
       .def("GetAsync", &PyFrameUploader::GetAsync)
-      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { vouch_for_frame(f, f.data(), (size_t)f.size(), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size()); },
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint8_t>& f) { if (self.Vouches()) vouch_for_frame(f, f.data(), (size_t)f.size(), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size()); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
-      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { vouch_for_frame(f, f.data(), (size_t)f.size() * sizeof(float), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<float>& f) { if (self.Vouches()) vouch_for_frame(f, f.data(), (size_t)f.size() * sizeof(float), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(float)); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>())
-      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint16_t>& f) { vouch_for_frame(f, f.data(), (size_t)f.size() * sizeof(uint16_t), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(uint16_t)); },
+      .def("UploadSingleFrame", [](PyFrameUploader& self, py::array_t<uint16_t>& f) { if (self.Vouches()) vouch_for_frame(f, f.data(), (size_t)f.size() * sizeof(uint16_t), self.Device()); return self.Upload(f.mutable_data(), (size_t)f.size() * sizeof(uint16_t)); },
            py::arg("frame").noconvert(true), py::keep_alive<0, 1>());
 
   py::class_<PySurfaceDownloader>(m, "PySurfaceDownloader")

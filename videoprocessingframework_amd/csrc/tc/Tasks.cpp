@@ -755,6 +755,14 @@ void HostPinCache::owner_gone(uint64_t owner) {
     if (S.e[i].owner == owner) { pin_release(S, S.e[i]); S.e.erase(S.e.begin() + (ptrdiff_t)i); } else i++;
   }
 }
+bool HostPinCache::covers(const void* ptr) {
+  PinState& S = pins();
+  const uintptr_t p = reinterpret_cast<uintptr_t>(ptr);
+  std::lock_guard<std::mutex> g(S.mu);
+  for (const PinEnt& x : S.e)
+    if (x.registered && p >= x.p && p < x.p + x.n) return true;
+  return false;
+}
 void HostPinCache::drop_all() {
   PinState& S = pins();
   std::lock_guard<std::mutex> g(S.mu);
@@ -775,6 +783,7 @@ HostPinCache::Stats HostPinCache::stats() {
 struct CudaUploadFrame::Impl {
   static constexpr int kSlots = 4;  // staging buffers / device surfaces in rotation: the host copy of frame i + 1 overlaps the DMA of frame i
   StreamRef sref;
+  bool async_in_place = false;  // SetAsyncInPlace(true): asynchronous uploads may read frames HostPinCache page-locked where they lie
   bool async = false;  // SetAsync(true) / VPF_HIP_UPLOAD_ASYNC=1: Run() returns once the copy is QUEUED (default: it waits for the copy, like the reference's task, Tasks.cpp:617-618)
   Pixel_Format fmt;
   hipStream_t copy_stream = nullptr;
@@ -810,6 +819,8 @@ CudaUploadFrame::CudaUploadFrame(HipStream str, HipContext ctx, uint32_t w, uint
 CudaUploadFrame::~CudaUploadFrame() {}
 void CudaUploadFrame::SetAsync(bool on) { pImpl->async = on; }
 bool CudaUploadFrame::GetAsync() const { return pImpl->async; }
+void CudaUploadFrame::SetAsyncInPlace(bool on) { pImpl->async_in_place = on; }
+bool CudaUploadFrame::GetAsyncInPlace() const { return pImpl->async_in_place; }
 CudaUploadFrame* CudaUploadFrame::Make(HipStream str, HipContext ctx, uint32_t w, uint32_t h, Pixel_Format f) {
   return new CudaUploadFrame(str, ctx, w, h, f);
 }
@@ -830,7 +841,10 @@ TaskExecStatus CudaUploadFrame::Run() {
   // memory is staged through the slot's pinned buffer (one host memcpy, then a true async copy)
   const uint8_t* src = host->GetDataAs<uint8_t>();
   hipPointerAttribute_t attr;
-  const bool pinned_src = (hipPointerGetAttributes(&attr, src) == hipSuccess) && attr.type == hipMemoryTypeHost;
+  bool pinned_src = (hipPointerGetAttributes(&attr, src) == hipSuccess) && attr.type == hipMemoryTypeHost;
+  // an asynchronous upload lets the caller reuse an ordinary frame at once: a frame that is page-locked only because HostPinCache registered it
+  // (by a blocking uploader, earlier) is still copied out first — unless the caller has promised to leave it alone (SetAsyncInPlace)
+  if (pinned_src && pImpl->async && !pImpl->async_in_place && HostPinCache::covers(src)) pinned_src = false;
   if (!pinned_src) {
     (void)hipGetLastError();  // a pageable pointer makes hipPointerGetAttributes fail: not an error for us
     host_copy_large(stage->GetRawMemPtr(), host->GetRawMemPtr(), s->HostMemSize());

@@ -105,12 +105,14 @@ private:
 // weak-reference callback when that array dies; a C++ caller passes any id and calls owner_gone() before it frees).  A range that overlaps a
 // registered one under another owner or other bounds evicts it first: a freed-and-reallocated buffer at an old address is a NEW buffer.
 // Least recently used entries leave when the cache is full (VPF_HIP_PIN_CACHE_MB, default 1024; 0 switches it off; at most 64 buffers).
-// One-shot buffers keep the staged copy.  Process-wide, thread-safe.
+// One-shot buffers keep the staged copy — and so does every ASYNCHRONOUS upload (SetAsync(true)): its contract lets the caller reuse an ordinary
+// frame the moment the call returns, which only holds while the frame is copied out before that.  Process-wide, thread-safe.
 class HostPinCache {
 public:
   enum Use { kStaged = 0, kInPlace = 1, kFirstSight = 2 };  // kFirstSight: `owner` has no buffer here yet (the binding installs its weak reference now)
   static Use note_use(const void* p, size_t bytes, uint64_t owner, int device);
   static void owner_gone(uint64_t owner);
+  static bool covers(const void* p);  // p lies in a range this cache has page-locked (not in an AllocPinned() buffer, which is the caller's own)
   static void drop_all();
   struct Stats { uint64_t registered, bytes, hits, staged, evictions, failures; };
   static Stats stats();
@@ -128,6 +130,10 @@ public:
   // next synchronisation of that stream.
   void SetAsync(bool on);
   bool GetAsync() const;
+  // Additive, asynchronous uploads only: frames that HostPinCache has page-locked may be read IN PLACE — the caller promises what it already promises
+  // for AllocPinned() frames: not to rewrite a frame before the stream has consumed it.  Default false: such frames are copied out first.
+  void SetAsyncInPlace(bool on);
+  bool GetAsyncInPlace() const;
 
 private:
   static const uint32_t numInputs = 1U, numOutputs = 1U;
