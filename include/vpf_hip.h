@@ -155,7 +155,8 @@ VPF_API vpf_status vpf_resize(const vpf_exec* exec, int fmt, int interp, vpf_siz
                               const vpf_plane src[3], vpf_size dst_size, const vpf_plane dst[3]);
 
 /* The same resize over `n` independent same-shape frames, every plane of every frame in as few dispatches as possible (one per 128
- * frames when a frame moves at most 7 000 000 bytes, source + destination — Y / NV12 / YUV420 at 1080p -> 720p and smaller —, else one
+ * frames when a frame moves at most 7 000 000 bytes, source + destination — Y / NV12 / YUV420 at 1080p -> 720p and smaller —, one per 64
+ * frames for bilinear / nearest frames of up to 10 000 000 bytes — packed RGB 1080p <-> 720p —, else one
  * per 32 frames; when all planes take the same kernel family — always the case for NV12 / YUV420 / planar surfaces allocated by this
  * library — one dispatch carries every plane).  A 720p plane is 2-3 us of GPU work, the same order as a kernel boundary: per-frame, per-plane dispatch leaves the chip
  * idle most of the time.  `frames` is a HOST array consumed before return.  vpf_resize is this call with n = 1. */
@@ -211,7 +212,7 @@ VPF_API vpf_status vpf_convert_resize(const vpf_exec* exec, int src_fmt, int dst
                                       const vpf_plane dst[3]);
 
 /* The same over `n` independent same-shape frames in as few dispatches as possible (one per 128 frames when a frame moves at most
- * 7 000 000 bytes, source + destination — up to 1080p -> 720p —, else one per 32 frames): a 720p output is ~2 us of HBM time, far below
+ * 7 000 000 bytes, source + destination — up to 1080p -> 720p —, one per 64 frames up to 10 000 000 bytes — 720p -> 1080p —, else one per 32 frames): a 720p output is ~2 us of HBM time, far below
  * a kernel boundary, so per-frame dispatch leaves the GPU mostly idle. */
 VPF_API vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int src_fmt, int dst_fmt, int color_space,
                                             int color_range, vpf_size src_size, vpf_size dst_size, uint32_t n,

@@ -173,7 +173,8 @@ def test_batch_sizes_in_the_docs_are_the_ones_in_the_code():
     abi = open(os.path.join(ROOT, "videoprocessingframework_amd", "csrc", "vpf_abi.hip")).read()
     small = int(re.search(r"constexpr int kSmallBatch = (\d+);", internal).group(1))
     large = int(re.search(r"constexpr int kMaxBatch = (\d+);", internal).group(1))
-    limit = int(re.search(r"bytes_per_frame <= (\d+)ull \? \(uint32_t\)kMaxBatch : \(uint32_t\)kSmallBatch", abi).group(1))
+    m = re.search(r"bytes_per_frame <= (\d+)ull \? \(uint32_t\)kMaxBatch : \(mid_ok && bytes_per_frame <= (\d+)ull\) \? (\d+)u : \(uint32_t\)kSmallBatch", abi)
+    limit, mid_limit, mid = int(m.group(1)), int(m.group(2)), int(m.group(3))
     # which loop each entry point runs: `base += kSmallBatch` (convert, remap) or `base += per` with per = frames_per_dispatch(...) (resize, fused)
     body = lambda fn: abi[abi.index(f"vpf_status {fn}("):abi.index("\n}\n", abi.index(f"vpf_status {fn}("))]  # noqa: E731
     assert "base += kSmallBatch" in body("vpf_convert_batch") and "base += kSmallBatch" in body("vpf_remap_batch")
@@ -181,10 +182,11 @@ def test_batch_sizes_in_the_docs_are_the_ones_in_the_code():
     header = open(os.path.join(ROOT, "include", "vpf_hip.h")).read()
     comment = lambda decl: header[header.rindex("/*", 0, header.index(decl)):header.index(decl)]  # noqa: E731
     millions = f"{limit // 1000000} 000 000"
+    mid_words = [f"one per {mid} frames", f"{mid_limit // 1000000} 000 000"]  # the middle tier (round 6): mid-sized bilinear / fused frames
     for decl, want, never in (("VPF_API vpf_status vpf_convert_batch(", [f"one per {small} frames"], [str(large)]),
                               ("VPF_API vpf_status vpf_remap_batch(", [f"one dispatch per {small} frames"], [str(large)]),
-                              ("VPF_API vpf_status vpf_resize_batch(", [f"one per {large}", millions, f"per {small} frames"], []),
-                              ("VPF_API vpf_status vpf_convert_resize_batch(", [f"one per {large} frames", millions, f"one per {small} frames"], [])):
+                              ("VPF_API vpf_status vpf_resize_batch(", [f"one per {large}", millions, f"per {small} frames"] + mid_words, []),
+                              ("VPF_API vpf_status vpf_convert_resize_batch(", [f"one per {large} frames", millions, f"one per {small} frames"] + mid_words, [])):
         c = " ".join(comment(decl).replace("*", " ").split())
         for w in want:
             assert w in c, (decl, w, c)

@@ -230,3 +230,27 @@ def test_execute_batch_beyond_32_frames(oracle):
         torch.cuda.synchronize()
         for i, o_ in enumerate(outs):
             assert np.array_equal(download(o_), wf[i % NSRC]), f"ExecuteBatch fused frame {i} of {n}"
+
+
+@pytest.mark.parametrize("n", [64, 65])
+def test_mid_sized_frames_go_64_to_a_dispatch(capi, oracle, n):
+    """round 6: bilinear frames that move 7-10 MB (packed RGB 1080p -> 720p: 9 MB) travel 64 to a dispatch through the 128-frame table, the fused
+    entry's 720p -> 1080p frames (7.6 MB) too; n = 65 is one dispatch of 64 and one of 1.  Every frame equals the oracle."""
+    of = oracle.RGB
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    srcs = [oracle.synth(of, sw, sh, 7700 + i) for i in range(NSRC)]
+    want = [oracle.resize(of, 1, sw, sh, s, dw, dh, oracle.FP32)[1] for s in srcs]
+    S = [DevPlanes(srcs[i % NSRC]) for i in range(n)]
+    _run_resize(capi, oracle, "RGB", 1, sw, sh, dw, dh, n, srcs, want, S, f"bilinear RGB 1080p -> 720p x {n}")
+    osf, odf = oracle.NV12, oracle.RGB
+    sw, sh, dw, dh = 1280, 720, 1920, 1080
+    fsrcs = [oracle.synth(osf, sw, sh, 7800 + i) for i in range(NSRC)]
+    fwant = [oracle.convert_resize(osf, odf, 1, 0, sw, sh, s, dw, dh)[1] for s in fsrcs]
+    FS = [DevPlanes(fsrcs[i % NSRC]) for i in range(n)]
+    FD = [DevPlanes(oracle.alloc(odf, dw, dh, fill=0x5A)) for _ in range(n)]
+    capi.convert_resize_batch(capi.make_exec(stream_handle()), capi.NV12, capi.RGB, 1, 0, sw, sh, dw, dh, capi.make_batch([(s.desc(), d.desc()) for s, d in zip(FS, FD)]))
+    torch.cuda.synchronize()
+    for i in (0, 1, 31, 32, 62, 63, n - 1):
+        got, intact = FD[i].download()
+        assert intact
+        assert_planes_equal(got, fwant[i % NSRC], f"fused 720p -> 1080p frame {i} of {n}")

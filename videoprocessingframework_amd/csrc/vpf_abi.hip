@@ -119,7 +119,13 @@ static uint32_t row_bytes(int f, int k, uint32_t w) {
 // frame, RGB 720p -> 1080p bilinear 1.82 -> 2.14: dispatches of 60 us and more had little tail to amortise, and the launch planners are fitted
 // at 32 and at 128 frames only).  Measured over seven shapes x 32 / 64 / 96 / 128 frames (profiles/r05_frames_per_dispatch_curve.txt): the
 // gain sits with the shapes that move up to ~7 MB per frame (source + destination).
-static uint32_t frames_per_dispatch(uint64_t bytes_per_frame) { return bytes_per_frame <= 7000000ull ? (uint32_t)kMaxBatch : (uint32_t)kSmallBatch; }
+// Round 6: between the two, bilinear / nearest frames of 7-10 MB (packed RGB 1080p <-> 720p) go 64 to a dispatch: the r05 curve has them at 1.72 -> 1.60 us
+// per frame (1080p -> 720p) and 1.82 -> 1.74 (720p -> 1080p) at 64 and losing again at 128; the Lanczos kernel is level at 64 and keeps 32.
+static uint32_t frames_per_dispatch(uint64_t bytes_per_frame, bool mid_ok = false) {
+  static const bool mid_on = [] { const char* e = std::getenv("VPF_HIP_MID_BATCH"); return !(e && e[0] == '0'); }();  // (A/B: VPF_HIP_MID_BATCH=0 keeps 32)
+  mid_ok = mid_ok && mid_on;
+  return bytes_per_frame <= 7000000ull ? (uint32_t)kMaxBatch : (mid_ok && bytes_per_frame <= 10000000ull) ? 64u : (uint32_t)kSmallBatch;
+}
 static uint64_t frame_bytes(int f, vpf_size s) {
   uint64_t b = 0;
   for (int k = 0; k < num_planes(f); k++) {
@@ -312,7 +318,7 @@ vpf_status vpf_resize_batch(const vpf_exec* exec, int fmt, int interp, vpf_size 
                                              static_cast<uint8_t*>(d0.ptr), d0.pitch);
     return status_of(e);
   }
-  const uint32_t per = frames_per_dispatch(frame_bytes(fmt, ss) + frame_bytes(fmt, ds));  // 128 for small planes, else 32 (the launchers take the small frame table for up to 32)
+  const uint32_t per = frames_per_dispatch(frame_bytes(fmt, ss) + frame_bytes(fmt, ds), interp != VPF_INTERP_LANCZOS3);  // 128 for small planes, 64 for mid-sized bilinear ones, else 32 (the launchers take the small frame table for up to 32)
   for (uint32_t base = 0; base < n; base += per) {
     const uint32_t m = (n - base < per) ? n - base : per;
     BatchArgsL a;
@@ -409,7 +415,7 @@ vpf_status vpf_convert_resize_batch(const vpf_exec* exec, int sf, int df, int cs
   if (guard.err != hipSuccess) return status_of(guard.err);
   Yuv2RgbCoef c;
   make_yuv2rgb(cs, cr, &c);
-  const uint32_t per = frames_per_dispatch(frame_bytes(sf, ss) + frame_bytes(df, ds));  // 128 for small frames (1080p -> 720p and smaller), else 32
+  const uint32_t per = frames_per_dispatch(frame_bytes(sf, ss) + frame_bytes(df, ds), true);  // 128 for small frames (1080p -> 720p and smaller), 64 for 7-10 MB ones (720p -> 1080p), else 32
   for (uint32_t base = 0; base < n; base += per) {
     const uint32_t m = (n - base < per) ? n - base : per;
     BatchArgsL a;
