@@ -87,6 +87,19 @@ void SetupNppContext(CUcontext, CUstream stream, NppStreamContext& ctx) {  // th
   ctx.hStream = stream;
 }
 
+namespace {
+// Host frames cross PCIe through a page-locked staging buffer of the harness's own (round 6): hipMemcpy2DAsync straight from / to the caller's
+// numpy memory makes the runtime page-lock that memory on the fly for every copy, and under four test workers sharing one GPU that path aborted
+// the process twice in 28 whole-suite runs (profiles/README.md, r06_z2 / r06_stress2).  Test infrastructure, not the product's upload path.
+struct Pinned {
+  void* p = nullptr;
+  explicit Pinned(size_t n) { if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) p = nullptr; }
+  ~Pinned() { if (p) (void)hipHostFree(p); }
+  Pinned(const Pinned&) = delete;
+  Pinned& operator=(const Pinned&) = delete;
+};
+}  // namespace
+
 extern "C" {
 // One conversion through the REFERENCE'S ConvertSurface on the GPU.  `src` / `dst` are tight host frames (planes concatenated at
 // tight width, the layout of CudaUploadFrame / CudaDownloadSurface, Tasks.cpp:643-658,815-854).  cs / cr < 0: no context token.
@@ -107,9 +120,12 @@ int ref_hip_convert(int in_fmt, int out_fmt, uint32_t w, uint32_t h, int cs, int
       if (!conv || !in) { (void)hipStreamDestroy(st); return -1; }
       if (in->HostMemSize() > src_bytes) { (void)hipStreamDestroy(st); return -3; }
       size_t off = 0;
+      Pinned up(in->HostMemSize()), down(dst_cap);
+      if (!up.p || !down.p) { (void)hipStreamDestroy(st); return -4; }
+      std::memcpy(up.p, src, in->HostMemSize());
       for (uint32_t p = 0; p < in->NumPlanes(); p++) {  // upload plane by plane, like CudaUploadFrame::Run
         const size_t wb = in->WidthInBytes(p), rows = in->Height(p);
-        if (hipMemcpy2DAsync((void*)(uintptr_t)in->PlanePtr(p), in->Pitch(p), src + off, wb, wb, rows, hipMemcpyHostToDevice, st) != hipSuccess) rc = -4;
+        if (hipMemcpy2DAsync((void*)(uintptr_t)in->PlanePtr(p), in->Pitch(p), (const uint8_t*)up.p + off, wb, wb, rows, hipMemcpyHostToDevice, st) != hipSuccess) rc = -4;
         off += wb * rows;
       }
       std::unique_ptr<Buffer> ctx_buf(Buffer::MakeOwnMem(sizeof(ColorspaceConversionContext)));
@@ -129,7 +145,7 @@ int ref_hip_convert(int in_fmt, int out_fmt, uint32_t w, uint32_t h, int cs, int
           off = 0;
           for (uint32_t p = 0; p < out->NumPlanes(); p++) {
             const size_t wb = out->WidthInBytes(p), rows = out->Height(p);
-            if (hipMemcpy2DAsync(dst + off, wb, (const void*)(uintptr_t)out->PlanePtr(p), out->Pitch(p), wb, rows, hipMemcpyDeviceToHost, st) != hipSuccess) rc = -4;
+            if (hipMemcpy2DAsync((uint8_t*)down.p + off, wb, (const void*)(uintptr_t)out->PlanePtr(p), out->Pitch(p), wb, rows, hipMemcpyDeviceToHost, st) != hipSuccess) rc = -4;
             off += wb * rows;
           }
           if (dst_bytes) *dst_bytes = off;
@@ -137,6 +153,7 @@ int ref_hip_convert(int in_fmt, int out_fmt, uint32_t w, uint32_t h, int cs, int
         }
       }
       if (hipStreamSynchronize(st) != hipSuccess) rc = -4;
+      if (rc == 1) std::memcpy(dst, down.p, off);
     }
     (void)hipStreamDestroy(st);
   } catch (std::exception& e) {
@@ -157,7 +174,7 @@ extern "C" void vpf_ref_uncompiled_part() {
 
 namespace {
 // tight host frame <-> the planes of a reference Surface (the layout of CudaUploadFrame / CudaDownloadSurface, Tasks.cpp:643-658,815-854)
-int upload_planes(Surface* s, const uint8_t* src, size_t src_bytes, hipStream_t st) {
+int upload_planes(Surface* s, const uint8_t* src, size_t src_bytes, hipStream_t st) {  // `src`: page-locked (run_task stages the caller's frame)
   if (s->HostMemSize() > src_bytes) return -3;
   size_t off = 0;
   for (uint32_t p = 0; p < s->NumPlanes(); p++) {
@@ -192,15 +209,21 @@ int run_task(MakeTask make, int fmt, uint32_t sw, uint32_t sh, const uint8_t* sr
       std::unique_ptr<Task> task(make((CUstream)st));
       std::unique_ptr<Surface> in(Surface::Make((Pixel_Format)fmt, sw, sh, nullptr));
       if (!task || !in) { (void)hipStreamDestroy(st); return -1; }
-      rc = upload_planes(in.get(), src, src_bytes, st);
+      Pinned up(in->HostMemSize() <= src_bytes ? in->HostMemSize() : 1), down(dst_cap);
+      if (!up.p || !down.p) { (void)hipStreamDestroy(st); return -4; }
+      if (in->HostMemSize() <= src_bytes) std::memcpy(up.p, src, in->HostMemSize());
+      rc = upload_planes(in.get(), (const uint8_t*)up.p, src_bytes, st);
       task->SetInput(in.get(), 0U);
       const auto status = rc == 0 ? task->Execute() : TaskExecStatus::TASK_EXEC_FAIL;  // (Execute ends with the task's cuda_stream_sync callback)
       auto* out = (Surface*)task->GetOutput(0U);
       if (rc == 0 && status == TaskExecStatus::TASK_EXEC_SUCCESS && out) {
         if (ow) *ow = out->Width();
         if (oh) *oh = out->Height();
-        rc = download_planes(out, dst, dst_cap, dst_bytes, st);
-        if (rc == 0) rc = 1;
+        size_t got = 0;
+        rc = download_planes(out, (uint8_t*)down.p, dst_cap, &got, st);
+        if (dst_bytes) *dst_bytes = got;
+        if (rc == 0) rc = hipStreamSynchronize(st) == hipSuccess ? 1 : -4;
+        if (rc == 1) std::memcpy(dst, down.p, got);
       }
       if (hipStreamSynchronize(st) != hipSuccess) rc = -4;
     }

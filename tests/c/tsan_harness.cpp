@@ -49,7 +49,9 @@ int main() {
         cache.end();
         (a.off16 ? (a.build ? builds : hits) : none)++;
         if ((i & 63) == 0) sync.completed.store(sync.next.load() - 1);  // "the GPU has caught up"
-        const int s = slots.slot_of(0, reinterpret_cast<const void*>((uintptr_t)(0x20000 + (i * 5 + t) % 70)), [&](int, const void* q) { return ((uintptr_t)q & 3) != 0; });
+        int set = -1;  // (round 6: a slot hands out its two counter sets in turn — take() — under the same lock)
+        const int s = slots.take(0, reinterpret_cast<const void*>((uintptr_t)(0x20000 + (i * 5 + t) % 70)), [&](int, const void* q) { return ((uintptr_t)q & 3) != 0; }, &set);
+        if (s >= 0 && set != 0 && set != 1) return;
         (s >= 0 ? slot_ok : slot_none)++;
       }
     });

@@ -4,9 +4,9 @@
 #      launch planners (tests/c/lzm_plan_capi.cpp, plan_bounds_capi.c, persist_capi.cpp), run under the existing CPU tests;
 #   2. a ThreadSanitizer build of tests/c/tsan_harness.cpp: eight threads cycling shapes through a four-entry table arena (LzmTableCache) and
 #      asking for counter slots (PersistSlotTable).
-# Writes the log to profiles/r05_sanitize.txt (or $1).  No GPU.
+# Writes the log to profiles/r06_sanitize.txt (or $1).  No GPU.
 cd "$(dirname "$0")/.."
-LOG=${1:-profiles/r05_sanitize.txt}
+LOG=${1:-profiles/r06_sanitize.txt}
 ASAN=$(gcc -print-file-name=libasan.so)
 {
   echo "# tools/sanitize.sh on $(date -u +%Y-%m-%dT%H:%MZ), $(gcc --version | head -1)"

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--source", choices=["pinned", "pageable"], default="pinned", help="where the stand-in decoder leaves its frames")
     ap.add_argument("--threads", action="store_true", help="one worker thread per clip (the reference sample's shape: the GIL is released inside "
                     "upload / convert, so the staging copies of different clips run in parallel) instead of one thread round-robin")
+    ap.add_argument("--no-pin-cache", action="store_true", help="leave the page-locked caller-buffer cache off (its default): pageable frames are staged through a copy")
     ap.add_argument("--no-numa", action="store_true", help="do not confine the rank to the CPUs of its GPU's NUMA node")
     a = ap.parse_args()
     rank, world, local = sharding.env_rank()
@@ -86,6 +87,8 @@ def main():
     red_dev = dev if a.backend == "nccl" else None
     w, h, pf = a.width, a.height, nvc.PixelFormat
     cc = nvc.ColorspaceConversionContext(nvc.ColorSpace.BT_709, nvc.ColorRange.MPEG)
+    if not a.no_pin_cache and not os.environ.get("VPF_HIP_PIN_CACHE_MB"):
+        nvc.PinCacheSetBudgetMB(1024)  # opt in: pageable frames that come back are page-locked where they lie (Tasks.hpp HostPinCache)
     mine = sharding.assign_clips(a.clips, world, rank)
     chains = []
     for c in mine:  # one stream + task chain per clip, like one worker thread per stream in the reference sample

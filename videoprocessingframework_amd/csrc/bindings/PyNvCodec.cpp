@@ -684,6 +684,8 @@ PYBIND11_MODULE(_PyNvCodec, m) {
   }, "additive: the cache of page-locked caller frame buffers (Tasks.hpp HostPinCache): buffers registered now, their bytes, uploads DMA'd in place / "
      "staged through a copy since start, registrations given up, registrations that failed");
   m.def("PinCacheDrop", []() { HostPinCache::drop_all(); }, "additive: unregister every page-locked caller buffer");
+  m.def("PinCacheSetBudgetMB", [](size_t mb) { HostPinCache::set_budget_mb(mb); }, py::arg("mb"),
+        "additive: switch the cache of page-locked caller frame buffers on (mb > 0: its byte budget) or off (0, the default unless VPF_HIP_PIN_CACHE_MB is set)");
   m.def("_UseHostAllocator", [](bool on) {
     static const DeviceAllocator host = {host_alloc, host_free, nullptr};
     SetDeviceAllocator(on ? &host : nullptr);

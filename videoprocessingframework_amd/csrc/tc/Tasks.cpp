@@ -678,7 +678,7 @@ struct PinState {
   HostPinCache::Stats st{};
   size_t cap_bytes = [] {
     const char* v = std::getenv("VPF_HIP_PIN_CACHE_MB");
-    return (size_t)(v ? std::strtoull(v, nullptr, 10) : 1024ull) << 20;
+    return (size_t)(v ? std::strtoull(v, nullptr, 10) : 0ull) << 20;  // opt-in (Tasks.hpp)
   }();
 };
 PinState& pins() { static PinState* s = new PinState; return *s; }  // (leaked on purpose: weak-reference callbacks may run during interpreter shutdown)
@@ -762,6 +762,12 @@ bool HostPinCache::covers(const void* ptr) {
   for (const PinEnt& x : S.e)
     if (x.registered && p >= x.p && p < x.p + x.n) return true;
   return false;
+}
+void HostPinCache::set_budget_mb(size_t mb) {
+  if (!mb) drop_all();
+  PinState& S = pins();
+  std::lock_guard<std::mutex> g(S.mu);
+  S.cap_bytes = mb << 20;
 }
 void HostPinCache::drop_all() {
   PinState& S = pins();

@@ -104,7 +104,9 @@ private:
 // `owner` names whatever keeps the memory alive (the Python binding passes the numpy array that owns the data and calls owner_gone() from a
 // weak-reference callback when that array dies; a C++ caller passes any id and calls owner_gone() before it frees).  A range that overlaps a
 // registered one under another owner or other bounds evicts it first: a freed-and-reallocated buffer at an old address is a NEW buffer.
-// Least recently used entries leave when the cache is full (VPF_HIP_PIN_CACHE_MB, default 1024; 0 switches it off; at most 64 buffers).
+// Least recently used entries leave when the cache is full (at most 64 buffers).  OPT-IN: the budget is 0 until VPF_HIP_PIN_CACHE_MB=N or
+// set_budget_mb(N) says otherwise — with the cache on, whole-suite runs on this image's ROCm aborted inside LATER pageable hipMemcpy calls of
+// torch / the test harness (2 of 9 single-process runs; 0 of 16 with it off or on the round-5 tree), not root-caused: DESIGN.md §5.
 // One-shot buffers keep the staged copy — and so does every ASYNCHRONOUS upload (SetAsync(true)): its contract lets the caller reuse an ordinary
 // frame the moment the call returns, which only holds while the frame is copied out before that.  Process-wide, thread-safe.
 class HostPinCache {
@@ -114,6 +116,7 @@ public:
   static void owner_gone(uint64_t owner);
   static bool covers(const void* p);  // p lies in a range this cache has page-locked (not in an AllocPinned() buffer, which is the caller's own)
   static void drop_all();
+  static void set_budget_mb(size_t mb);  // 0: off (and everything registered is released)
   struct Stats { uint64_t registered, bytes, hits, staged, evictions, failures; };
   static Stats stats();
 };
