@@ -1,6 +1,7 @@
 """-m gpu: caller frame buffers that come back are page-locked where they lie and DMA'd from there (Tasks.hpp HostPinCache) —
 and a buffer that was freed and reallocated at the same address is a NEW buffer, never served from a stale registration.
 Reference: PyFrameUploader copies straight from the caller's numpy buffer (src/TC/src/Tasks.cpp:625-662)."""
+import ctypes
 import gc
 import os
 import sys
@@ -16,6 +17,30 @@ if not torch.cuda.is_available():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "videoprocessingframework_amd"))
 import PyNvCodec as nvc  # noqa: E402
+
+# Only buffers that own their pages are page-locked (glibc serves them by mmap: PyNvCodec.cpp owns_its_pages).  glibc raises its mmap threshold
+# whenever a mapped chunk is freed, so in a process that has freed large arrays later ones are cut from the heap; a process that wants its frame
+# pool taken allocates it up front — or pins the threshold, like here (M_MMAP_THRESHOLD = -3).
+assert ctypes.CDLL(None).mallopt(-3, 128 * 1024) == 1
+_parked = []
+
+
+def owns_its_pages(a):
+    """what PyNvCodec.cpp's owns_its_pages() asks of a buffer: a glibc chunk served by mmap (user pointer 16 bytes into a page, IS_MMAPPED in the size word)"""
+    p = a.ctypes.data
+    return p % 4096 == 16 and (ctypes.c_size_t.from_address(p - 8).value & 2) != 0
+
+
+def mapped(make):
+    """an array whose memory is a mapping of its own.  Even above the mmap threshold malloc first looks for a free chunk on the heap (a long-lived
+    process has some): heap-cut results are parked — they use those chunks up — until the allocator has to map"""
+    for _ in range(200):
+        a = make()
+        if owns_its_pages(a):
+            return a
+        _parked.append(a)
+    raise AssertionError("the allocator never mapped a chunk")
+
 
 PF = nvc.PixelFormat
 W, H = 1920, 1080
@@ -38,7 +63,7 @@ def test_a_buffer_seen_twice_is_registered_and_read_in_place():
     nvc.PinCacheDrop()
     up = nvc.PyFrameUploader(W, H, PF.NV12, 0)
     rng = np.random.default_rng(5)
-    frame = rng.integers(0, 256, N, dtype=np.uint8)          # owns its data: somebody to vouch for the memory
+    frame = mapped(lambda: rng.integers(0, 256, N, dtype=np.uint8))   # owns its data (somebody to vouch for the memory) and its pages
     s0 = nvc.PinCacheStats()
     assert np.array_equal(download(up.UploadSingleFrame(frame)), frame)
     d = delta(s0)
@@ -60,7 +85,7 @@ def test_freed_and_reallocated_at_the_same_address_is_a_new_buffer():
     nvc.PinCacheDrop()
     up = nvc.PyFrameUploader(W, H, PF.NV12, 0)
     rng = np.random.default_rng(6)
-    a = rng.integers(0, 256, N, dtype=np.uint8)
+    a = mapped(lambda: rng.integers(0, 256, N, dtype=np.uint8))
     for _ in range(2):
         assert np.array_equal(download(up.UploadSingleFrame(a)), a)
     assert int(nvc.PinCacheStats()["registered"]) == 1
@@ -107,13 +132,37 @@ def test_memory_nobody_vouches_for_keeps_the_staged_copy():
     assert delta(s0)["registered"] == 0
 
 
+def test_heap_cut_buffers_keep_the_staged_copy():
+    """a buffer cut from the heap shares its first and last page with its neighbours, and unregistering works on whole pages (the GPU fault of
+    profiles/r06_pin_cache_fault.txt): such buffers are never page-locked"""
+    nvc.PinCacheDrop()
+    libc = ctypes.CDLL(None)
+    assert libc.mallopt(-3, 16 << 20) == 1                                            # M_MMAP_THRESHOLD (glibc caps it at 32 MiB): the next arrays come from the heap
+    try:
+        a = np.zeros(N, np.uint8)
+        a[:] = 7
+    finally:
+        assert libc.mallopt(-3, 128 * 1024) == 1
+    up = nvc.PyFrameUploader(W, H, PF.NV12, 0)
+    s0 = nvc.PinCacheStats()
+    for _ in range(3):
+        assert np.array_equal(download(up.UploadSingleFrame(a)), a)
+    d = delta(s0)
+    assert d["registered"] == 0 and d["in_place"] == 0
+    b = mapped(lambda: np.zeros(N, np.uint8))                                         # a chunk of whole pages of its own
+    assert b.ctypes.data % 4096 == 16
+    for _ in range(3):
+        assert np.array_equal(download(up.UploadSingleFrame(b)), b)
+    assert delta(s0)["registered"] == 1
+
+
 def test_least_recently_used_buffers_leave_a_full_cache():
     nvc.PinCacheDrop()
     w, h = 640, 360
     n = w * h * 3 // 2                                                                # 345 600 B: above the cache's 256-KiB floor
     up = nvc.PyFrameUploader(w, h, PF.NV12, 0)
     rng = np.random.default_rng(7)
-    pool = [rng.integers(0, 256, n, dtype=np.uint8) for _ in range(70)]               # more buffers than the cache has entries (64)
+    pool = [mapped(lambda: rng.integers(0, 256, n, dtype=np.uint8)) for _ in range(70)]   # more buffers than the cache has entries (64)
     s0 = nvc.PinCacheStats()
     for rnd in range(2):
         for i, f in enumerate(pool):
@@ -131,7 +180,7 @@ def test_async_uploads_keep_the_staged_copy():
     never read in place: not registered on their own, and copied out first when a blocking uploader had the buffer page-locked earlier"""
     nvc.PinCacheDrop()
     rng = np.random.default_rng(8)
-    frame = rng.integers(0, 256, N, dtype=np.uint8)
+    frame = mapped(lambda: rng.integers(0, 256, N, dtype=np.uint8))
     blocking = nvc.PyFrameUploader(W, H, PF.NV12, 0)
     for _ in range(2):
         assert np.array_equal(download(blocking.UploadSingleFrame(frame)), frame)
@@ -149,7 +198,7 @@ def test_async_uploads_keep_the_staged_copy():
         assert np.array_equal(download(surfs[k]), wants[k]), k                        # every upload saw ITS bytes: they were copied out before the call returned
     d = delta(s0)
     assert d["in_place"] == 0 and d["registered"] == 0
-    fresh = [rng.integers(0, 256, N, dtype=np.uint8) for _ in range(2)]
+    fresh = [mapped(lambda: rng.integers(0, 256, N, dtype=np.uint8)) for _ in range(2)]
     for rnd in range(3):
         for f in fresh:
             up.UploadSingleFrame(f)

@@ -43,6 +43,24 @@ def _async(up):
     return up
 
 
+_parked = []
+
+
+def _mapped_empty(n):
+    """np.empty(n) whose memory is a mapping of its own (what HostPinCache takes: a buffer that owns its pages).  glibc raises its mmap threshold
+    whenever a mapped chunk is freed — pinned here at 128 KiB (M_MMAP_THRESHOLD = -3) — and even above it malloc prefers a free heap chunk when it
+    has one: such results are parked until the allocator has to map"""
+    import ctypes
+    ctypes.CDLL(None).mallopt(-3, 128 * 1024)
+    for _ in range(64):
+        a = np.empty(n, np.uint8)
+        p = a.ctypes.data
+        if p % 4096 == 16 and (ctypes.c_size_t.from_address(p - 8).value & 2):
+            return a
+        _parked.append(a)
+    return a
+
+
 class SyntheticClip:
     """Stand-in for demux + software decode of one clip: `distinct` NV12 frames in host memory, seeded per clip — page-locked (what a decoder
     writing into AllocPinned() buffers produces: DMA'd in place) or ordinary pageable numpy arrays (what an unmodified decoder produces: the
@@ -52,7 +70,7 @@ class SyntheticClip:
         rng = np.random.default_rng(7000 + clip_id)
         self.frames = []
         for _ in range(distinct):
-            buf = nvc.AllocPinned(w * h * 3 // 2) if pinned else np.empty(w * h * 3 // 2, np.uint8)
+            buf = nvc.AllocPinned(w * h * 3 // 2) if pinned else _mapped_empty(w * h * 3 // 2)
             buf[:] = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
             self.frames.append(buf)
 

@@ -229,7 +229,21 @@ static PyObject* frame_owner(const py::array& f) {
   }
   return nullptr;
 }
+// Does the buffer own its PAGES?  hipHostRegister / hipHostUnregister work on whole pages, and unregistering tears the GPU mapping of every page of
+// the range down — also for whatever else lives in the range's first and last page.  The HIP runtime page-locks pageable memory on the fly for its
+// own copies (torch's .cpu(), hipMemcpy from a numpy array) and keeps track of what it has locked: when a buffer this cache releases shares a page
+// with memory the runtime believes locked, the runtime's next copy there faults on the GPU ("Memory access fault by GPU ... on address <host page>":
+// seen in 3 of 19 long single-process test runs, profiles/r06_pin_cache_fault.txt).  So only buffers that own their pages are taken: glibc serves
+// large requests by mmap — a chunk of whole pages of its own, user pointer 16 bytes in, IS_MMAPPED set in the size word in front of it (read only
+// when the pointer sits 16 bytes into a page: the word is then on the same, mapped, page).  Heap-cut buffers keep the staged copy.
+static bool owns_its_pages(const void* data, size_t bytes) {
+  const uintptr_t p = reinterpret_cast<uintptr_t>(data);
+  if ((p & 4095u) != 16u) return false;
+  const size_t word = reinterpret_cast<const size_t*>(p)[-1], chunk = word & ~(size_t)7;
+  return (word & 2u) != 0 && (chunk & 4095u) == 0 && chunk >= bytes + 16u;
+}
 static void vouch_for_frame(const py::array& f, const void* data, size_t bytes, int device) {
+  if (!owns_its_pages(data, bytes)) return;
   PyObject* owner = frame_owner(f);
   if (!owner) return;
   const uint64_t id = (uint64_t)(uintptr_t)owner;
@@ -679,7 +693,7 @@ PYBIND11_MODULE(_PyNvCodec, m) {
   m.def("PinCacheStats", []() {
     const HostPinCache::Stats t = HostPinCache::stats();
     py::dict d;
-    d["registered"] = t.registered; d["bytes"] = t.bytes; d["in_place"] = t.hits; d["staged"] = t.staged; d["evictions"] = t.evictions; d["failures"] = t.failures;
+    d["registered"] = t.registered; d["bytes"] = t.bytes; d["in_place"] = t.hits; d["staged"] = t.staged; d["evictions"] = t.evictions; d["failures"] = t.failures; d["budget"] = t.budget;
     return d;
   }, "additive: the cache of page-locked caller frame buffers (Tasks.hpp HostPinCache): buffers registered now, their bytes, uploads DMA'd in place / "
      "staged through a copy since start, registrations given up, registrations that failed");

@@ -778,7 +778,9 @@ void HostPinCache::drop_all() {
 HostPinCache::Stats HostPinCache::stats() {
   PinState& S = pins();
   std::lock_guard<std::mutex> g(S.mu);
-  return S.st;
+  Stats t = S.st;
+  t.budget = S.cap_bytes;
+  return t;
 }
 
 // ------------------------------------------------------------------------------------------ CudaUploadFrame

@@ -117,7 +117,7 @@ public:
   static bool covers(const void* p);  // p lies in a range this cache has page-locked (not in an AllocPinned() buffer, which is the caller's own)
   static void drop_all();
   static void set_budget_mb(size_t mb);  // 0: off (and everything registered is released)
-  struct Stats { uint64_t registered, bytes, hits, staged, evictions, failures; };
+  struct Stats { uint64_t registered, bytes, hits, staged, evictions, failures, budget; };
   static Stats stats();
 };
 
