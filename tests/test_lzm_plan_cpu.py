@@ -152,6 +152,29 @@ def test_planner_on_up_scales(lzp):
     assert plan(lzp, [(3, 1920, 1080, 3840, 1000)], 32)["up2"] is False   # (an up-scale in x only)
 
 
+def test_planner_on_one_up_scaled_frame_per_dispatch(lzp):
+    """Round 6: ONE frame per dispatch (an unmodified PySurfaceResizer.Execute()).  A lone launch is one round of waves and its time is that of the
+    fullest CU, so the best band height sits just under a multiple of 256 workgroups; for the ring-of-two kernels (up-scales) on launches whose
+    planes have equal strip counts (RGB, Y, NV12) the planner keeps its strip width and re-chooses the band height with an occupancy term fitted to
+    the n = 1 sweep (tools/lab/fit_lzm_lone.py): 20 cases, mean regret <= 2.5 %, worst <= 9 % (before: 3.2 % / 13 %); the picks it changes were
+    measured band height by band height (profiles/r06_m_lone_upscales.txt).  YUV420 (the first form of the rule lost 9-14 % there), down-scales,
+    forced band heights and launches of more than one frame are untouched."""
+    regrets = []
+    for fmt, sw, sh, dw, dh, nn, res in sweep_lines("r05_lanczos_shape_sweep_up_n1.txt"):
+        assert nn == 1
+        p = plan(lzp, planes_of(fmt, sw, sh, dw, dh), 1)
+        assert p["ok"] and p["up2"] and 2 <= p["r"] <= 64
+        regrets.append(pick_time(p, res) / min(res.values()) - 1.0)
+        assert regrets[-1] <= 0.09, (fmt, sw, dw, p, min(res.values()))
+    assert len(regrets) == 20 and float(np.mean(regrets)) <= 0.025, (len(regrets), np.mean(regrets))
+    # the case that motivated it: bands that fill whole multiples of the 256 CUs
+    assert plan(lzp, planes_of("RGB", 1920, 1080, 3840, 2160), 1)["r"] == 8      # 45 x 17 = 765 workgroups = 3 per CU (7 tiles: 900; 6: a second round)
+    # untouched: a forced band height, the ring of four (down-scales); launches of more than one frame: the sweep tests above and below
+    assert plan(lzp, planes_of("RGB", 1920, 1080, 3840, 2160), 1, forced=(4 << 8) | 5)["r"] == 5
+    assert plan(lzp, planes_of("RGB", 3840, 2160, 1920, 1080), 1)["r"] == 2 and plan(lzp, planes_of("YUV420", 3840, 2160, 2560, 1440), 1)["r"] == 2
+    assert plan(lzp, planes_of("NV12", 2560, 1440, 3840, 2160), 1)["r"] == 4 and plan(lzp, planes_of("YUV420", 1920, 1080, 3840, 2160), 1)["r"] == 4   # (YUV420: the model's own pick)
+
+
 @pytest.mark.parametrize("n,mean_max,worst_max", [(64, 0.06, 0.15), (128, 0.05, 0.15)])
 def test_planner_beyond_32_frames_per_dispatch(lzp, n, mean_max, worst_max):
     """Round 5 (up to 128 frames per dispatch): the cost model's large-launch branch (continuous rounds + a tail of one and a half wave lives)

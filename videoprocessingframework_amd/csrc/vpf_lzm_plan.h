@@ -183,6 +183,47 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
       if (!P.ok || cost < best) { best = cost; P = q; P.ok = true; P.band_tiles = r; }
     }
   }
+  // Round 6: ONE up-scaled frame per dispatch (what an unmodified PySurfaceResizer.Execute() issues).  Such a launch is a single round of waves
+  // that all start together, and its time is the time of the fullest CU: L = ceil(workgroups / 256) of them share each CU's SIMDs, a lone wave runs
+  // a tile at its latency (tl), L co-resident ones at L x their issue time (ti) — so the best band height sits just under a multiple of 256
+  // workgroups (RGB 1080p -> 4K: bands of 8 tiles = 765 workgroups 12.7 us, of 7 = 900 13.4, of 6 = 1 035, a second round, 16.0), which the model
+  // above, linear in the band height within a round, cannot see.  The strip width stays the model's pick; the band height is re-chosen by
+  //   cost = rounds x (a0 + a1 (L - 1) + work x max(tl, ti L)),
+  // four constants per kernel class fitted to the n = 1 sweeps (profiles/r05_lanczos_shape_sweep_up_n1.txt, 20 cases, bands of up to 16 tiles;
+  // tools/lab/fit_lzm_lone.py).  Measured at every band height from 3 to 9 tiles on one box (profiles/r06_m_lone_upscales.txt: the old pick against
+  // the new one): RGB 1080p -> 4K 13.24 -> 12.41 us, RGB 1440p -> 4K 18.2 -> 16.4, NV12 1440p -> 4K 9.46 -> 8.79, NV12 1080p -> 4K level.  Where it
+  // applies: the ring-of-two kernels (on the down-scales the same fit has no signal: the 4-tile strips' band heights tie in it, what it gains on
+  // 4K -> 1440p it loses on 1080p -> 900p) and launches whose planes all have the same number of strip groups (packed RGB, Y, NV12) — "the
+  // fullest CU holds ceil(workgroups / 256)" is wrong where they differ: YUV420 1080p -> 4K with bands of 4 tiles is 782 workgroups, 14 more than
+  // three per CU, and runs 9.9 us where the 629 of 5-tile bands take 10.9 (first form of this rule, same file).  Everything else keeps the pick above.
+  bool lone_rule = P.ok && n == 1u && tables && P.up2 && P.span <= 128u && !(forced > 1 && (forced & 0xff));
+  for (int p = 1; p < njobs && lone_rule; p++)
+    lone_rule = (jobs[p].dw * jobs[p].ch + 16u * P.nt - 1) / (16u * P.nt) == (jobs[0].dw * jobs[0].ch + 16u * P.nt - 1) / (16u * P.nt);
+  if (lone_rule) {
+    static const double K[2][4] = {{4.93, 0.0, 1.52, 0.86}, {4.65, 0.14, 1.42, 0.58}};  // a0 a1 tl ti: 8-tile strips, 4-tile strips
+    const double* k = K[P.nt == 8 ? 0 : 1];
+    const double slots = P.nt == 8 ? 768.0 : 1024.0, cap = slots / 256.0;
+    uint32_t tmax = 0;
+    for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15u) / 16u);
+    double best1 = 0.0;
+    uint32_t r1 = 0;
+    for (uint32_t r = std::min(2u, tmax); r <= std::min(tmax, 64u); r++) {
+      uint64_t wgs = 0;
+      double work = 0.0;
+      for (int p = 0; p < njobs; p++) {
+        const uint32_t tiles = (jobs[p].dh + 15u) / 16u, gxp = ((jobs[p].dw * jobs[p].ch + 16u * P.nt - 1) / (16u * P.nt) + 3) / 4;
+        wgs += (uint64_t)gxp * ((tiles + r - 1) / r);
+        const double scy = (double)jobs[p].sh / (double)jobs[p].dh;
+        const double w = P.nt == 8 ? 0.9 : jobs[p].ch == 3 ? 0.7 : jobs[p].ch == 2 ? 0.5 : 0.75;
+        const double vert = P.nt == 8 ? 0.5 + 0.5 * scy / 1.5 : 0.3 + 0.7 * scy / 1.5;
+        work = std::max(work, (double)std::min(r, tiles) * w * vert);
+      }
+      const double L = std::min(cap, std::ceil((double)wgs / 256.0));
+      const double cost = std::ceil((double)wgs / slots) * (k[0] + k[1] * (L - 1.0) + work * std::max(k[2], k[3] * L));
+      if (!r1 || cost < best1) { best1 = cost; r1 = r; }
+    }
+    if (r1) P.band_tiles = r1;
+  }
   return P;
 }
 
