@@ -1,4 +1,4 @@
-"""lone_lanczos.py LIB [--quick | --up]: Lanczos-3, ONE dispatch per frame (vpf_resize in a loop over a ring past the Infinity Cache), us per frame under
+"""lone_lanczos.py LIB [--quick | --up | --down]: Lanczos-3, ONE dispatch per frame (vpf_resize in a loop over a ring past the Infinity Cache), us per frame under
 bench.sustained for a list of VPF_TUNE_RESIZE_MFMA knob values, with the kernel library LIB (capi.LIB_PATH swapped before the first call) — the
 lone matrix-core launch of VERDICT r4 item 6 / r5 item 5 measured shape by shape, and, with tools/lab/ab/libvpfhip_r05_shared_columns.so (the round-5
 tree + tools/lab/lanczos_shared_columns.patch: knob | 0x100000), the shared-column form at one frame per dispatch, which round 5 only measured
@@ -11,6 +11,7 @@ from videoprocessingframework_amd import capi
 LIBP = os.path.abspath(sys.argv[1])
 capi.LIB_PATH = LIBP
 QUICK = "--quick" in sys.argv
+DOWN = "--down" in sys.argv   # the 4K down-scales (ring of four): policy against both strip widths at bands of 2 .. 6 tiles — the planner's n = 1 regret
 UP = "--up" in sys.argv   # the up-scales (ring of two): policy against forced 4-tile strips with bands of 3 .. 9 tiles — the band heights the n = 1 rule of the planner chooses among
 sys.argv = sys.argv[:1]
 from resize_batch_bench import surf, timed, clk  # noqa: E402
@@ -25,9 +26,11 @@ SHAPES = (
                                     0x40000 | SC | (4 << 8) | 1, 0x40000 | SC | (4 << 8) | 2, 0x40000 | SC | (4 << 8) | 3]),
     ("RGB", 3840, 2160, 2560, 1440, [0, (8 << 8) | 2, SC | (8 << 8) | 1, SC | (8 << 8) | 2, SC | (4 << 8) | 2, SC | (4 << 8) | 3]),
 )
+DOWNK = [0] + [(8 << 8) | r for r in (2, 3, 4, 6)] + [(4 << 8) | r for r in (2, 3, 4, 5, 6)]
+DOWN_SHAPES = tuple((f, 3840, 2160, dw, dh, DOWNK) for f in ("RGB", "NV12", "YUV420", "Y") for (dw, dh) in ((1920, 1080), (2560, 1440)))
 UPK = [0] + [(4 << 8) | r for r in (3, 4, 5, 6, 7, 8, 9)]
 UP_SHAPES = tuple((f, sw, sh, 3840, 2160, UPK) for f in ("RGB", "NV12", "YUV420") for (sw, sh) in ((1920, 1080), (2560, 1440))) + (("Y", 1920, 1080, 3840, 2160, UPK),)
-for fname, sw, sh, dw, dh, knobs in UP_SHAPES if UP else SHAPES[:2] if QUICK else SHAPES:
+for fname, sw, sh, dw, dh, knobs in UP_SHAPES if UP else DOWN_SHAPES if DOWN else SHAPES[:2] if QUICK else SHAPES:
     fmt = getattr(capi, fname)
     ring = max(32, min(256, int(600e6 // (sw * sh * 3 + dw * dh * 3)) // 32 * 32))
     S = [surf(fmt, sw, sh, True) for _ in range(ring)]
