@@ -7,7 +7,8 @@ REGRET of three planners is printed: the current cost model, the occupancy model
 its cross-class calibration is poor), and the hybrid — strip width by the current model, band height by this one.  The planner uses the hybrid
 for the ring-of-two kernels (up-scales) only: on the down-scales the 4-tile class fits badly (15 % mean error), its band heights TIE once the
 constants are rounded (r x L is constant where the issue term rules), and a refit with free channel factors gains on 4K -> 1440p what it loses
-on 1080p -> 900p — no signal.  CPU only."""
+on 1080p -> 900p — no signal.  The down-scales got a model of their own afterwards (second half of this file): with a ring-fill term, both strip
+widths as candidates, fitted to TWO boxes' sweeps and cross-validated between them.  CPU only."""
 import collections, math, os, sys
 import numpy as np
 from scipy.optimize import least_squares
@@ -99,7 +100,82 @@ def regret(cases_, K, how, verbose=False):
     return round(float(np.mean(out)), 4), round(float(np.max(out)), 4)
 
 
+# ---- the down-scales (ring of four): a band's ring fill counts, both strip widths are candidates, two boxes' sweeps cross-validate each other
+KD = {8: [4.26, 0.81, 0.91, 0.92, 0.49], 4: [3.32, 0.77, 1.05, 1.0, 0.15]}   # a0 ti w1 w2 cs as vpf_lzm_plan.h holds them (w3 = 1, tl = 1)
+GATE = 384                                                                  # the rule applies where the current pick has more workgroups than that
+
+
+def down_wave(planes, nt, r, k):
+    wgs, work = 0, 0.0
+    for ch, sw, sh, dw, dh in planes:
+        tiles = (dh + 15) // 16
+        wgs += ((dw * ch + 16 * nt - 1) // (16 * nt) + 3) // 4 * ((tiles + r - 1) // r)
+        rr = min(r, tiles)
+        work = max(work, {1: k[2], 2: k[3], 3: 1.0}[ch] * (k[4] * (rr * sh / dh + 2.0) + rr))
+    return wgs, work
+
+
+def down_cost(k, planes, nt, r):
+    slots = 512 if nt == 8 else 768
+    wgs, work = down_wave(planes, nt, r, k)
+    return math.ceil(wgs / slots) * (k[0] + work * max(1.0, k[1] * min(slots // 256, math.ceil(wgs / 256))))
+
+
+def visit_p_cases():
+    """profiles/r06_p_lone_downscales.txt -> the sweep files' case tuples (Y 4K -> 1080p left out: one such plane goes to the tile kernel by policy)"""
+    import re
+    cur, out = None, collections.OrderedDict()
+    for line in open(os.path.join(U.ROOT, "profiles", "r06_p_lone_downscales.txt")):
+        m = re.match(r"\[lone\] \S+\s+(\w+)\s+(\d+)x(\d+)->(\d+)x(\d+)", line)
+        if m:
+            cur = (m.group(1),) + tuple(int(v) for v in m.groups()[1:]); out[cur] = {}
+            continue
+        m = re.match(r"\[lone\]\s+(0x[0-9a-f]+): ([\d.]+) us", line)
+        if m and int(m.group(1), 16):
+            out[cur][(int(m.group(1), 16) >> 8, int(m.group(1), 16) & 255)] = float(m.group(2))
+    return [(f, sw, sh, dw, dh, 1, res) for (f, sw, sh, dw, dh), res in out.items() if not (f == "Y" and dw == 1920)]
+
+
+def down_fit(cases_):
+    K = {}
+    for nt in (8, 4):
+        rows = [(U.planes_of(f, sw, sh, dw, dh), r, v) for f, sw, sh, dw, dh, n, res in cases_ for (t, r), v in res.items()
+                if t == nt and r <= 8 and all(U.PB.pb_lzm_span(ch, s, d, nt) for ch, s, _, d, _ in U.planes_of(f, sw, sh, dw, dh))]
+        y = np.array([v for _, _, v in rows])
+        sols = [least_squares(lambda x: np.array([down_cost(x, pl, nt, r) for pl, r, _ in rows]) / y - 1, x0, bounds=([0, 0.05, 0.05, 0.05, 0.0], [30, 5, 3, 3, 5]))
+                for x0 in ([4, 0.6, 0.5, 0.6, 0.5], [2, 0.8, 0.8, 0.8, 1.0], [6, 0.5, 0.4, 0.5, 0.2])]
+        K[nt] = min(sols, key=lambda s: s.cost).x
+    return K
+
+
+def down_pick(planes, K, gate):
+    nt0, r0 = pick(planes, 1, {}, "current")
+    if down_wave(planes, nt0, r0, K[nt0])[0] <= gate:
+        return nt0, r0
+    tmax = max((p[4] + 15) // 16 for p in planes)
+    return min((down_cost(K[nt], planes, nt, r), -nt, r) for nt in (8, 4) if all(U.PB.pb_lzm_span(ch, s, d, nt) for ch, s, _, d, _ in planes)
+               for r in range(min(2, tmax), min(tmax, 64) + 1))[1:]
+
+
+def down_regret(cases_, K, gate):
+    out = []
+    for fmt, sw, sh, dw, dh, n, res in cases_:
+        nt, r = down_pick(U.planes_of(fmt, sw, sh, dw, dh), K, gate)
+        nt = abs(nt)
+        rs = sorted(rr for (t, rr) in res if t == nt)
+        lo = max([x for x in rs if x <= r], default=rs[0]); hi = min([x for x in rs if x >= r], default=rs[-1])
+        t = res[(nt, lo)] if lo == hi else float(np.interp(r, [lo, hi], [res[(nt, lo)], res[(nt, hi)]]))
+        out.append(t / min(res.values()) - 1.0)
+    return round(float(np.mean(out)), 4), round(float(np.max(out)), 4)
+
+
 if __name__ == "__main__":
+    a, b = list(D.cases("r05_lanczos_shape_sweep_down", (1,))), visit_p_cases()
+    print("down-scales, current planner: r05 sweep", regret(a, {}, "current"), " visit p", down_regret(b, KD, 1 << 30))
+    for name, train in (("the r05 sweep", a), ("visit p", b), ("both", a + b)):
+        K = down_fit(train)
+        print(f"  fitted on {name}: 8-tile {np.round(K[8], 2)} 4-tile {np.round(K[4], 2)} -> regret r05 {down_regret(a, K, GATE)}  visit p {down_regret(b, K, GATE)}   (no gate: {down_regret(a, K, 0)})")
+    print("  the planner's constants:", KD, "-> regret r05", down_regret(a, KD, GATE), " visit p", down_regret(b, KD, GATE))
     down = list(D.cases("r05_lanczos_shape_sweep_down", (1,)))
     up = list(D.cases("r05_lanczos_shape_sweep_up", (1,)))
     K = fit(down + up)

@@ -224,6 +224,56 @@ inline LzmPlan lzm_plan(int njobs, const LzmPlaneIn* jobs, uint32_t n, int force
     }
     if (r1) P.band_tiles = r1;
   }
+  // The same question for ONE down-scaled frame per dispatch (the ring of four).  Here a band's ring fill counts — a band of r destination tiles walks
+  // r scy + 2 source tiles, three per destination tile at r = 2 and 2.5 at r = 4 — and both strip widths are candidates again:
+  //   cost = rounds x (a0 + work x max(1, ti L)),   work = max over planes of w_ch (cs (r scy + 2) + r),   L = min(cap, ceil(workgroups / 256)),
+  // fitted per strip width to TWO boxes' sweeps of every band height (profiles/r05_lanczos_shape_sweep_down_n1.txt, 16 cases, and
+  // profiles/r06_p_lone_downscales.txt, 8 cases; tools/lab/fit_lzm_lone.py) and cross-validated between them: fitted on either, the other's mean regret
+  // falls (2.8 % -> 1.1 % with worst 18 % -> 6 %; 7.7 % -> 3.1 % with worst 21 % -> 12 %); the decisions do not move with the constants.  RGB 4K -> 1080p
+  // 15.2 -> 14.2 us (4-tile strips in bands of four), NV12 / YUV420 4K -> 1440p 10-13 % (bands of three).  Only for launches that fill the chip: where
+  // the pick above has at most 1.5 workgroups per CU, fewer and longer waves have nothing to collect (YUV420 1080p -> 900p, 323 workgroups: 6.9 us as
+  // picked, 7.6 with bands of three).  One-chunk windows, whole tiles, table launches, no forced shape; everything else keeps the pick above.
+  bool lone_down = P.ok && n == 1u && tables && !P.up2 && P.kc == 1 && P.rts == 4 && forced <= 1;
+  for (int p = 0; p < njobs && lone_down; p++) lone_down = jobs[p].sh >= jobs[p].dh;  // (no plane could take the ring of two under another strip width)
+  if (lone_down) {
+    static const double K[2][5] = {{4.26, 0.81, 0.91, 0.92, 0.49}, {3.32, 0.77, 1.05, 1.0, 0.15}};  // a0 ti w1 w2 cs: 8-tile strips, 4-tile strips (w3 = 1, tl = 1)
+    auto shape = [&](int nt, uint32_t r, uint64_t& wgs, double& work) {
+      const double* k = K[nt == 8 ? 0 : 1];
+      wgs = 0;
+      work = 0.0;
+      for (int p = 0; p < njobs; p++) {
+        const uint32_t tiles = (jobs[p].dh + 15u) / 16u, gxp = ((jobs[p].dw * jobs[p].ch + 16u * nt - 1) / (16u * nt) + 3) / 4, rr = std::min(r, tiles);
+        wgs += (uint64_t)gxp * ((tiles + r - 1) / r);
+        const double scy = (double)jobs[p].sh / (double)jobs[p].dh, w = jobs[p].ch == 1 ? k[2] : jobs[p].ch == 2 ? k[3] : 1.0;
+        work = std::max(work, w * (k[4] * ((double)rr * scy + 2.0) + (double)rr));
+      }
+    };
+    uint64_t wgs0;
+    double work0;
+    shape(P.nt, P.band_tiles, wgs0, work0);
+    if (wgs0 > 384u) {
+      uint32_t tmax = 0;
+      for (int p = 0; p < njobs; p++) tmax = std::max(tmax, (jobs[p].dh + 15u) / 16u);
+      double best1 = 0.0;
+      LzmPlan B = P;
+      bool have = false;
+      for (int nt = 8; nt >= 4; nt -= 4) {
+        LzmPlan q{false, nt, 0, 0, 0, 0, 0, 1, 4, false};
+        if (!fits(nt, 1, q)) continue;
+        const double* k = K[nt == 8 ? 0 : 1];
+        const double slots = nt == 8 ? 512.0 : 768.0, cap = slots / 256.0;
+        for (uint32_t r = std::min(2u, tmax); r <= std::min(tmax, 64u); r++) {
+          uint64_t wgs;
+          double work;
+          shape(nt, r, wgs, work);
+          const double L = std::min(cap, std::ceil((double)wgs / 256.0));
+          const double cost = std::ceil((double)wgs / slots) * (k[0] + work * std::max(1.0, k[1] * L));
+          if (!have || cost < best1) { best1 = cost; B = q; B.ok = true; B.band_tiles = r; have = true; }
+        }
+      }
+      if (have) P = B;
+    }
+  }
   return P;
 }
 
